@@ -1,0 +1,1387 @@
+/*
+ * mp2p_oracle.c -- CPU restatement of the mp2p_icp per-iteration hot path.
+ * TEST INFRASTRUCTURE ONLY: see mp2p_oracle.h for the rules and the pinning status.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no FMA contraction, so the fp32
+ * distance / threshold expressions round exactly like the reference's x86-64 build and like
+ * the HIP kernels, which use __fmul_rn/__fadd_rn).
+ */
+#include "mp2p_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+const char* orc_version(void) { return "mp2p_oracle 0.1 (restates MOLAorg/mp2p_icp v1.8.0)"; }
+
+/* ======================================================================================
+ *  Small dense helpers
+ * ====================================================================================== */
+static void mat3_mul(const double* A, const double* B, double* C)
+{
+    double r[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            r[i * 3 + j] = A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j] +
+                           A[i * 3 + 2] * B[2 * 3 + j];
+    memcpy(C, r, sizeof(r));
+}
+
+static void skew(const double w[3], double S[9])
+{
+    S[0] = 0, S[1] = -w[2], S[2] = w[1];
+    S[3] = w[2], S[4] = 0, S[5] = -w[0];
+    S[6] = -w[1], S[7] = w[0], S[8] = 0;
+}
+
+/* cyclic Jacobi eigen-solver for symmetric n x n (n<=4). Eigenvalues ascending,
+ * eigenvectors returned as ROWS of V (V[k*n + :] is the k-th eigenvector).
+ * Stands in for mrpt::math::CMatrixFixed::eig_symmetric (estimate_points_eigen.cpp:111,
+ * optimal_tf_horn.cpp:158); SURVEY.md Appendix C.7 (ascending order). */
+static void sym_eig_jacobi(int n, const double* Ain, double* eval, double* V)
+{
+    double A[16], Q[16];
+    for (int i = 0; i < n * n; i++) A[i] = Ain[i];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Q[i * n + j] = (i == j) ? 1.0 : 0.0;
+
+    for (int sweep = 0; sweep < 64; sweep++)
+    {
+        double off = 0;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+        if (off == 0.0) break;
+        for (int p = 0; p < n; p++)
+        {
+            for (int q = p + 1; q < n; q++)
+            {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double app = A[p * n + p], aqq = A[q * n + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t =
+                    (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++)
+                {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++)
+                {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++)
+                {
+                    const double qkp = Q[k * n + p], qkq = Q[k * n + q];
+                    Q[k * n + p] = c * qkp - s * qkq;
+                    Q[k * n + q] = s * qkp + c * qkq;
+                }
+            }
+        }
+    }
+    int order[4] = {0, 1, 2, 3};
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++)
+            if (A[order[j] * n + order[j]] < A[order[i] * n + order[i]])
+            {
+                int t = order[i];
+                order[i] = order[j];
+                order[j] = t;
+            }
+    for (int k = 0; k < n; k++)
+    {
+        eval[k] = A[order[k] * n + order[k]];
+        for (int i = 0; i < n; i++) V[k * n + i] = Q[i * n + order[k]];
+    }
+}
+
+/* LDL^T with diagonal pivoting for a symmetric 6x6 (stands in for Eigen's
+ * H.ldlt().solve(g), optimal_tf_gauss_newton.cpp:351). */
+static void ldlt6_solve(const double* H, const double* g, double* x)
+{
+    const int n = 6;
+    double    A[36];
+    int       perm[6];
+    memcpy(A, H, sizeof(A));
+    for (int i = 0; i < n; i++) perm[i] = i;
+    double L[36] = {0}, D[6] = {0};
+    for (int k = 0; k < n; k++)
+    {
+        /* pivot: largest |diag| of the remaining Schur complement */
+        int    piv  = k;
+        double best = fabs(A[k * n + k]);
+        for (int i = k + 1; i < n; i++)
+            if (fabs(A[i * n + i]) > best) best = fabs(A[i * n + i]), piv = i;
+        if (piv != k)
+        {
+            for (int j = 0; j < n; j++)
+            {
+                double t = A[k * n + j];
+                A[k * n + j] = A[piv * n + j];
+                A[piv * n + j] = t;
+            }
+            for (int i = 0; i < n; i++)
+            {
+                double t = A[i * n + k];
+                A[i * n + k] = A[i * n + piv];
+                A[i * n + piv] = t;
+            }
+            for (int j = 0; j < k; j++)
+            {
+                double t = L[k * n + j];
+                L[k * n + j] = L[piv * n + j];
+                L[piv * n + j] = t;
+            }
+            int t = perm[k];
+            perm[k] = perm[piv];
+            perm[piv] = t;
+        }
+        D[k]         = A[k * n + k];
+        L[k * n + k] = 1.0;
+        if (D[k] == 0.0) continue;
+        for (int i = k + 1; i < n; i++) L[i * n + k] = A[i * n + k] / D[k];
+        for (int i = k + 1; i < n; i++)
+            for (int j = k + 1; j < n; j++) A[i * n + j] -= L[i * n + k] * D[k] * L[j * n + k];
+    }
+    double b[6], y[6], z[6];
+    for (int i = 0; i < n; i++) b[i] = g[perm[i]];
+    for (int i = 0; i < n; i++)
+    {
+        double s = b[i];
+        for (int j = 0; j < i; j++) s -= L[i * n + j] * y[j];
+        y[i] = s;
+    }
+    for (int i = 0; i < n; i++) z[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
+    for (int i = n - 1; i >= 0; i--)
+    {
+        double s = z[i];
+        for (int j = i + 1; j < n; j++) s -= L[j * n + i] * y[j];
+        y[i] = s;
+    }
+    for (int i = 0; i < n; i++) x[perm[i]] = y[i];
+}
+
+/* ======================================================================================
+ *  SE(3)   (closed forms of the un-vendored MRPT calls)
+ * ====================================================================================== */
+void orc_pose_identity(double T[12])
+{
+    memset(T, 0, 12 * sizeof(double));
+    T[0] = T[4] = T[8] = 1.0;
+}
+
+/* CPose3D(x,y,z,yaw,pitch,roll): R = Rz(yaw) Ry(pitch) Rx(roll)   (Appendix C.1) */
+void orc_pose_from_xyzypr(double x, double y, double z, double yaw, double pitch, double roll,
+                          double T[12])
+{
+    const double cy = cos(yaw), sy = sin(yaw), cp = cos(pitch), sp = sin(pitch), cr = cos(roll),
+                 sr = sin(roll);
+    T[0] = cy * cp, T[1] = cy * sp * sr - sy * cr, T[2] = cy * sp * cr + sy * sr;
+    T[3] = sy * cp, T[4] = sy * sp * sr + cy * cr, T[5] = sy * sp * cr - cy * sr;
+    T[6] = -sp, T[7] = cp * sr, T[8] = cp * cr;
+    T[9] = x, T[10] = y, T[11] = z;
+}
+
+void orc_pose_to_xyzypr(const double T[12], double o[6])
+{
+    o[0] = T[9], o[1] = T[10], o[2] = T[11];
+    const double sp = -T[6];
+    double       pitch;
+    if (sp >= 1.0)
+        pitch = M_PI / 2;
+    else if (sp <= -1.0)
+        pitch = -M_PI / 2;
+    else
+        pitch = asin(sp);
+    o[4] = pitch;
+    if (fabs(fabs(sp) - 1.0) < 1e-12)
+    { /* gimbal lock: roll := 0 */
+        o[5] = 0;
+        o[3] = atan2(-T[1], T[4]);
+    }
+    else
+    {
+        o[3] = atan2(T[3], T[0]);
+        o[5] = atan2(T[7], T[8]);
+    }
+}
+
+void orc_pose_compose(const double A[12], const double B[12], double out[12])
+{
+    double r[12];
+    mat3_mul(A, B, r);
+    for (int i = 0; i < 3; i++)
+        r[9 + i] = A[i * 3 + 0] * B[9] + A[i * 3 + 1] * B[10] + A[i * 3 + 2] * B[11] + A[9 + i];
+    memcpy(out, r, sizeof(r));
+}
+
+void orc_pose_inverse(const double A[12], double out[12])
+{
+    double r[12];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r[i * 3 + j] = A[j * 3 + i];
+    for (int i = 0; i < 3; i++)
+        r[9 + i] = -(r[i * 3 + 0] * A[9] + r[i * 3 + 1] * A[10] + r[i * 3 + 2] * A[11]);
+    memcpy(out, r, sizeof(r));
+}
+
+/* CPose3D::composePoint in fp64, left-to-right (Appendix C.2) */
+void orc_pose_compose_point(const double T[12], double lx, double ly, double lz, double g[3])
+{
+    g[0] = T[0] * lx + T[1] * ly + T[2] * lz + T[9];
+    g[1] = T[3] * lx + T[4] * ly + T[5] * lz + T[10];
+    g[2] = T[6] * lx + T[7] * ly + T[8] * lz + T[11];
+}
+
+void orc_pose_inverse_compose_point(const double T[12], double gx, double gy, double gz,
+                                    double l[3])
+{
+    const double dx = gx - T[9], dy = gy - T[10], dz = gz - T[11];
+    l[0] = T[0] * dx + T[3] * dy + T[6] * dz;
+    l[1] = T[1] * dx + T[4] * dy + T[7] * dz;
+    l[2] = T[2] * dx + T[5] * dy + T[8] * dz;
+}
+
+static void so3_exp(const double w[3], double R[9])
+{
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th  = sqrt(th2);
+    double       a, b; /* a = sin(th)/th, b = (1-cos(th))/th^2 */
+    if (th < 1e-6)
+        a = 1.0 - th2 / 6.0, b = 0.5 - th2 / 24.0;
+    else
+        a = sin(th) / th, b = (1.0 - cos(th)) / th2;
+    double W[9], W2[9];
+    skew(w, W);
+    mat3_mul(W, W, W2);
+    for (int i = 0; i < 9; i++) R[i] = a * W[i] + b * W2[i];
+    R[0] += 1.0, R[4] += 1.0, R[8] += 1.0;
+}
+
+static void so3_log(const double R[9], double w[3])
+{
+    const double tr = R[0] + R[4] + R[8];
+    double       c  = 0.5 * (tr - 1.0);
+    if (c > 1.0) c = 1.0;
+    if (c < -1.0) c = -1.0;
+    const double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1];
+    const double s  = 0.5 * sqrt(vx * vx + vy * vy + vz * vz); /* = sin(theta) */
+    const double th = atan2(s, c);
+    if (th < 1e-6)
+    {
+        const double k = 0.5 * (1.0 + th * th / 6.0);
+        w[0] = k * vx, w[1] = k * vy, w[2] = k * vz;
+        return;
+    }
+    if (M_PI - th < 1e-6)
+    { /* near pi: axis from the diagonal of (R+I)/2 */
+        double ax[3] = {sqrt(fmax(0.0, 0.5 * (R[0] + 1.0))), sqrt(fmax(0.0, 0.5 * (R[4] + 1.0))),
+                        sqrt(fmax(0.0, 0.5 * (R[8] + 1.0)))};
+        int    k     = 0;
+        if (ax[1] > ax[k]) k = 1;
+        if (ax[2] > ax[k]) k = 2;
+        /* signs from the symmetric part relative to the largest component */
+        for (int i = 0; i < 3; i++)
+            if (i != k && (R[k * 3 + i] + R[i * 3 + k]) < 0) ax[i] = -ax[i];
+        /* overall sign from the antisymmetric part when it is not exactly zero */
+        if (vx * ax[0] + vy * ax[1] + vz * ax[2] < 0)
+            for (int i = 0; i < 3; i++) ax[i] = -ax[i];
+        w[0] = th * ax[0], w[1] = th * ax[1], w[2] = th * ax[2];
+        return;
+    }
+    const double k = th / (2.0 * s);
+    w[0] = k * vx, w[1] = k * vy, w[2] = k * vz;
+}
+
+/* Lie::SE<3>::exp, true exponential, xi = [v; w]   (Appendix C.3) */
+void orc_se3_exp(const double xi[6], double T[12])
+{
+    const double* v = xi;
+    const double* w = xi + 3;
+    so3_exp(w, T);
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th  = sqrt(th2);
+    double       b, c; /* b = (1-cos)/th^2, c = (th - sin)/th^3 */
+    if (th < 1e-6)
+        b = 0.5 - th2 / 24.0, c = 1.0 / 6.0 - th2 / 120.0;
+    else
+        b = (1.0 - cos(th)) / th2, c = (th - sin(th)) / (th2 * th);
+    double W[9], W2[9], V[9];
+    skew(w, W);
+    mat3_mul(W, W, W2);
+    for (int i = 0; i < 9; i++) V[i] = b * W[i] + c * W2[i];
+    V[0] += 1.0, V[4] += 1.0, V[8] += 1.0;
+    for (int i = 0; i < 3; i++) T[9 + i] = V[i * 3] * v[0] + V[i * 3 + 1] * v[1] + V[i * 3 + 2] * v[2];
+}
+
+/* Lie::SE<3>::log -> [v; w] (ICP.cpp:194-196 splits it that way) */
+void orc_se3_log(const double T[12], double xi[6])
+{
+    double w[3];
+    so3_log(T, w);
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th  = sqrt(th2);
+    double       k; /* V^-1 = I - W/2 + k W^2 */
+    if (th < 1e-6)
+        k = 1.0 / 12.0 + th2 / 720.0;
+    else
+        k = (1.0 - (th * sin(th)) / (2.0 * (1.0 - cos(th)))) / th2;
+    double W[9], W2[9], Vi[9];
+    skew(w, W);
+    mat3_mul(W, W, W2);
+    for (int i = 0; i < 9; i++) Vi[i] = -0.5 * W[i] + k * W2[i];
+    Vi[0] += 1.0, Vi[4] += 1.0, Vi[8] += 1.0;
+    for (int i = 0; i < 3; i++)
+        xi[i] = Vi[i * 3] * T[9] + Vi[i * 3 + 1] * T[10] + Vi[i * 3 + 2] * T[11];
+    xi[3] = w[0], xi[4] = w[1], xi[5] = w[2];
+}
+
+/* Lie::SE<3>::jacob_dDexpe_de(D): d vec([R t] (+) exp(eps)) / d eps at 0, 12x6,
+ * rows = column-major [c1;c2;c3;t], eps=[v;w]   (optimal_tf_gauss_newton.cpp:73,
+ * closed form SURVEY.md Appendix B) */
+void orc_jacob_dDexpe_de(const double T[12], double J[72])
+{
+    memset(J, 0, 72 * sizeof(double));
+    /* rows 0..8, cols 3..5:  -R [e_k]x  for column k */
+    for (int k = 0; k < 3; k++)
+    {
+        double e[3] = {0, 0, 0}, E[9], M[9];
+        e[k] = 1.0;
+        skew(e, E);
+        mat3_mul(T, E, M);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) J[(3 * k + i) * 6 + 3 + j] = -M[i * 3 + j];
+    }
+    /* rows 9..11, cols 0..2: R */
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) J[(9 + i) * 6 + j] = T[i * 3 + j];
+}
+
+/* ======================================================================================
+ *  Error terms (errorTerms.cpp) and robust kernels (robust_kernels.h)
+ * ====================================================================================== */
+static void fill_J2(double lx, double ly, double lz, double J[36])
+{
+    /* [lx*I ly*I lz*I I]   errorTerms.cpp:54-59 */
+    memset(J, 0, 36 * sizeof(double));
+    for (int i = 0; i < 3; i++)
+    {
+        J[i * 12 + 0 + i] = lx;
+        J[i * 12 + 3 + i] = ly;
+        J[i * 12 + 6 + i] = lz;
+        J[i * 12 + 9 + i] = 1.0;
+    }
+}
+
+/* errorTerms.cpp:36-66 */
+void orc_error_point2point(const orc_pair_pt2pt* p, const double T[12], double e[3],
+                           double J1[36])
+{
+    double g[3];
+    orc_pose_compose_point(T, p->lx, p->ly, p->lz, g);
+    e[0] = g[0] - (double)p->gx;
+    e[1] = g[1] - (double)p->gy;
+    e[2] = g[2] - (double)p->gz;
+    if (J1) fill_J2(p->lx, p->ly, p->lz, J1);
+}
+
+/* errorTerms.cpp:115-161 */
+void orc_error_point2plane(const orc_pair_pt2pl* p, const double T[12], double e[3],
+                           double J1[36])
+{
+    double g[3];
+    orc_pose_compose_point(T, p->lx, p->ly, p->lz, g);
+    const double* c     = p->plane;
+    const double  mod_n = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    const double  s     = c[0] * g[0] + c[1] * g[1] + c[2] * g[2] + c[3];
+    e[0] = -(c[0] / mod_n) * s;
+    e[1] = -(c[1] / mod_n) * s;
+    e[2] = -(c[2] / mod_n) * s;
+    if (J1)
+    {
+        double A[9], J2[36];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) A[i * 3 + j] = -c[i] * c[j] / mod_n;
+        fill_J2(p->lx, p->ly, p->lz, J2);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 12; j++)
+                J1[i * 12 + j] =
+                    A[i * 3 + 0] * J2[0 * 12 + j] + A[i * 3 + 1] * J2[1 * 12 + j] + A[i * 3 + 2] * J2[2 * 12 + j];
+    }
+}
+
+/* errorTerms.cpp:68-113 */
+void orc_error_point2line(const orc_pair_pt2ln* p, const double T[12], double e[3],
+                          double J1[36])
+{
+    double g[3];
+    orc_pose_compose_point(T, p->lx, p->ly, p->lz, g);
+    const double* u  = p->director;
+    const double  q[3] = {g[0] - p->pbase[0], g[1] - p->pbase[1], g[2] - p->pbase[2]};
+    const double  uq   = u[0] * q[0] + u[1] * q[1] + u[2] * q[2];
+    e[0] = q[0] - u[0] * uq;
+    e[1] = q[1] - u[1] * uq;
+    e[2] = q[2] - u[2] * uq;
+    if (J1)
+    {
+        double A[9], J2[36];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) A[i * 3 + j] = (i == j ? 1.0 : 0.0) - u[i] * u[j];
+        fill_J2(p->lx, p->ly, p->lz, J2);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 12; j++)
+                J1[i * 12 + j] =
+                    A[i * 3 + 0] * J2[0 * 12 + j] + A[i * 3 + 1] * J2[1 * 12 + j] + A[i * 3 + 2] * J2[2 * 12 + j];
+    }
+}
+
+/* robust_kernels.h:57-94: weight functor on the SQUARED error */
+double orc_robust_weight(int32_t kernel, double c, double errSq)
+{
+    const double c2 = c * c;
+    switch (kernel)
+    {
+        case ORC_KERNEL_GEMANMCCLURE:
+            return c2 / ((errSq + c) * (errSq + c)); /* :76-77 (denominator uses c, not c^2) */
+        case ORC_KERNEL_CAUCHY:
+            return c2 / (errSq + c2); /* :88-89 */
+        default:
+            return 1.0;
+    }
+}
+
+/* ======================================================================================
+ *  a3: transform_local_to_global  (Matcher_Points_Base.cpp:183-249, all-points branch)
+ * ====================================================================================== */
+void orc_transform_local_to_global(const float* lx, const float* ly, const float* lz, size_t n,
+                                   const double T[12], float* ox, float* oy, float* oz,
+                                   float bmin[3], float bmax[3])
+{
+    /* TransformedLocalPointCloud initialises localMin=+max, localMax=-max
+     * (Matcher_Points_Base.h:98-112) */
+    bmin[0] = bmin[1] = bmin[2] = FLT_MAX;
+    bmax[0] = bmax[1] = bmax[2] = -FLT_MAX;
+    for (size_t i = 0; i < n; i++)
+    {
+        double g[3];
+        orc_pose_compose_point(T, lx[i], ly[i], lz[i], g); /* fp64, :216 */
+        const float x = (float)g[0], y = (float)g[1], z = (float)g[2]; /* narrowed once, :217 */
+        ox[i] = x, oy[i] = y, oz[i] = z;
+        if (x > bmax[0]) bmax[0] = x;
+        if (y > bmax[1]) bmax[1] = y;
+        if (z > bmax[2]) bmax[2] = z;
+        if (x < bmin[0]) bmin[0] = x;
+        if (y < bmin[1]) bmin[1] = y;
+        if (z < bmin[2]) bmin[2] = z;
+    }
+}
+
+/* ======================================================================================
+ *  a5: exact k nearest neighbours.  fp32 metric, accumulation order x,y,z
+ *  (SURVEY.md Appendix C.4); tie winner = lowest index (this repo's stated policy).
+ * ====================================================================================== */
+static inline float dist2f(float ax, float ay, float az, float bx, float by, float bz)
+{
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+/* sorted insertion into an ascending (d2, idx) list of capacity k */
+static inline void knn_insert(uint32_t* idx, float* d2, int* count, int k, uint32_t i, float d)
+{
+    int pos = *count;
+    if (pos == k)
+    {
+        /* full: reject if not better than the worst */
+        if (d > d2[k - 1] || (d == d2[k - 1] && i > idx[k - 1])) return;
+        pos = k - 1;
+    }
+    else
+        (*count)++;
+    while (pos > 0 && (d2[pos - 1] > d || (d2[pos - 1] == d && idx[pos - 1] > i)))
+    {
+        d2[pos]  = d2[pos - 1];
+        idx[pos] = idx[pos - 1];
+        pos--;
+    }
+    d2[pos]  = d;
+    idx[pos] = i;
+}
+
+int orc_brute_knn(const float* x, const float* y, const float* z, size_t n, float qx, float qy,
+                  float qz, int k, float max_d2, uint32_t* out_idx, float* out_d2)
+{
+    int count = 0;
+    for (size_t i = 0; i < n; i++)
+    {
+        const float d = dist2f(qx, qy, qz, x[i], y[i], z[i]);
+        if (max_d2 >= 0 && !(d < max_d2)) continue;
+        knn_insert(out_idx, out_d2, &count, k, (uint32_t)i, d);
+    }
+    return count;
+}
+
+/* ---- KD-tree (nanoflann-style: widest-dimension midpoint split, leaf buckets) ---------- */
+typedef struct
+{
+    int32_t  left, right; /* children (node ids) or -1 for leaf */
+    int32_t  dim;
+    float    split_lo, split_hi; /* max of left side / min of right side along dim */
+    uint32_t begin, end;         /* leaf: range in perm */
+} kd_node;
+
+struct orc_kdtree
+{
+    const float *x, *y, *z;
+    size_t       n;
+    uint32_t*    perm;
+    kd_node*     nodes;
+    size_t       n_nodes, cap_nodes;
+    int          leaf_max;
+    float        bmin[3], bmax[3];
+    /* leaf-ordered copies for cache-friendly scans */
+    float *      px, *py, *pz;
+};
+
+static int32_t kd_new_node(orc_kdtree* t)
+{
+    if (t->n_nodes == t->cap_nodes)
+    {
+        t->cap_nodes = t->cap_nodes ? t->cap_nodes * 2 : 1024;
+        t->nodes     = (kd_node*)realloc(t->nodes, t->cap_nodes * sizeof(kd_node));
+    }
+    return (int32_t)t->n_nodes++;
+}
+
+static inline float kd_coord(const orc_kdtree* t, uint32_t i, int d)
+{
+    return d == 0 ? t->x[i] : (d == 1 ? t->y[i] : t->z[i]);
+}
+
+static int32_t kd_build_rec(orc_kdtree* t, uint32_t b, uint32_t e)
+{
+    const int32_t id = kd_new_node(t);
+    if ((int)(e - b) <= t->leaf_max)
+    {
+        kd_node* nd = &t->nodes[id];
+        nd->left = nd->right = -1;
+        nd->begin = b, nd->end = e;
+        nd->dim = 0, nd->split_lo = nd->split_hi = 0;
+        return id;
+    }
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (uint32_t i = b; i < e; i++)
+        for (int d = 0; d < 3; d++)
+        {
+            const float v = kd_coord(t, t->perm[i], d);
+            if (v < lo[d]) lo[d] = v;
+            if (v > hi[d]) hi[d] = v;
+        }
+    int dim = 0;
+    if (hi[1] - lo[1] > hi[dim] - lo[dim]) dim = 1;
+    if (hi[2] - lo[2] > hi[dim] - lo[dim]) dim = 2;
+    const float mid = 0.5f * (lo[dim] + hi[dim]);
+    /* partition: < mid left, >= mid right; balance degenerate cases */
+    uint32_t i = b, j = e;
+    while (i < j)
+    {
+        if (kd_coord(t, t->perm[i], dim) < mid)
+            i++;
+        else
+        {
+            j--;
+            uint32_t tmp = t->perm[i];
+            t->perm[i]   = t->perm[j];
+            t->perm[j]   = tmp;
+        }
+    }
+    uint32_t m = i;
+    if (m == b || m == e)
+    { /* all equal along dim (or all on one side): split by count */
+        m = b + (e - b) / 2;
+    }
+    float slo = -FLT_MAX, shi = FLT_MAX;
+    for (uint32_t q = b; q < m; q++)
+    {
+        const float v = kd_coord(t, t->perm[q], dim);
+        if (v > slo) slo = v;
+    }
+    for (uint32_t q = m; q < e; q++)
+    {
+        const float v = kd_coord(t, t->perm[q], dim);
+        if (v < shi) shi = v;
+    }
+    const int32_t l = kd_build_rec(t, b, m);
+    const int32_t r = kd_build_rec(t, m, e);
+    kd_node*      nd = &t->nodes[id];
+    nd->left = l, nd->right = r, nd->dim = dim;
+    nd->split_lo = slo, nd->split_hi = shi;
+    nd->begin = b, nd->end = e;
+    return id;
+}
+
+orc_kdtree* orc_kdtree_build(const float* x, const float* y, const float* z, size_t n,
+                             int leaf_max)
+{
+    orc_kdtree* t = (orc_kdtree*)calloc(1, sizeof(orc_kdtree));
+    t->x = x, t->y = y, t->z = z, t->n = n;
+    t->leaf_max = leaf_max > 0 ? leaf_max : 10;
+    t->perm     = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    for (size_t i = 0; i < n; i++) t->perm[i] = (uint32_t)i;
+    if (n) kd_build_rec(t, 0, (uint32_t)n);
+    t->px = (float*)malloc((n ? n : 1) * sizeof(float));
+    t->py = (float*)malloc((n ? n : 1) * sizeof(float));
+    t->pz = (float*)malloc((n ? n : 1) * sizeof(float));
+    for (size_t i = 0; i < n; i++)
+    {
+        t->px[i] = x[t->perm[i]];
+        t->py[i] = y[t->perm[i]];
+        t->pz[i] = z[t->perm[i]];
+    }
+    return t;
+}
+
+void orc_kdtree_free(orc_kdtree* t)
+{
+    if (!t) return;
+    free(t->perm);
+    free(t->nodes);
+    free(t->px);
+    free(t->py);
+    free(t->pz);
+    free(t);
+}
+
+typedef struct
+{
+    const orc_kdtree* t;
+    float             q[3];
+    int               k, count;
+    float             max_d2;
+    uint32_t*         idx;
+    float*            d2;
+} kd_query;
+
+static inline double kd_worst(const kd_query* s)
+{
+    if (s->count == s->k) return (double)s->d2[s->k - 1];
+    return s->max_d2 >= 0 ? (double)s->max_d2 : DBL_MAX;
+}
+
+static void kd_search_rec(kd_query* s, int32_t id, double mind2, double off[3])
+{
+    const kd_node* nd = &s->t->nodes[id];
+    if (nd->left < 0)
+    {
+        const orc_kdtree* t = s->t;
+        for (uint32_t i = nd->begin; i < nd->end; i++)
+        {
+            const float d = dist2f(s->q[0], s->q[1], s->q[2], t->px[i], t->py[i], t->pz[i]);
+            if (s->max_d2 >= 0 && !(d < s->max_d2)) continue;
+            knn_insert(s->idx, s->d2, &s->count, s->k, t->perm[i], d);
+        }
+        return;
+    }
+    const int    dim = nd->dim;
+    const double v   = (double)s->q[dim];
+    /* distance (along dim) to each child's slab */
+    const double dl = v > (double)nd->split_lo ? v - (double)nd->split_lo : 0.0;
+    const double dr = v < (double)nd->split_hi ? (double)nd->split_hi - v : 0.0;
+    int32_t      first, second;
+    double       dsecond;
+    if (dl <= dr)
+        first = nd->left, second = nd->right, dsecond = dr;
+    else
+        first = nd->right, second = nd->left, dsecond = dl;
+    kd_search_rec(s, first, mind2, off);
+    const double old   = off[dim];
+    const double mind2b = mind2 - old * old + dsecond * dsecond;
+    /* conservative, non-strict pruning: computed fp32 distances may be a few ulp below the
+     * real ones, and ties must still be visited for the lowest-index rule */
+    if (mind2b * (1.0 - 1e-6) <= kd_worst(s))
+    {
+        off[dim] = dsecond > old ? dsecond : old;
+        const double m2 = mind2 - old * old + off[dim] * off[dim];
+        kd_search_rec(s, second, m2, off);
+        off[dim] = old;
+    }
+}
+
+int orc_kdtree_knn(const orc_kdtree* t, float qx, float qy, float qz, int k, float max_d2,
+                   uint32_t* out_idx, float* out_d2)
+{
+    if (!t || t->n == 0 || k <= 0) return 0;
+    kd_query s;
+    s.t = t, s.q[0] = qx, s.q[1] = qy, s.q[2] = qz;
+    s.k = k, s.count = 0, s.max_d2 = max_d2, s.idx = out_idx, s.d2 = out_d2;
+    double off[3] = {0, 0, 0};
+    kd_search_rec(&s, 0, 0.0, off);
+    return s.count;
+}
+
+static int nn_search(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                     size_t n_g, float qx, float qy, float qz, int k, float max_d2,
+                     uint32_t* idx, float* d2)
+{
+    if (tree) return orc_kdtree_knn(tree, qx, qy, qz, k, max_d2, idx, d2);
+    return orc_brute_knn(gx, gy, gz, n_g, qx, qy, qz, k, max_d2, idx, d2);
+}
+
+static void bbox_of(const float* x, const float* y, const float* z, size_t n, float mn[3],
+                    float mx[3])
+{
+    mn[0] = mn[1] = mn[2] = FLT_MAX;
+    mx[0] = mx[1] = mx[2] = -FLT_MAX;
+    for (size_t i = 0; i < n; i++)
+    {
+        if (x[i] < mn[0]) mn[0] = x[i];
+        if (y[i] < mn[1]) mn[1] = y[i];
+        if (z[i] < mn[2]) mn[2] = z[i];
+        if (x[i] > mx[0]) mx[0] = x[i];
+        if (y[i] > mx[1]) mx[1] = y[i];
+        if (z[i] > mx[2]) mx[2] = z[i];
+    }
+}
+
+/* TBoundingBoxf::intersection(other, eps).has_value():
+ * both boxes inflated by eps must overlap on every axis. */
+static int bbox_intersects(const float amin[3], const float amax[3], const float bmin[3],
+                           const float bmax[3], float eps)
+{
+    for (int d = 0; d < 3; d++)
+    {
+        const float lo = fmaxf(amin[d] - eps, bmin[d] - eps);
+        const float hi = fminf(amax[d] + eps, bmax[d] + eps);
+        if (lo > hi) return 0;
+    }
+    return 1;
+}
+
+/* ======================================================================================
+ *  a4: Matcher_Points_DistanceThreshold::implMatchOneLayer
+ *      (Matcher_Points_DistanceThreshold.cpp:48-121, sequential branch :206-266)
+ * ====================================================================================== */
+#define ORC_MAX_K 64
+
+size_t orc_match_pt2pt(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                       size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
+                       const double T[12], const orc_pt2pt_params* prm, uint8_t* local_taken,
+                       uint8_t* global_taken, orc_pair_pt2pt* out, uint64_t* potential_pairings)
+{
+    const int K = (int)prm->pairingsPerPoint;
+    if (potential_pairings) *potential_pairings += (uint64_t)n_l * prm->pairingsPerPoint; /* :64 */
+    if (n_g == 0 || n_l == 0 || K < 1 || K > ORC_MAX_K) return 0;                         /* :67 */
+
+    float* tx = (float*)malloc(n_l * sizeof(float));
+    float* ty = (float*)malloc(n_l * sizeof(float));
+    float* tz = (float*)malloc(n_l * sizeof(float));
+    float  lmin[3], lmax[3], gmin[3], gmax[3];
+    orc_transform_local_to_global(lx, ly, lz, n_l, T, tx, ty, tz, lmin, lmax); /* :69-70 */
+    bbox_of(gx, gy, gz, n_g, gmin, gmax);
+
+    size_t   n_out     = 0;
+    uint8_t* own_taken = NULL; /* MatchState always exists in the reference (Matcher.h:44-70) */
+    if (!global_taken && !prm->allowMatchAlreadyMatchedGlobalPoints)
+        global_taken = own_taken = (uint8_t*)calloc(n_g, 1);
+    /* :73-75 */
+    if (bbox_intersects(gmin, gmax, lmin, lmax, (float)(prm->threshold + prm->bbox_eps)))
+    {
+        /* :82-83  mrpt::square(double) narrowed to float */
+        const float  maxDistSq = (float)(prm->threshold * prm->threshold);
+        const double angRad    = prm->thresholdAngularDeg * M_PI / 180.0;
+        const float  angSq     = (float)(angRad * angRad);
+
+        uint32_t nidx[ORC_MAX_K];
+        float    nd2[ORC_MAX_K];
+        for (size_t i = 0; i < n_l; i++) /* :214 */
+        {
+            if (!prm->allowMatchAlreadyMatchedPoints && local_taken && local_taken[i])
+                continue; /* :218-220 */
+            const float x = tx[i], y = ty[i], z = tz[i];
+            const float normSq = (x * x + y * y) + z * z; /* :223-225 */
+            int         found;
+            if (K == 1)
+                found = nn_search(tree, gx, gy, gz, n_g, x, y, z, 1, -1.0f, nidx, nd2); /* :235 */
+            else if (prm->multi_search_radius_mode)
+                found = nn_search(tree, gx, gy, gz, n_g, x, y, z, K, maxDistSq, nidx, nd2); /* :174 */
+            else
+                found = nn_search(tree, gx, gy, gz, n_g, x, y, z, K, -1.0f, nidx, nd2); /* :246 */
+
+            for (int k = 0; k < found; k++) /* :252 */
+            {
+                const float thr = maxDistSq + angSq * normSq; /* :256-257 */
+                if (nd2[k] >= thr) break;                     /* :259 */
+                /* lambdaAddPair :94-121 */
+                const uint32_t g = nidx[k];
+                if (!prm->allowMatchAlreadyMatchedGlobalPoints && global_taken &&
+                    global_taken[g])
+                    continue;
+                orc_pair_pt2pt* p = &out[n_out++];
+                p->globalIdx = g, p->localIdx = (uint32_t)i;
+                p->gx = gx[g], p->gy = gy[g], p->gz = gz[g];
+                p->lx = lx[i], p->ly = ly[i], p->lz = lz[i]; /* untransformed */
+                p->errSq = nd2[k];
+                if (!prm->allowMatchAlreadyMatchedGlobalPoints)
+                {
+                    if (local_taken) local_taken[i] = 1;
+                    if (global_taken) global_taken[g] = 1;
+                }
+            }
+        }
+    }
+    free(tx), free(ty), free(tz), free(own_taken);
+    return n_out;
+}
+
+/* ---- multi-threaded CPU baseline of the same contract (K==1, fresh MatchState) -------- */
+typedef struct
+{
+    const orc_kdtree* tree;
+    const float *     tx, *ty, *tz;
+    size_t            b, e;
+    float             maxDistSq, angSq;
+    uint32_t*         nn_idx;
+    float*            nn_d2;
+} mt_job;
+
+static void* mt_worker(void* arg)
+{
+    mt_job* j = (mt_job*)arg;
+    for (size_t i = j->b; i < j->e; i++)
+    {
+        const float x = j->tx[i], y = j->ty[i], z = j->tz[i];
+        const float normSq = (x * x + y * y) + z * z;
+        uint32_t    id;
+        float       d2;
+        const int   f   = orc_kdtree_knn(j->tree, x, y, z, 1, -1.0f, &id, &d2);
+        const float thr = j->maxDistSq + j->angSq * normSq;
+        if (f && d2 < thr)
+            j->nn_idx[i] = id, j->nn_d2[i] = d2;
+        else
+            j->nn_idx[i] = 0xFFFFFFFFu, j->nn_d2[i] = 0;
+    }
+    return NULL;
+}
+
+typedef struct
+{
+    const float *lx, *ly, *lz;
+    const double* T;
+    float *       tx, *ty, *tz;
+    size_t        b, e;
+} tf_job;
+
+static void* tf_worker(void* arg)
+{
+    tf_job* j = (tf_job*)arg;
+    for (size_t i = j->b; i < j->e; i++)
+    {
+        double g[3];
+        orc_pose_compose_point(j->T, j->lx[i], j->ly[i], j->lz[i], g);
+        j->tx[i] = (float)g[0], j->ty[i] = (float)g[1], j->tz[i] = (float)g[2];
+    }
+    return NULL;
+}
+
+size_t orc_match_pt2pt_mt(const orc_kdtree* tree, const float* gx, const float* gy,
+                          const float* gz, size_t n_g, const float* lx, const float* ly,
+                          const float* lz, size_t n_l, const double T[12],
+                          const orc_pt2pt_params* prm, orc_pair_pt2pt* out, int n_threads)
+{
+    if (!tree || n_g == 0 || n_l == 0 || prm->pairingsPerPoint != 1) return 0;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    float*    tx  = (float*)malloc(n_l * sizeof(float));
+    float*    ty  = (float*)malloc(n_l * sizeof(float));
+    float*    tz  = (float*)malloc(n_l * sizeof(float));
+    uint32_t* nn  = (uint32_t*)malloc(n_l * sizeof(uint32_t));
+    float*    nd  = (float*)malloc(n_l * sizeof(float));
+    pthread_t th[1024];
+    {
+        tf_job jobs[1024];
+        for (int t = 0; t < n_threads; t++)
+        {
+            jobs[t] = (tf_job){lx, ly, lz, T, tx, ty, tz, n_l * t / n_threads,
+                               n_l * (t + 1) / n_threads};
+            pthread_create(&th[t], NULL, tf_worker, &jobs[t]);
+        }
+        for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    }
+    float lmin[3], lmax[3], gmin[3], gmax[3];
+    bbox_of(tx, ty, tz, n_l, lmin, lmax);
+    bbox_of(gx, gy, gz, n_g, gmin, gmax);
+    size_t n_out = 0;
+    if (bbox_intersects(gmin, gmax, lmin, lmax, (float)(prm->threshold + prm->bbox_eps)))
+    {
+        const float  maxDistSq = (float)(prm->threshold * prm->threshold);
+        const double angRad    = prm->thresholdAngularDeg * M_PI / 180.0;
+        const float  angSq     = (float)(angRad * angRad);
+        mt_job       jobs[1024];
+        for (int t = 0; t < n_threads; t++)
+        {
+            jobs[t] = (mt_job){tree,      tx,    ty, tz, n_l * t / n_threads,
+                               n_l * (t + 1) / n_threads, maxDistSq, angSq, nn, nd};
+            pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+        }
+        for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+        /* sequential resolution of the unique-global filter (lowest local index wins) */
+        uint8_t* taken = prm->allowMatchAlreadyMatchedGlobalPoints ? NULL : (uint8_t*)calloc(n_g, 1);
+        for (size_t i = 0; i < n_l; i++)
+        {
+            const uint32_t g = nn[i];
+            if (g == 0xFFFFFFFFu) continue;
+            if (taken)
+            {
+                if (taken[g]) continue;
+                taken[g] = 1;
+            }
+            orc_pair_pt2pt* p = &out[n_out++];
+            p->globalIdx = g, p->localIdx = (uint32_t)i;
+            p->gx = gx[g], p->gy = gy[g], p->gz = gz[g];
+            p->lx = lx[i], p->ly = ly[i], p->lz = lz[i];
+            p->errSq = nd[i];
+        }
+        free(taken);
+    }
+    free(tx), free(ty), free(tz), free(nn), free(nd);
+    return n_out;
+}
+
+/* ======================================================================================
+ *  estimate_points_eigen (estimate_points_eigen.cpp:27-123, totalCount branch)
+ * ====================================================================================== */
+void orc_estimate_points_eigen(const float* xs, const float* ys, const float* zs, size_t n,
+                               float mean[3], double cov[9], double eval[3], double evec[9])
+{
+    float       mx = 0, my = 0, mz = 0;
+    const float inv_n = 1.0f / (float)n; /* :45 */
+    for (size_t i = 0; i < n; i++) mx += xs[i], my += ys[i], mz += zs[i]; /* :46-51, fp32 */
+    mx *= inv_n, my *= inv_n, mz *= inv_n;                                 /* :52 */
+    double a00 = 0, a10 = 0, a20 = 0, a11 = 0, a21 = 0, a22 = 0;
+    for (size_t i = 0; i < n; i++)
+    {
+        /* TPoint3Df - TPoint3Df: fp32 differences; products formed in fp32, then
+         * accumulated into the double matrix (:55-61) */
+        const float ax = xs[i] - mx, ay = ys[i] - my, az = zs[i] - mz;
+        a00 += (double)(ax * ax);
+        a10 += (double)(ax * ay);
+        a20 += (double)(ax * az);
+        a11 += (double)(ay * ay);
+        a21 += (double)(ay * az);
+        a22 += (double)(az * az);
+    }
+    const double s = (double)inv_n; /* mat_a *= inv_n (:63) */
+    a00 *= s, a10 *= s, a20 *= s, a11 *= s, a21 *= s, a22 *= s;
+    cov[0] = a00, cov[1] = a10, cov[2] = a20;
+    cov[3] = a10, cov[4] = a11, cov[5] = a21;
+    cov[6] = a20, cov[7] = a21, cov[8] = a22;
+    mean[0] = mx, mean[1] = my, mean[2] = mz;
+    sym_eig_jacobi(3, cov, eval, evec); /* :108-117 */
+}
+
+/* ======================================================================================
+ *  a6: Matcher_Point2Plane::implMatchOneLayer (Matcher_Point2Plane.cpp:41-114) with this
+ *  repo's DECLARED nn_search_pt2pl (parity unpinned):
+ *    k nearest global points with d2 <= searchRadius^2 (filter as Matcher_Point2Line.cpp:
+ *    113-129); need >= minimumPlanePoints; estimate_points_eigen over them in ascending
+ *    (d2, idx) order; planar iff e0 < thr*e1 && e0 < thr*e2 (Matcher_Adaptive.cpp:241-242);
+ *    plane = TPlane(centroid, eigvec0) normalised so that its largest |component| is
+ *    positive; distance = |plane.distance(q)| as float.
+ * ====================================================================================== */
+size_t orc_match_pt2pl(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                       size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
+                       const double T[12], const orc_pt2pl_params* prm, uint8_t* local_taken,
+                       orc_pair_pt2pl* out, uint32_t* out_local_idx,
+                       uint64_t* potential_pairings)
+{
+    const int K = (int)prm->knn;
+    if (potential_pairings) *potential_pairings += (uint64_t)n_l; /* :54 */
+    if (n_g == 0 || n_l == 0 || K < 3 || K > ORC_MAX_K) return 0;
+
+    float* tx = (float*)malloc(n_l * sizeof(float));
+    float* ty = (float*)malloc(n_l * sizeof(float));
+    float* tz = (float*)malloc(n_l * sizeof(float));
+    float  lmin[3], lmax[3], gmin[3], gmax[3];
+    orc_transform_local_to_global(lx, ly, lz, n_l, T, tx, ty, tz, lmin, lmax); /* :59-60 */
+    bbox_of(gx, gy, gz, n_g, gmin, gmax);
+    size_t n_out = 0;
+    if (bbox_intersects(gmin, gmax, lmin, lmax,
+                        (float)(prm->distanceThreshold + prm->bbox_eps))) /* :63-66 */
+    {
+        const float radSq   = (float)(prm->searchRadius * prm->searchRadius);
+        const float distThr = (float)prm->distanceThreshold;
+        uint32_t    nidx[ORC_MAX_K];
+        float       nd2[ORC_MAX_K], kx[ORC_MAX_K], ky[ORC_MAX_K], kz[ORC_MAX_K];
+        for (size_t i = 0; i < n_l; i++) /* :79 */
+        {
+            if (!prm->allowMatchAlreadyMatchedPoints && local_taken && local_taken[i])
+                continue; /* :83-85 */
+            const float x = tx[i], y = ty[i], z = tz[i];
+            int found = nn_search(tree, gx, gy, gz, n_g, x, y, z, K, -1.0f, nidx, nd2);
+            int m     = 0;
+            while (m < found && !(nd2[m] > radSq)) m++; /* keep d2 <= radius^2 */
+            if (m < (int)prm->minimumPlanePoints || m < 3) continue;
+            for (int k = 0; k < m; k++)
+                kx[k] = gx[nidx[k]], ky[k] = gy[nidx[k]], kz[k] = gz[nidx[k]];
+            float  mean[3];
+            double cov[9], ev[3], evec[9];
+            orc_estimate_points_eigen(kx, ky, kz, (size_t)m, mean, cov, ev, evec);
+            if (!(ev[0] < prm->planeEigenThreshold * ev[2] &&
+                  ev[0] < prm->planeEigenThreshold * ev[1]))
+                continue;
+            /* TPlane(point, normal): unit normal, d = -n.c */
+            double       n[3] = {evec[0], evec[1], evec[2]};
+            const double nn   = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            n[0] /= nn, n[1] /= nn, n[2] /= nn;
+            int big = 0;
+            if (fabs(n[1]) > fabs(n[big])) big = 1;
+            if (fabs(n[2]) > fabs(n[big])) big = 2;
+            if (n[big] < 0) n[0] = -n[0], n[1] = -n[1], n[2] = -n[2];
+            const double c[3] = {(double)mean[0], (double)mean[1], (double)mean[2]};
+            const double d    = -(n[0] * c[0] + n[1] * c[1] + n[2] * c[2]);
+            const float  dist = (float)fabs(n[0] * (double)x + n[1] * (double)y + n[2] * (double)z + d);
+            if (dist > distThr) continue; /* :100-101 */
+            orc_pair_pt2pl* p = &out[n_out];
+            p->plane[0] = n[0], p->plane[1] = n[1], p->plane[2] = n[2], p->plane[3] = d;
+            p->centroid[0] = c[0], p->centroid[1] = c[1], p->centroid[2] = c[2];
+            p->lx = lx[i], p->ly = ly[i], p->lz = lz[i]; /* :104-106 untransformed */
+            p->_pad = 0;
+            if (out_local_idx) out_local_idx[n_out] = (uint32_t)i;
+            n_out++;
+            if (local_taken) local_taken[i] = 1; /* :109 */
+        }
+    }
+    free(tx), free(ty), free(tz);
+    return n_out;
+}
+
+/* ======================================================================================
+ *  a10: optimal_tf_gauss_newton (optimal_tf_gauss_newton.cpp:36-372)
+ *  Sequential summation order; H and g reset at the top of every inner iteration (the
+ *  TBB-build meaning :145-146).
+ * ====================================================================================== */
+static void accum_term(const double e[3], const double J1[36], const double dD[72], double w,
+                       double* H, double* g)
+{
+    /* Ji = J1 (3x12) * dDexpe_de (12x6)   :176 */
+    double Ji[18];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 6; j++)
+        {
+            double s = 0;
+            for (int k = 0; k < 12; k++) s += J1[i * 12 + k] * dD[k * 6 + j];
+            Ji[i * 6 + j] = s;
+        }
+    for (int a = 0; a < 6; a++)
+    {
+        g[a] += w * (Ji[0 * 6 + a] * e[0] + Ji[1 * 6 + a] * e[1] + Ji[2 * 6 + a] * e[2]); /* :177 */
+        for (int b = 0; b < 6; b++)
+            H[a * 6 + b] += w * (Ji[0 * 6 + a] * Ji[0 * 6 + b] + Ji[1 * 6 + a] * Ji[1 * 6 + b] +
+                                 Ji[2 * 6 + a] * Ji[2 * 6 + b]); /* :178 */
+    }
+}
+
+/* prior term :311-341.  df_de2 = d log(P1^-1 P2 exp(eps)) / d eps evaluated by central
+ * differences (MRPT's jacob_dDinvP1invP2_de1e2 is un-vendored). */
+static void prior_term(const double T[12], const orc_gn_params* prm, double* H, double* g)
+{
+    double Pinv[12], A[12], err[6];
+    orc_pose_inverse(prm->prior_mean, Pinv);
+    orc_pose_compose(Pinv, T, A); /* result.optimalPose - priorMean  :321 */
+    orc_se3_log(A, err);          /* :322 */
+    double       J[36];
+    const double h = 1e-6;
+    for (int j = 0; j < 6; j++)
+    {
+        double xi[6] = {0, 0, 0, 0, 0, 0}, E[12], Ap[12], Am[12], lp[6], lm[6];
+        xi[j] = h;
+        orc_se3_exp(xi, E);
+        orc_pose_compose(A, E, Ap);
+        xi[j] = -h;
+        orc_se3_exp(xi, E);
+        orc_pose_compose(A, E, Am);
+        orc_se3_log(Ap, lp);
+        orc_se3_log(Am, lm);
+        for (int i = 0; i < 6; i++) J[i * 6 + j] = (lp[i] - lm[i]) / (2 * h);
+    }
+    /* g += (J^T Lambda) err ; H += (J^T Lambda) J   :338-340 */
+    double JtL[36];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++)
+        {
+            double s = 0;
+            for (int k = 0; k < 6; k++) s += J[k * 6 + i] * prm->prior_cov_inv[k * 6 + j];
+            JtL[i * 6 + j] = s;
+        }
+    for (int i = 0; i < 6; i++)
+    {
+        double s = 0;
+        for (int k = 0; k < 6; k++) s += JtL[i * 6 + k] * err[k];
+        g[i] += s;
+        for (int j = 0; j < 6; j++)
+        {
+            double q = 0;
+            for (int k = 0; k < 6; k++) q += JtL[i * 6 + k] * J[k * 6 + j];
+            H[i * 6 + j] += q;
+        }
+    }
+}
+
+int orc_optimal_tf_gauss_newton(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
+                                const orc_pair_pt2pl* pt2pl, size_t n_pt2pl,
+                                const orc_pair_pt2ln* pt2ln, size_t n_pt2ln,
+                                const double T0[12], const orc_gn_params* prm, double T_out[12],
+                                double* H_out, double* g_out)
+{
+    double T[12];
+    memcpy(T, T0, sizeof(T)); /* :48 */
+    double H[36], g[6];
+    memset(H, 0, sizeof(H));
+    memset(g, 0, sizeof(g));
+
+    const int has_w     = prm->n_weight_blocks > 0; /* :66 */
+    uint32_t  cur_block = 0;                        /* :67 */
+    size_t    cur_start = 0;                        /* :68 */
+    double    w_pt2pt   = prm->w_pt2pt;
+
+    int iters = 0;
+    for (uint32_t iter = 0; iter < prm->maxInnerLoopIterations; iter++) /* :70 */
+    {
+        iters++;
+        double dD[72];
+        orc_jacob_dDexpe_de(T, dD); /* :73 */
+        double errNormSqr = 0;      /* :75 */
+        memset(H, 0, sizeof(H));    /* TBB-branch meaning :145-146 */
+        memset(g, 0, sizeof(g));
+        if (prm->reset_weight_cursor_each_iter) cur_block = 0, cur_start = 0;
+
+        for (size_t i = 0; i < n_pt2pt; i++) /* :149-180 */
+        {
+            double e[3], J1[36];
+            orc_error_point2point(&pt2pt[i], T, e, J1);
+            if (has_w)
+            {
+                if (i >= cur_start + prm->weight_block_count[cur_block] &&
+                    cur_block + 1 < prm->n_weight_blocks)
+                {
+                    cur_block++;
+                    cur_start = i;
+                }
+                w_pt2pt = prm->weight_block_w[cur_block];
+            }
+            double       w   = w_pt2pt;
+            const double esq = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+            if (prm->kernel != ORC_KERNEL_NONE) w *= orc_robust_weight(prm->kernel, prm->kernelParam, esq);
+            errNormSqr += w * esq; /* :175 */
+            accum_term(e, J1, dD, w, H, g);
+        }
+        for (size_t i = 0; i < n_pt2ln; i++) /* :184-202 */
+        {
+            double e[3], J1[36];
+            orc_error_point2line(&pt2ln[i], T, e, J1);
+            double       w   = prm->w_pt2ln;
+            const double esq = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+            if (prm->kernel != ORC_KERNEL_NONE) w *= orc_robust_weight(prm->kernel, prm->kernelParam, esq);
+            errNormSqr += w * w * esq; /* :198 */
+            accum_term(e, J1, dD, w, H, g);
+        }
+        for (size_t i = 0; i < n_pt2pl; i++) /* TBB branch :229-259 */
+        {
+            double e[3], J1[36];
+            orc_error_point2plane(&pt2pl[i], T, e, J1);
+            double       w   = prm->w_pt2pl;
+            const double esq = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+            if (prm->kernel != ORC_KERNEL_NONE) w *= orc_robust_weight(prm->kernel, prm->kernelParam, esq);
+            errNormSqr += w * esq; /* :249 */
+            accum_term(e, J1, dD, w, H, g);
+        }
+        if (prm->has_prior) prior_term(T, prm, H, g); /* :311-341 */
+
+        if (sqrt(errNormSqr) <= prm->maxCost) break; /* :344-346 */
+
+        double delta[6], rhs[6];
+        for (int i = 0; i < 6; i++) rhs[i] = g[i];
+        ldlt6_solve(H, rhs, delta);
+        for (int i = 0; i < 6; i++) delta[i] = -delta[i]; /* :351 */
+        double dE[12];
+        orc_se3_exp(delta, dE);      /* :354 */
+        orc_pose_compose(T, dE, T);  /* :356 */
+        double nrm = 0;
+        for (int i = 0; i < 6; i++) nrm += delta[i] * delta[i];
+        if (sqrt(nrm) < prm->minDelta) break; /* :365 */
+    }
+    memcpy(T_out, T, sizeof(T));
+    if (H_out) memcpy(H_out, H, sizeof(H));
+    if (g_out) memcpy(g_out, g, sizeof(g));
+    return iters;
+}
+
+/* ---- multi-threaded accumulation (CPU baseline only; same math, per-thread partials) -- */
+typedef struct
+{
+    const orc_pair_pt2pt* pt2pt;
+    const orc_pair_pt2pl* pt2pl;
+    size_t                b1, e1, b2, e2;
+    const double *        T, *dD;
+    const orc_gn_params*  prm;
+    double                H[36], g[6], err;
+} gn_job;
+
+static void* gn_worker(void* arg)
+{
+    gn_job* j = (gn_job*)arg;
+    memset(j->H, 0, sizeof(j->H));
+    memset(j->g, 0, sizeof(j->g));
+    j->err = 0;
+    for (size_t i = j->b1; i < j->e1; i++)
+    {
+        double e[3], J1[36];
+        orc_error_point2point(&j->pt2pt[i], j->T, e, J1);
+        double       w   = j->prm->w_pt2pt;
+        const double esq = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        if (j->prm->kernel != ORC_KERNEL_NONE)
+            w *= orc_robust_weight(j->prm->kernel, j->prm->kernelParam, esq);
+        j->err += w * esq;
+        accum_term(e, J1, j->dD, w, j->H, j->g);
+    }
+    for (size_t i = j->b2; i < j->e2; i++)
+    {
+        double e[3], J1[36];
+        orc_error_point2plane(&j->pt2pl[i], j->T, e, J1);
+        double       w   = j->prm->w_pt2pl;
+        const double esq = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        if (j->prm->kernel != ORC_KERNEL_NONE)
+            w *= orc_robust_weight(j->prm->kernel, j->prm->kernelParam, esq);
+        j->err += w * esq;
+        accum_term(e, J1, j->dD, w, j->H, j->g);
+    }
+    return NULL;
+}
+
+int orc_optimal_tf_gauss_newton_mt(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
+                                   const orc_pair_pt2pl* pt2pl, size_t n_pt2pl,
+                                   const double T0[12], const orc_gn_params* prm,
+                                   double T_out[12], int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    double T[12];
+    memcpy(T, T0, sizeof(T));
+    gn_job*   jobs = (gn_job*)malloc(sizeof(gn_job) * n_threads);
+    pthread_t th[1024];
+    int       iters = 0;
+    for (uint32_t iter = 0; iter < prm->maxInnerLoopIterations; iter++)
+    {
+        iters++;
+        double dD[72], H[36], g[6], err = 0;
+        orc_jacob_dDexpe_de(T, dD);
+        memset(H, 0, sizeof(H));
+        memset(g, 0, sizeof(g));
+        for (int t = 0; t < n_threads; t++)
+        {
+            jobs[t].pt2pt = pt2pt, jobs[t].pt2pl = pt2pl;
+            jobs[t].b1 = n_pt2pt * t / n_threads, jobs[t].e1 = n_pt2pt * (t + 1) / n_threads;
+            jobs[t].b2 = n_pt2pl * t / n_threads, jobs[t].e2 = n_pt2pl * (t + 1) / n_threads;
+            jobs[t].T = T, jobs[t].dD = dD, jobs[t].prm = prm;
+            pthread_create(&th[t], NULL, gn_worker, &jobs[t]);
+        }
+        for (int t = 0; t < n_threads; t++)
+        {
+            pthread_join(th[t], NULL);
+            for (int i = 0; i < 36; i++) H[i] += jobs[t].H[i];
+            for (int i = 0; i < 6; i++) g[i] += jobs[t].g[i];
+            err += jobs[t].err;
+        }
+        if (prm->has_prior) prior_term(T, prm, H, g);
+        if (sqrt(err) <= prm->maxCost) break;
+        double delta[6];
+        ldlt6_solve(H, g, delta);
+        for (int i = 0; i < 6; i++) delta[i] = -delta[i];
+        double dE[12];
+        orc_se3_exp(delta, dE);
+        orc_pose_compose(T, dE, T);
+        double nrm = 0;
+        for (int i = 0; i < 6; i++) nrm += delta[i] * delta[i];
+        if (sqrt(nrm) < prm->minDelta) break;
+    }
+    free(jobs);
+    memcpy(T_out, T, sizeof(T));
+    return iters;
+}
+
+/* ======================================================================================
+ *  next #1: optimal_tf_horn (optimal_tf_horn.cpp:77-252), point pairs only, no scale
+ *  outlier detector, no robust kernel, no per-block weights.
+ * ====================================================================================== */
+int orc_optimal_tf_horn(const orc_pair_pt2pt* p, size_t n, double w_pt2pt, double T_out[12])
+{
+    if (n < 3) return 0; /* :98 */
+    /* eval_centroids_robust, Pairings.cpp:68-110 */
+    double cl[3] = {0, 0, 0}, cg[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; i++)
+    {
+        cg[0] += p[i].gx, cg[1] += p[i].gy, cg[2] += p[i].gz;
+        cl[0] += p[i].lx, cl[1] += p[i].ly, cl[2] += p[i].lz;
+    }
+    const double wc = 1.0 / (double)n;
+    for (int d = 0; d < 3; d++) cl[d] *= wc, cg[d] *= wc;
+
+    /* visit_correspondences.h:76-86: waPoints = wPt / (wPt * nPt2Pt) */
+    const double wa = w_pt2pt * (1.0 / (w_pt2pt * (double)n));
+    double       S[9] = {0}, w_sum = 0;
+    for (size_t i = 0; i < n; i++)
+    {
+        const double bi[3] = {p[i].gx - cg[0], p[i].gy - cg[1], p[i].gz - cg[2]};
+        const double ri[3] = {p[i].lx - cl[0], p[i].ly - cl[1], p[i].lz - cl[2]};
+        const double bn = sqrt(bi[0] * bi[0] + bi[1] * bi[1] + bi[2] * bi[2]);
+        const double rn = sqrt(ri[0] * ri[0] + ri[1] * ri[1] + ri[2] * ri[2]);
+        if (bn < 1e-4 || rn < 1e-4) continue; /* visit_correspondences.h:135-140 */
+        const double wi = wa;
+        w_sum += wi;
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) S[a * 3 + b] += wi * ri[a] * bi[b]; /* :112-122 */
+    }
+    if (w_sum > 0)
+        for (int i = 0; i < 9; i++) S[i] *= 1.0 / w_sum; /* :128 */
+    double N[16];
+    N[0]  = S[0] + S[4] + S[8];
+    N[1]  = S[5] - S[7];
+    N[2]  = S[6] - S[2];
+    N[3]  = S[1] - S[3];
+    N[4]  = N[1];
+    N[5]  = S[0] - S[4] - S[8];
+    N[6]  = S[1] + S[3];
+    N[7]  = S[6] + S[2];
+    N[8]  = N[2];
+    N[9]  = N[6];
+    N[10] = -S[0] + S[4] - S[8];
+    N[11] = S[5] + S[7];
+    N[12] = N[3];
+    N[13] = N[7];
+    N[14] = N[11];
+    N[15] = -S[0] - S[4] + S[8];
+    double ev[4], V[16];
+    sym_eig_jacobi(4, N, ev, V);
+    double q[4] = {V[12], V[13], V[14], V[15]}; /* largest eigenvalue :160 */
+    if (q[0] < 0)
+        for (int i = 0; i < 4; i++) q[i] = -q[i]; /* :165-171 */
+    const double qn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) q[i] /= qn;
+    const double r = q[0], x = q[1], y = q[2], z = q[3];
+    double       T[12];
+    T[0] = r * r + x * x - y * y - z * z, T[1] = 2 * (x * y - r * z), T[2] = 2 * (z * x + r * y);
+    T[3] = 2 * (x * y + r * z), T[4] = r * r - x * x + y * y - z * z, T[5] = 2 * (y * z - r * x);
+    T[6] = 2 * (z * x - r * y), T[7] = 2 * (y * z + r * x), T[8] = r * r - x * x - y * y + z * z;
+    T[9] = T[10] = T[11] = 0;
+    double pp[3];
+    orc_pose_compose_point(T, cl[0], cl[1], cl[2], pp); /* :241-242 */
+    T[9] = cg[0] - pp[0], T[10] = cg[1] - pp[1], T[11] = cg[2] - pp[2]; /* :245-247 */
+    memcpy(T_out, T, sizeof(T));
+    return 1;
+}

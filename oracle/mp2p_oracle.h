@@ -1,0 +1,214 @@
+/*
+ * mp2p_oracle.h -- CPU restatement ("oracle") of the mp2p_icp per-iteration hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (libmp2p_hip.so) never links,
+ * loads or calls anything in this directory.
+ *
+ * It restates, in dependency-free C, the *sequential* branches of the reference
+ * (MOLAorg/mp2p_icp v1.8.0), with H and g reset at every Gauss-Newton inner iteration
+ * (the shipped TBB-build meaning).  Every function cites the reference
+ * file:line it follows (paths relative to /root/reference).
+ *
+ * Pinning status: the reference itself cannot be compiled here (MRPT, Eigen, TBB and
+ * mola_common are absent) so oracle/_ref does not exist.  The oracle is
+ * pinned against the reference's own known-answer tests, restated in tests/:
+ *   tests/test-mp2p_matcher_pt2pt.cpp:56-107        (exact indices, 4 poses)
+ *   tests/test-mp2p_optimize_pt2pl.cpp:36-128       (15 poses, 1e-3)
+ *   tests/test-mp2p_optimize_with_prior.cpp:36-108  (3 cases)
+ *   tests/test-mp2p_optimize_pt2ln.cpp:25-76        (1e-3)
+ *   tests/test-mp2p_error_terms_jacobians.cpp:45-252 (J1*dDexpe_de vs finite differences)
+ * Matcher_Point2Plane's neighbour search / plane fit has no arithmetic inside the
+ * reference: its semantics are declared by this repo from
+ * Matcher_Adaptive.cpp:227-270 + estimate_points_eigen.cpp:27-123 and are PARITY UNPINNED
+ * beyond the (disabled upstream) tests/test-mp2p_matcher_pt2pl.cpp expectations.
+ *
+ * Conventions
+ *   pose  : double T[12] = R (row-major 3x3) followed by t (3)      [CPose3D]
+ *   xi    : double[6]    = [v; w]  translation part first           [Lie::SE<3>]
+ *   points: SoA float arrays (CPointsMap::getPointsBufferRef_{x,y,z})
+ */
+#ifndef MP2P_ORACLE_H
+#define MP2P_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- data contracts (byte-compatible with the reference containers) ---------------- */
+
+/* mrpt::tfest::TMatchingPair as used at Matcher_Points_DistanceThreshold.cpp:106-113 */
+typedef struct
+{
+    uint32_t globalIdx, localIdx;
+    float    gx, gy, gz; /* global (NN map point)            */
+    float    lx, ly, lz; /* local  (UNtransformed)           */
+    float    errSq;      /* errorSquareAfterTransformation   */
+} orc_pair_pt2pt; /* 36 bytes */
+
+/* mp2p_icp::point_plane_pair_t (point_plane_pair_t.h:34-46, plane_patch.h:30-40) */
+typedef struct
+{
+    double plane[4];    /* TPlane coefs a,b,c,d   */
+    double centroid[3]; /* plane_patch_t::centroid */
+    float  lx, ly, lz;  /* pt_local (untransformed) */
+    float  _pad;
+} orc_pair_pt2pl; /* 72 bytes */
+
+/* mp2p_icp::point_line_pair_t: TLine3D{pBase,director} + pt_local */
+typedef struct
+{
+    double pbase[3];
+    double director[3];
+    float  lx, ly, lz;
+    float  _pad;
+} orc_pair_pt2ln; /* 64 bytes */
+
+enum
+{
+    ORC_KERNEL_NONE         = 0, /* robust_kernels.h:33-43 */
+    ORC_KERNEL_GEMANMCCLURE = 1,
+    ORC_KERNEL_CAUCHY       = 2
+};
+
+typedef struct
+{
+    double   threshold;           /* Matcher_Points_DistanceThreshold.cpp:43 */
+    double   thresholdAngularDeg; /* :44 */
+    uint32_t pairingsPerPoint;    /* :45 */
+    int32_t  allowMatchAlreadyMatchedPoints;       /* Matcher_Points_Base.cpp:168-169 */
+    int32_t  allowMatchAlreadyMatchedGlobalPoints; /* :171-172 */
+    double   bbox_eps; /* bounding_box_intersection_check_epsilon, default 0.20 (:179-180) */
+    int32_t  multi_search_radius_mode; /* K>1 only: 0 = nn_multiple_search (sequential
+                                          branch :246-248), 1 = nn_radius_search(maxDistSq)
+                                          (TBB branch :174-177).  SURVEY.md F9. */
+} orc_pt2pt_params;
+
+typedef struct
+{
+    double   distanceThreshold; /* Matcher_Point2Plane.cpp:38 */
+    /* parameters of the NearestPlaneCapable map (declared semantics, see header note) */
+    double   searchRadius;
+    uint32_t knn;
+    uint32_t minimumPlanePoints;
+    double   planeEigenThreshold;
+    int32_t  allowMatchAlreadyMatchedPoints;
+    double   bbox_eps;
+} orc_pt2pl_params;
+
+typedef struct
+{
+    uint32_t maxInnerLoopIterations; /* optimal_tf_gauss_newton.h:32-61 */
+    double   minDelta;               /* 1e-7 */
+    double   maxCost;                /* 0    */
+    int32_t  kernel;                 /* ORC_KERNEL_*  */
+    double   kernelParam;
+    double   w_pt2pt, w_pt2pl, w_pt2ln; /* PairWeights */
+    int32_t  has_prior;
+    double   prior_mean[12];    /* pose                               */
+    double   prior_cov_inv[36]; /* 6x6 row-major information matrix   */
+    /* Pairings::point_weights run-length blocks (count, weight); n_blocks==0 -> none */
+    uint32_t      n_weight_blocks;
+    const size_t* weight_block_count;
+    const double* weight_block_w;
+    int32_t  reset_weight_cursor_each_iter; /* 0 = literal reference (cursor not reset,
+                                               optimal_tf_gauss_newton.cpp:66-68), 1 = intended */
+} orc_gn_params;
+
+/* ---- SE(3) helpers (closed forms of un-vendored MRPT) ------- */
+void orc_pose_from_xyzypr(double x, double y, double z, double yaw, double pitch, double roll,
+                          double T[12]);
+void orc_pose_to_xyzypr(const double T[12], double out6[6]);
+void orc_pose_identity(double T[12]);
+void orc_pose_compose(const double A[12], const double B[12], double out[12]);
+void orc_pose_inverse(const double A[12], double out[12]);
+void orc_pose_compose_point(const double T[12], double lx, double ly, double lz, double g[3]);
+void orc_pose_inverse_compose_point(const double T[12], double gx, double gy, double gz,
+                                    double l[3]);
+void orc_se3_exp(const double xi[6], double T[12]);
+void orc_se3_log(const double T[12], double xi[6]);
+void orc_jacob_dDexpe_de(const double T[12], double J[72]); /* 12x6 row-major */
+
+/* ---- error terms (errorTerms.cpp) ---------------------------------------------------- */
+void orc_error_point2point(const orc_pair_pt2pt* p, const double T[12], double e[3],
+                           double J1[36] /* 3x12 row-major, may be NULL */);
+void orc_error_point2plane(const orc_pair_pt2pl* p, const double T[12], double e[3],
+                           double J1[36]);
+void orc_error_point2line(const orc_pair_pt2ln* p, const double T[12], double e[3],
+                          double J1[36]);
+double orc_robust_weight(int32_t kernel, double kernelParam, double errSq);
+
+/* ---- a3: transform_local_to_global (Matcher_Points_Base.cpp:183-249) --------------- */
+void orc_transform_local_to_global(const float* lx, const float* ly, const float* lz, size_t n,
+                                   const double T[12], float* ox, float* oy, float* oz,
+                                   float bbox_min[3], float bbox_max[3]);
+
+/* ---- a5: exact nearest neighbours ---------------------------------------------------- */
+typedef struct orc_kdtree orc_kdtree;
+orc_kdtree* orc_kdtree_build(const float* x, const float* y, const float* z, size_t n,
+                             int leaf_max);
+void        orc_kdtree_free(orc_kdtree* t);
+/* k nearest, ascending (d2, idx); returns number found (<=k).  max_d2<0 => unbounded;
+ * otherwise only neighbours with d2 < max_d2 (strict, nanoflann RadiusResultSet). */
+int orc_kdtree_knn(const orc_kdtree* t, float qx, float qy, float qz, int k, float max_d2,
+                   uint32_t* out_idx, float* out_d2);
+/* brute-force version of the same contract: THE definition of the expected answer
+ * (fp32 d2 = ((dx*dx)+(dy*dy))+(dz*dz), ties -> lowest index). */
+int orc_brute_knn(const float* x, const float* y, const float* z, size_t n, float qx, float qy,
+                  float qz, int k, float max_d2, uint32_t* out_idx, float* out_d2);
+
+/* ---- a4: Matcher_Points_DistanceThreshold::implMatchOneLayer ------------------------- */
+/* tree may be NULL -> brute force.  local_taken / global_taken: byte per point (0/1), may be
+ * NULL (= all clear); updated like MatchState.  Returns number of pairs written
+ * (capacity must be >= n_l * pairingsPerPoint). */
+size_t orc_match_pt2pt(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                       size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
+                       const double T[12], const orc_pt2pt_params* prm, uint8_t* local_taken,
+                       uint8_t* global_taken, orc_pair_pt2pt* out, uint64_t* potential_pairings);
+
+/* multi-threaded variant used ONLY as the CPU baseline (range split of the query loop,
+ * unique-global filter resolved afterwards by "lowest local index wins" -- identical
+ * output to the sequential function). */
+size_t orc_match_pt2pt_mt(const orc_kdtree* tree, const float* gx, const float* gy,
+                          const float* gz, size_t n_g, const float* lx, const float* ly,
+                          const float* lz, size_t n_l, const double T[12],
+                          const orc_pt2pt_params* prm, orc_pair_pt2pt* out, int n_threads);
+
+/* ---- a6: Matcher_Point2Plane::implMatchOneLayer + declared nn_search_pt2pl ------------ */
+size_t orc_match_pt2pl(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                       size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
+                       const double T[12], const orc_pt2pl_params* prm, uint8_t* local_taken,
+                       orc_pair_pt2pl* out, uint32_t* out_local_idx,
+                       uint64_t* potential_pairings);
+
+/* estimate_points_eigen (estimate_points_eigen.cpp:27-123): fp32 mean, fp64 covariance,
+ * eigenvalues ascending with eigenvectors as rows of evec[3][3]. */
+void orc_estimate_points_eigen(const float* xs, const float* ys, const float* zs, size_t n,
+                               float mean[3], double cov[9], double eval[3], double evec[9]);
+
+/* ---- a10: optimal_tf_gauss_newton ----------------------------------------------------- */
+/* Returns number of inner iterations executed.  H_out(36)/g_out(6) = last assembled
+ * normal equations (may be NULL). */
+int orc_optimal_tf_gauss_newton(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
+                                const orc_pair_pt2pl* pt2pl, size_t n_pt2pl,
+                                const orc_pair_pt2ln* pt2ln, size_t n_pt2ln,
+                                const double T0[12], const orc_gn_params* prm, double T_out[12],
+                                double* H_out, double* g_out);
+/* multi-threaded accumulation, CPU baseline only */
+int orc_optimal_tf_gauss_newton_mt(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
+                                   const orc_pair_pt2pl* pt2pl, size_t n_pt2pl,
+                                   const double T0[12], const orc_gn_params* prm,
+                                   double T_out[12], int n_threads);
+
+/* ---- next #1: Horn closed form (optimal_tf_horn.cpp:77-252, no scale, no outlier det.) */
+int orc_optimal_tf_horn(const orc_pair_pt2pt* pt2pt, size_t n, double w_pt2pt, double T_out[12]);
+
+const char* orc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,389 @@
+"""ctypes binding of oracle/_build/libmp2p_oracle.so.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Never imported by the mp2p_icp_amd product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmp2p_oracle.so")
+
+PAIR_PT2PT = np.dtype(
+    [("globalIdx", "<u4"), ("localIdx", "<u4"), ("gx", "<f4"), ("gy", "<f4"), ("gz", "<f4"),
+     ("lx", "<f4"), ("ly", "<f4"), ("lz", "<f4"), ("errSq", "<f4")])
+PAIR_PT2PL = np.dtype(
+    [("plane", "<f8", (4,)), ("centroid", "<f8", (3,)), ("lx", "<f4"), ("ly", "<f4"),
+     ("lz", "<f4"), ("_pad", "<f4")])
+PAIR_PT2LN = np.dtype(
+    [("pbase", "<f8", (3,)), ("director", "<f8", (3,)), ("lx", "<f4"), ("ly", "<f4"),
+     ("lz", "<f4"), ("_pad", "<f4")])
+assert PAIR_PT2PT.itemsize == 36 and PAIR_PT2PL.itemsize == 72 and PAIR_PT2LN.itemsize == 64
+
+KERNEL_NONE, KERNEL_GEMANMCCLURE, KERNEL_CAUCHY = 0, 1, 2
+
+
+class Pt2PtParams(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("thresholdAngularDeg", C.c_double),
+                ("pairingsPerPoint", C.c_uint32),
+                ("allowMatchAlreadyMatchedPoints", C.c_int32),
+                ("allowMatchAlreadyMatchedGlobalPoints", C.c_int32),
+                ("bbox_eps", C.c_double), ("multi_search_radius_mode", C.c_int32)]
+
+
+class Pt2PlParams(C.Structure):
+    _fields_ = [("distanceThreshold", C.c_double), ("searchRadius", C.c_double),
+                ("knn", C.c_uint32), ("minimumPlanePoints", C.c_uint32),
+                ("planeEigenThreshold", C.c_double),
+                ("allowMatchAlreadyMatchedPoints", C.c_int32), ("bbox_eps", C.c_double)]
+
+
+class GNParams(C.Structure):
+    _fields_ = [("maxInnerLoopIterations", C.c_uint32), ("minDelta", C.c_double),
+                ("maxCost", C.c_double), ("kernel", C.c_int32), ("kernelParam", C.c_double),
+                ("w_pt2pt", C.c_double), ("w_pt2pl", C.c_double), ("w_pt2ln", C.c_double),
+                ("has_prior", C.c_int32), ("prior_mean", C.c_double * 12),
+                ("prior_cov_inv", C.c_double * 36), ("n_weight_blocks", C.c_uint32),
+                ("weight_block_count", C.POINTER(C.c_size_t)),
+                ("weight_block_w", C.POINTER(C.c_double)),
+                ("reset_weight_cursor_each_iter", C.c_int32)]
+
+
+def build(force=False):
+    """Compile the oracle (gcc).  Building the checker is not using it."""
+    if force or not os.path.exists(_SO) or (
+            os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                        for f in ("mp2p_oracle.c", "mp2p_oracle.h", "Makefile"))):
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _declare(_lib)
+    return _lib
+
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _declare(L):
+    L.orc_version.restype = C.c_char_p
+    L.orc_pose_from_xyzypr.argtypes = [C.c_double] * 6 + [_dp]
+    L.orc_pose_to_xyzypr.argtypes = [_dp, _dp]
+    L.orc_pose_compose.argtypes = [_dp, _dp, _dp]
+    L.orc_pose_inverse.argtypes = [_dp, _dp]
+    L.orc_se3_exp.argtypes = [_dp, _dp]
+    L.orc_se3_log.argtypes = [_dp, _dp]
+    L.orc_jacob_dDexpe_de.argtypes = [_dp, _dp]
+    for n in ("orc_error_point2point", "orc_error_point2plane", "orc_error_point2line"):
+        getattr(L, n).argtypes = [C.c_void_p, _dp, _dp, _dp]
+    L.orc_robust_weight.argtypes = [C.c_int32, C.c_double, C.c_double]
+    L.orc_robust_weight.restype = C.c_double
+    L.orc_transform_local_to_global.argtypes = [_fp, _fp, _fp, C.c_size_t, _dp, _fp, _fp, _fp,
+                                                _fp, _fp]
+    L.orc_kdtree_build.argtypes = [_fp, _fp, _fp, C.c_size_t, C.c_int]
+    L.orc_kdtree_build.restype = C.c_void_p
+    L.orc_kdtree_free.argtypes = [C.c_void_p]
+    L.orc_kdtree_knn.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int,
+                                 C.c_float, _u32p, _fp]
+    L.orc_kdtree_knn.restype = C.c_int
+    L.orc_brute_knn.argtypes = [_fp, _fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float,
+                                C.c_int, C.c_float, _u32p, _fp]
+    L.orc_brute_knn.restype = C.c_int
+    L.orc_match_pt2pt.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp,
+                                  C.c_size_t, _dp, C.POINTER(Pt2PtParams), _u8p, _u8p,
+                                  C.c_void_p, C.POINTER(C.c_uint64)]
+    L.orc_match_pt2pt.restype = C.c_size_t
+    L.orc_match_pt2pt_mt.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp,
+                                     C.c_size_t, _dp, C.POINTER(Pt2PtParams), C.c_void_p,
+                                     C.c_int]
+    L.orc_match_pt2pt_mt.restype = C.c_size_t
+    L.orc_match_pt2pl.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp,
+                                  C.c_size_t, _dp, C.POINTER(Pt2PlParams), _u8p, C.c_void_p,
+                                  _u32p, C.POINTER(C.c_uint64)]
+    L.orc_match_pt2pl.restype = C.c_size_t
+    L.orc_estimate_points_eigen.argtypes = [_fp, _fp, _fp, C.c_size_t, _fp, _dp, _dp, _dp]
+    L.orc_optimal_tf_gauss_newton.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                              C.c_void_p, C.c_size_t, _dp,
+                                              C.POINTER(GNParams), _dp, _dp, _dp]
+    L.orc_optimal_tf_gauss_newton.restype = C.c_int
+    L.orc_optimal_tf_gauss_newton_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                 _dp, C.POINTER(GNParams), _dp, C.c_int]
+    L.orc_optimal_tf_gauss_newton_mt.restype = C.c_int
+    L.orc_optimal_tf_horn.argtypes = [C.c_void_p, C.c_size_t, C.c_double, _dp]
+    L.orc_optimal_tf_horn.restype = C.c_int
+
+
+# ------------------------------------------------------------------------------------------
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def pose_from_xyzypr(x, y, z, yaw=0.0, pitch=0.0, roll=0.0):
+    T = np.zeros(12)
+    lib().orc_pose_from_xyzypr(x, y, z, yaw, pitch, roll, _d(T))
+    return T
+
+
+def pose_to_xyzypr(T):
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    o = np.zeros(6)
+    lib().orc_pose_to_xyzypr(_d(T), _d(o))
+    return o
+
+
+def pose_identity():
+    return pose_from_xyzypr(0, 0, 0)
+
+
+def pose_compose(A, B):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    o = np.zeros(12)
+    lib().orc_pose_compose(_d(A), _d(B), _d(o))
+    return o
+
+
+def pose_inverse(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    o = np.zeros(12)
+    lib().orc_pose_inverse(_d(A), _d(o))
+    return o
+
+
+def pose_compose_point(T, p):
+    R = np.asarray(T[:9]).reshape(3, 3)
+    return R @ np.asarray(p, dtype=np.float64) + np.asarray(T[9:12])
+
+
+def pose_inverse_compose_point(T, g):
+    R = np.asarray(T[:9]).reshape(3, 3)
+    return R.T @ (np.asarray(g, dtype=np.float64) - np.asarray(T[9:12]))
+
+
+def se3_exp(xi):
+    xi = np.ascontiguousarray(xi, dtype=np.float64)
+    T = np.zeros(12)
+    lib().orc_se3_exp(_d(xi), _d(T))
+    return T
+
+
+def se3_log(T):
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    xi = np.zeros(6)
+    lib().orc_se3_log(_d(T), _d(xi))
+    return xi
+
+
+def pose_err(A, B):
+    """|| log(B^-1 A) || -- the check used all over the reference tests
+    (e.g. test-mp2p_optimize_pt2pl.cpp:75)."""
+    return float(np.linalg.norm(se3_log(pose_compose(pose_inverse(B), A))))
+
+
+def pose_err_split(A, B):
+    xi = se3_log(pose_compose(pose_inverse(B), A))
+    return float(np.linalg.norm(xi[:3])), float(np.linalg.norm(xi[3:]))
+
+
+def jacob_dDexpe_de(T):
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    J = np.zeros(72)
+    lib().orc_jacob_dDexpe_de(_d(T), _d(J))
+    return J.reshape(12, 6)
+
+
+def _err_term(fn, pair, T, want_jac=True):
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    e = np.zeros(3)
+    J = np.zeros(36)
+    getattr(lib(), fn)(pair.ctypes.data, _d(T), _d(e), _d(J) if want_jac else None)
+    return e, J.reshape(3, 12)
+
+
+def error_point2point(pair, T):
+    return _err_term("orc_error_point2point", pair, T)
+
+
+def error_point2plane(pair, T):
+    return _err_term("orc_error_point2plane", pair, T)
+
+
+def error_point2line(pair, T):
+    return _err_term("orc_error_point2line", pair, T)
+
+
+def robust_weight(kernel, c, esq):
+    return lib().orc_robust_weight(kernel, c, esq)
+
+
+def transform_local_to_global(lx, ly, lz, T):
+    lx, ly, lz = _f32(lx), _f32(ly), _f32(lz)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    n = lx.size
+    ox, oy, oz = (np.empty(n, np.float32) for _ in range(3))
+    bmin, bmax = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    lib().orc_transform_local_to_global(_f(lx), _f(ly), _f(lz), n, _d(T), _f(ox), _f(oy), _f(oz),
+                                        _f(bmin), _f(bmax))
+    return ox, oy, oz, bmin, bmax
+
+
+class KDTree:
+    """Exact fp32 KD-tree over SoA points (kept alive with the arrays)."""
+
+    def __init__(self, x, y, z, leaf_max=10):
+        self.x, self.y, self.z = _f32(x), _f32(y), _f32(z)
+        self.n = self.x.size
+        self._h = lib().orc_kdtree_build(_f(self.x), _f(self.y), _f(self.z), self.n, leaf_max)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_kdtree_free(self._h)
+            self._h = None
+
+    def knn(self, q, k=1, max_d2=-1.0):
+        idx = np.zeros(k, np.uint32)
+        d2 = np.zeros(k, np.float32)
+        n = lib().orc_kdtree_knn(self._h, float(q[0]), float(q[1]), float(q[2]), k, max_d2,
+                                 idx.ctypes.data_as(_u32p), _f(d2))
+        return idx[:n], d2[:n]
+
+
+def brute_knn(x, y, z, q, k=1, max_d2=-1.0):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    idx = np.zeros(k, np.uint32)
+    d2 = np.zeros(k, np.float32)
+    n = lib().orc_brute_knn(_f(x), _f(y), _f(z), x.size, float(q[0]), float(q[1]), float(q[2]),
+                            k, max_d2, idx.ctypes.data_as(_u32p), _f(d2))
+    return idx[:n], d2[:n]
+
+
+def match_pt2pt(gx, gy, gz, lx, ly, lz, T, threshold, thresholdAngularDeg, pairingsPerPoint=1,
+                allowMatchAlreadyMatchedPoints=False, allowMatchAlreadyMatchedGlobalPoints=False,
+                bbox_eps=0.20, tree=None, local_taken=None, global_taken=None,
+                multi_search_radius_mode=0, threads=0):
+    """Matcher_Points_DistanceThreshold::implMatchOneLayer.  Returns (pairs, potential)."""
+    gx, gy, gz, lx, ly, lz = map(_f32, (gx, gy, gz, lx, ly, lz))
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    prm = Pt2PtParams(threshold, thresholdAngularDeg, pairingsPerPoint,
+                      int(allowMatchAlreadyMatchedPoints),
+                      int(allowMatchAlreadyMatchedGlobalPoints), bbox_eps,
+                      multi_search_radius_mode)
+    out = np.zeros(max(1, lx.size * pairingsPerPoint), PAIR_PT2PT)
+    pot = C.c_uint64(0)
+    th = tree._h if tree is not None else None
+    if threads and threads > 0:
+        assert tree is not None
+        n = lib().orc_match_pt2pt_mt(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
+                                     lx.size, _d(T), C.byref(prm), out.ctypes.data, threads)
+        return out[:n].copy(), lx.size * pairingsPerPoint
+    lt = local_taken.ctypes.data_as(_u8p) if local_taken is not None else None
+    gt = global_taken.ctypes.data_as(_u8p) if global_taken is not None else None
+    n = lib().orc_match_pt2pt(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
+                              lx.size, _d(T), C.byref(prm), lt, gt, out.ctypes.data,
+                              C.byref(pot))
+    return out[:n].copy(), pot.value
+
+
+def match_pt2pl(gx, gy, gz, lx, ly, lz, T, distanceThreshold, searchRadius, knn,
+                minimumPlanePoints, planeEigenThreshold, allowMatchAlreadyMatchedPoints=False,
+                bbox_eps=0.20, tree=None, local_taken=None):
+    """Matcher_Point2Plane::implMatchOneLayer with the declared nn_search_pt2pl.
+    Returns (pairs, local_idx, potential)."""
+    gx, gy, gz, lx, ly, lz = map(_f32, (gx, gy, gz, lx, ly, lz))
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    prm = Pt2PlParams(distanceThreshold, searchRadius, knn, minimumPlanePoints,
+                      planeEigenThreshold, int(allowMatchAlreadyMatchedPoints), bbox_eps)
+    out = np.zeros(max(1, lx.size), PAIR_PT2PL)
+    oidx = np.zeros(max(1, lx.size), np.uint32)
+    pot = C.c_uint64(0)
+    th = tree._h if tree is not None else None
+    lt = local_taken.ctypes.data_as(_u8p) if local_taken is not None else None
+    n = lib().orc_match_pt2pl(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
+                              lx.size, _d(T), C.byref(prm), lt, out.ctypes.data,
+                              oidx.ctypes.data_as(_u32p), C.byref(pot))
+    return out[:n].copy(), oidx[:n].copy(), pot.value
+
+
+def estimate_points_eigen(xs, ys, zs):
+    xs, ys, zs = map(_f32, (xs, ys, zs))
+    mean = np.zeros(3, np.float32)
+    cov, ev, evec = np.zeros(9), np.zeros(3), np.zeros(9)
+    lib().orc_estimate_points_eigen(_f(xs), _f(ys), _f(zs), xs.size, _f(mean), _d(cov), _d(ev),
+                                    _d(evec))
+    return mean, cov.reshape(3, 3), ev, evec.reshape(3, 3)
+
+
+def make_gn_params(maxIterations, kernel=KERNEL_NONE, kernelParam=1.0, w_pt2pt=1.0, w_pt2pl=1.0,
+                   w_pt2ln=1.0, prior_mean=None, prior_cov_inv=None, minDelta=1e-7, maxCost=0.0,
+                   weight_blocks=None, reset_weight_cursor_each_iter=0):
+    p = GNParams()
+    p.maxInnerLoopIterations = maxIterations
+    p.minDelta, p.maxCost = minDelta, maxCost
+    p.kernel, p.kernelParam = kernel, kernelParam
+    p.w_pt2pt, p.w_pt2pl, p.w_pt2ln = w_pt2pt, w_pt2pl, w_pt2ln
+    p.has_prior = 0
+    keep = []
+    if prior_mean is not None:
+        p.has_prior = 1
+        p.prior_mean = (C.c_double * 12)(*np.asarray(prior_mean, dtype=np.float64))
+        p.prior_cov_inv = (C.c_double * 36)(*np.asarray(prior_cov_inv, dtype=np.float64).ravel())
+    p.n_weight_blocks = 0
+    if weight_blocks:
+        cnt = (C.c_size_t * len(weight_blocks))(*[int(c) for c, _ in weight_blocks])
+        ww = (C.c_double * len(weight_blocks))(*[float(w) for _, w in weight_blocks])
+        keep += [cnt, ww]
+        p.n_weight_blocks = len(weight_blocks)
+        p.weight_block_count = C.cast(cnt, C.POINTER(C.c_size_t))
+        p.weight_block_w = C.cast(ww, C.POINTER(C.c_double))
+    p.reset_weight_cursor_each_iter = reset_weight_cursor_each_iter
+    p._keep = keep
+    return p
+
+
+def optimal_tf_gauss_newton(pt2pt, pt2pl, pt2ln, T0, prm, threads=0):
+    """Returns (T, iters, H, g)."""
+    T0 = np.ascontiguousarray(T0, dtype=np.float64)
+    pt2pt = np.ascontiguousarray(pt2pt if pt2pt is not None else np.zeros(0, PAIR_PT2PT))
+    pt2pl = np.ascontiguousarray(pt2pl if pt2pl is not None else np.zeros(0, PAIR_PT2PL))
+    pt2ln = np.ascontiguousarray(pt2ln if pt2ln is not None else np.zeros(0, PAIR_PT2LN))
+    T = np.zeros(12)
+    H, g = np.zeros(36), np.zeros(6)
+    if threads and threads > 0:
+        it = lib().orc_optimal_tf_gauss_newton_mt(pt2pt.ctypes.data, pt2pt.size,
+                                                  pt2pl.ctypes.data, pt2pl.size, _d(T0),
+                                                  C.byref(prm), _d(T), threads)
+        return T, it, None, None
+    it = lib().orc_optimal_tf_gauss_newton(pt2pt.ctypes.data, pt2pt.size, pt2pl.ctypes.data,
+                                           pt2pl.size, pt2ln.ctypes.data, pt2ln.size, _d(T0),
+                                           C.byref(prm), _d(T), _d(H), _d(g))
+    return T, it, H.reshape(6, 6), g
+
+
+def optimal_tf_horn(pt2pt, w_pt2pt=1.0):
+    pt2pt = np.ascontiguousarray(pt2pt)
+    T = np.zeros(12)
+    ok = lib().orc_optimal_tf_horn(pt2pt.ctypes.data, pt2pt.size, w_pt2pt, _d(T))
+    return T, bool(ok)

@@ -1,0 +1,281 @@
+"""Pins the CPU oracle against the reference's own known-answer tests.
+
+Each test restates one reference test file; expected values are the ones asserted there.
+"""
+import math
+
+import numpy as np
+import pytest
+
+DEG = math.pi / 180.0
+
+
+# ------------------------------------------------------------------------------------------
+# tests/test-mp2p_matcher_pt2pt.cpp:26-107
+# ------------------------------------------------------------------------------------------
+def _kat_global():
+    g = [(i * 0.01, 5.0, 0.0) for i in range(10)] + [(10.0, i * 0.01, 1.0) for i in range(10)]
+    return np.array(g, dtype=np.float32)
+
+
+def _kat_local():
+    return np.array([(0, 0, 0), (2, 0, 0)], dtype=np.float32)
+
+
+KAT_POSES = [
+    ((0, 0, 0, 0, 0, 0), []),                       # :72-73 identity -> empty
+    ((0, 5, 0, 0, 0, 0), [(0, 0)]),                 # :82-85 (localIdx, globalIdx)
+    ((-2, 5, 0, 0, 0, 0), [(1, 0)]),                # :92-95
+    ((8.5, -1.0, 1, 45.0 * DEG, 0, 0), [(1, 19)]),  # :102-106
+]
+
+
+@pytest.mark.parametrize("use_tree", [False, True])
+@pytest.mark.parametrize("pose,expected", KAT_POSES)
+def test_matcher_pt2pt_kat(oracle, pose, expected, use_tree):
+    g, l = _kat_global(), _kat_local()
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2]) if use_tree else None
+    T = oracle.pose_from_xyzypr(*pose)
+    pairs, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T,
+                                    threshold=1.05, thresholdAngularDeg=0.001, tree=tree)
+    got = [(int(p["localIdx"]), int(p["globalIdx"])) for p in pairs]
+    assert got == expected
+    assert pot == 2
+
+
+# ------------------------------------------------------------------------------------------
+# tests/test-mp2p_optimize_pt2pl.cpp:26-129
+# ------------------------------------------------------------------------------------------
+def _plane_from_point_normal(p, n):
+    n = np.asarray(n, float)
+    n = n / np.linalg.norm(n)
+    return np.array([n[0], n[1], n[2], -float(n @ np.asarray(p, float))])
+
+
+PT2PL_POSES = [
+    (0, 0, 0, 0, 0, 0), (1, 0, 0, 0, 0, 0), (0, 1, 0, 0, 0, 0), (0, 0, 1, 0, 0, 0),
+    (-2, 0, 0, 0, 0, 0), (0, -3, 0, 0, 0, 0), (0, 0, -4, 0, 0, 0),
+    (0, 0, 0, 20 * DEG, 0, 0), (0, 0, 0, -20 * DEG, 0, 0),
+    (0, 0, 0, 0, 10 * DEG, 0), (0, 0, 0, 0, -10 * DEG, 0),
+    (0, 0, 0, 0, 0, 15 * DEG), (0, 0, 0, 0, 0, -15 * DEG),
+    (1, 2, 3, 0, 0, 0), (1, 2, 3, -10 * DEG, 5 * DEG, 30 * DEG),
+]
+
+
+def make_pt2pl_kat(oracle, gt):
+    pl = np.zeros(3, oracle.PAIR_PT2PL)
+    specs = [((0, 0, 1), (0.5, 0, 0)), ((1, 0, 0), (0, 0.8, 0)), ((0, 1, 0), (0, 0, 0.3))]
+    for i, (n, gp) in enumerate(specs):
+        pl[i]["plane"] = _plane_from_point_normal((0, 0, 0), n)
+        pl[i]["centroid"] = (0, 0, 0)
+        loc = oracle.pose_inverse_compose_point(gt, gp)
+        pl[i]["lx"], pl[i]["ly"], pl[i]["lz"] = loc  # TPoint3Df: narrowed to float
+    pt = np.zeros(1, oracle.PAIR_PT2PT)
+    loc = oracle.pose_inverse_compose_point(gt, (0, 0, 0))
+    pt[0]["lx"], pt[0]["ly"], pt[0]["lz"] = loc
+    return pt, pl
+
+
+@pytest.mark.parametrize("pose", PT2PL_POSES)
+def test_optimize_pt2pl_kat(oracle, pose):
+    gt = oracle.pose_from_xyzypr(*pose)
+    pt, pl = make_pt2pl_kat(oracle, gt)
+    prm = oracle.make_gn_params(maxIterations=25)
+    T, iters, H, g = oracle.optimal_tf_gauss_newton(pt, pl, None, oracle.pose_identity(), prm)
+    assert oracle.pose_err(T, gt) < 1e-3  # :75
+
+
+# ------------------------------------------------------------------------------------------
+# tests/test-mp2p_optimize_with_prior.cpp:25-123
+# ------------------------------------------------------------------------------------------
+PRIOR_GT = [(1.0, 2.0, 3.0, 5 * DEG, 15 * DEG, 20 * DEG)]  # :132
+
+
+def make_prior_kat(oracle, gt):
+    pt = np.zeros(3, oracle.PAIR_PT2PT)
+    for i, gp in enumerate([(1, 0, 0), (0, 1, 0), (0, 0, 1)]):
+        pt[i]["gx"], pt[i]["gy"], pt[i]["gz"] = gp
+        pt[i]["lx"], pt[i]["ly"], pt[i]["lz"] = oracle.pose_inverse_compose_point(gt, gp)
+    return pt
+
+
+@pytest.mark.parametrize("gtp", PRIOR_GT)
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_optimize_with_prior_kat(oracle, gtp, case):
+    gt = oracle.pose_from_xyzypr(*gtp)
+    pt = make_prior_kat(oracle, gt)
+    prior_mean6 = (2.0, 3.0, 4.0, 10 * DEG, 10 * DEG, 10 * DEG)
+    prior_mean = oracle.pose_from_xyzypr(*prior_mean6)
+    cov_inv = np.zeros((6, 6))
+    if case == 0:
+        prm = oracle.make_gn_params(maxIterations=25)
+    else:
+        rng = range(0, 3) if case == 1 else range(3, 6)
+        for i in rng:
+            cov_inv[i, i] = 100.0
+        prm = oracle.make_gn_params(maxIterations=25, prior_mean=prior_mean,
+                                    prior_cov_inv=cov_inv)
+    T, *_ = oracle.optimal_tf_gauss_newton(pt, None, None, oracle.pose_identity(), prm)
+    if case == 0:
+        assert oracle.pose_err(T, gt) < 1e-3
+    else:
+        got = oracle.pose_to_xyzypr(T)
+        rng = range(0, 3) if case == 1 else range(3, 6)
+        for i in rng:
+            assert abs(got[i] - prior_mean6[i]) < 0.05
+
+
+# ------------------------------------------------------------------------------------------
+# tests/test-mp2p_optimize_pt2ln.cpp:25-76
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pose", PT2PL_POSES)
+def test_optimize_pt2ln_kat(oracle, pose):
+    gt = oracle.pose_from_xyzypr(*pose)
+    ln = np.zeros(3, oracle.PAIR_PT2LN)
+    specs = [((1, 0, 0), (0.5, 0, 0)), ((0, 1, 0), (0, 0.4, 0)), ((0, 0, 1), (0, 0, 0.2))]
+    for i, (d, gp) in enumerate(specs):
+        ln[i]["pbase"] = (0, 0, 0)
+        ln[i]["director"] = d
+        ln[i]["lx"], ln[i]["ly"], ln[i]["lz"] = oracle.pose_inverse_compose_point(gt, gp)
+    prm = oracle.make_gn_params(maxIterations=25)
+    T, *_ = oracle.optimal_tf_gauss_newton(None, None, ln, oracle.pose_identity(), prm)
+    assert oracle.pose_err(T, gt) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------
+# tests/test-mp2p_error_terms_jacobians.cpp:45-252: analytic J1*dDexpe_de vs finite diff.
+# ------------------------------------------------------------------------------------------
+def _numeric_jac(fn, T, oracle, h=1e-6):
+    J = np.zeros((3, 6))
+    for j in range(6):
+        xi = np.zeros(6)
+        xi[j] = h
+        ep = fn(oracle.pose_compose(T, oracle.se3_exp(xi)))
+        xi[j] = -h
+        em = fn(oracle.pose_compose(T, oracle.se3_exp(xi)))
+        J[:, j] = (ep - em) / (2 * h)
+    return J
+
+
+@pytest.mark.parametrize("kind", ["pt2pt", "pt2pl", "pt2ln"])
+def test_error_term_jacobians(oracle, kind):
+    rng = np.random.default_rng(1234)
+    for _ in range(200):
+        p6 = np.concatenate([rng.uniform(-10, 10, 3), rng.uniform(-math.pi / 2 * 0.9, math.pi / 2 * 0.9, 3)])
+        T = oracle.pose_from_xyzypr(*p6)
+        if kind == "pt2pt":
+            pair = np.zeros(1, oracle.PAIR_PT2PT)
+            pair[0]["gx"], pair[0]["gy"], pair[0]["gz"] = rng.uniform(-10, 10, 3)
+            f = oracle.error_point2point
+        elif kind == "pt2pl":
+            pair = np.zeros(1, oracle.PAIR_PT2PL)
+            n = rng.normal(size=3)
+            pair[0]["plane"] = _plane_from_point_normal(rng.uniform(-5, 5, 3), n) * rng.uniform(0.5, 2)
+            f = oracle.error_point2plane
+        else:
+            pair = np.zeros(1, oracle.PAIR_PT2LN)
+            d = rng.normal(size=3)
+            pair[0]["director"] = d / np.linalg.norm(d)
+            pair[0]["pbase"] = rng.uniform(-5, 5, 3)
+            f = oracle.error_point2line
+        pair[0]["lx"], pair[0]["ly"], pair[0]["lz"] = rng.uniform(-10, 10, 3)
+        e, J1 = f(pair, T)
+        Ja = J1 @ oracle.jacob_dDexpe_de(T)
+        Jn = _numeric_jac(lambda TT: f(pair, TT)[0], T, oracle)
+        assert np.max(np.abs(Ja - Jn)) < 1e-5  # reference tolerance
+
+
+def test_se3_exp_log_roundtrip(oracle):
+    rng = np.random.default_rng(7)
+    for _ in range(300):
+        w = rng.normal(size=3)
+        w *= rng.uniform(0, 3.0) / np.linalg.norm(w)  # |w| < pi
+        xi = np.concatenate([rng.uniform(-5, 5, 3), w])
+        T = oracle.se3_exp(xi)
+        R = T[:9].reshape(3, 3)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
+        assert np.allclose(oracle.se3_log(T), xi, atol=1e-9)
+    # tiny angles
+    xi = np.array([1, 2, 3, 1e-9, -2e-9, 1e-10])
+    assert np.allclose(oracle.se3_log(oracle.se3_exp(xi)), xi, atol=1e-12)
+
+
+def test_robust_kernels(oracle):
+    # robust_kernels.h:76-77, :88-89
+    c, e2 = 0.15, 0.04
+    assert oracle.robust_weight(oracle.KERNEL_GEMANMCCLURE, c, e2) == pytest.approx(c * c / (e2 + c) ** 2)
+    assert oracle.robust_weight(oracle.KERNEL_CAUCHY, c, e2) == pytest.approx(c * c / (e2 + c * c))
+    assert oracle.robust_weight(oracle.KERNEL_NONE, c, e2) == 1.0
+
+
+def test_kdtree_matches_brute(oracle):
+    rng = np.random.default_rng(42)
+    g = rng.uniform(-20, 20, (5000, 3)).astype(np.float32)
+    g[100:110] = g[0]  # duplicates -> exact ties, lowest index must win
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    qs = np.concatenate([rng.uniform(-25, 25, (300, 3)), g[:20].astype(np.float64)]).astype(np.float32)
+    for q in qs:
+        for k, md in [(1, -1.0), (5, -1.0), (7, 4.0)]:
+            bi, bd = oracle.brute_knn(g[:, 0], g[:, 1], g[:, 2], q, k, md)
+            ti, td = tree.knn(q, k, md)
+            assert np.array_equal(bi, ti)
+            assert np.array_equal(bd, td)
+
+
+def test_horn_recovers_pose(oracle):
+    rng = np.random.default_rng(5)
+    gt = oracle.pose_from_xyzypr(1, -2, 0.5, 0.3, -0.1, 0.2)
+    l = rng.uniform(-10, 10, (200, 3))
+    pt = np.zeros(200, oracle.PAIR_PT2PT)
+    R = gt[:9].reshape(3, 3)
+    gpts = l @ R.T + gt[9:]
+    pt["lx"], pt["ly"], pt["lz"] = l.T
+    pt["gx"], pt["gy"], pt["gz"] = gpts.T
+    T, ok = oracle.optimal_tf_horn(pt)
+    assert ok and oracle.pose_err(T, gt) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------
+# tests/test-mp2p_matcher_pt2pl.cpp:29-131 (disabled upstream; semantic spec for the declared
+# nn_search_pt2pl)
+# ------------------------------------------------------------------------------------------
+def pt2pl_kat_global():
+    pts = []
+    for ix in range(10):
+        for iy in range(10):
+            pts.append((ix * 0.01, 5.0 + iy * 0.01, 0.0))
+    for iy in range(10):
+        for iz in range(10):
+            pts.append((10.0, iy * 0.01, iz * 0.01))
+    for ix in range(10):
+        for iy in range(10):
+            for iz in range(10):
+                pts.append((20.0 + ix * 0.01, iy * 0.01, iz * 0.01))
+    return np.array(pts, dtype=np.float32)
+
+
+PT2PL_MATCH_PRM = dict(distanceThreshold=0.1, searchRadius=0.1, knn=5, minimumPlanePoints=5,
+                       planeEigenThreshold=0.1)
+
+
+def test_matcher_pt2pl_kat(oracle):
+    g, l = pt2pl_kat_global(), _kat_local()
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+
+    def run(pose):
+        T = oracle.pose_from_xyzypr(*pose)
+        return oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T,
+                                  tree=tree, **PT2PL_MATCH_PRM)
+
+    pairs, idx, pot = run((0, 0, 0, 0, 0, 0))
+    assert len(pairs) == 0 and pot == 2                    # :87-88
+    pairs, idx, _ = run((0, 5, 0, 0, 0, 0))
+    assert len(pairs) == 1                                 # :95-97
+    pairs, idx, _ = run((8.04, 0, 0, 0, 0, 0))
+    assert len(pairs) == 1                                 # :104-105
+    p0 = pairs[0]
+    assert abs(p0["lx"] - 2.0) < 1e-3 and abs(p0["ly"]) < 1e-3 and abs(p0["lz"]) < 1e-3
+    assert np.allclose(p0["centroid"], (10, 0, 0), atol=0.01)          # :113-115
+    assert np.allclose(p0["plane"], (1, 0, 0, -10), atol=1e-3)         # :118-121
+    pairs, idx, _ = run((18.053, 0.05, 0.03, 0, 0, 0))
+    assert len(pairs) == 0                                 # :129-130 (cube: not a plane)

@@ -1,0 +1,283 @@
+/*
+ * mp2p_hip.h -- C ABI of libmp2p_hip.so: MI355X (gfx950) implementation of the
+ * mp2p_icp per-iteration hot path (nearest-neighbour correspondence search +
+ * Gauss-Newton normal-equation reduction).
+ *
+ * Plain C, caller-owned buffers, no MRPT / Eigen / torch types.  This is the drop-in
+ * boundary: every entry point states the reference interface (file:line, relative to
+ * MOLAorg/mp2p_icp v1.8.0) it replaces.  INTEGRATION.md shows the C++ adapter a
+ * maintainer would add on the reference side (classes deriving mp2p_icp::Matcher /
+ * mp2p_icp::Solver that call these functions).
+ *
+ * Conventions
+ *   pose   : double[12] = R (row-major 3x3) then t (3)                      [CPose3D]
+ *   points : SoA float arrays                 [CPointsMap::getPointsBufferRef_{x,y,z}]
+ *   return : 0 = MP2P_HIP_OK, <0 = error; mp2p_hip_last_error(ctx) has the text.
+ *   Every handle belongs to the context that created it.  A context owns one HIP
+ *   stream; calls on one context are serialised by the caller (ICP::align is
+ *   single-threaded per ICP object); different contexts are independent.
+ *   There is NO CPU fallback: without a HIP device every compute call fails with
+ *   MP2P_HIP_ERR_NO_DEVICE.
+ */
+#ifndef MP2P_HIP_H
+#define MP2P_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP2P_HIP_ABI_VERSION 1
+
+enum
+{
+    MP2P_HIP_OK            = 0,
+    MP2P_HIP_ERR_INVALID   = -1, /* bad argument (what ASSERT_/THROW_EXCEPTION guards upstream) */
+    MP2P_HIP_ERR_HIP       = -2, /* a HIP runtime call failed                                  */
+    MP2P_HIP_ERR_NOMEM     = -3,
+    MP2P_HIP_ERR_CAPACITY  = -4, /* caller-provided output capacity too small                  */
+    MP2P_HIP_ERR_NO_DEVICE = -5
+};
+
+typedef struct mp2p_hip_ctx   mp2p_hip_ctx;
+typedef struct mp2p_hip_map   mp2p_hip_map;   /* a global point layer + its NN index        */
+typedef struct mp2p_hip_cloud mp2p_hip_cloud; /* a local point layer                        */
+typedef struct mp2p_hip_pairs mp2p_hip_pairs; /* device-resident mp2p_icp::Pairings         */
+typedef struct mp2p_hip_mstate mp2p_hip_mstate; /* device-resident MatchState bit-fields    */
+
+/* ---- context ------------------------------------------------------------------------ */
+int  mp2p_hip_abi_version(void);
+int  mp2p_hip_device_count(void);
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream) or NULL to create one. */
+int  mp2p_hip_ctx_create(int device_id, void* hip_stream, mp2p_hip_ctx** out);
+void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx);
+const char* mp2p_hip_last_error(const mp2p_hip_ctx* ctx); /* ctx may be NULL (global text) */
+int  mp2p_hip_sync(mp2p_hip_ctx* ctx);
+void* mp2p_hip_ctx_stream(mp2p_hip_ctx* ctx);
+
+/* ---- global map layer: replaces mrpt::maps::NearestNeighborsCapable of the global layer
+ *      (nn_prepare_for_3d_queries, Matcher_Points_DistanceThreshold.cpp:92; MRPT's
+ *      nanoflann build) with a Morton-sorted multi-level voxel hash (kernel K2). ---------- */
+typedef struct
+{
+    float    cell_size;       /* finest voxel edge [m]; <=0 = choose from the point density   */
+    float    target_per_cell; /* density target for the automatic choice (<=0 -> 6)           */
+    uint32_t max_levels;      /* 0 -> default (12)                                            */
+} mp2p_hip_map_params;
+
+typedef struct
+{
+    uint64_t n_points;
+    float    bbox_min[3], bbox_max[3];
+    float    cell_size;
+    uint32_t n_levels;
+    uint64_t n_cells_total;
+    uint64_t n_cells_level0;
+    uint64_t hash_capacity;
+    uint64_t device_bytes;
+    double   build_ms; /* wall time of the last build, device-synchronised */
+} mp2p_hip_map_info;
+
+/* x,y,z: HOST pointers (CPointsMap buffers).  The index is rebuilt only by a new upload;
+ * the adapter keys uploads on the map object + its modification state. */
+int  mp2p_hip_map_upload(mp2p_hip_ctx* ctx, const float* x, const float* y, const float* z,
+                         size_t n, const mp2p_hip_map_params* prm, mp2p_hip_map** out);
+/* same, from DEVICE pointers (zero-copy path for data already in HBM) */
+int  mp2p_hip_map_upload_device(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y,
+                                const float* d_z, size_t n, const mp2p_hip_map_params* prm,
+                                mp2p_hip_map** out);
+void mp2p_hip_map_free(mp2p_hip_ctx* ctx, mp2p_hip_map* map);
+int  mp2p_hip_map_get_info(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, mp2p_hip_map_info* out);
+
+/* ---- local layer (the cloud being registered).  Uploaded once per ICP::align; stored
+ *      Morton-sorted in its own frame so that 64 consecutive queries stay spatially
+ *      coherent under any rigid pose. -------------------------------------------------- */
+int  mp2p_hip_cloud_upload(mp2p_hip_ctx* ctx, const float* x, const float* y, const float* z,
+                           size_t n, mp2p_hip_cloud** out);
+int  mp2p_hip_cloud_upload_device(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y,
+                                  const float* d_z, size_t n, mp2p_hip_cloud** out);
+void mp2p_hip_cloud_free(mp2p_hip_ctx* ctx, mp2p_hip_cloud* cloud);
+size_t mp2p_hip_cloud_size(const mp2p_hip_cloud* cloud);
+
+/* ---- MatchState (Matcher.h:44-70): one byte per point, 0/1 ---------------------------- */
+int  mp2p_hip_mstate_create(mp2p_hip_ctx* ctx, size_t n_global, size_t n_local,
+                            mp2p_hip_mstate** out); /* all clear */
+int  mp2p_hip_mstate_reset(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms);
+void mp2p_hip_mstate_free(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms);
+/* host <-> device copies of the two bit-fields (either pointer may be NULL) */
+int  mp2p_hip_mstate_download(mp2p_hip_ctx* ctx, const mp2p_hip_mstate* ms,
+                              uint8_t* global_taken, uint8_t* local_taken);
+int  mp2p_hip_mstate_upload(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms, const uint8_t* global_taken,
+                            const uint8_t* local_taken);
+
+/* ---- Pairings (Pairings.h:84-169), device resident ------------------------------------ */
+/* host images, byte-compatible with the reference containers */
+typedef struct
+{
+    uint32_t globalIdx, localIdx;
+    float    global_xyz[3];
+    float    local_xyz[3]; /* UNtransformed local point */
+    float    errorSquareAfterTransformation;
+} mp2p_hip_pair_pt2pt; /* = mrpt::tfest::TMatchingPair, 36 B */
+
+typedef struct
+{
+    double plane[4];    /* TPlane coefs            */
+    double centroid[3]; /* plane_patch_t::centroid */
+    float  pt_local[3]; /* untransformed           */
+    float  _pad;
+} mp2p_hip_pair_pt2pl; /* = mp2p_icp::point_plane_pair_t, 72 B */
+
+int  mp2p_hip_pairs_create(mp2p_hip_ctx* ctx, size_t cap_pt2pt, size_t cap_pt2pl,
+                           mp2p_hip_pairs** out);
+void mp2p_hip_pairs_free(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p);
+int  mp2p_hip_pairs_clear(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p); /* out = Pairings() */
+/* counts (synchronises the stream; 24 B read back) */
+int  mp2p_hip_pairs_counts(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, uint64_t* n_pt2pt,
+                           uint64_t* n_pt2pl, uint64_t* potential_pairings);
+/* materialise the host containers (what ICP::align needs for quality / covariance / logs) */
+int  mp2p_hip_pairs_download_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
+                                   mp2p_hip_pair_pt2pt* out, size_t capacity, size_t* n_out);
+int  mp2p_hip_pairs_download_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
+                                   mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx,
+                                   size_t capacity, size_t* n_out);
+/* a solver handed host Pairings it did not produce uploads them first */
+int  mp2p_hip_pairs_upload(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p, const mp2p_hip_pair_pt2pt* pt2pt,
+                           size_t n_pt2pt, const mp2p_hip_pair_pt2pl* pt2pl, size_t n_pt2pl);
+
+/* ---- Matcher_Points_DistanceThreshold::implMatchOneLayer
+ *      (Matcher_Points_DistanceThreshold.cpp:48-269) incl. transform_local_to_global
+ *      (Matcher_Points_Base.cpp:183-249) and the bounding-box early-out (:73-75).
+ *      Kernels K1 (fused), K3, K4.  Appends to `out` like the reference appends to
+ *      out.paired_pt2pt; adds n_local*pairingsPerPoint to potential_pairings (:64). ------ */
+typedef struct
+{
+    double   threshold;           /* [m]   Matcher_Points_DistanceThreshold.cpp:43 (formula) */
+    double   thresholdAngularDeg; /* [deg] :44 */
+    uint32_t pairingsPerPoint;    /* :45 (only 1 is implemented in this round) */
+    int32_t  allowMatchAlreadyMatchedPoints;       /* Matcher_Points_Base.cpp:168-169 */
+    int32_t  allowMatchAlreadyMatchedGlobalPoints; /* :171-172 */
+    double   bounding_box_intersection_check_epsilon; /* :179-180, default 0.20 */
+    /* multi-GPU: this rank's cloud is the slice [local_index_offset, +n) of the whole local
+     * layer; claims use the whole-layer index so that "lowest local index wins" holds
+     * across ranks.  0 on a single GPU. */
+    uint64_t local_index_offset;
+    /* tuning (0 = default): first search radius in units of the finest cell */
+    float    initial_radius_cells;
+    uint32_t queries_per_wave; /* 64, 16, 4 or 1; 0 = default */
+} mp2p_hip_pt2pt_params;
+
+/* ms may be NULL (fresh MatchState with nothing marked, marks discarded). */
+int mp2p_hip_match_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                         const double pose[12], const mp2p_hip_pt2pt_params* prm,
+                         mp2p_hip_mstate* ms, mp2p_hip_pairs* out);
+
+/* split form for a local layer sharded over several GPUs: phase1 = search + claims,
+ * then the caller min-all-reduces the claim words (int64 MIN, RCCL), then phase2 =
+ * winner check + ordered compaction.  mp2p_hip_match_pt2pt == phase1 ; phase2. */
+int mp2p_hip_match_pt2pt_phase1(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
+                                const mp2p_hip_cloud* cloud, const double pose[12],
+                                const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms);
+int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
+                                const mp2p_hip_cloud* cloud, const mp2p_hip_pt2pt_params* prm,
+                                mp2p_hip_mstate* ms, mp2p_hip_pairs* out);
+/* device pointer / element count of the claim words (int64, one per global point) */
+void*  mp2p_hip_map_claims_ptr(const mp2p_hip_map* map);
+size_t mp2p_hip_map_claims_count(const mp2p_hip_map* map);
+/* transformed-local bounding box of the last phase1 on this ctx (6 floats min,max; device)
+ * -- to be min/max all-reduced across ranks before phase2 */
+void* mp2p_hip_ctx_local_bbox_ptr(mp2p_hip_ctx* ctx);
+
+/* ---- Matcher_Point2Plane::implMatchOneLayer (Matcher_Point2Plane.cpp:41-114) with the
+ *      NearestPlaneCapable::nn_search_pt2pl contract (NearestPlaneCapable.h:33-52)
+ *      implemented as: k-NN in radius -> 3x3 covariance -> eigen -> planarity test
+ *      (semantics declared in oracle/mp2p_oracle.c; parity unpinned upstream).  K5. ------ */
+typedef struct
+{
+    double   distanceThreshold; /* Matcher_Point2Plane.cpp:38 (formula) */
+    double   searchRadius;
+    uint32_t knn;                /* 3..16 */
+    uint32_t minimumPlanePoints;
+    double   planeEigenThreshold;
+    int32_t  allowMatchAlreadyMatchedPoints;
+    double   bounding_box_intersection_check_epsilon;
+    float    initial_radius_cells;
+    uint32_t queries_per_wave;
+} mp2p_hip_pt2pl_params;
+
+int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                         const double pose[12], const mp2p_hip_pt2pl_params* prm,
+                         mp2p_hip_mstate* ms, mp2p_hip_pairs* out);
+
+/* ---- optimal_tf_gauss_newton (optimal_tf_gauss_newton.cpp:36-372) as called by
+ *      Solver_GaussNewton::impl_optimal_pose (Solver_GaussNewton.cpp:42-67).
+ *      Kernels K6, K7, K8.  H and g are rebuilt at every inner iteration (TBB-build
+ *      meaning, optimal_tf_gauss_newton.cpp:145-146). ------------------------------------ */
+enum
+{
+    MP2P_HIP_KERNEL_NONE         = 0, /* robust_kernels.h:33-43 */
+    MP2P_HIP_KERNEL_GEMANMCCLURE = 1,
+    MP2P_HIP_KERNEL_CAUCHY       = 2
+};
+
+typedef struct
+{
+    uint32_t maxInnerLoopIterations; /* Solver_GaussNewton 'maxIterations' */
+    double   minDelta;               /* 1e-7 (optimal_tf_gauss_newton.h:46-58) */
+    double   maxCost;                /* 0 */
+    int32_t  kernel;                 /* MP2P_HIP_KERNEL_* */
+    double   kernelParam;            /* robustKernelParam (formula) */
+    double   w_pt2pt, w_pt2pl;       /* PairWeights */
+    int32_t  has_prior;              /* SolverContext::prior */
+    double   prior_mean[12];
+    double   prior_cov_inv[36];
+    /* Pairings::point_weights run-length blocks for pt2pt; 0 blocks = none.  At most 8. */
+    uint32_t n_weight_blocks;
+    uint64_t weight_block_count[8];
+    double   weight_block_w[8];
+} mp2p_hip_gn_params;
+
+typedef struct
+{
+    double   pose[12];    /* OptimalTF_Result::optimalPose */
+    double   H[36], g[6]; /* last assembled normal equations (row-major) */
+    double   cost;        /* errNormSqr of the last assembled iteration */
+    uint32_t iterations;  /* inner iterations executed */
+} mp2p_hip_gn_result;
+
+int mp2p_hip_gn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[12],
+                      const mp2p_hip_gn_params* prm, mp2p_hip_gn_result* out);
+
+/* split form (sharded pairs): begin ; { accumulate ; <all-reduce sums> ; step } x N ; end */
+#define MP2P_HIP_GN_NSUMS 48 /* 17 pt2pt + 28 pt2pl sums, padded */
+int   mp2p_hip_gn_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[12],
+                        const mp2p_hip_gn_params* prm);
+int   mp2p_hip_gn_accumulate(mp2p_hip_ctx* ctx);
+void* mp2p_hip_gn_sums_ptr(mp2p_hip_ctx* ctx); /* device double[MP2P_HIP_GN_NSUMS] */
+int   mp2p_hip_gn_step(mp2p_hip_ctx* ctx);
+int   mp2p_hip_gn_end(mp2p_hip_ctx* ctx, mp2p_hip_gn_result* out);
+
+/* ---- next #1: optimal_tf_horn (optimal_tf_horn.cpp:77-252), point pairs only ---------- */
+int mp2p_hip_horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, double w_pt2pt,
+                        double pose_out[12], int32_t* solved);
+
+/* ---- instrumentation ------------------------------------------------------------------ */
+typedef struct
+{
+    double   ms_nn;      /* K1+K3 (transform + search + claims), last match call */
+    double   ms_compact; /* K4 */
+    double   ms_gn;      /* all inner iterations of the last gn_solve */
+    uint64_t nn_tiles, nn_passes, nn_cells_visited, nn_candidates_tested, nn_points_staged;
+    uint64_t nn_queries, nn_unresolved_after_first_pass;
+} mp2p_hip_stats;
+/* 0 = off; 1 = bracket the kernels with hipEvents (ms_* fields; each call then ends with a
+ * stream synchronisation); 2 = additionally collect the device counters (nn_* fields, slower). */
+int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable);
+int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MP2P_HIP_H */

@@ -1,0 +1,58 @@
+"""Builds libmp2p_hip.so (the C-ABI drop-in, include/mp2p_hip.h) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU; the .so is written in-tree (mp2p_icp_amd/libmp2p_hip.so)
+so that it travels to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC_DIR = os.path.join(HERE, "csrc")
+UNITY = os.path.join(SRC_DIR, "mp2p_hip_all.hip")
+LIB = os.path.join(HERE, "libmp2p_hip.so")
+
+# -ffp-contract=off: the fp32 distance / threshold / transform expressions must round exactly
+# like the reference's x86-64 build (no FMA); see csrc/device_utils.hpp.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wno-unused-result"]
+
+
+def sources():
+    out = [os.path.join(HERE, "..", "include", "mp2p_hip.h")]
+    for f in sorted(os.listdir(SRC_DIR)):
+        if f.endswith((".hip", ".hpp")):
+            out.append(os.path.join(SRC_DIR, f))
+    return out
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in sources())
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library if missing or stale.  Returns the path of the .so."""
+    if not force and not needs_build():
+        return LIB
+    cc = hipcc_path()
+    if not os.path.exists(cc):
+        raise RuntimeError("hipcc not found: cannot build libmp2p_hip.so")
+    cmd = [cc] + FLAGS + [UNITY, "-o", LIB + ".tmp"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stderr[-8000:])
+    os.replace(LIB + ".tmp", LIB)
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

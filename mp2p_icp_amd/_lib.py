@@ -1,0 +1,178 @@
+"""ctypes binding of libmp2p_hip.so (include/mp2p_hip.h).
+
+The product path is the HIP library; there is no CPU fallback.  Loading fails loudly when the
+library is missing (and cannot be built), and every compute call fails loudly without a GPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+PAIR_PT2PT = np.dtype(
+    [("globalIdx", "<u4"), ("localIdx", "<u4"), ("global", "<f4", (3,)), ("local", "<f4", (3,)),
+     ("errorSquareAfterTransformation", "<f4")])
+PAIR_PT2PL = np.dtype(
+    [("plane", "<f8", (4,)), ("centroid", "<f8", (3,)), ("pt_local", "<f4", (3,)), ("_pad", "<f4")])
+assert PAIR_PT2PT.itemsize == 36 and PAIR_PT2PL.itemsize == 72
+
+OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+KERNEL_NONE, KERNEL_GEMANMCCLURE, KERNEL_CAUCHY = 0, 1, 2
+GN_NSUMS = 48
+
+
+class MapParams(C.Structure):
+    _fields_ = [("cell_size", C.c_float), ("target_per_cell", C.c_float),
+                ("max_levels", C.c_uint32)]
+
+
+class MapInfo(C.Structure):
+    _fields_ = [("n_points", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
+                ("cell_size", C.c_float), ("n_levels", C.c_uint32), ("n_cells_total", C.c_uint64),
+                ("n_cells_level0", C.c_uint64), ("hash_capacity", C.c_uint64),
+                ("device_bytes", C.c_uint64), ("build_ms", C.c_double)]
+
+
+class Pt2PtParams(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("thresholdAngularDeg", C.c_double),
+                ("pairingsPerPoint", C.c_uint32),
+                ("allowMatchAlreadyMatchedPoints", C.c_int32),
+                ("allowMatchAlreadyMatchedGlobalPoints", C.c_int32),
+                ("bounding_box_intersection_check_epsilon", C.c_double),
+                ("local_index_offset", C.c_uint64), ("initial_radius_cells", C.c_float),
+                ("queries_per_wave", C.c_uint32)]
+
+
+class Pt2PlParams(C.Structure):
+    _fields_ = [("distanceThreshold", C.c_double), ("searchRadius", C.c_double),
+                ("knn", C.c_uint32), ("minimumPlanePoints", C.c_uint32),
+                ("planeEigenThreshold", C.c_double),
+                ("allowMatchAlreadyMatchedPoints", C.c_int32),
+                ("bounding_box_intersection_check_epsilon", C.c_double),
+                ("initial_radius_cells", C.c_float), ("queries_per_wave", C.c_uint32)]
+
+
+class GNParams(C.Structure):
+    _fields_ = [("maxInnerLoopIterations", C.c_uint32), ("minDelta", C.c_double),
+                ("maxCost", C.c_double), ("kernel", C.c_int32), ("kernelParam", C.c_double),
+                ("w_pt2pt", C.c_double), ("w_pt2pl", C.c_double), ("has_prior", C.c_int32),
+                ("prior_mean", C.c_double * 12), ("prior_cov_inv", C.c_double * 36),
+                ("n_weight_blocks", C.c_uint32), ("weight_block_count", C.c_uint64 * 8),
+                ("weight_block_w", C.c_double * 8)]
+
+
+class GNResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 12), ("H", C.c_double * 36), ("g", C.c_double * 6),
+                ("cost", C.c_double), ("iterations", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ms_nn", C.c_double), ("ms_compact", C.c_double), ("ms_gn", C.c_double),
+                ("nn_tiles", C.c_uint64), ("nn_passes", C.c_uint64),
+                ("nn_cells_visited", C.c_uint64), ("nn_candidates_tested", C.c_uint64),
+                ("nn_points_staged", C.c_uint64), ("nn_queries", C.c_uint64),
+                ("nn_unresolved_after_first_pass", C.c_uint64)]
+
+
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_u64p = C.POINTER(C.c_uint64)
+
+# name -> (restype, argtypes).  tests/test_abi.py checks this table against include/mp2p_hip.h.
+SIGNATURES = {
+    "mp2p_hip_abi_version": (C.c_int, []),
+    "mp2p_hip_device_count": (C.c_int, []),
+    "mp2p_hip_ctx_create": (C.c_int, [C.c_int, _P, _PP]),
+    "mp2p_hip_ctx_destroy": (None, [_P]),
+    "mp2p_hip_last_error": (C.c_char_p, [_P]),
+    "mp2p_hip_sync": (C.c_int, [_P]),
+    "mp2p_hip_ctx_stream": (_P, [_P]),
+    "mp2p_hip_map_upload": (C.c_int, [_P, _fp, _fp, _fp, C.c_size_t, C.POINTER(MapParams), _PP]),
+    "mp2p_hip_map_upload_device": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(MapParams), _PP]),
+    "mp2p_hip_map_free": (None, [_P, _P]),
+    "mp2p_hip_map_get_info": (C.c_int, [_P, _P, C.POINTER(MapInfo)]),
+    "mp2p_hip_cloud_upload": (C.c_int, [_P, _fp, _fp, _fp, C.c_size_t, _PP]),
+    "mp2p_hip_cloud_upload_device": (C.c_int, [_P, _P, _P, _P, C.c_size_t, _PP]),
+    "mp2p_hip_cloud_free": (None, [_P, _P]),
+    "mp2p_hip_cloud_size": (C.c_size_t, [_P]),
+    "mp2p_hip_mstate_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, _PP]),
+    "mp2p_hip_mstate_reset": (C.c_int, [_P, _P]),
+    "mp2p_hip_mstate_free": (None, [_P, _P]),
+    "mp2p_hip_mstate_download": (C.c_int, [_P, _P, _u8p, _u8p]),
+    "mp2p_hip_mstate_upload": (C.c_int, [_P, _P, _u8p, _u8p]),
+    "mp2p_hip_pairs_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, _PP]),
+    "mp2p_hip_pairs_free": (None, [_P, _P]),
+    "mp2p_hip_pairs_clear": (C.c_int, [_P, _P]),
+    "mp2p_hip_pairs_counts": (C.c_int, [_P, _P, _u64p, _u64p, _u64p]),
+    "mp2p_hip_pairs_download_pt2pt": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mp2p_hip_pairs_download_pt2pl": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint32), C.c_size_t,
+                                                C.POINTER(C.c_size_t)]),
+    "mp2p_hip_pairs_upload": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_size_t]),
+    "mp2p_hip_match_pt2pt": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PtParams), _P, _P]),
+    "mp2p_hip_match_pt2pt_phase1": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PtParams), _P]),
+    "mp2p_hip_match_pt2pt_phase2": (C.c_int, [_P, _P, _P, C.POINTER(Pt2PtParams), _P, _P]),
+    "mp2p_hip_map_claims_ptr": (_P, [_P]),
+    "mp2p_hip_map_claims_count": (C.c_size_t, [_P]),
+    "mp2p_hip_ctx_local_bbox_ptr": (_P, [_P]),
+    "mp2p_hip_match_pt2pl": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PlParams), _P, _P]),
+    "mp2p_hip_gn_solve": (C.c_int, [_P, _P, _dp, C.POINTER(GNParams), C.POINTER(GNResult)]),
+    "mp2p_hip_gn_begin": (C.c_int, [_P, _P, _dp, C.POINTER(GNParams)]),
+    "mp2p_hip_gn_accumulate": (C.c_int, [_P]),
+    "mp2p_hip_gn_sums_ptr": (_P, [_P]),
+    "mp2p_hip_gn_step": (C.c_int, [_P]),
+    "mp2p_hip_gn_end": (C.c_int, [_P, C.POINTER(GNResult)]),
+    "mp2p_hip_horn_solve": (C.c_int, [_P, _P, C.c_double, _dp, C.POINTER(C.c_int32)]),
+    "mp2p_hip_set_profiling": (C.c_int, [_P, C.c_int]),
+    "mp2p_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+}
+
+
+class Mp2pHipError(RuntimeError):
+    """Raised for every non-zero return code of libmp2p_hip (the adapter rethrows these as
+    std::runtime_error, like the reference's THROW_EXCEPTION / ASSERT_)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libmp2p_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """dlopen the HIP library (building it first if the sources are newer and hipcc exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.needs_build():
+        try:
+            _build.build()
+        except Exception as e:  # stale or missing and cannot rebuild
+            if not os.path.exists(path):
+                raise ImportError(
+                    f"libmp2p_hip.so is missing and could not be built ({e}); "
+                    "mp2p_icp_amd has no CPU fallback") from e
+    L = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError = symbol missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if L.mp2p_hip_abi_version() != 1:
+        raise ImportError("libmp2p_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = load().mp2p_hip_last_error(ctx)
+        raise Mp2pHipError(rc, msg.decode() if msg else "?")

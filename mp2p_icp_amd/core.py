@@ -1,0 +1,268 @@
+"""Thin object wrappers over the C ABI handles (context, map index, local cloud, MatchState,
+device-resident Pairings).  No numerics here: everything is computed by libmp2p_hip.so."""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _pose(T):
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(-1)
+    if T.size != 12:
+        raise ValueError("pose must be 12 doubles: R row-major (9) + t (3)")
+    return T
+
+
+class Context:
+    """One HIP stream on one device.  `stream` may be a raw hipStream_t (int), e.g.
+    torch.cuda.current_stream().cuda_stream, to share ordering with torch.distributed."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.mp2p_hip_ctx_create(int(device), C.c_void_p(stream) if stream else None,
+                                          C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self._fin = weakref.finalize(self, self._L.mp2p_hip_ctx_destroy, h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        check(self._L.mp2p_hip_sync(self._h), self._h)
+
+    def set_profiling(self, on):
+        check(self._L.mp2p_hip_set_profiling(self._h, 1 if on else 0), self._h)
+
+    def stats(self):
+        s = _lib.Stats()
+        check(self._L.mp2p_hip_get_stats(self._h, C.byref(s)), self._h)
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def local_bbox_ptr(self):
+        return self._L.mp2p_hip_ctx_local_bbox_ptr(self._h)
+
+    def gn_sums_ptr(self):
+        return self._L.mp2p_hip_gn_sums_ptr(self._h)
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class GlobalMap:
+    """NN index of one global point layer (replaces the layer's NearestNeighborsCapable)."""
+
+    def __init__(self, ctx, x, y, z, cell_size=0.0, target_per_cell=0.0, max_levels=0,
+                 device_ptrs=False):
+        self.ctx = ctx
+        L = ctx._L
+        prm = _lib.MapParams(cell_size, target_per_cell, max_levels)
+        h = C.c_void_p()
+        if device_ptrs:
+            n = int(device_ptrs)
+            check(L.mp2p_hip_map_upload_device(ctx.handle, x, y, z, n, C.byref(prm), C.byref(h)),
+                  ctx.handle)
+            self.n = n
+        else:
+            x, y, z = _f32(x), _f32(y), _f32(z)
+            assert x.size == y.size == z.size
+            check(L.mp2p_hip_map_upload(ctx.handle, _fp(x), _fp(y), _fp(z), x.size, C.byref(prm),
+                                        C.byref(h)), ctx.handle)
+            self.n = x.size
+        self._h = h
+        self._fin = weakref.finalize(self, L.mp2p_hip_map_free, ctx.handle, h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        i = _lib.MapInfo()
+        check(self.ctx._L.mp2p_hip_map_get_info(self.ctx.handle, self._h, C.byref(i)),
+              self.ctx.handle)
+        d = {k: getattr(i, k) for k, _ in i._fields_}
+        d["bbox_min"] = list(i.bbox_min)
+        d["bbox_max"] = list(i.bbox_max)
+        return d
+
+    def claims_ptr(self):
+        return self.ctx._L.mp2p_hip_map_claims_ptr(self._h)
+
+
+class LocalCloud:
+    def __init__(self, ctx, x, y, z, device_ptrs=False):
+        self.ctx = ctx
+        L = ctx._L
+        h = C.c_void_p()
+        if device_ptrs:
+            n = int(device_ptrs)
+            check(L.mp2p_hip_cloud_upload_device(ctx.handle, x, y, z, n, C.byref(h)), ctx.handle)
+            self.n = n
+        else:
+            x, y, z = _f32(x), _f32(y), _f32(z)
+            assert x.size == y.size == z.size
+            check(L.mp2p_hip_cloud_upload(ctx.handle, _fp(x), _fp(y), _fp(z), x.size, C.byref(h)),
+                  ctx.handle)
+            self.n = x.size
+        self._h = h
+        self._fin = weakref.finalize(self, L.mp2p_hip_cloud_free, ctx.handle, h)
+
+    @property
+    def handle(self):
+        return self._h
+
+
+class DeviceMatchState:
+    def __init__(self, ctx, n_global, n_local):
+        self.ctx, self.n_global, self.n_local = ctx, n_global, n_local
+        h = C.c_void_p()
+        check(ctx._L.mp2p_hip_mstate_create(ctx.handle, n_global, n_local, C.byref(h)), ctx.handle)
+        self._h = h
+        self._fin = weakref.finalize(self, ctx._L.mp2p_hip_mstate_free, ctx.handle, h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def reset(self):
+        check(self.ctx._L.mp2p_hip_mstate_reset(self.ctx.handle, self._h), self.ctx.handle)
+
+    def download(self):
+        g = np.zeros(max(1, self.n_global), np.uint8)
+        l = np.zeros(max(1, self.n_local), np.uint8)
+        u8 = C.POINTER(C.c_uint8)
+        check(self.ctx._L.mp2p_hip_mstate_download(self.ctx.handle, self._h, g.ctypes.data_as(u8),
+                                                   l.ctypes.data_as(u8)), self.ctx.handle)
+        return g[:self.n_global], l[:self.n_local]
+
+    def upload(self, global_taken=None, local_taken=None):
+        u8 = C.POINTER(C.c_uint8)
+        g = np.ascontiguousarray(global_taken, np.uint8) if global_taken is not None else None
+        l = np.ascontiguousarray(local_taken, np.uint8) if local_taken is not None else None
+        check(self.ctx._L.mp2p_hip_mstate_upload(
+            self.ctx.handle, self._h, g.ctypes.data_as(u8) if g is not None else None,
+            l.ctypes.data_as(u8) if l is not None else None), self.ctx.handle)
+
+
+class DevicePairs:
+    """Device-resident mp2p_icp::Pairings (pt2pt + pt2pl lists, potential_pairings)."""
+
+    def __init__(self, ctx, cap_pt2pt, cap_pt2pl=0):
+        self.ctx, self.cap_pt2pt, self.cap_pt2pl = ctx, int(cap_pt2pt), int(cap_pt2pl)
+        h = C.c_void_p()
+        check(ctx._L.mp2p_hip_pairs_create(ctx.handle, self.cap_pt2pt, self.cap_pt2pl, C.byref(h)),
+              ctx.handle)
+        self._h = h
+        self._fin = weakref.finalize(self, ctx._L.mp2p_hip_pairs_free, ctx.handle, h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def clear(self):
+        check(self.ctx._L.mp2p_hip_pairs_clear(self.ctx.handle, self._h), self.ctx.handle)
+
+    def counts(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(self.ctx._L.mp2p_hip_pairs_counts(self.ctx.handle, self._h, C.byref(a), C.byref(b),
+                                                C.byref(c)), self.ctx.handle)
+        return a.value, b.value, c.value
+
+    def download_pt2pt(self):
+        n, _, _ = self.counts()
+        out = np.zeros(max(1, n), _lib.PAIR_PT2PT)
+        got = C.c_size_t()
+        check(self.ctx._L.mp2p_hip_pairs_download_pt2pt(self.ctx.handle, self._h, out.ctypes.data,
+                                                        out.size, C.byref(got)), self.ctx.handle)
+        return out[:got.value]
+
+    def download_pt2pl(self):
+        _, n, _ = self.counts()
+        out = np.zeros(max(1, n), _lib.PAIR_PT2PL)
+        idx = np.zeros(max(1, n), np.uint32)
+        got = C.c_size_t()
+        check(self.ctx._L.mp2p_hip_pairs_download_pt2pl(
+            self.ctx.handle, self._h, out.ctypes.data, idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+            out.size, C.byref(got)), self.ctx.handle)
+        return out[:got.value], idx[:got.value]
+
+    def upload(self, pt2pt=None, pt2pl=None):
+        a = np.ascontiguousarray(pt2pt, _lib.PAIR_PT2PT) if pt2pt is not None else np.zeros(0, _lib.PAIR_PT2PT)
+        b = np.ascontiguousarray(pt2pl, _lib.PAIR_PT2PL) if pt2pl is not None else np.zeros(0, _lib.PAIR_PT2PL)
+        check(self.ctx._L.mp2p_hip_pairs_upload(self.ctx.handle, self._h,
+                                                a.ctypes.data if a.size else None, a.size,
+                                                b.ctypes.data if b.size else None, b.size),
+              self.ctx.handle)
+
+
+def match_pt2pt(ctx, gmap, cloud, pose, prm, mstate, pairs):
+    T = _pose(pose)
+    check(ctx._L.mp2p_hip_match_pt2pt(ctx.handle, gmap.handle, cloud.handle,
+                                      T.ctypes.data_as(C.POINTER(C.c_double)), C.byref(prm),
+                                      mstate.handle if mstate is not None else None,
+                                      pairs.handle), ctx.handle)
+
+
+def match_pt2pt_phase1(ctx, gmap, cloud, pose, prm, mstate):
+    T = _pose(pose)
+    check(ctx._L.mp2p_hip_match_pt2pt_phase1(ctx.handle, gmap.handle, cloud.handle,
+                                             T.ctypes.data_as(C.POINTER(C.c_double)),
+                                             C.byref(prm),
+                                             mstate.handle if mstate is not None else None),
+          ctx.handle)
+
+
+def match_pt2pt_phase2(ctx, gmap, cloud, prm, mstate, pairs):
+    check(ctx._L.mp2p_hip_match_pt2pt_phase2(ctx.handle, gmap.handle, cloud.handle, C.byref(prm),
+                                             mstate.handle if mstate is not None else None,
+                                             pairs.handle), ctx.handle)
+
+
+def match_pt2pl(ctx, gmap, cloud, pose, prm, mstate, pairs):
+    T = _pose(pose)
+    check(ctx._L.mp2p_hip_match_pt2pl(ctx.handle, gmap.handle, cloud.handle,
+                                      T.ctypes.data_as(C.POINTER(C.c_double)), C.byref(prm),
+                                      mstate.handle if mstate is not None else None,
+                                      pairs.handle), ctx.handle)
+
+
+def gn_solve(ctx, pairs, pose0, prm):
+    T = _pose(pose0)
+    res = _lib.GNResult()
+    check(ctx._L.mp2p_hip_gn_solve(ctx.handle, pairs.handle,
+                                   T.ctypes.data_as(C.POINTER(C.c_double)), C.byref(prm),
+                                   C.byref(res)), ctx.handle)
+    return res
+
+
+def gn_result_to_dict(res):
+    return dict(pose=np.array(res.pose), H=np.array(res.H).reshape(6, 6), g=np.array(res.g),
+                cost=res.cost, iterations=res.iterations)
+
+
+def horn_solve(ctx, pairs, w_pt2pt=1.0):
+    T = np.zeros(12)
+    ok = C.c_int32(0)
+    check(ctx._L.mp2p_hip_horn_solve(ctx.handle, pairs.handle, float(w_pt2pt),
+                                     T.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ok)),
+          ctx.handle)
+    return T, bool(ok.value)

@@ -1,0 +1,474 @@
+// api.hip -- extern "C" entry points of libmp2p_hip.so (see include/mp2p_hip.h).
+#include <mutex>
+
+#include "device_utils.hpp"
+
+namespace mp2p
+{
+static std::mutex  g_err_mu;
+static std::string g_err;
+
+void set_global_err(const char* fmt, ...)
+{
+    char    buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_err = buf;
+}
+
+int set_err(mp2p_hip_ctx* ctx, int code, const char* fmt, ...)
+{
+    char    buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+    {
+        std::lock_guard<std::mutex> lk(g_err_mu);
+        g_err = buf;
+    }
+    return code;
+}
+
+static int upload3(mp2p_hip_ctx* ctx, const float* x, const float* y, const float* z, size_t n,
+                   DevBuf<float>& dx, DevBuf<float>& dy, DevBuf<float>& dz)
+{
+    MP2P_TRY_HIP(ctx, dx.alloc(n ? n : 1));
+    MP2P_TRY_HIP(ctx, dy.alloc(n ? n : 1));
+    MP2P_TRY_HIP(ctx, dz.alloc(n ? n : 1));
+    if (n)
+    {
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(dx.p, x, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(dy.p, y, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(dz.p, z, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MP2P_HIP_OK;
+}
+}  // namespace mp2p
+
+using namespace mp2p;
+
+extern "C" {
+
+int mp2p_hip_abi_version(void) { return MP2P_HIP_ABI_VERSION; }
+
+int mp2p_hip_device_count(void)
+{
+    int        n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char* mp2p_hip_last_error(const mp2p_hip_ctx* ctx)
+{
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    static thread_local std::string copy;
+    copy = g_err;
+    return copy.c_str();
+}
+
+int mp2p_hip_ctx_create(int device_id, void* hip_stream, mp2p_hip_ctx** out)
+{
+    if (!out) return MP2P_HIP_ERR_INVALID;
+    *out = nullptr;
+    const int n = mp2p_hip_device_count();
+    if (n <= 0)
+        return set_err(nullptr, MP2P_HIP_ERR_NO_DEVICE,
+                       "no HIP device visible: libmp2p_hip has no CPU fallback");
+    if (device_id < 0 || device_id >= n)
+        return set_err(nullptr, MP2P_HIP_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, n);
+    hipError_t e = hipSetDevice(device_id);
+    if (e != hipSuccess)
+        return set_err(nullptr, MP2P_HIP_ERR_HIP, "hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
+    auto* ctx   = new mp2p_hip_ctx();
+    ctx->device = device_id;
+    if (hip_stream)
+        ctx->stream = (hipStream_t)hip_stream, ctx->own_stream = false;
+    else
+    {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+        {
+            delete ctx;
+            return set_err(nullptr, MP2P_HIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        ctx->own_stream = true;
+    }
+    for (auto& ev : ctx->ev)
+    {
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess)
+        {
+            delete ctx;
+            return set_err(nullptr, MP2P_HIP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+    }
+    *out = ctx;
+    return MP2P_HIP_OK;
+}
+
+void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->nn_spos.release(), ctx->nn_d2.release(), ctx->tile_bbox.release();
+    ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release();
+    ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release();
+    ctx->aos_stage.release(), ctx->pl_slots.release();
+    for (auto& ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int mp2p_hip_sync(mp2p_hip_ctx* ctx)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+void* mp2p_hip_ctx_stream(mp2p_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ---- map ------------------------------------------------------------------------------------
+int mp2p_hip_map_upload(mp2p_hip_ctx* ctx, const float* x, const float* y, const float* z,
+                        size_t n, const mp2p_hip_map_params* prm, mp2p_hip_map** out)
+{
+    if (!ctx || !out) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, n == 0 || (x && y && z), "null coordinate buffer");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<float> dx, dy, dz;
+    int           rc = upload3(ctx, x, y, z, n, dx, dy, dz);
+    if (!rc) rc = mp2p_hip_map_upload_device(ctx, dx.p, dy.p, dz.p, n, prm, out);
+    dx.release(), dy.release(), dz.release();
+    return rc;
+}
+
+int mp2p_hip_map_upload_device(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y,
+                               const float* d_z, size_t n, const mp2p_hip_map_params* prm,
+                               mp2p_hip_map** out)
+{
+    if (!ctx || !out) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    auto* m  = new mp2p_hip_map();
+    int   rc = build_map(ctx, d_x, d_y, d_z, n, prm, m);
+    if (rc)
+    {
+        mp2p_hip_map_free(ctx, m);
+        return rc;
+    }
+    *out = m;
+    return MP2P_HIP_OK;
+}
+
+void mp2p_hip_map_free(mp2p_hip_ctx* ctx, mp2p_hip_map* map)
+{
+    if (!map) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    map->pts.release(), map->table.release(), map->claims.release();
+    delete map;
+}
+
+int mp2p_hip_map_get_info(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, mp2p_hip_map_info* out)
+{
+    if (!ctx || !map || !out) return MP2P_HIP_ERR_INVALID;
+    *out = map->info;
+    return MP2P_HIP_OK;
+}
+
+void*  mp2p_hip_map_claims_ptr(const mp2p_hip_map* map) { return map ? (void*)map->claims.p : nullptr; }
+size_t mp2p_hip_map_claims_count(const mp2p_hip_map* map) { return map ? map->n : 0; }
+
+// ---- cloud ----------------------------------------------------------------------------------
+int mp2p_hip_cloud_upload(mp2p_hip_ctx* ctx, const float* x, const float* y, const float* z,
+                          size_t n, mp2p_hip_cloud** out)
+{
+    if (!ctx || !out) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, n == 0 || (x && y && z), "null coordinate buffer");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<float> dx, dy, dz;
+    int           rc = upload3(ctx, x, y, z, n, dx, dy, dz);
+    if (!rc) rc = mp2p_hip_cloud_upload_device(ctx, dx.p, dy.p, dz.p, n, out);
+    dx.release(), dy.release(), dz.release();
+    return rc;
+}
+
+int mp2p_hip_cloud_upload_device(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y,
+                                 const float* d_z, size_t n, mp2p_hip_cloud** out)
+{
+    if (!ctx || !out) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    auto* c  = new mp2p_hip_cloud();
+    int   rc = build_cloud(ctx, d_x, d_y, d_z, n, c);
+    if (rc)
+    {
+        mp2p_hip_cloud_free(ctx, c);
+        return rc;
+    }
+    *out = c;
+    return MP2P_HIP_OK;
+}
+
+void mp2p_hip_cloud_free(mp2p_hip_ctx* ctx, mp2p_hip_cloud* c)
+{
+    if (!c) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    c->sorted.release(), c->x.release(), c->y.release(), c->z.release();
+    delete c;
+}
+
+size_t mp2p_hip_cloud_size(const mp2p_hip_cloud* c) { return c ? c->n : 0; }
+
+// ---- MatchState -----------------------------------------------------------------------------
+int mp2p_hip_mstate_create(mp2p_hip_ctx* ctx, size_t n_global, size_t n_local,
+                           mp2p_hip_mstate** out)
+{
+    if (!ctx || !out) return MP2P_HIP_ERR_INVALID;
+    auto* ms = new mp2p_hip_mstate();
+    ms->ctx  = ctx;
+    MP2P_TRY_HIP(ctx, ms->global_taken.alloc(n_global ? n_global : 1));
+    MP2P_TRY_HIP(ctx, ms->local_taken.alloc(n_local ? n_local : 1));
+    ms->global_taken.n = n_global ? n_global : 1;
+    ms->local_taken.n  = n_local ? n_local : 1;
+    *out               = ms;
+    return mp2p_hip_mstate_reset(ctx, ms);
+}
+
+int mp2p_hip_mstate_reset(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms)
+{
+    if (!ctx || !ms) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipMemsetAsync(ms->global_taken.p, 0, ms->global_taken.n, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemsetAsync(ms->local_taken.p, 0, ms->local_taken.n, ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+void mp2p_hip_mstate_free(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms)
+{
+    if (!ms) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    ms->global_taken.release(), ms->local_taken.release();
+    delete ms;
+}
+
+int mp2p_hip_mstate_download(mp2p_hip_ctx* ctx, const mp2p_hip_mstate* ms, uint8_t* global_taken,
+                             uint8_t* local_taken)
+{
+    if (!ctx || !ms) return MP2P_HIP_ERR_INVALID;
+    if (global_taken)
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(global_taken, ms->global_taken.p, ms->global_taken.n,
+                                         hipMemcpyDeviceToHost, ctx->stream));
+    if (local_taken)
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(local_taken, ms->local_taken.p, ms->local_taken.n,
+                                         hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_mstate_upload(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms, const uint8_t* global_taken,
+                           const uint8_t* local_taken)
+{
+    if (!ctx || !ms) return MP2P_HIP_ERR_INVALID;
+    if (global_taken)
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(ms->global_taken.p, global_taken, ms->global_taken.n,
+                                         hipMemcpyHostToDevice, ctx->stream));
+    if (local_taken)
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(ms->local_taken.p, local_taken, ms->local_taken.n,
+                                         hipMemcpyHostToDevice, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+// ---- Matcher_Points_DistanceThreshold ----------------------------------------------------------
+static int check_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                       const mp2p_hip_pt2pt_params* prm, const mp2p_hip_mstate* ms)
+{
+    MP2P_REQUIRE(ctx, map && cloud && prm, "null argument");
+    MP2P_REQUIRE(ctx, map->ctx == ctx && cloud->ctx == ctx, "handle belongs to another context");
+    // ASSERT_(pairingsPerPoint >= 1); ASSERT_GT_(threshold, .0); ASSERT_GE_(thresholdAngularDeg, .0)
+    // (Matcher_Points_DistanceThreshold.cpp:57-59)
+    MP2P_REQUIRE(ctx, prm->pairingsPerPoint >= 1, "pairingsPerPoint must be >= 1");
+    MP2P_REQUIRE(ctx, prm->threshold > 0.0, "threshold must be > 0");
+    MP2P_REQUIRE(ctx, prm->thresholdAngularDeg >= 0.0, "thresholdAngularDeg must be >= 0");
+    MP2P_REQUIRE(ctx, prm->pairingsPerPoint == 1, "pairingsPerPoint > 1 is not implemented yet");
+    MP2P_REQUIRE(ctx, prm->local_index_offset + cloud->n <= 0xFFFFFFFFull,
+                 "whole-layer local index must fit 32 bits");
+    if (ms)
+    {
+        MP2P_REQUIRE(ctx, ms->global_taken.n >= std::max<size_t>(map->n, 1), "MatchState too small (global)");
+        MP2P_REQUIRE(ctx, ms->local_taken.n >= std::max<size_t>(cloud->n, 1), "MatchState too small (local)");
+    }
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_match_pt2pt_phase1(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
+                                const mp2p_hip_cloud* cloud, const double pose[12],
+                                const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    int rc = check_pt2pt(ctx, map, cloud, prm, ms);
+    if (rc) return rc;
+    MP2P_REQUIRE(ctx, pose, "null pose");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (map->n == 0 || cloud->n == 0) return MP2P_HIP_OK;  // :67
+    return launch_nn_pt2pt(ctx, map, cloud, pose, prm, ms);
+}
+
+int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
+                                const mp2p_hip_cloud* cloud, const mp2p_hip_pt2pt_params* prm,
+                                mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    int rc = check_pt2pt(ctx, map, cloud, prm, ms);
+    if (rc) return rc;
+    MP2P_REQUIRE(ctx, out && out->ctx == ctx, "bad Pairings handle");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (map->n == 0 || cloud->n == 0)  // potential_pairings is added BEFORE the early-out (:64-67)
+        return launch_add_potential(ctx, out, (unsigned long long)cloud->n * prm->pairingsPerPoint);
+    rc = launch_compact_pt2pt(ctx, map, cloud, prm, ms, out);
+    if (!rc && ctx->profiling)
+    {
+        ctx->pending_match = ctx->profiling;  // read back lazily in mp2p_hip_get_stats
+        ctx->pending_map_n = map->n;
+        ctx->stats.nn_queries = cloud->n;
+    }
+    return rc;
+}
+
+int mp2p_hip_match_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                         const double pose[12], const mp2p_hip_pt2pt_params* prm,
+                         mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
+{
+    int rc = mp2p_hip_match_pt2pt_phase1(ctx, map, cloud, pose, prm, ms);
+    if (rc) return rc;
+    rc = mp2p_hip_match_pt2pt_phase2(ctx, map, cloud, prm, ms, out);
+    if (rc) return rc;
+    return MP2P_HIP_OK;
+}
+
+void* mp2p_hip_ctx_local_bbox_ptr(mp2p_hip_ctx* ctx)
+{
+    if (!ctx) return nullptr;
+    if (!ctx->local_bbox.p && ctx->local_bbox.ensure(6) != hipSuccess) return nullptr;
+    return ctx->local_bbox.p;
+}
+
+// ---- Matcher_Point2Plane -----------------------------------------------------------------------
+int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                         const double pose[12], const mp2p_hip_pt2pl_params* prm,
+                         mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, map && cloud && prm && pose && out, "null argument");
+    MP2P_REQUIRE(ctx, map->ctx == ctx && cloud->ctx == ctx && out->ctx == ctx,
+                 "handle belongs to another context");
+    MP2P_REQUIRE(ctx, prm->distanceThreshold > 0.0, "distanceThreshold must be > 0");
+    MP2P_REQUIRE(ctx, prm->searchRadius > 0.0, "searchRadius must be > 0");
+    MP2P_REQUIRE(ctx, prm->knn >= 3 && prm->knn <= 16, "knn must be in [3,16]");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (map->n == 0 || cloud->n == 0)  // Matcher_Point2Plane.cpp:54-57
+        return launch_add_potential(ctx, out, (unsigned long long)cloud->n);
+    return launch_match_pt2pl(ctx, map, cloud, pose, prm, ms, out);
+}
+
+// ---- Solver_GaussNewton ------------------------------------------------------------------------
+int mp2p_hip_gn_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[12],
+                      const mp2p_hip_gn_params* prm)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return gn_begin(ctx, pairs, pose0, prm);
+}
+int   mp2p_hip_gn_accumulate(mp2p_hip_ctx* ctx) { return ctx ? gn_accumulate(ctx) : MP2P_HIP_ERR_INVALID; }
+void* mp2p_hip_gn_sums_ptr(mp2p_hip_ctx* ctx) { return ctx ? (void*)ctx->gn_sums.p : nullptr; }
+int   mp2p_hip_gn_step(mp2p_hip_ctx* ctx) { return ctx ? gn_step(ctx) : MP2P_HIP_ERR_INVALID; }
+int   mp2p_hip_gn_end(mp2p_hip_ctx* ctx, mp2p_hip_gn_result* out) { return ctx ? gn_end(ctx, out) : MP2P_HIP_ERR_INVALID; }
+
+int mp2p_hip_gn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[12],
+                      const mp2p_hip_gn_params* prm, mp2p_hip_gn_result* out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = gn_begin(ctx, pairs, pose0, prm);
+    if (rc) return rc;
+    // the whole inner loop is enqueued without a host round trip; iterations after the
+    // convergence test (:365) or the cost test (:344) has fired are no-ops on the device
+    for (uint32_t it = 0; it < prm->maxInnerLoopIterations; it++)
+    {
+        rc = gn_accumulate(ctx);
+        if (rc) return rc;
+        rc = gn_step(ctx);
+        if (rc) return rc;
+    }
+    rc = gn_end(ctx, out);
+    if (rc) return rc;
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, double w_pt2pt,
+                        double pose_out[12], int32_t* solved)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, pairs && pose_out && solved, "null argument");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return horn_solve(ctx, pairs, w_pt2pt, pose_out, solved);
+}
+
+// ---- instrumentation ---------------------------------------------------------------------------
+int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    ctx->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
+{
+    if (!ctx || !out) return MP2P_HIP_ERR_INVALID;
+    if (ctx->pending_match || ctx->pending_gn) MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pending_match)
+    {
+        float ms_nn = 0, ms_cp = 0;
+        MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_nn, ctx->ev[0], ctx->ev[1]));
+        MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_cp, ctx->ev[2], ctx->ev[3]));
+        ctx->stats.ms_nn = ms_nn, ctx->stats.ms_compact = ms_cp;
+        if (ctx->pending_match >= 2)
+        {
+            unsigned long long c[8];
+            MP2P_TRY_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+            ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1];
+            ctx->stats.nn_cells_visited = c[2], ctx->stats.nn_candidates_tested = c[3];
+            ctx->stats.nn_unresolved_after_first_pass = c[4];
+            std::vector<unsigned char> t(ctx->pending_map_n);
+            MP2P_TRY_HIP(ctx, hipMemcpy(t.data(), ctx->pl_slots.p, t.size(), hipMemcpyDeviceToHost));
+            uint64_t k = 0;
+            for (unsigned char b : t) k += b;
+            ctx->stats.nn_points_staged = k;
+        }
+        ctx->pending_match = 0;
+    }
+    if (ctx->pending_gn)
+    {
+        float ms = 0;
+        MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+        ctx->stats.ms_gn = ms;
+        ctx->pending_gn = 0;
+    }
+    *out = ctx->stats;
+    return MP2P_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+// common.hpp -- internal declarations shared by the HIP translation units of libmp2p_hip.so
+// (gfx950 only; no CUDA shims, no host fallback).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mp2p_hip.h"
+
+namespace mp2p
+{
+constexpr uint32_t NONE_U32 = 0xFFFFFFFFu;
+
+// ---------------------------------------------------------------------------------------
+// device cell hash entry: one occupied voxel of one grid level
+// ---------------------------------------------------------------------------------------
+struct Cell
+{
+    unsigned long long key;  // level<<60 | cz<<40 | cy<<20 | cx ; ~0 = empty
+    uint32_t           start, end;  // range in the Morton-sorted point array
+};
+constexpr unsigned long long CELL_EMPTY = ~0ull;
+
+struct GridView
+{
+    const float4* pts;  // sorted points {x,y,z,bits(original index)}
+    uint32_t      n;
+    const Cell*   table;
+    uint64_t      mask;            // capacity-1
+    float         ox, oy, oz;      // grid origin (= bbox min)
+    float         hf, inv_hf;      // FINE cell edge (level "-shift0")
+    uint32_t      shift0;          // fine -> level-0 shift
+    uint32_t      n_levels;        // level j uses shift0+j
+    float         bbmin[3], bbmax[3];
+    float         slack;           // fp32 rounding slack for conservative geometric tests [m]
+};
+
+// ---------------------------------------------------------------------------------------
+// host-side objects behind the opaque C handles
+// ---------------------------------------------------------------------------------------
+template <class T>
+struct DevBuf
+{
+    T*     p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count)
+    {
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        else p = nullptr;
+        return e;
+    }
+    hipError_t ensure(size_t count)
+    {
+        if (count <= n) return hipSuccess;
+        return alloc(count + count / 8);
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+struct GnState
+{
+    const mp2p_hip_pairs* pairs = nullptr;
+    mp2p_hip_gn_params    prm{};
+    bool                  active = false;
+};
+
+}  // namespace mp2p
+
+struct mp2p_hip_ctx
+{
+    int         device     = 0;
+    hipStream_t stream     = nullptr;
+    bool        own_stream = false;
+    std::string err;
+    int         profiling = 0;  // 0 off, 1 hipEvent timing, 2 + device counters
+    hipEvent_t  ev[6]     = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int         pending_match = 0, pending_gn = 0;
+    size_t      pending_map_n = 0;
+    mp2p_hip_stats stats{};
+    uint64_t    epoch = 0;  // claim epoch (see nn_query.hip)
+
+    // per-call scratch, grown on demand
+    mp2p::DevBuf<uint32_t>           nn_spos;      // [n_local] by ORIGINAL local index
+    mp2p::DevBuf<float>              nn_d2;        // [n_local]
+    mp2p::DevBuf<float>              tile_bbox;    // [n_tiles][6]
+    mp2p::DevBuf<float>              local_bbox;   // [6] min xyz, max xyz of transformed local
+    mp2p::DevBuf<uint32_t>           block_counts; // compaction
+    mp2p::DevBuf<unsigned long long> counters;     // profiling counters
+    mp2p::DevBuf<double>             gn_partials;  // [GN_BLOCKS][NSUMS]
+    mp2p::DevBuf<double>             gn_sums;      // [NSUMS]
+    mp2p::DevBuf<double>             gn_state;     // pose(12) H(36) g(6) cost(1) iters(1) done(1)
+    mp2p::DevBuf<unsigned char>      aos_stage;    // download staging
+    mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
+    mp2p::GnState                    gn;
+    uint32_t last_n_tiles = 0;
+    uint32_t last_q       = 64;
+};
+
+struct mp2p_hip_map
+{
+    mp2p_hip_ctx*                    ctx = nullptr;
+    size_t                           n   = 0;
+    mp2p::DevBuf<float4>             pts;     // Morton-sorted {x,y,z,idx}
+    mp2p::DevBuf<mp2p::Cell>         table;
+    mp2p::DevBuf<unsigned long long> claims;  // [n] indexed by SORTED position
+    mp2p::GridView                   view{};
+    mp2p_hip_map_info                info{};
+};
+
+struct mp2p_hip_cloud
+{
+    mp2p_hip_ctx*        ctx = nullptr;
+    size_t               n   = 0;
+    mp2p::DevBuf<float4> sorted;  // Morton-sorted (own frame) {x,y,z,idx}
+    mp2p::DevBuf<float>  x, y, z; // original order (pair output)
+};
+
+struct mp2p_hip_mstate
+{
+    mp2p_hip_ctx*               ctx = nullptr;
+    mp2p::DevBuf<unsigned char> global_taken, local_taken;  // by ORIGINAL index
+};
+
+struct mp2p_hip_pairs
+{
+    mp2p_hip_ctx* ctx = nullptr;
+    size_t        cap_pt2pt = 0, cap_pt2pl = 0;
+    // pt2pt SoA
+    mp2p::DevBuf<uint32_t> lidx, gidx;
+    mp2p::DevBuf<float>    lx, ly, lz, gx, gy, gz, err;
+    // pt2pl SoA
+    mp2p::DevBuf<uint32_t> pl_lidx;
+    mp2p::DevBuf<double>   pl_coef;  // [cap][4]  a,b,c,d
+    mp2p::DevBuf<double>   pl_cen;   // [cap][3]
+    mp2p::DevBuf<float>    pl_lx, pl_ly, pl_lz;
+    // counts: [0]=n_pt2pt [1]=n_pt2pl [2]=potential_pairings [3]=write base scratch
+    // [4]=overflow flag
+    mp2p::DevBuf<unsigned long long> counts;
+};
+
+namespace mp2p
+{
+int  set_err(mp2p_hip_ctx* ctx, int code, const char* fmt, ...);
+void set_global_err(const char* fmt, ...);
+
+#define MP2P_TRY_HIP(ctx, expr)                                                              \
+    do                                                                                       \
+    {                                                                                        \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return mp2p::set_err((ctx), MP2P_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr,    \
+                                 hipGetErrorString(e__), __FILE__, __LINE__);                \
+    } while (0)
+
+#define MP2P_REQUIRE(ctx, cond, msg)                                                         \
+    do                                                                                       \
+    {                                                                                        \
+        if (!(cond)) return mp2p::set_err((ctx), MP2P_HIP_ERR_INVALID, "%s (%s)", msg, #cond); \
+    } while (0)
+
+// implemented in the .hip units
+int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float* d_z, size_t n,
+              const mp2p_hip_map_params* prm, mp2p_hip_map* map);
+int build_cloud(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float* d_z,
+                size_t n, mp2p_hip_cloud* cloud);
+
+}  // namespace mp2p

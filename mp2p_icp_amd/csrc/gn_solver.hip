@@ -1,0 +1,585 @@
+// gn_solver.hip -- K6/K7/K8: Gauss-Newton normal equations and SE(3) update.
+//
+// Replaces optimal_tf_gauss_newton (optimal_tf_gauss_newton.cpp:36-372).  Per inner
+// iteration the reference forms, for every pair, J1 (3x12) * dDexpe_de (12x6), then
+// H += w Ji^T Ji and g += w Ji^T e through dense Eigen products (~900 flop / pair).
+// With Ji = [R | -R [l]x] (pt2pt) and Ji = -n n^T [R | -R [l]x] (pt2pl) those sums collapse to
+// (SURVEY.md Appendix B):
+//   pt2pt : 17 fp64 sums  {Sw, Sw*l (3), Sw*l l^T (6), Sw*e' (3), Sw*(l x e') (3), Sw*|e|^2}
+//           with e' = R^T e, independent of R in the Hessian part;
+//   pt2pl : 28 fp64 sums  {Sw*a a^T (21 upper), Sw*a*r (6), Sw*r^2}, a = [n' ; l x n'],
+//           n' = R^T n/|n|, r = signed point-plane distance.
+// The kernels stream the pair arrays once per inner iteration (HBM-bound: 24 B / pt2pt pair,
+// 44 B / pt2pl pair), reduce per lane -> wave (shuffles) -> block (LDS) -> fixed-order final
+// sum (deterministic, no fp64 atomics).  The 6x6 solve, the prior term and the retraction
+// run in a single-thread kernel so that the whole inner loop needs no host round trip;
+// between "sums" and "step" a multi-GPU caller all-reduces the 48 doubles.
+// H and g are rebuilt every inner iteration (TBB-build meaning, :145-146).
+#include "device_utils.hpp"
+
+namespace mp2p
+{
+constexpr int GN_BLOCKS  = 512;
+constexpr int GN_THREADS = 256;
+constexpr int NS         = MP2P_HIP_GN_NSUMS;  // 48
+constexpr int NS_PT      = 17;
+constexpr int NS_PL      = 28;
+
+// gn_state layout (doubles): pose[12] H[36] g[6] cost iters done
+constexpr int ST_POSE = 0, ST_H = 12, ST_G = 48, ST_COST = 54, ST_ITERS = 55, ST_DONE = 56,
+              ST_SIZE = 64;
+
+struct GnKernelPrm
+{
+    int    kernel;
+    double c, c2;
+    double w_pt2pt, w_pt2pl;
+    uint32_t           n_blocks;  // weight blocks
+    unsigned long long blk_end[8];
+    double             blk_w[8];
+};
+
+// robust_kernels.h:57-94 (weight on the SQUARED error)
+__device__ __forceinline__ double robust_w(const GnKernelPrm& p, double esq)
+{
+    if (p.kernel == MP2P_HIP_KERNEL_GEMANMCCLURE)
+    {
+        const double d = esq + p.c;
+        return p.c2 / (d * d);
+    }
+    if (p.kernel == MP2P_HIP_KERNEL_CAUCHY) return p.c2 / (esq + p.c2);
+    return 1.0;
+}
+
+template <int N>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* __restrict__ out)
+{
+    __shared__ double s[GN_THREADS / 64][N];
+    const int         lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N; k++) acc[k] = wave_sum_f64(acc[k]);
+    if (lane == 0)
+    {
+#pragma unroll
+        for (int k = 0; k < N; k++) s[w][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < N)
+    {
+        double t = 0;
+        for (int k = 0; k < GN_THREADS / 64; k++) t += s[k][threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+}
+
+// ---- K6: point-to-point (errorTerms.cpp:36-66 + optimal_tf_gauss_newton.cpp:149-180) --------
+__global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pt_kernel(
+    const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ lz,
+    const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz,
+    const unsigned long long* __restrict__ counts, const double* __restrict__ state,
+    const GnKernelPrm prm, double* __restrict__ partials)
+{
+    double acc[NS_PT];
+#pragma unroll
+    for (int k = 0; k < NS_PT; k++) acc[k] = 0;
+    const bool done = state[ST_DONE] != 0.0;
+    const unsigned long long n = done ? 0ull : counts[0];
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = state[ST_POSE + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = state[ST_POSE + 9 + k];
+
+    for (unsigned long long i = (unsigned long long)blockIdx.x * GN_THREADS + threadIdx.x; i < n;
+         i += (unsigned long long)GN_BLOCKS * GN_THREADS)
+    {
+        const double l0 = lx[i], l1 = ly[i], l2 = lz[i];
+        // e = R l + t - g   (composePoint then subtract, errorTerms.cpp:44-48)
+        const double e0 = R[0] * l0 + R[1] * l1 + R[2] * l2 + t[0] - (double)gx[i];
+        const double e1 = R[3] * l0 + R[4] * l1 + R[5] * l2 + t[1] - (double)gy[i];
+        const double e2 = R[6] * l0 + R[7] * l1 + R[8] * l2 + t[2] - (double)gz[i];
+        const double esq = e0 * e0 + e1 * e1 + e2 * e2;
+        double       w   = prm.w_pt2pt;
+        if (prm.n_blocks)
+        {  // Pairings::point_weights run-length blocks (:159-167)
+            uint32_t b = 0;
+            while (b + 1 < prm.n_blocks && i >= prm.blk_end[b]) b++;
+            w = prm.blk_w[b];
+        }
+        w *= robust_w(prm, esq);
+        // e' = R^T e
+        const double p0 = R[0] * e0 + R[3] * e1 + R[6] * e2;
+        const double p1 = R[1] * e0 + R[4] * e1 + R[7] * e2;
+        const double p2 = R[2] * e0 + R[5] * e1 + R[8] * e2;
+        acc[0] += w;
+        acc[1] += w * l0, acc[2] += w * l1, acc[3] += w * l2;
+        acc[4] += w * l0 * l0, acc[5] += w * l0 * l1, acc[6] += w * l0 * l2;
+        acc[7] += w * l1 * l1, acc[8] += w * l1 * l2, acc[9] += w * l2 * l2;
+        acc[10] += w * p0, acc[11] += w * p1, acc[12] += w * p2;
+        acc[13] += w * (l1 * p2 - l2 * p1);
+        acc[14] += w * (l2 * p0 - l0 * p2);
+        acc[15] += w * (l0 * p1 - l1 * p0);
+        acc[16] += w * esq;
+    }
+    block_reduce_store<NS_PT>(acc, partials + (size_t)blockIdx.x * NS);
+}
+
+// ---- K7: point-to-plane (errorTerms.cpp:115-161 + optimal_tf_gauss_newton.cpp:229-259) ------
+__global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pl_kernel(
+    const double* __restrict__ coef, const float* __restrict__ lx, const float* __restrict__ ly,
+    const float* __restrict__ lz, const unsigned long long* __restrict__ counts,
+    const double* __restrict__ state, const GnKernelPrm prm, double* __restrict__ partials)
+{
+    double acc[NS_PL];
+#pragma unroll
+    for (int k = 0; k < NS_PL; k++) acc[k] = 0;
+    const bool done = state[ST_DONE] != 0.0;
+    const unsigned long long n = done ? 0ull : counts[1];
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = state[ST_POSE + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = state[ST_POSE + 9 + k];
+
+    for (unsigned long long i = (unsigned long long)blockIdx.x * GN_THREADS + threadIdx.x; i < n;
+         i += (unsigned long long)GN_BLOCKS * GN_THREADS)
+    {
+        const double2 ab = *reinterpret_cast<const double2*>(coef + i * 4);
+        const double2 cd = *reinterpret_cast<const double2*>(coef + i * 4 + 2);
+        const double  l0 = lx[i], l1 = ly[i], l2 = lz[i];
+        const double  g0 = R[0] * l0 + R[1] * l1 + R[2] * l2 + t[0];
+        const double  g1 = R[3] * l0 + R[4] * l1 + R[5] * l2 + t[1];
+        const double  g2 = R[6] * l0 + R[7] * l1 + R[8] * l2 + t[2];
+        const double  m    = ab.x * ab.x + ab.y * ab.y + cd.x * cd.x;  // |n|^2 (not assumed 1)
+        const double  inv  = 1.0 / sqrt(m);
+        const double  nx = ab.x * inv, ny = ab.y * inv, nz = cd.x * inv;
+        const double  r  = (ab.x * g0 + ab.y * g1 + cd.x * g2 + cd.y) * inv;  // |e|^2 = r^2
+        const double  w  = prm.w_pt2pl * robust_w(prm, r * r);
+        // n' = R^T n ;  a = [n' ; l x n']
+        double a[6];
+        a[0] = R[0] * nx + R[3] * ny + R[6] * nz;
+        a[1] = R[1] * nx + R[4] * ny + R[7] * nz;
+        a[2] = R[2] * nx + R[5] * ny + R[8] * nz;
+        a[3] = l1 * a[2] - l2 * a[1];
+        a[4] = l2 * a[0] - l0 * a[2];
+        a[5] = l0 * a[1] - l1 * a[0];
+        int k = 0;
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+        {
+            const double wa = w * a[p];
+#pragma unroll
+            for (int q = p; q < 6; q++) acc[k++] += wa * a[q];
+        }
+#pragma unroll
+        for (int p = 0; p < 6; p++) acc[21 + p] += w * a[p] * r;
+        acc[27] += w * r * r;
+    }
+    block_reduce_store<NS_PL>(acc, partials + (size_t)blockIdx.x * NS + NS_PT);
+}
+
+// fixed-order sum of the block partials -> sums[48]
+__global__ __launch_bounds__(256) void gn_sums_kernel(const double* __restrict__ partials,
+                                                      const double* __restrict__ state,
+                                                      int use_pt, int use_pl,
+                                                      double* __restrict__ sums)
+{
+    // 4 partial sums per quantity (blocks b%4), combined in fixed order
+    __shared__ double s[4][NS];
+    const int         q = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const bool        done = state[ST_DONE] != 0.0;
+    double            t = 0;
+    const bool        mine = q < NS && ((q < NS_PT && use_pt) || (q >= NS_PT && q < NS_PT + NS_PL && use_pl));
+    if (mine && !done)
+        for (int b = part; b < GN_BLOCKS; b += 4) t += partials[(size_t)b * NS + q];
+    if (q < NS) s[part][q] = t;
+    __syncthreads();
+    if (threadIdx.x < NS) sums[threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+
+// ---- small dense helpers (single thread) -----------------------------------------------------
+__device__ void d_mat3_mul(const double* A, const double* B, double* C)
+{
+    double r[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            r[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+    for (int i = 0; i < 9; i++) C[i] = r[i];
+}
+__device__ void d_skew(const double* w, double* S)
+{
+    S[0] = 0, S[1] = -w[2], S[2] = w[1];
+    S[3] = w[2], S[4] = 0, S[5] = -w[0];
+    S[6] = -w[1], S[7] = w[0], S[8] = 0;
+}
+__device__ void d_pose_compose(const double* A, const double* B, double* out)
+{
+    double r[12];
+    d_mat3_mul(A, B, r);
+    for (int i = 0; i < 3; i++)
+        r[9 + i] = A[i * 3] * B[9] + A[i * 3 + 1] * B[10] + A[i * 3 + 2] * B[11] + A[9 + i];
+    for (int i = 0; i < 12; i++) out[i] = r[i];
+}
+__device__ void d_pose_inverse(const double* A, double* out)
+{
+    double r[12];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r[i * 3 + j] = A[j * 3 + i];
+    for (int i = 0; i < 3; i++) r[9 + i] = -(r[i * 3] * A[9] + r[i * 3 + 1] * A[10] + r[i * 3 + 2] * A[11]);
+    for (int i = 0; i < 12; i++) out[i] = r[i];
+}
+// Lie::SE<3>::exp, xi = [v; w] (true exponential)
+__device__ void d_se3_exp(const double* xi, double* T)
+{
+    const double* v   = xi;
+    const double* w   = xi + 3;
+    const double  th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double  th  = sqrt(th2);
+    double        a, b, c;
+    if (th < 1e-6)
+        a = 1.0 - th2 / 6.0, b = 0.5 - th2 / 24.0, c = 1.0 / 6.0 - th2 / 120.0;
+    else
+        a = sin(th) / th, b = (1.0 - cos(th)) / th2, c = (th - sin(th)) / (th2 * th);
+    double W[9], W2[9];
+    d_skew(w, W);
+    d_mat3_mul(W, W, W2);
+    for (int i = 0; i < 9; i++) T[i] = a * W[i] + b * W2[i];
+    T[0] += 1.0, T[4] += 1.0, T[8] += 1.0;
+    double V[9];
+    for (int i = 0; i < 9; i++) V[i] = b * W[i] + c * W2[i];
+    V[0] += 1.0, V[4] += 1.0, V[8] += 1.0;
+    for (int i = 0; i < 3; i++) T[9 + i] = V[i * 3] * v[0] + V[i * 3 + 1] * v[1] + V[i * 3 + 2] * v[2];
+}
+__device__ void d_so3_log(const double* R, double* w)
+{
+    const double tr = R[0] + R[4] + R[8];
+    double       c  = 0.5 * (tr - 1.0);
+    c               = fmin(1.0, fmax(-1.0, c));
+    const double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1];
+    const double s  = 0.5 * sqrt(vx * vx + vy * vy + vz * vz);
+    const double th = atan2(s, c);
+    if (th < 1e-6)
+    {
+        const double k = 0.5 * (1.0 + th * th / 6.0);
+        w[0] = k * vx, w[1] = k * vy, w[2] = k * vz;
+        return;
+    }
+    if (3.14159265358979323846 - th < 1e-6)
+    {
+        double ax[3] = {sqrt(fmax(0.0, 0.5 * (R[0] + 1.0))), sqrt(fmax(0.0, 0.5 * (R[4] + 1.0))),
+                        sqrt(fmax(0.0, 0.5 * (R[8] + 1.0)))};
+        int    k     = 0;
+        if (ax[1] > ax[k]) k = 1;
+        if (ax[2] > ax[k]) k = 2;
+        for (int i = 0; i < 3; i++)
+            if (i != k && (R[k * 3 + i] + R[i * 3 + k]) < 0) ax[i] = -ax[i];
+        if (vx * ax[0] + vy * ax[1] + vz * ax[2] < 0)
+            for (int i = 0; i < 3; i++) ax[i] = -ax[i];
+        w[0] = th * ax[0], w[1] = th * ax[1], w[2] = th * ax[2];
+        return;
+    }
+    const double k = th / (2.0 * s);
+    w[0] = k * vx, w[1] = k * vy, w[2] = k * vz;
+}
+__device__ void d_se3_log(const double* T, double* xi)
+{
+    double w[3];
+    d_so3_log(T, w);
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th  = sqrt(th2);
+    double       k;
+    if (th < 1e-6)
+        k = 1.0 / 12.0 + th2 / 720.0;
+    else
+        k = (1.0 - (th * sin(th)) / (2.0 * (1.0 - cos(th)))) / th2;
+    double W[9], W2[9], Vi[9];
+    d_skew(w, W);
+    d_mat3_mul(W, W, W2);
+    for (int i = 0; i < 9; i++) Vi[i] = -0.5 * W[i] + k * W2[i];
+    Vi[0] += 1.0, Vi[4] += 1.0, Vi[8] += 1.0;
+    for (int i = 0; i < 3; i++) xi[i] = Vi[i * 3] * T[9] + Vi[i * 3 + 1] * T[10] + Vi[i * 3 + 2] * T[11];
+    xi[3] = w[0], xi[4] = w[1], xi[5] = w[2];
+}
+
+// LDL^T with diagonal pivoting (role of Eigen's H.ldlt().solve(g), :351)
+__device__ void d_ldlt6_solve(const double* H, const double* g, double* x)
+{
+    const int n = 6;
+    double    A[36], L[36], D[6];
+    int       perm[6];
+    for (int i = 0; i < 36; i++) A[i] = H[i], L[i] = 0;
+    for (int i = 0; i < n; i++) perm[i] = i, D[i] = 0;
+    for (int k = 0; k < n; k++)
+    {
+        int    piv  = k;
+        double best = fabs(A[k * n + k]);
+        for (int i = k + 1; i < n; i++)
+            if (fabs(A[i * n + i]) > best) best = fabs(A[i * n + i]), piv = i;
+        if (piv != k)
+        {
+            for (int j = 0; j < n; j++)
+            {
+                const double t = A[k * n + j];
+                A[k * n + j] = A[piv * n + j], A[piv * n + j] = t;
+            }
+            for (int i = 0; i < n; i++)
+            {
+                const double t = A[i * n + k];
+                A[i * n + k] = A[i * n + piv], A[i * n + piv] = t;
+            }
+            for (int j = 0; j < k; j++)
+            {
+                const double t = L[k * n + j];
+                L[k * n + j] = L[piv * n + j], L[piv * n + j] = t;
+            }
+            const int t = perm[k];
+            perm[k] = perm[piv], perm[piv] = t;
+        }
+        D[k]         = A[k * n + k];
+        L[k * n + k] = 1.0;
+        if (D[k] == 0.0) continue;
+        for (int i = k + 1; i < n; i++) L[i * n + k] = A[i * n + k] / D[k];
+        for (int i = k + 1; i < n; i++)
+            for (int j = k + 1; j < n; j++) A[i * n + j] -= L[i * n + k] * D[k] * L[j * n + k];
+    }
+    double b[6], y[6], z[6];
+    for (int i = 0; i < n; i++) b[i] = g[perm[i]];
+    for (int i = 0; i < n; i++)
+    {
+        double s = b[i];
+        for (int j = 0; j < i; j++) s -= L[i * n + j] * y[j];
+        y[i] = s;
+    }
+    for (int i = 0; i < n; i++) z[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
+    for (int i = n - 1; i >= 0; i--)
+    {
+        double s = z[i];
+        for (int j = i + 1; j < n; j++) s -= L[j * n + i] * y[j];
+        y[i] = s;
+    }
+    for (int i = 0; i < n; i++) x[perm[i]] = y[i];
+}
+
+struct GnStepPrm
+{
+    double minDelta, maxCost;
+    int    has_prior;
+    double prior_mean[12];
+    double prior_cov_inv[36];
+    int    use_pt, use_pl;
+};
+
+// ---- K8: assemble H,g from the sums, prior, solve, retract (one thread) -----------------------
+__global__ void gn_step_kernel(const double* __restrict__ sums, double* __restrict__ state,
+                               const GnStepPrm prm)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (state[ST_DONE] != 0.0) return;
+    double T[12];
+    for (int i = 0; i < 12; i++) T[i] = state[ST_POSE + i];
+    double H[36], g[6];
+    for (int i = 0; i < 36; i++) H[i] = 0;
+    for (int i = 0; i < 6; i++) g[i] = 0;
+    double cost = 0;
+    if (prm.use_pt)
+    {
+        const double* s  = sums;
+        const double  sw = s[0];
+        const double  sl[3] = {s[1], s[2], s[3]};
+        const double  xx = s[4], xy = s[5], xz = s[6], yy = s[7], yz = s[8], zz = s[9];
+        // H_vv = Sw I
+        H[0 * 6 + 0] += sw, H[1 * 6 + 1] += sw, H[2 * 6 + 2] += sw;
+        // H_vw = -[Sw l]x ; H_wv = transpose
+        double K[9];
+        d_skew(sl, K);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+            {
+                H[i * 6 + 3 + j] += -K[i * 3 + j];
+                H[(3 + j) * 6 + i] += -K[i * 3 + j];
+            }
+        // H_ww = tr(Sll) I - Sll
+        const double tr = xx + yy + zz;
+        H[3 * 6 + 3] += tr - xx, H[3 * 6 + 4] += -xy, H[3 * 6 + 5] += -xz;
+        H[4 * 6 + 3] += -xy, H[4 * 6 + 4] += tr - yy, H[4 * 6 + 5] += -yz;
+        H[5 * 6 + 3] += -xz, H[5 * 6 + 4] += -yz, H[5 * 6 + 5] += tr - zz;
+        for (int i = 0; i < 6; i++) g[i] += s[10 + i];
+        cost += s[16];
+    }
+    if (prm.use_pl)
+    {
+        const double* s = sums + NS_PT;
+        int           k = 0;
+        for (int p = 0; p < 6; p++)
+            for (int q = p; q < 6; q++)
+            {
+                H[p * 6 + q] += s[k];
+                if (q != p) H[q * 6 + p] += s[k];
+                k++;
+            }
+        for (int p = 0; p < 6; p++) g[p] += s[21 + p];
+        cost += s[27];
+    }
+    if (prm.has_prior)
+    {
+        // :311-341  err = log(prior^-1 * pose); J = d log(A exp(eps))/d eps (central differences)
+        double Pinv[12], A[12], err[6], J[36];
+        d_pose_inverse(prm.prior_mean, Pinv);
+        d_pose_compose(Pinv, T, A);
+        d_se3_log(A, err);
+        const double h = 1e-6;
+        for (int j = 0; j < 6; j++)
+        {
+            double xi[6] = {0, 0, 0, 0, 0, 0}, E[12], Ap[12], Am[12], lp[6], lm[6];
+            xi[j] = h;
+            d_se3_exp(xi, E);
+            d_pose_compose(A, E, Ap);
+            xi[j] = -h;
+            d_se3_exp(xi, E);
+            d_pose_compose(A, E, Am);
+            d_se3_log(Ap, lp);
+            d_se3_log(Am, lm);
+            for (int i = 0; i < 6; i++) J[i * 6 + j] = (lp[i] - lm[i]) / (2 * h);
+        }
+        double JtL[36];
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++)
+            {
+                double s = 0;
+                for (int k = 0; k < 6; k++) s += J[k * 6 + i] * prm.prior_cov_inv[k * 6 + j];
+                JtL[i * 6 + j] = s;
+            }
+        for (int i = 0; i < 6; i++)
+        {
+            double s = 0;
+            for (int k = 0; k < 6; k++) s += JtL[i * 6 + k] * err[k];
+            g[i] += s;
+            for (int j = 0; j < 6; j++)
+            {
+                double q = 0;
+                for (int k = 0; k < 6; k++) q += JtL[i * 6 + k] * J[k * 6 + j];
+                H[i * 6 + j] += q;
+            }
+        }
+    }
+    for (int i = 0; i < 36; i++) state[ST_H + i] = H[i];
+    for (int i = 0; i < 6; i++) state[ST_G + i] = g[i];
+    state[ST_COST] = cost;
+    state[ST_ITERS] += 1.0;
+    if (sqrt(cost) <= prm.maxCost)  // :344-346
+    {
+        state[ST_DONE] = 1.0;
+        return;
+    }
+    double delta[6];
+    d_ldlt6_solve(H, g, delta);
+    for (int i = 0; i < 6; i++) delta[i] = -delta[i];  // :351
+    double dE[12], Tn[12];
+    d_se3_exp(delta, dE);       // :354
+    d_pose_compose(T, dE, Tn);  // :356
+    for (int i = 0; i < 12; i++) state[ST_POSE + i] = Tn[i];
+    double nrm = 0;
+    for (int i = 0; i < 6; i++) nrm += delta[i] * delta[i];
+    if (sqrt(nrm) < prm.minDelta) state[ST_DONE] = 1.0;  // :365
+}
+
+static GnKernelPrm make_kernel_prm(const mp2p_hip_gn_params& p)
+{
+    GnKernelPrm k;
+    memset(&k, 0, sizeof(k));
+    k.kernel  = p.kernel;
+    k.c       = p.kernelParam;
+    k.c2      = p.kernelParam * p.kernelParam;
+    k.w_pt2pt = p.w_pt2pt, k.w_pt2pl = p.w_pt2pl;
+    k.n_blocks = p.n_weight_blocks;
+    unsigned long long end = 0;
+    for (uint32_t b = 0; b < p.n_weight_blocks && b < 8; b++)
+    {
+        end += p.weight_block_count[b];
+        k.blk_end[b] = end;
+        k.blk_w[b]   = p.weight_block_w[b];
+    }
+    return k;
+}
+
+int gn_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[12],
+             const mp2p_hip_gn_params* prm)
+{
+    MP2P_REQUIRE(ctx, pairs && pose0 && prm, "null argument");
+    MP2P_REQUIRE(ctx, prm->n_weight_blocks <= 8, "at most 8 point_weights blocks are supported");
+    MP2P_TRY_HIP(ctx, ctx->gn_partials.ensure((size_t)GN_BLOCKS * NS));
+    MP2P_TRY_HIP(ctx, ctx->gn_sums.ensure(NS));
+    MP2P_TRY_HIP(ctx, ctx->gn_state.ensure(ST_SIZE));
+    double st[ST_SIZE];
+    memset(st, 0, sizeof(st));
+    for (int i = 0; i < 12; i++) st[ST_POSE + i] = pose0[i];
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->gn_state.p, st, sizeof(st), hipMemcpyHostToDevice, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));  // 'st' is a stack buffer
+    MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->gn_partials.p, 0, (size_t)GN_BLOCKS * NS * sizeof(double), ctx->stream));
+    ctx->gn.pairs  = pairs;
+    ctx->gn.prm    = *prm;
+    ctx->gn.active = true;
+    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+int gn_accumulate(mp2p_hip_ctx* ctx)
+{
+    MP2P_REQUIRE(ctx, ctx->gn.active, "gn_accumulate without gn_begin");
+    const mp2p_hip_pairs* P = ctx->gn.pairs;
+    const GnKernelPrm     k = make_kernel_prm(ctx->gn.prm);
+    const int use_pt = P->cap_pt2pt > 0, use_pl = P->cap_pt2pl > 0;
+    if (use_pt)
+        hipLaunchKernelGGL(gn_accum_pt2pt_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
+                           P->lx.p, P->ly.p, P->lz.p, P->gx.p, P->gy.p, P->gz.p, P->counts.p,
+                           ctx->gn_state.p, k, ctx->gn_partials.p);
+    if (use_pl)
+        hipLaunchKernelGGL(gn_accum_pt2pl_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
+                           P->pl_coef.p, P->pl_lx.p, P->pl_ly.p, P->pl_lz.p, P->counts.p,
+                           ctx->gn_state.p, k, ctx->gn_partials.p);
+    hipLaunchKernelGGL(gn_sums_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->gn_partials.p,
+                       ctx->gn_state.p, use_pt, use_pl, ctx->gn_sums.p);
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
+}
+
+int gn_step(mp2p_hip_ctx* ctx)
+{
+    MP2P_REQUIRE(ctx, ctx->gn.active, "gn_step without gn_begin");
+    const mp2p_hip_gn_params& p = ctx->gn.prm;
+    GnStepPrm                 s;
+    memset(&s, 0, sizeof(s));
+    s.minDelta = p.minDelta, s.maxCost = p.maxCost, s.has_prior = p.has_prior;
+    memcpy(s.prior_mean, p.prior_mean, sizeof(s.prior_mean));
+    memcpy(s.prior_cov_inv, p.prior_cov_inv, sizeof(s.prior_cov_inv));
+    s.use_pt = ctx->gn.pairs->cap_pt2pt > 0, s.use_pl = ctx->gn.pairs->cap_pt2pl > 0;
+    hipLaunchKernelGGL(gn_step_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->gn_sums.p,
+                       ctx->gn_state.p, s);
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
+}
+
+int gn_end(mp2p_hip_ctx* ctx, mp2p_hip_gn_result* out)
+{
+    MP2P_REQUIRE(ctx, ctx->gn.active, "gn_end without gn_begin");
+    double st[ST_SIZE];
+    if (ctx->profiling)
+    {
+        MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+        ctx->pending_gn = 1;
+    }
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(st, ctx->gn_state.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->gn.active = false;
+    if (out)
+    {
+        memcpy(out->pose, st + ST_POSE, 12 * sizeof(double));
+        memcpy(out->H, st + ST_H, 36 * sizeof(double));
+        memcpy(out->g, st + ST_G, 6 * sizeof(double));
+        out->cost       = st[ST_COST];
+        out->iterations = (uint32_t)st[ST_ITERS];
+    }
+    return MP2P_HIP_OK;
+}
+
+}  // namespace mp2p

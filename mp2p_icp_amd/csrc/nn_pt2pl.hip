@@ -1,0 +1,490 @@
+// nn_pt2pl.hip -- K5: Matcher_Point2Plane::implMatchOneLayer (Matcher_Point2Plane.cpp:41-114)
+// with NearestPlaneCapable::nn_search_pt2pl (NearestPlaneCapable.h:33-52) implemented as
+//   exact k-NN (fp32 metric, (d2,idx) order) restricted to d2 <= searchRadius^2
+//   -> estimate_points_eigen (estimate_points_eigen.cpp:27-123: fp32 mean, fp32 products
+//      accumulated in fp64, scaled by fp32 1/n) -> symmetric 3x3 eigen (cyclic Jacobi)
+//   -> planar iff e0 < thr*e1 && e0 < thr*e2 (Matcher_Adaptive.cpp:241-242)
+//   -> plane (centroid, eigvec0), unit normal with its largest |component| positive
+//   -> |plane.distance(q)| <= distanceThreshold (Matcher_Point2Plane.cpp:100-101).
+// The arithmetic that decides WHICH local points get a pairing is sequenced exactly as in
+// oracle/mp2p_oracle.c (no FMA contraction: this unit is built with -ffp-contract=off), so
+// the pair lists match bit for bit; upstream has no in-repo implementor of nn_search_pt2pl
+//  -> "parity unpinned" beyond the disabled test's expectations.
+//
+// Same tile machinery as nn_query.hip (wave64 tile, LDS-staged voxel buckets); each lane keeps
+// a sorted k-list in registers.
+#include "device_utils.hpp"
+
+namespace mp2p
+{
+constexpr int      PL_CAP         = 256;
+constexpr uint32_t PL_CELL_BUDGET = 256;
+
+struct PlArgs
+{
+    GridView      g;
+    const float4* lpts;
+    uint32_t      n_l;
+    PoseRt        pose;
+    float         radSq, rad, distThr, r0;
+    double        eigThr;
+    uint32_t      minPts;
+    const unsigned char* local_taken;
+    unsigned char*       out_flag;  // [n_l] by original local index
+    double*              out_rec;   // [n_l][7] plane(4) + centroid(3)
+    float*               tile_bbox;
+};
+
+// cyclic Jacobi, identical operation order to sym_eig_jacobi(3, ...) of the oracle
+__device__ void jacobi3(const double* Ain, double* eval, double* evec0)
+{
+    double A[9], Q[9];
+    for (int i = 0; i < 9; i++) A[i] = Ain[i];
+    Q[0] = 1, Q[1] = 0, Q[2] = 0, Q[3] = 0, Q[4] = 1, Q[5] = 0, Q[6] = 0, Q[7] = 0, Q[8] = 1;
+    const int n = 3;
+    for (int sweep = 0; sweep < 64; sweep++)
+    {
+        double off = 0;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+        if (off == 0.0) break;
+        for (int p = 0; p < n; p++)
+        {
+            for (int q = p + 1; q < n; q++)
+            {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double app = A[p * n + p], aqq = A[q * n + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++)
+                {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++)
+                {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++)
+                {
+                    const double qkp = Q[k * n + p], qkq = Q[k * n + q];
+                    Q[k * n + p] = c * qkp - s * qkq;
+                    Q[k * n + q] = s * qkp + c * qkq;
+                }
+            }
+        }
+    }
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++)
+            if (A[order[j] * n + order[j]] < A[order[i] * n + order[i]])
+            {
+                const int t = order[i];
+                order[i] = order[j], order[j] = t;
+            }
+    for (int k = 0; k < 3; k++) eval[k] = A[order[k] * n + order[k]];
+    for (int i = 0; i < 3; i++) evec0[i] = Q[i * n + order[0]];
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
+{
+    __shared__ float4   s_cand[PL_CAP];
+    __shared__ uint32_t s_spos[PL_CAP];
+    __shared__ uint32_t s_cstart[64];
+    __shared__ uint32_t s_coff[65];
+
+    const GridView& g     = a.g;
+    const int       lane  = threadIdx.x;
+    const uint32_t  tile  = blockIdx.x;
+    const uint32_t  qi    = tile * 64 + lane;
+    const bool      valid = qi < a.n_l;
+    float4          lp    = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) lp = a.lpts[qi];
+    const uint32_t orig = __float_as_uint(lp.w);
+    float          qx, qy, qz;
+    compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
+    {
+        const float bx0 = wave_min(valid ? qx : INFINITY), by0 = wave_min(valid ? qy : INFINITY),
+                    bz0 = wave_min(valid ? qz : INFINITY);
+        const float bx1 = wave_max(valid ? qx : -INFINITY), by1 = wave_max(valid ? qy : -INFINITY),
+                    bz1 = wave_max(valid ? qz : -INFINITY);
+        if (lane == 0)
+        {
+            float* o = a.tile_bbox + (size_t)tile * 6;
+            o[0] = bx0, o[1] = by0, o[2] = bz0, o[3] = bx1, o[4] = by1, o[5] = bz1;
+        }
+    }
+    const float fin    = fadd(fadd(qx, qy), qz);
+    bool        active = valid && (fin - fin == 0.0f);
+    if (active && a.local_taken && a.local_taken[orig]) active = false;  // Matcher_Point2Plane.cpp:83-85
+
+    const float rmax = a.rad * 1.002f + g.slack;
+    float       r    = fminf(a.r0, rmax);
+    bool        done = !active;
+
+    float    kd2[K];
+    uint32_t kidx[K], kspos[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) kd2[j] = INFINITY, kidx[j] = NONE_U32, kspos[j] = NONE_U32;
+
+    while (true)
+    {
+        if (__ballot(!done) == 0ull) break;
+        float lox = wave_min(done ? INFINITY : qx - r), loy = wave_min(done ? INFINITY : qy - r),
+              loz = wave_min(done ? INFINITY : qz - r);
+        float hix = wave_max(done ? -INFINITY : qx + r), hiy = wave_max(done ? -INFINITY : qy + r),
+              hiz = wave_max(done ? -INFINITY : qz + r);
+        const float rmin_t = wave_min(done ? INFINITY : r);
+        const float rmax_t = wave_max(done ? 0.f : r);
+        const float qlx = lox + rmin_t, qly = loy + rmin_t, qlz = loz + rmin_t;
+        const float qhx = hix - rmin_t, qhy = hiy - rmin_t, qhz = hiz - rmin_t;
+        lox = fmaxf(lox, g.bbmin[0]), loy = fmaxf(loy, g.bbmin[1]), loz = fmaxf(loz, g.bbmin[2]);
+        hix = fminf(hix, g.bbmax[0]), hiy = fminf(hiy, g.bbmax[1]), hiz = fminf(hiz, g.bbmax[2]);
+        const bool empty_box = (lox > hix) || (loy > hiy) || (loz > hiz);
+
+        uint32_t           nx = 0, ny = 0, nz = 0, cx0 = 0, cy0 = 0, cz0 = 0, s = g.shift0, lev = 0;
+        unsigned long long ncell = 0;
+        if (!empty_box)
+        {
+            const uint32_t flx = cell_fine(lox, g.ox, g.inv_hf), fhx = cell_fine(hix, g.ox, g.inv_hf);
+            const uint32_t fly = cell_fine(loy, g.oy, g.inv_hf), fhy = cell_fine(hiy, g.oy, g.inv_hf);
+            const uint32_t flz = cell_fine(loz, g.oz, g.inv_hf), fhz = cell_fine(hiz, g.oz, g.inv_hf);
+            for (;;)
+            {
+                cx0 = flx >> s, cy0 = fly >> s, cz0 = flz >> s;
+                nx = (fhx >> s) - cx0 + 1, ny = (fhy >> s) - cy0 + 1, nz = (fhz >> s) - cz0 + 1;
+                ncell = (unsigned long long)nx * ny * nz;
+                if (ncell <= PL_CELL_BUDGET || lev + 1 >= g.n_levels) break;
+                s++, lev++;
+            }
+        }
+        const float hs     = g.hf * (float)(1u << s);
+        const float prune  = rmax_t + 4.f * g.slack;
+        const float prune2 = prune * prune;
+
+        // a repeated pass rescans voxels already seen: restart the k-list so that no neighbour
+        // is inserted twice
+#pragma unroll
+        for (int j = 0; j < K; j++)
+            if (!done) kd2[j] = INFINITY, kidx[j] = NONE_U32, kspos[j] = NONE_U32;
+
+        for (unsigned long long cb = 0; cb < ncell; cb += 64)
+        {
+            const unsigned long long cid = cb + lane;
+            uint32_t                 cnt = 0, start = 0;
+            if (cid < ncell)
+            {
+                const uint32_t ix = (uint32_t)(cid % nx), iy = (uint32_t)((cid / nx) % ny),
+                               iz = (uint32_t)(cid / ((unsigned long long)nx * ny));
+                const uint32_t cx = cx0 + ix, cy = cy0 + iy, cz = cz0 + iz;
+                const float vx0 = g.ox + (float)cx * hs, vy0 = g.oy + (float)cy * hs,
+                            vz0 = g.oz + (float)cz * hs;
+                const float dx = fmaxf(0.f, fmaxf(vx0 - qhx, qlx - (vx0 + hs)));
+                const float dy = fmaxf(0.f, fmaxf(vy0 - qhy, qly - (vy0 + hs)));
+                const float dz = fmaxf(0.f, fmaxf(vz0 - qhz, qlz - (vz0 + hs)));
+                if (dx * dx + dy * dy + dz * dz <= prune2)
+                {
+                    uint32_t e = 0;
+                    if (cell_lookup(g, cell_key(lev, cx, cy, cz), start, e)) cnt = e - start;
+                }
+            }
+            const uint32_t incl  = wave_incl_scan(cnt, lane);
+            const uint32_t total = __shfl(incl, 63, 64);
+            s_cstart[lane] = start;
+            s_coff[lane]   = incl - cnt;
+            if (lane == 63) s_coff[64] = total;
+            __syncthreads();
+            for (uint32_t base = 0; base < total; base += PL_CAP)
+            {
+                const uint32_t m = min((uint32_t)PL_CAP, total - base);
+                for (uint32_t t = lane; t < m; t += 64)
+                {
+                    const uint32_t gt = base + t;
+                    int            lo = 0, hi = 63;
+                    while (lo < hi)
+                    {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (s_coff[mid] <= gt) lo = mid;
+                        else hi = mid - 1;
+                    }
+                    const uint32_t src = s_cstart[lo] + (gt - s_coff[lo]);
+                    s_cand[t]          = g.pts[src];
+                    s_spos[t]          = src;
+                }
+                __syncthreads();
+                for (uint32_t j = 0; j < m; j++)
+                {
+                    const float4 c  = s_cand[j];
+                    const float  d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
+                    if (!done && d2 <= kd2[K - 1] && d2 <= a.radSq)
+                    {
+                        float    cd = d2;
+                        uint32_t ci = __float_as_uint(c.w), cs = s_spos[j];
+#pragma unroll
+                        for (int q = 0; q < K; q++)
+                        {
+                            const bool less = (cd < kd2[q]) || (cd == kd2[q] && ci < kidx[q]);
+                            if (less)
+                            {
+                                const float    td = kd2[q];
+                                const uint32_t ti = kidx[q], ts = kspos[q];
+                                kd2[q] = cd, kidx[q] = ci, kspos[q] = cs;
+                                cd = td, ci = ti, cs = ts;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (!done)
+        {
+            const float gr = r * (1.0f - 1.0f / 1024.0f) - g.slack;
+            if (r >= rmax || (gr > 0.f && kd2[K - 1] < gr * gr))
+                done = true;
+            else
+            {
+                const float rn = (kidx[K - 1] != NONE_U32)
+                                     ? sqrtf(kd2[K - 1]) * (1.0f + 1.0f / 512.0f) + 4.f * g.slack
+                                     : 2.0f * r;
+                r = fminf(fmaxf(rn, r * 1.0009765625f), rmax);
+            }
+        }
+    }
+
+    // ---- plane fit (per lane) ------------------------------------------------------------------
+    if (!valid) return;
+    unsigned char flag = 0;
+    if (active)
+    {
+        int m = 0;
+#pragma unroll
+        for (int j = 0; j < K; j++)
+            if (kidx[j] != NONE_U32) m++;  // all stored entries satisfy d2 <= radSq
+        if (m >= (int)a.minPts && m >= 3)
+        {
+            float px[K], py[K], pz[K];
+            float mx = 0.f, my = 0.f, mz = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; j++)
+            {
+                if (j < m)
+                {
+                    const float4 p = g.pts[kspos[j]];
+                    px[j] = p.x, py[j] = p.y, pz[j] = p.z;
+                    mx = fadd(mx, p.x), my = fadd(my, p.y), mz = fadd(mz, p.z);
+                }
+            }
+            const float inv_n = 1.0f / (float)m;
+            mx = fmul(mx, inv_n), my = fmul(my, inv_n), mz = fmul(mz, inv_n);
+            double a00 = 0, a10 = 0, a20 = 0, a11 = 0, a21 = 0, a22 = 0;
+#pragma unroll
+            for (int j = 0; j < K; j++)
+            {
+                if (j < m)
+                {
+                    const float ax = fsub(px[j], mx), ay = fsub(py[j], my), az = fsub(pz[j], mz);
+                    a00 = dadd(a00, (double)fmul(ax, ax));
+                    a10 = dadd(a10, (double)fmul(ax, ay));
+                    a20 = dadd(a20, (double)fmul(ax, az));
+                    a11 = dadd(a11, (double)fmul(ay, ay));
+                    a21 = dadd(a21, (double)fmul(ay, az));
+                    a22 = dadd(a22, (double)fmul(az, az));
+                }
+            }
+            const double sc = (double)inv_n;
+            a00 = dmul(a00, sc), a10 = dmul(a10, sc), a20 = dmul(a20, sc);
+            a11 = dmul(a11, sc), a21 = dmul(a21, sc), a22 = dmul(a22, sc);
+            const double cov[9] = {a00, a10, a20, a10, a11, a21, a20, a21, a22};
+            double       ev[3], n[3];
+            jacobi3(cov, ev, n);
+            if (ev[0] < a.eigThr * ev[2] && ev[0] < a.eigThr * ev[1])
+            {
+                const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                n[0] /= nn, n[1] /= nn, n[2] /= nn;
+                int big = 0;
+                if (fabs(n[1]) > fabs(n[big])) big = 1;
+                if (fabs(n[2]) > fabs(n[big])) big = 2;
+                if (n[big] < 0) n[0] = -n[0], n[1] = -n[1], n[2] = -n[2];
+                const double c0 = (double)mx, c1 = (double)my, c2 = (double)mz;
+                const double d  = -(n[0] * c0 + n[1] * c1 + n[2] * c2);
+                const float  dist =
+                    (float)fabs(n[0] * (double)qx + n[1] * (double)qy + n[2] * (double)qz + d);
+                if (!(dist > a.distThr))
+                {
+                    flag      = 1;
+                    double* o = a.out_rec + (size_t)orig * 7;
+                    o[0] = n[0], o[1] = n[1], o[2] = n[2], o[3] = d;
+                    o[4] = c0, o[5] = c1, o[6] = c2;
+                }
+            }
+        }
+    }
+    a.out_flag[orig] = flag;
+}
+
+// ---- ordered compaction of the per-query plane slots ---------------------------------------------
+constexpr int PC_THREADS = 256, PC_ITEMS = 4, PC_TILE = PC_THREADS * PC_ITEMS;
+
+struct PlCompactArgs
+{
+    const unsigned char* flag;
+    const double*        rec;
+    uint32_t             n_l;
+    const float*         local_bbox;
+    float                gbb[6];
+    float                margin;
+    const float *        lx, *ly, *lz;
+    uint32_t*            block_counts;
+    unsigned long long*  counts;
+    unsigned long long   cap;
+    uint32_t*            o_lidx;
+    double *             o_coef, *o_cen;
+    float *              o_lx, *o_ly, *o_lz;
+    unsigned char*       ms_local;
+};
+
+__device__ __forceinline__ bool pl_bbox_overlap(const float* g, const float* l, float eps)
+{
+    for (int d = 0; d < 3; d++)
+    {
+        if (l[d] - eps > g[3 + d]) return false;
+        if (l[3 + d] + eps < g[d]) return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(PC_THREADS) void pl_count_kernel(const PlCompactArgs a)
+{
+    __shared__ uint32_t s_w[PC_THREADS / 64];
+    uint32_t            c = 0;
+    if (pl_bbox_overlap(a.gbb, a.local_bbox, a.margin))
+    {
+        const uint32_t base = blockIdx.x * PC_TILE + threadIdx.x * PC_ITEMS;
+#pragma unroll
+        for (int k = 0; k < PC_ITEMS; k++)
+            if (base + k < a.n_l && a.flag[base + k]) c++;
+    }
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t t = 0;
+        for (int w = 0; w < PC_THREADS / 64; w++) t += s_w[w];
+        a.block_counts[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(PC_THREADS) void pl_write_kernel(const PlCompactArgs a)
+{
+    __shared__ uint32_t s_w[PC_THREADS / 64];
+    if (!pl_bbox_overlap(a.gbb, a.local_bbox, a.margin)) return;
+    const uint32_t base = blockIdx.x * PC_TILE + threadIdx.x * PC_ITEMS;
+    bool           f[PC_ITEMS];
+    uint32_t       c = 0;
+#pragma unroll
+    for (int k = 0; k < PC_ITEMS; k++)
+    {
+        f[k] = (base + k < a.n_l) && a.flag[base + k];
+        c += f[k] ? 1u : 0u;
+    }
+    const int      lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(c, lane);
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; k++) woff += s_w[k];
+    unsigned long long dst = a.counts[3] + a.block_counts[blockIdx.x] + woff + incl - c;
+#pragma unroll
+    for (int k = 0; k < PC_ITEMS; k++)
+    {
+        if (!f[k]) continue;
+        const uint32_t i = base + k;
+        if (dst < a.cap)
+        {
+            const double* r = a.rec + (size_t)i * 7;
+            for (int q = 0; q < 4; q++) a.o_coef[dst * 4 + q] = r[q];
+            for (int q = 0; q < 3; q++) a.o_cen[dst * 3 + q] = r[4 + q];
+            a.o_lidx[dst] = i;
+            a.o_lx[dst] = a.lx[i], a.o_ly[dst] = a.ly[i], a.o_lz[dst] = a.lz[i];
+            if (a.ms_local) a.ms_local[i] = 1;  // Matcher_Point2Plane.cpp:109
+        }
+        dst++;
+    }
+}
+
+template <int K>
+static void launch_k(const PlArgs& a, uint32_t n_tiles, hipStream_t st)
+{
+    hipLaunchKernelGGL(pt2pl_tile_kernel<K>, dim3(n_tiles), dim3(64), 0, st, a);
+}
+
+int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                       const double pose[12], const mp2p_hip_pt2pl_params* prm,
+                       mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
+{
+    const size_t   n_l     = cloud->n;
+    const uint32_t n_tiles = (uint32_t)((n_l + 63) / 64);
+    MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_tiles * 6));
+    MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
+    MP2P_TRY_HIP(ctx, ctx->pl_slots.ensure(n_l * (7 * sizeof(double) + 1) + 64));
+    // layout: [n_l][7] doubles, then [n_l] flags
+    double*        rec  = reinterpret_cast<double*>(ctx->pl_slots.p);
+    unsigned char* flag = ctx->pl_slots.p + n_l * 7 * sizeof(double);
+
+    PlArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = map->view, a.lpts = cloud->sorted.p, a.n_l = (uint32_t)n_l;
+    for (int i = 0; i < 9; i++) a.pose.r[i] = pose[i];
+    for (int i = 0; i < 3; i++) a.pose.t[i] = pose[9 + i];
+    a.radSq   = (float)(prm->searchRadius * prm->searchRadius);
+    a.rad     = (float)prm->searchRadius;
+    a.distThr = (float)prm->distanceThreshold;
+    const float cell0 = map->view.hf * (float)(1u << map->view.shift0);
+    a.r0     = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 2.0f);
+    a.eigThr = prm->planeEigenThreshold;
+    a.minPts = prm->minimumPlanePoints;
+    a.local_taken = (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
+    a.out_flag = flag, a.out_rec = rec, a.tile_bbox = ctx->tile_bbox.p;
+
+    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    const uint32_t K = prm->knn;
+    if (K <= 5) launch_k<5>(a, n_tiles, ctx->stream);
+    else if (K <= 8) launch_k<8>(a, n_tiles, ctx->stream);
+    else if (K <= 12) launch_k<12>(a, n_tiles, ctx->stream);
+    else launch_k<16>(a, n_tiles, ctx->stream);
+    hipLaunchKernelGGL(tile_bbox_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream,
+                       ctx->tile_bbox.p, n_tiles, ctx->local_bbox.p);
+    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+
+    const uint32_t n_blocks = (uint32_t)((n_l + PC_TILE - 1) / PC_TILE);
+    MP2P_TRY_HIP(ctx, ctx->block_counts.ensure(n_blocks ? n_blocks : 1));
+    PlCompactArgs c;
+    memset(&c, 0, sizeof(c));
+    c.flag = flag, c.rec = rec, c.n_l = (uint32_t)n_l, c.local_bbox = ctx->local_bbox.p;
+    for (int d = 0; d < 3; d++) c.gbb[d] = map->view.bbmin[d], c.gbb[3 + d] = map->view.bbmax[d];
+    c.margin = (float)(prm->distanceThreshold + prm->bounding_box_intersection_check_epsilon);
+    c.lx = cloud->x.p, c.ly = cloud->y.p, c.lz = cloud->z.p;
+    c.block_counts = ctx->block_counts.p, c.counts = out->counts.p, c.cap = out->cap_pt2pl;
+    c.o_lidx = out->pl_lidx.p, c.o_coef = out->pl_coef.p, c.o_cen = out->pl_cen.p;
+    c.o_lx = out->pl_lx.p, c.o_ly = out->pl_ly.p, c.o_lz = out->pl_lz.p;
+    c.ms_local = ms ? ms->local_taken.p : nullptr;
+    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    hipLaunchKernelGGL(pl_count_kernel, dim3(n_blocks), dim3(PC_THREADS), 0, ctx->stream, c);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                       ctx->block_counts.p, n_blocks, out->counts.p, c.cap,
+                       (unsigned long long)n_l, 1);
+    hipLaunchKernelGGL(pl_write_kernel, dim3(n_blocks), dim3(PC_THREADS), 0, ctx->stream, c);
+    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
+}
+
+}  // namespace mp2p

@@ -1,0 +1,440 @@
+// pairs.hip -- K4: threshold/claim resolution + ORDER-PRESERVING compaction into the
+// device-resident Pairings, and the Pairings container itself.
+//
+// Sequential meaning reproduced (Matcher_Points_DistanceThreshold.cpp:94-121, 206-266):
+//   local points are visited in ascending index; a pair (i,g) is emitted unless g was
+//   already paired; emitting marks i and g.  A skipped candidate has no side effect, hence
+//   winner(g) = min{ i : NN(i)=g, d2 < thr } -- exactly what the atomicMin claims of
+//   nn_query.hip computed -- and the output order is ascending i (stable compaction).
+#include "device_utils.hpp"
+
+namespace mp2p
+{
+constexpr int CP_THREADS = 256;
+constexpr int CP_ITEMS   = 4;
+constexpr int CP_TILE    = CP_THREADS * CP_ITEMS;
+
+struct CompactArgs
+{
+    const uint32_t*           nn_spos;  // [n_l] by original local index
+    const float*              nn_d2;
+    uint32_t                  n_l;
+    const unsigned long long* claims;  // null when global re-use is allowed
+    unsigned long long        claim_hi, local_offset;
+    const float*              local_bbox;  // device [6]
+    float                     gbb[6];      // global layer bbox
+    float                     margin;      // threshold + epsilon (:73-75)
+    const float4*             gpts;
+    const float *             lx, *ly, *lz;  // original-order local coordinates
+    uint32_t*                 block_counts;
+    unsigned long long*       counts;  // pairs->counts
+    unsigned long long        cap;
+    unsigned long long        potential_add;
+    // outputs
+    uint32_t *     o_lidx, *o_gidx;
+    float *        o_lx, *o_ly, *o_lz, *o_gx, *o_gy, *o_gz, *o_err;
+    unsigned char *ms_local, *ms_global;  // MatchState marks (or null)
+};
+
+// TBoundingBoxf::intersection(other, eps).has_value()  (Matcher_Points_DistanceThreshold.cpp:
+// 73-75; MRPT semantics: no overlap when a box, inflated by eps, is strictly beyond the other)
+__device__ __forceinline__ bool bbox_overlap(const float* g, const float* l, float eps)
+{
+    for (int d = 0; d < 3; d++)
+    {
+        if (l[d] - eps > g[3 + d]) return false;
+        if (l[3 + d] + eps < g[d]) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool pair_flag(const CompactArgs& a, uint32_t i, uint32_t& spos)
+{
+    spos = a.nn_spos[i];
+    if (spos == NONE_U32) return false;
+    if (a.claims && a.claims[spos] != (a.claim_hi | (a.local_offset + i))) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const CompactArgs a)
+{
+    __shared__ uint32_t s_w[CP_THREADS / 64];
+    uint32_t            c = 0;
+    if (bbox_overlap(a.gbb, a.local_bbox, a.margin))
+    {
+        const uint32_t base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; k++)
+        {
+            uint32_t sp;
+            if (base + k < a.n_l && pair_flag(a, base + k, sp)) c++;
+        }
+    }
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t t = 0;
+        for (int w = 0; w < CP_THREADS / 64; w++) t += s_w[w];
+        a.block_counts[blockIdx.x] = t;
+    }
+}
+
+// single block: exclusive scan of the block counts (in place), update the Pairings counters
+__global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t* block_counts,
+                                                            uint32_t n_blocks,
+                                                            unsigned long long* counts,
+                                                            unsigned long long cap,
+                                                            unsigned long long potential_add,
+                                                            int which /*0 pt2pt, 1 pt2pl*/)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_run;
+    const int           lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 1024)
+    {
+        const uint32_t i    = b0 + threadIdx.x;
+        const uint32_t v    = i < n_blocks ? block_counts[i] : 0;
+        const uint32_t incl = wave_incl_scan(v, lane);
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; k++) woff += s_w[k];
+        const uint32_t run = s_run;
+        if (i < n_blocks) block_counts[i] = run + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_run = run + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        const unsigned long long total = s_run;
+        const unsigned long long old   = counts[which];
+        counts[3]                      = old;  // write base for the scatter kernel
+        unsigned long long nw          = old + total;
+        if (nw > cap)
+        {
+            counts[4] = 1;  // overflow: caller-provided capacity too small
+            nw        = cap;
+        }
+        counts[which] = nw;
+        counts[2] += potential_add;
+    }
+}
+
+__global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const CompactArgs a)
+{
+    __shared__ uint32_t s_w[CP_THREADS / 64];
+    if (!bbox_overlap(a.gbb, a.local_bbox, a.margin)) return;
+    const uint32_t base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
+    uint32_t       sp[CP_ITEMS];
+    bool           f[CP_ITEMS];
+    uint32_t       c = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; k++)
+    {
+        f[k] = (base + k < a.n_l) && pair_flag(a, base + k, sp[k]);
+        c += f[k] ? 1u : 0u;
+    }
+    const int      lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(c, lane);
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; k++) woff += s_w[k];
+    unsigned long long dst = a.counts[3] + a.block_counts[blockIdx.x] + woff + incl - c;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; k++)
+    {
+        if (!f[k]) continue;
+        const uint32_t i = base + k;
+        if (dst < a.cap)
+        {
+            const float4   gp = a.gpts[sp[k]];
+            const uint32_t gi = __float_as_uint(gp.w);
+            a.o_lidx[dst] = i, a.o_gidx[dst] = gi;
+            a.o_lx[dst] = a.lx[i], a.o_ly[dst] = a.ly[i], a.o_lz[dst] = a.lz[i];  // UNtransformed
+            a.o_gx[dst] = gp.x, a.o_gy[dst] = gp.y, a.o_gz[dst] = gp.z;
+            a.o_err[dst] = a.nn_d2[i];
+            if (a.claims)
+            {  // marks are only left when global re-use is forbidden (:116-120)
+                if (a.ms_local) a.ms_local[i] = 1;
+                if (a.ms_global) a.ms_global[gi] = 1;
+            }
+        }
+        dst++;
+    }
+}
+
+int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                         const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms,
+                         mp2p_hip_pairs* out)
+{
+    const size_t   n_l      = cloud->n;
+    const uint32_t n_blocks = (uint32_t)((n_l + CP_TILE - 1) / CP_TILE);
+    MP2P_TRY_HIP(ctx, ctx->block_counts.ensure(n_blocks ? n_blocks : 1));
+    CompactArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nn_spos = ctx->nn_spos.p, a.nn_d2 = ctx->nn_d2.p, a.n_l = (uint32_t)n_l;
+    a.claims       = prm->allowMatchAlreadyMatchedGlobalPoints ? nullptr : map->claims.p;
+    a.claim_hi     = (~(unsigned long long)ctx->epoch) << 32;
+    a.local_offset = prm->local_index_offset;
+    a.local_bbox   = ctx->local_bbox.p;
+    for (int d = 0; d < 3; d++) a.gbb[d] = map->view.bbmin[d], a.gbb[3 + d] = map->view.bbmax[d];
+    a.margin = (float)(prm->threshold + prm->bounding_box_intersection_check_epsilon);
+    a.gpts   = map->pts.p;
+    a.lx = cloud->x.p, a.ly = cloud->y.p, a.lz = cloud->z.p;
+    a.block_counts  = ctx->block_counts.p;
+    a.counts        = out->counts.p;
+    a.cap           = out->cap_pt2pt;
+    a.potential_add = (unsigned long long)n_l * prm->pairingsPerPoint;
+    a.o_lidx = out->lidx.p, a.o_gidx = out->gidx.p;
+    a.o_lx = out->lx.p, a.o_ly = out->ly.p, a.o_lz = out->lz.p;
+    a.o_gx = out->gx.p, a.o_gy = out->gy.p, a.o_gz = out->gz.p, a.o_err = out->err.p;
+    a.ms_local  = ms ? ms->local_taken.p : nullptr;
+    a.ms_global = ms ? ms->global_taken.p : nullptr;
+
+    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (n_blocks)
+        hipLaunchKernelGGL(compact_count_kernel, dim3(n_blocks), dim3(CP_THREADS), 0, ctx->stream, a);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                       ctx->block_counts.p, n_blocks, out->counts.p, a.cap, a.potential_add, 0);
+    if (n_blocks)
+        hipLaunchKernelGGL(compact_write_kernel, dim3(n_blocks), dim3(CP_THREADS), 0, ctx->stream, a);
+    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
+}
+
+// only the potential_pairings bookkeeping (empty map / empty local: :64-67)
+__global__ void add_potential_kernel(unsigned long long* counts, unsigned long long add)
+{
+    counts[2] += add;
+}
+int launch_add_potential(mp2p_hip_ctx* ctx, mp2p_hip_pairs* out, unsigned long long add)
+{
+    hipLaunchKernelGGL(add_potential_kernel, dim3(1), dim3(1), 0, ctx->stream, out->counts.p, add);
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
+}
+
+// ---- host images <-> SoA -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_pt2pt_kernel(
+    const uint32_t* lidx, const uint32_t* gidx, const float* lx, const float* ly, const float* lz,
+    const float* gx, const float* gy, const float* gz, const float* err, uint32_t n,
+    mp2p_hip_pair_pt2pt* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    mp2p_hip_pair_pt2pt p;
+    p.globalIdx = gidx[i], p.localIdx = lidx[i];
+    p.global_xyz[0] = gx[i], p.global_xyz[1] = gy[i], p.global_xyz[2] = gz[i];
+    p.local_xyz[0] = lx[i], p.local_xyz[1] = ly[i], p.local_xyz[2] = lz[i];
+    p.errorSquareAfterTransformation = err[i];
+    out[i]                           = p;
+}
+
+__global__ __launch_bounds__(256) void unpack_pt2pt_kernel(const mp2p_hip_pair_pt2pt* in,
+                                                           uint32_t n, uint32_t* lidx,
+                                                           uint32_t* gidx, float* lx, float* ly,
+                                                           float* lz, float* gx, float* gy,
+                                                           float* gz, float* err)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mp2p_hip_pair_pt2pt p = in[i];
+    gidx[i] = p.globalIdx, lidx[i] = p.localIdx;
+    gx[i] = p.global_xyz[0], gy[i] = p.global_xyz[1], gz[i] = p.global_xyz[2];
+    lx[i] = p.local_xyz[0], ly[i] = p.local_xyz[1], lz[i] = p.local_xyz[2];
+    err[i] = p.errorSquareAfterTransformation;
+}
+
+__global__ __launch_bounds__(256) void pack_pt2pl_kernel(const double* coef, const double* cen,
+                                                         const float* lx, const float* ly,
+                                                         const float* lz, uint32_t n,
+                                                         mp2p_hip_pair_pt2pl* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    mp2p_hip_pair_pt2pl p;
+    for (int k = 0; k < 4; k++) p.plane[k] = coef[(size_t)i * 4 + k];
+    for (int k = 0; k < 3; k++) p.centroid[k] = cen[(size_t)i * 3 + k];
+    p.pt_local[0] = lx[i], p.pt_local[1] = ly[i], p.pt_local[2] = lz[i];
+    p._pad = 0.f;
+    out[i] = p;
+}
+
+__global__ __launch_bounds__(256) void unpack_pt2pl_kernel(const mp2p_hip_pair_pt2pl* in,
+                                                           uint32_t n, double* coef, double* cen,
+                                                           float* lx, float* ly, float* lz,
+                                                           uint32_t* lidx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mp2p_hip_pair_pt2pl p = in[i];
+    for (int k = 0; k < 4; k++) coef[(size_t)i * 4 + k] = p.plane[k];
+    for (int k = 0; k < 3; k++) cen[(size_t)i * 3 + k] = p.centroid[k];
+    lx[i] = p.pt_local[0], ly[i] = p.pt_local[1], lz[i] = p.pt_local[2];
+    lidx[i] = i;
+}
+
+}  // namespace mp2p
+
+using namespace mp2p;
+
+extern "C" {
+
+int mp2p_hip_pairs_create(mp2p_hip_ctx* ctx, size_t cap_pt2pt, size_t cap_pt2pl,
+                          mp2p_hip_pairs** out)
+{
+    if (!ctx || !out) return MP2P_HIP_ERR_INVALID;
+    auto* p = new mp2p_hip_pairs();
+    p->ctx  = ctx;
+    p->cap_pt2pt = cap_pt2pt, p->cap_pt2pl = cap_pt2pl;
+    const size_t c1 = cap_pt2pt ? cap_pt2pt : 1, c2 = cap_pt2pl ? cap_pt2pl : 1;
+    MP2P_TRY_HIP(ctx, p->lidx.alloc(c1));
+    MP2P_TRY_HIP(ctx, p->gidx.alloc(c1));
+    MP2P_TRY_HIP(ctx, p->lx.alloc(c1));
+    MP2P_TRY_HIP(ctx, p->ly.alloc(c1));
+    MP2P_TRY_HIP(ctx, p->lz.alloc(c1));
+    MP2P_TRY_HIP(ctx, p->gx.alloc(c1));
+    MP2P_TRY_HIP(ctx, p->gy.alloc(c1));
+    MP2P_TRY_HIP(ctx, p->gz.alloc(c1));
+    MP2P_TRY_HIP(ctx, p->err.alloc(c1));
+    MP2P_TRY_HIP(ctx, p->pl_lidx.alloc(c2));
+    MP2P_TRY_HIP(ctx, p->pl_coef.alloc(c2 * 4));
+    MP2P_TRY_HIP(ctx, p->pl_cen.alloc(c2 * 3));
+    MP2P_TRY_HIP(ctx, p->pl_lx.alloc(c2));
+    MP2P_TRY_HIP(ctx, p->pl_ly.alloc(c2));
+    MP2P_TRY_HIP(ctx, p->pl_lz.alloc(c2));
+    MP2P_TRY_HIP(ctx, p->counts.alloc(8));
+    MP2P_TRY_HIP(ctx, hipMemsetAsync(p->counts.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    *out = p;
+    return MP2P_HIP_OK;
+}
+
+void mp2p_hip_pairs_free(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p)
+{
+    if (!p) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    p->lidx.release(), p->gidx.release();
+    p->lx.release(), p->ly.release(), p->lz.release();
+    p->gx.release(), p->gy.release(), p->gz.release(), p->err.release();
+    p->pl_lidx.release(), p->pl_coef.release(), p->pl_cen.release();
+    p->pl_lx.release(), p->pl_ly.release(), p->pl_lz.release();
+    p->counts.release();
+    delete p;
+}
+
+int mp2p_hip_pairs_clear(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipMemsetAsync(p->counts.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_counts(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, uint64_t* n_pt2pt,
+                          uint64_t* n_pt2pl, uint64_t* potential)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    unsigned long long h[8];
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(h, p->counts.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_pt2pt) *n_pt2pt = h[0];
+    if (n_pt2pl) *n_pt2pl = h[1];
+    if (potential) *potential = h[2];
+    if (h[4])
+        return set_err(ctx, MP2P_HIP_ERR_CAPACITY,
+                       "Pairings capacity exceeded (cap_pt2pt=%zu cap_pt2pl=%zu)", p->cap_pt2pt,
+                       p->cap_pt2pl);
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_download_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
+                                  mp2p_hip_pair_pt2pt* out, size_t capacity, size_t* n_out)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    uint64_t n = 0;
+    int      rc = mp2p_hip_pairs_counts(ctx, p, &n, nullptr, nullptr);
+    if (rc) return rc;
+    if (n_out) *n_out = (size_t)n;
+    if (n == 0) return MP2P_HIP_OK;
+    if (!out || capacity < n)
+        return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "download_pt2pt: capacity %zu < %llu", capacity,
+                       (unsigned long long)n);
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pt)));
+    auto* d = reinterpret_cast<mp2p_hip_pair_pt2pt*>(ctx->aos_stage.p);
+    hipLaunchKernelGGL(pack_pt2pt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, p->lidx.p, p->gidx.p, p->lx.p, p->ly.p, p->lz.p, p->gx.p,
+                       p->gy.p, p->gz.p, p->err.p, (uint32_t)n, d);
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, d, n * sizeof(mp2p_hip_pair_pt2pt), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_download_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
+                                  mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx,
+                                  size_t capacity, size_t* n_out)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    uint64_t n = 0;
+    int      rc = mp2p_hip_pairs_counts(ctx, p, nullptr, &n, nullptr);
+    if (rc) return rc;
+    if (n_out) *n_out = (size_t)n;
+    if (n == 0) return MP2P_HIP_OK;
+    if (!out || capacity < n)
+        return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "download_pt2pl: capacity %zu < %llu", capacity,
+                       (unsigned long long)n);
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pl)));
+    auto* d = reinterpret_cast<mp2p_hip_pair_pt2pl*>(ctx->aos_stage.p);
+    hipLaunchKernelGGL(pack_pt2pl_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, p->pl_coef.p, p->pl_cen.p, p->pl_lx.p, p->pl_ly.p, p->pl_lz.p,
+                       (uint32_t)n, d);
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, d, n * sizeof(mp2p_hip_pair_pt2pl), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_local_idx)
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(out_local_idx, p->pl_lidx.p, n * sizeof(uint32_t),
+                                         hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_upload(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p, const mp2p_hip_pair_pt2pt* pt2pt,
+                          size_t n_pt2pt, const mp2p_hip_pair_pt2pl* pt2pl, size_t n_pt2pl)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    if (n_pt2pt > p->cap_pt2pt || n_pt2pl > p->cap_pt2pl)
+        return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "pairs_upload: capacity exceeded");
+    const size_t bytes = std::max(n_pt2pt * sizeof(mp2p_hip_pair_pt2pt),
+                                  n_pt2pl * sizeof(mp2p_hip_pair_pt2pl));
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(bytes ? bytes : 1));
+    if (n_pt2pt)
+    {
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->aos_stage.p, pt2pt, n_pt2pt * sizeof(mp2p_hip_pair_pt2pt),
+                                         hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(unpack_pt2pt_kernel, dim3((uint32_t)((n_pt2pt + 255) / 256)), dim3(256),
+                           0, ctx->stream,
+                           reinterpret_cast<const mp2p_hip_pair_pt2pt*>(ctx->aos_stage.p),
+                           (uint32_t)n_pt2pt, p->lidx.p, p->gidx.p, p->lx.p, p->ly.p, p->lz.p,
+                           p->gx.p, p->gy.p, p->gz.p, p->err.p);
+        MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging buffer is reused below
+    }
+    if (n_pt2pl)
+    {
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->aos_stage.p, pt2pl, n_pt2pl * sizeof(mp2p_hip_pair_pt2pl),
+                                         hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(unpack_pt2pl_kernel, dim3((uint32_t)((n_pt2pl + 255) / 256)), dim3(256),
+                           0, ctx->stream,
+                           reinterpret_cast<const mp2p_hip_pair_pt2pl*>(ctx->aos_stage.p),
+                           (uint32_t)n_pt2pl, p->pl_coef.p, p->pl_cen.p, p->pl_lx.p, p->pl_ly.p,
+                           p->pl_lz.p, p->pl_lidx.p);
+    }
+    unsigned long long h[8] = {n_pt2pt, n_pt2pl, 0, 0, 0, 0, 0, 0};
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(p->counts.p, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+}  // extern "C"

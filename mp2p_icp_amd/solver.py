@@ -1,0 +1,189 @@
+"""Host-side mirror of the reference's Solver plugin interface for the hot path.
+
+  Solver / SolverContext   mp2p_icp/src/Solver.cpp:28-64, Solver.h:43-102
+  Solver_GaussNewton       Solver_GaussNewton.cpp:29-67 -> optimal_tf_gauss_newton
+  Solver_Horn              Solver_Horn.cpp:33-61 -> optimal_tf_horn (point pairs only)
+  run_solvers              ICP.cpp:469-479
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, core, se3
+from .parameterizable import Parameterizable
+
+ROBUST_KERNELS = {"RobustKernel::None": _lib.KERNEL_NONE, "None": _lib.KERNEL_NONE,
+                  "RobustKernel::GemanMcClure": _lib.KERNEL_GEMANMCCLURE,
+                  "GemanMcClure": _lib.KERNEL_GEMANMCCLURE,
+                  "RobustKernel::Cauchy": _lib.KERNEL_CAUCHY, "Cauchy": _lib.KERNEL_CAUCHY}
+
+
+class OptimalTF_Result:  # OptimalTF_Result.h:32-39
+    def __init__(self):
+        self.optimalPose = se3.identity()
+        self.optimalScale = 1.0
+        self.outliers = []
+        self.gn = None  # extra: last normal equations / iteration count of the GN solver
+
+
+class PosePrior:
+    """SolverContext::prior (CPose3DPDFGaussianInf): mean pose + 6x6 information matrix"""
+
+    def __init__(self, mean, cov_inv):
+        self.mean = np.asarray(mean, dtype=np.float64)
+        self.cov_inv = np.asarray(cov_inv, dtype=np.float64).reshape(6, 6)
+
+
+class SolverContext:  # Solver.h:43-62
+    def __init__(self):
+        self.guessRelativePose = None
+        self.currentCorrectionFromInitialGuess = None
+        self.lastIcpStepIncrement = None
+        self.icpIteration = None
+        self.prior = None
+        self.perSolverPersistentData = {}
+
+
+class PairWeights:  # PairWeights.h:34-52
+    def __init__(self):
+        self.pt2pt = self.pt2ln = self.pt2pl = self.ln2ln = self.pl2pl = 1.0
+
+    def load_from(self, p):  # PairWeights.cpp:26-34: all five required
+        for k in ("pt2pt", "pt2pl", "pt2ln", "ln2ln", "pl2pl"):
+            if k not in p:
+                raise KeyError(f"Required parameter `{k}` not an existing key in dictionary.")
+            setattr(self, k, float(p[k]))
+
+
+class Solver(Parameterizable):
+    def __init__(self):
+        super().__init__()
+        self.runFromIteration = 0
+        self.runUpToIteration = 0
+        self.enabled = True
+        self.runUntilTranslationCorrectionSmallerThan = 0.0
+
+    def initialize(self, params):
+        params = params or {}
+        self.runFromIteration = int(params.get("runFromIteration", 0))
+        self.runUpToIteration = int(params.get("runUpToIteration", 0))
+        self.enabled = bool(params.get("enabled", True))
+        self.runUntilTranslationCorrectionSmallerThan = float(
+            params.get("runUntilTranslationCorrectionSmallerThan", 0.0))
+
+    def optimal_pose(self, pairings, out, sc):  # Solver.cpp:36-64
+        if not self.enabled:
+            return False
+        it = sc.icpIteration
+        if it is not None and it < self.runFromIteration:
+            return False
+        if it is not None and self.runUpToIteration > 0 and it > self.runUpToIteration:
+            return False
+        if self.runUntilTranslationCorrectionSmallerThan > 0:
+            my = sc.perSolverPersistentData.setdefault(id(self), {})
+            if "finished" in my:
+                return False
+            if sc.lastIcpStepIncrement is not None and np.linalg.norm(
+                    sc.lastIcpStepIncrement[9:12]) < self.runUntilTranslationCorrectionSmallerThan:
+                my["finished"] = True
+                return False
+        return self.impl_optimal_pose(pairings, out, sc)
+
+
+class Solver_GaussNewton(Solver):
+    def __init__(self):
+        super().__init__()
+        self.maxIterations = 5
+        self.innerLoopVerbose = False
+        self.robustKernel = _lib.KERNEL_NONE
+        self.robustKernelParam = 1.0
+        self.pairWeights = PairWeights()
+
+    def initialize(self, params):  # Solver_GaussNewton.cpp:29-40
+        super().initialize(params)
+        if params is None or "maxIterations" not in params:
+            raise KeyError("Required parameter `maxIterations` not an existing key in dictionary.")
+        self.maxIterations = int(params["maxIterations"])
+        self.innerLoopVerbose = bool(params.get("innerLoopVerbose", False))
+        rk = params.get("robustKernel", "RobustKernel::None")
+        if rk not in ROBUST_KERNELS:
+            raise ValueError(f"Unknown kernel type: {rk}")
+        self.robustKernel = ROBUST_KERNELS[rk]
+        self.declare_parameter_opt(params, "robustKernelParam")
+        if "pair_weights" in params:
+            self.pairWeights.load_from(params["pair_weights"])
+
+    def gn_params(self, sc, point_weights=None):
+        p = _lib.GNParams()
+        p.maxInnerLoopIterations = self.maxIterations
+        p.minDelta, p.maxCost = 1e-7, 0.0  # optimal_tf_gauss_newton.h:46-58
+        p.kernel, p.kernelParam = self.robustKernel, float(self.robustKernelParam)
+        p.w_pt2pt, p.w_pt2pl = self.pairWeights.pt2pt, self.pairWeights.pt2pl
+        p.has_prior = 0
+        if sc.prior is not None:
+            p.has_prior = 1
+            p.prior_mean = (C.c_double * 12)(*sc.prior.mean)
+            p.prior_cov_inv = (C.c_double * 36)(*sc.prior.cov_inv.ravel())
+        p.n_weight_blocks = 0
+        if point_weights:
+            if len(point_weights) > 8:
+                raise ValueError("at most 8 point_weights blocks are supported")
+            p.n_weight_blocks = len(point_weights)
+            for i, (cnt, w) in enumerate(point_weights):
+                p.weight_block_count[i] = int(cnt)
+                p.weight_block_w[i] = float(w)
+        return p
+
+    def impl_optimal_pose(self, pairings, out, sc):  # Solver_GaussNewton.cpp:42-67
+        self.checkAllParametersAreRealized()
+        if sc.guessRelativePose is None:
+            raise RuntimeError("ASSERT_(sc.guessRelativePose.has_value())")
+        ctx = pairings.ctx or core.default_context()
+        dev = pairings.device
+        if dev is None:
+            dev = pairings._ensure_dev(ctx, 1, 0)
+        res = core.gn_solve(ctx, dev, sc.guessRelativePose, self.gn_params(sc, pairings.point_weights))
+        out.__init__()
+        out.optimalPose = np.array(res.pose)
+        out.gn = core.gn_result_to_dict(res)
+        return True  # optimal_tf_gauss_newton always returns true (:369)
+
+
+class Solver_Horn(Solver):
+    """Point pairs only, no scale outlier detector, no robust kernel."""
+
+    def __init__(self):
+        super().__init__()
+        self.pairWeights = PairWeights()
+
+    def initialize(self, params):
+        super().initialize(params)
+        params = params or {}
+        wp = params.get("pairingsWeightParameters")
+        if wp:
+            if wp.get("use_scale_outlier_detector", False):
+                raise NotImplementedError("use_scale_outlier_detector is not implemented")
+            if ROBUST_KERNELS.get(wp.get("robust_kernel", "RobustKernel::None"), 0) != 0:
+                raise NotImplementedError("robust kernel in Solver_Horn is not implemented")
+            if "pair_weights" in wp:
+                self.pairWeights.load_from(wp["pair_weights"])
+
+    def impl_optimal_pose(self, pairings, out, sc):
+        ctx = pairings.ctx or core.default_context()
+        if pairings.device is None:
+            return False
+        if pairings.device.counts()[1] != 0:
+            raise RuntimeError("This solver cannot handle point-to-plane pairings yet.")
+        T, ok = core.horn_solve(ctx, pairings.device, self.pairWeights.pt2pt)
+        out.__init__()
+        if ok:
+            out.optimalPose = T
+        return ok
+
+
+def run_solvers(solvers, pairings, out, sc):  # ICP.cpp:469-479
+    for s in solvers:
+        assert s is not None
+        if s.optimal_pose(pairings, out, sc):
+            return True
+    return False

@@ -749,16 +749,20 @@ static void bbox_of(const float* x, const float* y, const float* z, size_t n, fl
     }
 }
 
-/* TBoundingBoxf::intersection(other, eps).has_value():
- * both boxes inflated by eps must overlap on every axis. */
+/* TBoundingBoxf::intersection(other, eps).has_value() (Matcher_Points_DistanceThreshold.cpp:
+ * 73-75).  MRPT (un-vendored) returns no intersection when `other`, inflated by eps, lies
+ * strictly beyond `this` on some axis:
+ *     b.min - eps > max  ||  b.max + eps < min
+ * (a = global layer box = "this", b = transformed local box).  With thresholdAngularDeg == 0
+ * the early-out cannot change the result: eps = threshold + 0.2 exceeds any accepted pair
+ * distance.  SURVEY.md Appendix C.6 lists this as an assumption to re-check against MRPT. */
 static int bbox_intersects(const float amin[3], const float amax[3], const float bmin[3],
                            const float bmax[3], float eps)
 {
     for (int d = 0; d < 3; d++)
     {
-        const float lo = fmaxf(amin[d] - eps, bmin[d] - eps);
-        const float hi = fminf(amax[d] + eps, bmax[d] + eps);
-        if (lo > hi) return 0;
+        if (bmin[d] - eps > amax[d]) return 0;
+        if (bmax[d] + eps < amin[d]) return 0;
     }
     return 1;
 }

@@ -1,0 +1,205 @@
+"""GPU parity of Matcher_Points_DistanceThreshold (HIP path, through the C ABI) against the CPU
+oracle and the reference's own known-answer test.  Correspondence lists must be BIT-EXACT
+(indices, order, coordinates, errorSquareAfterTransformation)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DEG = math.pi / 180.0
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import mp2p_icp_amd
+    return mp2p_icp_amd
+
+
+def _maps(amd, g, l, **layer_kw):
+    pcG = amd.metric_map_t({amd.PT_LAYER_RAW: amd.PointLayer(g, **layer_kw)})
+    pcL = amd.metric_map_t({amd.PT_LAYER_RAW: amd.PointLayer(l)})
+    return pcG, pcL
+
+
+def _hip_match(amd, pcG, pcL, pose, params, ms=None):
+    m = amd.Matcher_Points_DistanceThreshold()
+    m.initialize(params)
+    pairs = amd.Pairings()
+    ms = ms or amd.MatchState(pcG, pcL)
+    assert m.match(pcG, pcL, pose, amd.MatchContext(), ms, pairs)
+    return pairs, ms
+
+
+def _assert_same_pairs(hip_pairs, orc_pairs):
+    assert len(hip_pairs) == len(orc_pairs), (len(hip_pairs), len(orc_pairs))
+    if len(orc_pairs) == 0:
+        return
+    assert np.array_equal(hip_pairs["localIdx"], orc_pairs["localIdx"])
+    assert np.array_equal(hip_pairs["globalIdx"], orc_pairs["globalIdx"])
+    for k, (a, b, c) in (("global", ("gx", "gy", "gz")), ("local", ("lx", "ly", "lz"))):
+        want = np.stack([orc_pairs[a], orc_pairs[b], orc_pairs[c]], 1)
+        assert np.array_equal(hip_pairs[k].view(np.uint32), want.view(np.uint32)), k
+    assert np.array_equal(hip_pairs["errorSquareAfterTransformation"].view(np.uint32),
+                          orc_pairs["errSq"].view(np.uint32))
+
+
+# ---- tests/test-mp2p_matcher_pt2pt.cpp:26-107 through the mirrored plugin interface ----------
+def test_reference_known_answers(amd, oracle):
+    from test_oracle_kat import KAT_POSES, _kat_global, _kat_local
+    g, l = _kat_global(), _kat_local()
+    pcG, pcL = _maps(amd, g, l)
+    m = amd.Matcher_Points_DistanceThreshold()
+    m.initialize({"threshold": 1.05, "thresholdAngularDeg": 0.001})
+    assert abs(m.threshold - 1.05) < 1e-4 and abs(m.thresholdAngularDeg - 0.001) < 1e-4
+    for pose6, expected in KAT_POSES:
+        pairs = amd.Pairings()
+        ms = amd.MatchState(pcG, pcL)
+        m.match(pcG, pcL, amd.se3.from_xyzypr(*pose6), amd.MatchContext(), ms, pairs)
+        got = [(int(p["localIdx"]), int(p["globalIdx"])) for p in pairs.paired_pt2pt]
+        assert got == expected, (pose6, got)
+        assert pairs.empty() == (len(expected) == 0)
+        assert pairs.potential_pairings == 2
+
+
+CASES = [
+    # n_g, n_l, threshold, angular, seed, layer kwargs
+    (5000, 1000, 0.5, 0.0, 1, {}),
+    (5000, 1000, 2.0, 0.0, 2, {}),
+    (20000, 4097, 0.3, 0.5, 3, {}),
+    (20000, 63, 1.0, 0.0, 4, {}),
+    (3000, 3000, 5.0, 0.0, 5, {}),           # r_max far larger than the voxels
+    (50000, 10000, 0.2, 0.0, 6, dict(cell_size=0.05)),
+    (50000, 10000, 0.7, 0.1, 7, dict(cell_size=3.0)),   # very coarse voxels
+    (777, 129, 0.4, 0.0, 8, dict(target_per_cell=1.0)),
+]
+
+
+@pytest.mark.parametrize("n_g,n_l,thr,ang,seed,kw", CASES)
+@pytest.mark.parametrize("q", [64, 16, 4, 1])
+def test_random_parity_vs_oracle(amd, oracle, n_g, n_l, thr, ang, seed, kw, q):
+    from mp2p_icp_amd import synthetic
+    d = synthetic.random_cloud_pair(n_l, n_g, seed, outlier_frac=0.1)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG, pcL = _maps(amd, g, l, **kw)
+    for pose in (d["T_gt"], d["T_init"]):
+        want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose,
+                                       thr, ang, tree=tree)
+        pairs, _ = _hip_match(amd, pcG, pcL, pose,
+                              {"threshold": thr, "thresholdAngularDeg": ang,
+                               "hip_queries_per_wave": q})
+        _assert_same_pairs(pairs.paired_pt2pt, want)
+        assert pairs.potential_pairings == pot
+
+
+def test_brute_force_definition_small(amd, oracle):
+    """against the brute-force oracle (THE definition), including exact duplicates -> ties"""
+    rng = np.random.default_rng(11)
+    g = rng.uniform(-3, 3, (600, 3)).astype(np.float32)
+    g[100:140] = g[0:40]          # duplicated global points: lowest index must win
+    l = np.concatenate([g[:300] + rng.normal(0, 0.01, (300, 3)).astype(np.float32), g[50:60]])
+    pcG, pcL = _maps(amd, g, l)
+    T = amd.se3.identity()
+    for allow in (False, True):
+        want, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, 0.3, 0.0,
+                                     allowMatchAlreadyMatchedGlobalPoints=allow, tree=None)
+        pairs, _ = _hip_match(amd, pcG, pcL, T, {"threshold": 0.3, "thresholdAngularDeg": 0.0,
+                                                 "allowMatchAlreadyMatchedGlobalPoints": allow})
+        _assert_same_pairs(pairs.paired_pt2pt, want)
+
+
+def test_allow_flags_and_match_state(amd, oracle):
+    from mp2p_icp_amd import synthetic
+    d = synthetic.random_cloud_pair(3000, 8000, 21)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG, pcL = _maps(amd, g, l)
+    rng = np.random.default_rng(5)
+    gt0 = (rng.random(g.shape[0]) < 0.3).astype(np.uint8)
+    lt0 = (rng.random(l.shape[0]) < 0.3).astype(np.uint8)
+    for allowL in (False, True):
+        for allowG in (False, True):
+            gt, lt = gt0.copy(), lt0.copy()
+            want, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2],
+                                         d["T_init"], 0.6, 0.0, tree=tree,
+                                         allowMatchAlreadyMatchedPoints=allowL,
+                                         allowMatchAlreadyMatchedGlobalPoints=allowG,
+                                         local_taken=lt, global_taken=gt)
+            ms = amd.MatchState(pcG, pcL)
+            ms.for_layers("raw", "raw").upload(gt0, lt0)
+            pairs, ms = _hip_match(amd, pcG, pcL, d["T_init"],
+                                   {"threshold": 0.6, "thresholdAngularDeg": 0.0,
+                                    "allowMatchAlreadyMatchedPoints": allowL,
+                                    "allowMatchAlreadyMatchedGlobalPoints": allowG}, ms)
+            _assert_same_pairs(pairs.paired_pt2pt, want)
+            g_after, l_after = ms.for_layers("raw", "raw").download()
+            assert np.array_equal(g_after, gt) and np.array_equal(l_after, lt)
+
+
+def test_edge_cases(amd, oracle):
+    rng = np.random.default_rng(3)
+    g = rng.uniform(-5, 5, (2000, 3)).astype(np.float32)
+    l = rng.uniform(-5, 5, (100, 3)).astype(np.float32)
+    prm = {"threshold": 0.5, "thresholdAngularDeg": 0.0}
+    # empty local
+    pcG, pcL = _maps(amd, g, np.zeros((0, 3), np.float32))
+    pairs, _ = _hip_match(amd, pcG, pcL, amd.se3.identity(), prm)
+    assert pairs.empty() and pairs.potential_pairings == 0
+    # empty global: potential_pairings still counted (Matcher_Points_DistanceThreshold.cpp:64-67)
+    pcG, pcL = _maps(amd, np.zeros((0, 3), np.float32), l)
+    pairs, _ = _hip_match(amd, pcG, pcL, amd.se3.identity(), prm)
+    assert pairs.empty() and pairs.potential_pairings == 100
+    # disjoint bounding boxes -> early out, no pairs
+    pcG, pcL = _maps(amd, g, l)
+    pairs, _ = _hip_match(amd, pcG, pcL, amd.se3.from_xyzypr(100, 0, 0), prm)
+    assert pairs.empty() and pairs.potential_pairings == 100
+    # single global point / single local point
+    pcG, pcL = _maps(amd, g[:1], g[:1] + np.float32(0.01))
+    pairs, _ = _hip_match(amd, pcG, pcL, amd.se3.identity(), prm)
+    assert len(pairs.paired_pt2pt) == 1 and pairs.paired_pt2pt[0]["globalIdx"] == 0
+    # non-finite local point is never paired
+    l2 = l.copy()
+    l2[7] = np.nan
+    pcG, pcL = _maps(amd, g, l2)
+    l3 = l.copy()
+    l3[7] = 1e6  # the oracle's stand-in for "cannot be paired"
+    want, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l3[:, 0], l3[:, 1], l3[:, 2],
+                                 amd.se3.identity(), 0.5, 0.0)
+    pairs, _ = _hip_match(amd, pcG, pcL, amd.se3.identity(), prm)
+    assert 7 not in pairs.paired_pt2pt["localIdx"]
+    _assert_same_pairs(pairs.paired_pt2pt, want)
+    # invalid parameters raise (ASSERT_GT_(threshold, .0))
+    with pytest.raises(amd.Mp2pHipError):
+        _hip_match(amd, pcG, pcL, amd.se3.identity(), {"threshold": 0.0, "thresholdAngularDeg": 0.0})
+    with pytest.raises(KeyError):
+        amd.Matcher_Points_DistanceThreshold().initialize({"threshold": 1.0})
+
+
+def test_formula_parameters(amd):
+    """tests/test-mp2p_matcher_pt2pt_parameterizable.cpp:28-52"""
+    m = amd.Matcher_Points_DistanceThreshold()
+    m.initialize({"threshold": "MATCH_THRESHOLD*2.0", "thresholdAngularDeg": 0.0})
+    with pytest.raises(RuntimeError):
+        m.checkAllParametersAreRealized()
+    ps = amd.ParameterSource()
+    m.attachToParameterSource(ps)
+    ps.updateVariable("MATCH_THRESHOLD", 0.75)
+    ps.realize()
+    m.checkAllParametersAreRealized()
+    assert abs(m.threshold - 1.5) < 1e-12
+
+
+def test_kitti_shape_c2_parity(amd, oracle):
+    """BASELINE config 2 shape at reduced size: 120k-point scan vs 500k-point map."""
+    from mp2p_icp_amd import synthetic
+    d = synthetic.make_pair(120_000, 500_000, 2001)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG, pcL = _maps(amd, g, l)
+    for pose in (d["T_gt"], d["T_init"]):
+        want, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose,
+                                     2.0, 0.0, tree=tree, threads=8)
+        pairs, _ = _hip_match(amd, pcG, pcL, pose, {"threshold": 2.0, "thresholdAngularDeg": 0.0})
+        _assert_same_pairs(pairs.paired_pt2pt, want)

@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--q", type=int, default=0, help="queries per wave (tuning)")
     ap.add_argument("--r0", type=float, default=0.0, help="initial radius in cells (tuning)")
+    ap.add_argument("--grp", type=float, default=0.0, help="group radius factor (tuning)")
     ap.add_argument("--cell", type=float, default=0.0, help="voxel edge [m] (0 = automatic)")
     ap.add_argument("--target-per-cell", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,7 +151,7 @@ def main():
         f"{info['build_ms']:.1f} ms (upload+build {t_index * 1e3:.0f} ms); cloud {t_cloud * 1e3:.0f} ms")
 
     n_l = l.shape[0]
-    prm = _lib.Pt2PtParams(args.threshold, 0.0, 1, 0, 0, 0.20, rank * n_l, args.r0, args.q)
+    prm = _lib.Pt2PtParams(args.threshold, 0.0, 1, 0, 0, 0.20, rank * n_l, args.r0, args.q, args.grp)
     gnp = _lib.GNParams()
     gnp.maxInnerLoopIterations = args.gn_iters
     gnp.minDelta, gnp.maxCost = 1e-7, 0.0
@@ -198,7 +199,7 @@ def main():
     state = {"pose": d["T_init"].copy(), "s": 0}
     for _ in range(args.warmup):
         one_step()
-    touched, cand, passes, pair_counts = [], [], [], []
+    touched, cand, passes, pair_counts, maxcand, maxpass = [], [], [], [], [], []
     for _ in range(args.steps):
         one_step()
         pair_counts.append(pairs.counts()[0])
@@ -212,6 +213,8 @@ def main():
         touched.append(st["nn_points_staged"])
         cand.append(st["nn_candidates_tested"])
         passes.append(st["nn_passes"] / max(1, st["nn_tiles"]))
+        maxcand.append(st["nn_max_candidates_one_tile"])
+        maxpass.append(st["nn_max_passes_one_tile"])
         state["pose"], _ = reg.solve(state["pose"])
         state["s"] += 1
     ctx.set_profiling(0)
@@ -264,6 +267,8 @@ def main():
         "nn_stats": {"avg_passes_per_tile": float(np.mean(passes)),
                      "candidates_tested_per_query": float(np.mean(cand)) / n_l,
                      "global_points_touched": float(np.mean(touched)),
+                     "max_candidates_one_tile": int(np.max(maxcand)),
+                     "max_passes_one_tile": int(np.max(maxpass)),
                      "voxel_m": info["cell_size"]},
         "index_build_ms": info["build_ms"],
         "final_pose_error": {"trans_m": float(np.linalg.norm(final_err[:3])),

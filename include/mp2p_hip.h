@@ -166,7 +166,9 @@ typedef struct
     uint64_t local_index_offset;
     /* tuning (0 = default): first search radius in units of the finest cell */
     float    initial_radius_cells;
-    uint32_t queries_per_wave; /* 64, 16, 4 or 1; 0 = default */
+    uint32_t queries_per_wave;    /* 64 or 16; 0 = default (64) */
+    float    group_radius_factor; /* queries of a tile farther than this many search radii
+                                     from the first pending one wait for a later pass; 0 = 4 */
 } mp2p_hip_pt2pt_params;
 
 /* ms may be NULL (fresh MatchState with nothing marked, marks discarded). */
@@ -271,6 +273,7 @@ typedef struct
     double   ms_gn;      /* all inner iterations of the last gn_solve */
     uint64_t nn_tiles, nn_passes, nn_cells_visited, nn_candidates_tested, nn_points_staged;
     uint64_t nn_queries, nn_unresolved_after_first_pass;
+    uint64_t nn_max_candidates_one_tile, nn_max_passes_one_tile;
 } mp2p_hip_stats;
 /* 0 = off; 1 = bracket the kernels with hipEvents (ms_* fields; each call then ends with a
  * stream synchronisation); 2 = additionally collect the device counters (nn_* fields, slower). */

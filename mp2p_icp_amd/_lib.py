@@ -41,7 +41,7 @@ class Pt2PtParams(C.Structure):
                 ("allowMatchAlreadyMatchedGlobalPoints", C.c_int32),
                 ("bounding_box_intersection_check_epsilon", C.c_double),
                 ("local_index_offset", C.c_uint64), ("initial_radius_cells", C.c_float),
-                ("queries_per_wave", C.c_uint32)]
+                ("queries_per_wave", C.c_uint32), ("group_radius_factor", C.c_float)]
 
 
 class Pt2PlParams(C.Structure):
@@ -72,7 +72,8 @@ class Stats(C.Structure):
                 ("nn_tiles", C.c_uint64), ("nn_passes", C.c_uint64),
                 ("nn_cells_visited", C.c_uint64), ("nn_candidates_tested", C.c_uint64),
                 ("nn_points_staged", C.c_uint64), ("nn_queries", C.c_uint64),
-                ("nn_unresolved_after_first_pass", C.c_uint64)]
+                ("nn_unresolved_after_first_pass", C.c_uint64),
+                ("nn_max_candidates_one_tile", C.c_uint64), ("nn_max_passes_one_tile", C.c_uint64)]
 
 
 _P = C.c_void_p
@@ -153,6 +154,12 @@ def load():
     if _lib is not None:
         return _lib
     path = _build.LIB
+    try:
+        # torch wheels bundle their own HIP runtime; loading it FIRST makes our library bind to
+        # the same libamdhip64 (two runtimes in one process do not both see the device)
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if _build.needs_build():
         try:
             _build.build()

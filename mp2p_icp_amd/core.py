@@ -45,7 +45,7 @@ class Context:
         check(self._L.mp2p_hip_sync(self._h), self._h)
 
     def set_profiling(self, on):
-        check(self._L.mp2p_hip_set_profiling(self._h, 1 if on else 0), self._h)
+        check(self._L.mp2p_hip_set_profiling(self._h, int(on)), self._h)
 
     def stats(self):
         s = _lib.Stats()

@@ -452,6 +452,7 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
             ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1];
             ctx->stats.nn_cells_visited = c[2], ctx->stats.nn_candidates_tested = c[3];
             ctx->stats.nn_unresolved_after_first_pass = c[4];
+            ctx->stats.nn_max_candidates_one_tile = c[5], ctx->stats.nn_max_passes_one_tile = c[6];
             std::vector<unsigned char> t(ctx->pending_map_n);
             MP2P_TRY_HIP(ctx, hipMemcpy(t.data(), ctx->pl_slots.p, t.size(), hipMemcpyDeviceToHost));
             uint64_t k = 0;

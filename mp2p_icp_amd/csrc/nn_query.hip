@@ -23,8 +23,9 @@
 
 namespace mp2p
 {
-constexpr int      NN_CAP         = 256;  // staged candidates per round (LDS: 4 KB + 1 KB)
-constexpr uint32_t NN_CELL_BUDGET = 256;  // voxels of the search box per pass (4 lookups/lane)
+constexpr int      NN_CAP         = 512;   // staged candidates per round (LDS: 5 x 2 KB)
+constexpr uint32_t NN_CELL_BUDGET = 2048;  // voxels of the search box per pass (<=32 lookups/lane)
+constexpr int      NN_COOP_MAX    = 4;     // group size up to which the scan is cooperative
 
 struct NNArgs
 {
@@ -34,6 +35,7 @@ struct NNArgs
     PoseRt        pose;
     float         maxDistSq, angSq;  // Matcher_Points_DistanceThreshold.cpp:82-83
     float         r0;                // first search radius [m]
+    float         grp_factor;        // group extent in units of the seed's radius
     const unsigned char* local_taken;   // by original local index, or null
     const unsigned char* global_taken;  // by original global index, or null
     unsigned long long*  claims;        // by sorted global position, or null
@@ -50,7 +52,10 @@ template <int Q>
 __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
 {
     constexpr int S = 64 / Q;
-    __shared__ float4   s_cand[NN_CAP];
+    __shared__ __attribute__((aligned(16))) float s_x[NN_CAP];
+    __shared__ __attribute__((aligned(16))) float s_y[NN_CAP];
+    __shared__ __attribute__((aligned(16))) float s_z[NN_CAP];
+    __shared__ uint32_t s_idx[NN_CAP];
     __shared__ uint32_t s_spos[NN_CAP];
     __shared__ uint32_t s_cstart[64];
     __shared__ uint32_t s_coff[65];
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
     const GridView& g     = a.g;
     const int       lane  = threadIdx.x;
     const int       qslot = lane & (Q - 1);
-    const int       slice = lane / Q;
+    const int       slice = (Q == 64) ? 0 : lane / Q;
     const uint32_t  tile  = blockIdx.x;
     const uint32_t  qi    = tile * Q + qslot;
     const bool      valid = qi < a.n_l;
@@ -98,21 +103,35 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
     float    best_d2  = INFINITY;
     uint32_t best_idx = NONE_U32, best_spos = NONE_U32;
 
-    uint32_t st_pass = 0, st_cells = 0, st_cand = 0;
+    uint32_t st_pass = 0, st_cells = 0, st_cand = 0, st_maxcand = 0;
 
     while (true)
     {
-        if (__ballot(!done) == 0ull) break;
+        const unsigned long long pend = __ballot(!done);
+        if (pend == 0ull) break;
         st_pass++;
 
-        // ---- search box of the tile = union of the pending queries' cubes -----------------
-        float lox = wave_min(done ? INFINITY : qx - r), loy = wave_min(done ? INFINITY : qy - r),
-              loz = wave_min(done ? INFINITY : qz - r);
-        float hix = wave_max(done ? -INFINITY : qx + r), hiy = wave_max(done ? -INFINITY : qy + r),
-              hiz = wave_max(done ? -INFINITY : qz + r);
-        const float rmin_t = wave_min(done ? INFINITY : r);
-        const float rmax_t = wave_max(done ? 0.f : r);
-        // conservative bounding box of the pending queries themselves
+        // ---- this pass serves a GROUP of pending queries: those within grp_factor radii of
+        //      the first pending one (and of comparable radius).  A Morton-consecutive tile is
+        //      normally one group; a tile straddling a jump of the curve (or holding far-range
+        //      returns) is split so that the search box never dwarfs the search balls.  The
+        //      other pending lanes still test the staged points (every candidate is a valid
+        //      upper bound) but only group members may conclude. -------------------------------
+        const int   seed = __ffsll((long long)pend) - 1;
+        const float sx = __shfl(qx, seed, 64), sy = __shfl(qy, seed, 64), sz = __shfl(qz, seed, 64);
+        const float sr = __shfl(r, seed, 64);
+        const float G  = a.grp_factor * sr;
+        const bool  grp = !done && fabsf(qx - sx) <= G && fabsf(qy - sy) <= G &&
+                         fabsf(qz - sz) <= G && r <= 2.0f * sr;
+
+        // ---- search box = union of the group's cubes ---------------------------------------
+        float lox = wave_min(grp ? qx - r : INFINITY), loy = wave_min(grp ? qy - r : INFINITY),
+              loz = wave_min(grp ? qz - r : INFINITY);
+        float hix = wave_max(grp ? qx + r : -INFINITY), hiy = wave_max(grp ? qy + r : -INFINITY),
+              hiz = wave_max(grp ? qz + r : -INFINITY);
+        const float rmin_t = wave_min(grp ? r : INFINITY);
+        const float rmax_t = wave_max(grp ? r : 0.f);
+        // conservative bounding box of the group's queries themselves
         const float qlx = lox + rmin_t, qly = loy + rmin_t, qlz = loz + rmin_t;
         const float qhx = hix - rmin_t, qhy = hiy - rmin_t, qhz = hiz - rmin_t;
 
@@ -141,16 +160,49 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
         const float prune  = rmax_t + 4.f * g.slack;
         const float prune2 = prune * prune;
 
+        // ---- small group: switch to the COOPERATIVE scan (lanes split the candidates of up
+        //      to 4 member queries and a wave arg-min merges them): a sparse far-range return
+        //      then costs 1/64 of the per-lane scan ------------------------------------------
+        const unsigned long long gmask = __ballot(grp);
+        const int                k_grp = __popcll(gmask);
+        const bool               coop  = (S == 1) && (k_grp <= NN_COOP_MAX);
+        float    mqx[NN_COOP_MAX], mqy[NN_COOP_MAX], mqz[NN_COOP_MAX];
+        float    pb_d2[NN_COOP_MAX];
+        uint32_t pb_idx[NN_COOP_MAX], pb_spos[NN_COOP_MAX];
+        int      mlane[NN_COOP_MAX];
+        {
+            unsigned long long tmp = gmask;
+#pragma unroll
+            for (int t = 0; t < NN_COOP_MAX; t++)
+            {
+                mlane[t] = tmp ? (__ffsll((long long)tmp) - 1) : 0;
+                tmp &= tmp - 1;
+                mqx[t] = __shfl(qx, mlane[t], 64), mqy[t] = __shfl(qy, mlane[t], 64),
+                mqz[t] = __shfl(qz, mlane[t], 64);
+                pb_d2[t] = INFINITY, pb_idx[t] = NONE_U32, pb_spos[t] = NONE_U32;
+            }
+        }
+
+        const bool small_grid = ncell <= 0xFFFFFFFFull;
         for (unsigned long long cb = 0; cb < ncell; cb += 64)
         {
             const unsigned long long cid = cb + lane;
             uint32_t                 cnt = 0, start = 0;
             if (cid < ncell)
             {
-                const uint32_t ix = (uint32_t)(cid % nx), iy = (uint32_t)((cid / nx) % ny),
-                               iz = (uint32_t)(cid / ((unsigned long long)nx * ny));
+                uint32_t ix, iy, iz;
+                if (small_grid)
+                {
+                    const uint32_t c32 = (uint32_t)cid, row = c32 / nx;
+                    ix = c32 - row * nx, iz = row / ny, iy = row - iz * ny;
+                }
+                else
+                {
+                    ix = (uint32_t)(cid % nx), iy = (uint32_t)((cid / nx) % ny);
+                    iz = (uint32_t)(cid / ((unsigned long long)nx * ny));
+                }
                 const uint32_t cx = cx0 + ix, cy = cy0 + iy, cz = cz0 + iz;
-                // voxel box vs bounding box of the pending queries
+                // voxel box vs bounding box of the group's queries
                 const float vx0 = g.ox + (float)cx * hs, vy0 = g.oy + (float)cy * hs,
                             vz0 = g.oz + (float)cz * hs;
                 const float dx = fmaxf(0.f, fmaxf(vx0 - qhx, qlx - (vx0 + hs)));
@@ -163,51 +215,130 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
                 }
             }
             const uint32_t incl  = wave_incl_scan(cnt, lane);
-            const uint32_t total = __shfl(incl, 63, 64);
+            const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
+            st_cells += (uint32_t)min((unsigned long long)64, ncell - cb);
+            if (total == 0) continue;  // uniform: no occupied voxel in this batch
             s_cstart[lane] = start;
             s_coff[lane]   = incl - cnt;
             if (lane == 63) s_coff[64] = total;
             __syncthreads();
-            st_cells += (uint32_t)min((unsigned long long)64, ncell - cb);
             st_cand += total;
+            st_maxcand = max(st_maxcand, total);
 
             for (uint32_t base = 0; base < total; base += NN_CAP)
             {
-                const uint32_t m = min((uint32_t)NN_CAP, total - base);
-                // ---- stage: coalesced 16-byte loads, lane t <- t-th candidate of the round
-                for (uint32_t t = lane; t < m; t += 64)
+                const uint32_t m     = min((uint32_t)NN_CAP, total - base);
+                const uint32_t m_pad = (m + 31u) & ~31u;
+                // ---- stage: coalesced 16-byte loads, lane t <- t-th candidate of the round,
+                //      stored as SoA so that the scan reads 4 candidates per ds_read_b128
+                for (uint32_t t = lane; t < m_pad; t += 64)
                 {
-                    const uint32_t gt = base + t;
-                    int            lo = 0, hi = 63;
-                    while (lo < hi)
+                    float4   c   = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
+                    uint32_t src = NONE_U32;
+                    if (t < m)
                     {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (s_coff[mid] <= gt) lo = mid;
-                        else hi = mid - 1;
+                        const uint32_t gt = base + t;
+                        int            lo = 0, hi = 63;
+                        while (lo < hi)
+                        {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (s_coff[mid] <= gt) lo = mid;
+                            else hi = mid - 1;
+                        }
+                        src = s_cstart[lo] + (gt - s_coff[lo]);
+                        c   = g.pts[src];
+                        if (a.touched) a.touched[src] = 1;
                     }
-                    const uint32_t src = s_cstart[lo] + (gt - s_coff[lo]);
-                    s_cand[t]          = g.pts[src];
-                    s_spos[t]          = src;
-                    if (a.touched) a.touched[src] = 1;
+                    s_x[t] = c.x, s_y[t] = c.y, s_z[t] = c.z;
+                    s_idx[t]  = __float_as_uint(c.w);
+                    s_spos[t] = src;
                 }
                 __syncthreads();
-                // ---- scan: every lane tests its slice of the bucket against its query
-                for (uint32_t j = slice; j < m; j += S)
+                if (coop)
                 {
-                    const float4 c  = s_cand[j];
-                    const float  d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
-                    if (!done && d2 <= best_d2)
+                    for (uint32_t j = lane; j < m; j += 64)
                     {
-                        const uint32_t ci = __float_as_uint(c.w);
-                        if (d2 < best_d2 || ci < best_idx)
+                        const float    cx = s_x[j], cy = s_y[j], cz = s_z[j];
+                        const uint32_t ci = s_idx[j];
+#pragma unroll
+                        for (int t = 0; t < NN_COOP_MAX; t++)
                         {
-                            best_d2   = d2;
-                            best_idx  = ci;
-                            best_spos = s_spos[j];
+                            if (t < k_grp)
+                            {
+                                const float d2 = dist2(mqx[t], mqy[t], mqz[t], cx, cy, cz);
+                                if (d2 < pb_d2[t] || (d2 == pb_d2[t] && ci < pb_idx[t]))
+                                    pb_d2[t] = d2, pb_idx[t] = ci, pb_spos[t] = s_spos[j];
+                            }
+                        }
+                    }
+                }
+                else
+                {
+                    // ---- scan: every lane tests (its slice of) the bucket against its query,
+                    //      8 candidates per step; the update path is rare after the first few
+                    for (uint32_t jb = (uint32_t)slice * 8u; jb < m_pad; jb += 8u * S)
+                    {
+                        const float4 xa = *reinterpret_cast<const float4*>(&s_x[jb]);
+                        const float4 xb = *reinterpret_cast<const float4*>(&s_x[jb + 4]);
+                        const float4 ya = *reinterpret_cast<const float4*>(&s_y[jb]);
+                        const float4 yb = *reinterpret_cast<const float4*>(&s_y[jb + 4]);
+                        const float4 za = *reinterpret_cast<const float4*>(&s_z[jb]);
+                        const float4 zb = *reinterpret_cast<const float4*>(&s_z[jb + 4]);
+                        float        d[8];
+                        d[0] = dist2(qx, qy, qz, xa.x, ya.x, za.x);
+                        d[1] = dist2(qx, qy, qz, xa.y, ya.y, za.y);
+                        d[2] = dist2(qx, qy, qz, xa.z, ya.z, za.z);
+                        d[3] = dist2(qx, qy, qz, xa.w, ya.w, za.w);
+                        d[4] = dist2(qx, qy, qz, xb.x, yb.x, zb.x);
+                        d[5] = dist2(qx, qy, qz, xb.y, yb.y, zb.y);
+                        d[6] = dist2(qx, qy, qz, xb.z, yb.z, zb.z);
+                        d[7] = dist2(qx, qy, qz, xb.w, yb.w, zb.w);
+                        const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])),
+                                               fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+                        if (!done && mn <= best_d2)
+                        {
+#pragma unroll
+                            for (int k = 0; k < 8; k++)
+                            {
+                                if (d[k] <= best_d2)
+                                {
+                                    const uint32_t ci = s_idx[jb + k];
+                                    if (d[k] < best_d2 || ci < best_idx)
+                                    {
+                                        best_d2   = d[k];
+                                        best_idx  = ci;
+                                        best_spos = s_spos[jb + k];
+                                    }
+                                }
+                            }
                         }
                     }
                 }
                 __syncthreads();
+            }
+        }
+
+        if (coop)
+        {
+            // wave arg-min per member, merged into the member's own lane
+#pragma unroll
+            for (int t = 0; t < NN_COOP_MAX; t++)
+            {
+                if (t < k_grp)
+                {
+                    float    bd = pb_d2[t];
+                    uint32_t bi = pb_idx[t], bs = pb_spos[t];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1)
+                    {
+                        const float    od = __shfl_xor(bd, off, 64);
+                        const uint32_t oi = __shfl_xor(bi, off, 64);
+                        const uint32_t os = __shfl_xor(bs, off, 64);
+                        if (od < bd || (od == bd && oi < bi)) bd = od, bi = oi, bs = os;
+                    }
+                    if (lane == mlane[t] && (bd < best_d2 || (bd == best_d2 && bi < best_idx)))
+                        best_d2 = bd, best_idx = bi, best_spos = bs;
+                }
             }
         }
 
@@ -226,7 +357,7 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
         }
 
         // ---- final?  (visited voxels cover the whole cube of half-edge r around the query)
-        if (!done)
+        if (grp)
         {
             const float gr = r * (1.0f - 1.0f / 1024.0f) - g.slack;
             if (r >= rmax || (gr > 0.f && best_d2 < gr * gr))
@@ -258,6 +389,8 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
         atomicAdd(&a.counters[2], (unsigned long long)st_cells);
         atomicAdd(&a.counters[3], (unsigned long long)st_cand);
         if (st_pass > 1) atomicAdd(&a.counters[4], 1ull);
+        atomicMax(&a.counters[5], (unsigned long long)st_cand);
+        atomicMax(&a.counters[6], (unsigned long long)st_pass);
     }
 }
 
@@ -293,7 +426,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
 {
     const size_t n_l = cloud->n;
     uint32_t     Q   = prm->queries_per_wave ? prm->queries_per_wave : 64;
-    MP2P_REQUIRE(ctx, Q == 64 || Q == 16 || Q == 4 || Q == 1, "queries_per_wave must be 64/16/4/1");
+    MP2P_REQUIRE(ctx, Q == 64 || Q == 16, "queries_per_wave must be 64 or 16");
     const uint32_t n_tiles = (uint32_t)((n_l + Q - 1) / Q);
 
     MP2P_TRY_HIP(ctx, ctx->nn_spos.ensure(n_l));
@@ -316,6 +449,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.angSq             = (float)(angRad * angRad);
     const float cell0   = map->view.hf * (float)(1u << map->view.shift0);
     a.r0 = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 1.0f);
+    a.grp_factor = prm->group_radius_factor > 0 ? prm->group_radius_factor : 4.0f;
     a.local_taken =
         (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
     a.global_taken =
@@ -344,9 +478,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         switch (Q)
         {
             case 64: hipLaunchKernelGGL(nn_tile_kernel<64>, dim3(n_tiles), dim3(64), 0, ctx->stream, a); break;
-            case 16: hipLaunchKernelGGL(nn_tile_kernel<16>, dim3(n_tiles), dim3(64), 0, ctx->stream, a); break;
-            case 4: hipLaunchKernelGGL(nn_tile_kernel<4>, dim3(n_tiles), dim3(64), 0, ctx->stream, a); break;
-            default: hipLaunchKernelGGL(nn_tile_kernel<1>, dim3(n_tiles), dim3(64), 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL(nn_tile_kernel<16>, dim3(n_tiles), dim3(64), 0, ctx->stream, a); break;
         }
     }
     // ev[0]..ev[1] brackets exactly the search kernel (the roofline kernel of bench.py)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# first GPU contact: smoke, parity tests, small bench
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+rocm-smi --showproductname 2>/dev/null | head -5 > gpurun_out/smi.txt
+nproc > gpurun_out/nproc.txt; lscpu | head -20 >> gpurun_out/nproc.txt
+timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
+timeout 900 python -m pytest tests -m gpu -q -x --timeout=600 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+timeout 600 python bench.py --n-local 120000 --n-global 2000000 --steps 10 --warmup 3 --cpu-sample 120000 > gpurun_out/bench_small.json 2> gpurun_out/bench_small.err; echo "bench rc=$?" >> gpurun_out/bench_small.err
+tail -5 gpurun_out/smoke.log; tail -30 gpurun_out/pytest_gpu.log; tail -5 gpurun_out/bench_small.err; cat gpurun_out/bench_small.json

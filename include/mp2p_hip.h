@@ -274,6 +274,9 @@ typedef struct
     uint64_t nn_tiles, nn_passes, nn_cells_visited, nn_candidates_tested, nn_points_staged;
     uint64_t nn_queries, nn_unresolved_after_first_pass;
     uint64_t nn_max_candidates_one_tile, nn_max_passes_one_tile;
+    uint64_t nn_tile_ticks_sum, nn_tile_ticks_max; /* 100 MHz wall_clock64 ticks per tile */
+    uint64_t nn_coop_passes;
+    uint64_t nn_tile_ticks_hist[24]; /* log2 bins */
 } mp2p_hip_stats;
 /* 0 = off; 1 = bracket the kernels with hipEvents (ms_* fields; each call then ends with a
  * stream synchronisation); 2 = additionally collect the device counters (nn_* fields, slower). */

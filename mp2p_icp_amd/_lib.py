@@ -73,7 +73,9 @@ class Stats(C.Structure):
                 ("nn_cells_visited", C.c_uint64), ("nn_candidates_tested", C.c_uint64),
                 ("nn_points_staged", C.c_uint64), ("nn_queries", C.c_uint64),
                 ("nn_unresolved_after_first_pass", C.c_uint64),
-                ("nn_max_candidates_one_tile", C.c_uint64), ("nn_max_passes_one_tile", C.c_uint64)]
+                ("nn_max_candidates_one_tile", C.c_uint64), ("nn_max_passes_one_tile", C.c_uint64),
+                ("nn_tile_ticks_sum", C.c_uint64), ("nn_tile_ticks_max", C.c_uint64),
+                ("nn_coop_passes", C.c_uint64), ("nn_tile_ticks_hist", C.c_uint64 * 24)]
 
 
 _P = C.c_void_p

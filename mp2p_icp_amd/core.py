@@ -50,7 +50,9 @@ class Context:
     def stats(self):
         s = _lib.Stats()
         check(self._L.mp2p_hip_get_stats(self._h, C.byref(s)), self._h)
-        return {k: getattr(s, k) for k, _ in s._fields_}
+        d = {k: getattr(s, k) for k, _ in s._fields_}
+        d["nn_tile_ticks_hist"] = list(s.nn_tile_ticks_hist)
+        return d
 
     def local_bbox_ptr(self):
         return self._L.mp2p_hip_ctx_local_bbox_ptr(self._h)

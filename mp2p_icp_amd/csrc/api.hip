@@ -447,8 +447,11 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
         ctx->stats.ms_nn = ms_nn, ctx->stats.ms_compact = ms_cp;
         if (ctx->pending_match >= 2)
         {
-            unsigned long long c[8];
+            unsigned long long c[64];
             MP2P_TRY_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+            ctx->stats.nn_tile_ticks_sum = c[7], ctx->stats.nn_tile_ticks_max = c[8];
+            ctx->stats.nn_coop_passes = c[9];
+            for (int i = 0; i < 24; i++) ctx->stats.nn_tile_ticks_hist[i] = c[16 + i];
             ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1];
             ctx->stats.nn_cells_visited = c[2], ctx->stats.nn_candidates_tested = c[3];
             ctx->stats.nn_unresolved_after_first_pass = c[4];

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
     float    best_d2  = INFINITY;
     uint32_t best_idx = NONE_U32, best_spos = NONE_U32;
 
-    uint32_t st_pass = 0, st_cells = 0, st_cand = 0, st_maxcand = 0;
+    uint32_t st_pass = 0, st_cells = 0, st_cand = 0, st_maxcand = 0, st_coop = 0;
+    const long long t_start = a.counters ? (long long)wall_clock64() : 0;
 
     while (true)
     {
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
         const unsigned long long gmask = __ballot(grp);
         const int                k_grp = __popcll(gmask);
         const bool               coop  = (S == 1) && (k_grp <= NN_COOP_MAX);
+        st_coop += coop ? 1u : 0u;
         float    mqx[NN_COOP_MAX], mqy[NN_COOP_MAX], mqz[NN_COOP_MAX];
         float    pb_d2[NN_COOP_MAX];
         uint32_t pb_idx[NN_COOP_MAX], pb_spos[NN_COOP_MAX];
@@ -391,6 +393,14 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
         if (st_pass > 1) atomicAdd(&a.counters[4], 1ull);
         atomicMax(&a.counters[5], (unsigned long long)st_cand);
         atomicMax(&a.counters[6], (unsigned long long)st_pass);
+        const unsigned long long dt = (unsigned long long)((long long)wall_clock64() - t_start);
+        atomicAdd(&a.counters[7], dt);
+        atomicMax(&a.counters[8], dt);
+        atomicAdd(&a.counters[9], (unsigned long long)st_coop);
+        // histogram of per-tile wall time, log2 bins of 100 MHz ticks
+        int b = 63 - __clzll((long long)(dt | 1ull));
+        if (b > 23) b = 23;
+        atomicAdd(&a.counters[16 + b], 1ull);
     }
 }
 
@@ -465,8 +475,8 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.touched      = nullptr;
     if (ctx->profiling >= 2)
     {
-        MP2P_TRY_HIP(ctx, ctx->counters.ensure(8 + 0));
-        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        MP2P_TRY_HIP(ctx, ctx->counters.ensure(64));
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64 * sizeof(unsigned long long), ctx->stream));
         a.counters = ctx->counters.p;
         MP2P_TRY_HIP(ctx, ctx->pl_slots.ensure(map->n));
         MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->pl_slots.p, 0, map->n, ctx->stream));

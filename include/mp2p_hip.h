@@ -166,9 +166,13 @@ typedef struct
     uint64_t local_index_offset;
     /* tuning (0 = default): first search radius in units of the finest cell */
     float    initial_radius_cells;
-    uint32_t queries_per_wave;    /* 64 or 16; 0 = default (64) */
+    uint32_t queries_per_wave;    /* 64, 32 or 16; 0 = default (32) */
     float    group_radius_factor; /* queries of a tile farther than this many search radii
                                      from the first pending one wait for a later pass; 0 = 4 */
+    uint32_t cell_budget;         /* max voxels of one search box before a coarser level is
+                                     used; 0 = 512 */
+    float    defer_radius_cells;  /* a query whose search radius exceeds this many cells leaves
+                                     its tile for the one-query-per-wave kernel; 0 = 3 */
 } mp2p_hip_pt2pt_params;
 
 /* ms may be NULL (fresh MatchState with nothing marked, marks discarded). */
@@ -269,13 +273,16 @@ int mp2p_hip_horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, double w
 typedef struct
 {
     double   ms_nn;      /* K1+K3 (transform + search + claims), last match call */
+    double   ms_nn_tile, ms_nn_single; /* its two kernels */
     double   ms_compact; /* K4 */
     double   ms_gn;      /* all inner iterations of the last gn_solve */
     uint64_t nn_tiles, nn_passes, nn_cells_visited, nn_candidates_tested, nn_points_staged;
     uint64_t nn_queries, nn_unresolved_after_first_pass;
     uint64_t nn_max_candidates_one_tile, nn_max_passes_one_tile;
     uint64_t nn_tile_ticks_sum, nn_tile_ticks_max; /* 100 MHz wall_clock64 ticks per tile */
-    uint64_t nn_coop_passes;
+    uint64_t nn_coop_passes; /* queries deferred to the one-query-per-wave kernel */
+    uint64_t nn_single_queries, nn_single_passes, nn_single_cells, nn_single_candidates;
+    uint64_t nn_single_max_candidates;
     uint64_t nn_tile_ticks_hist[24]; /* log2 bins */
 } mp2p_hip_stats;
 /* 0 = off; 1 = bracket the kernels with hipEvents (ms_* fields; each call then ends with a

@@ -41,7 +41,8 @@ class Pt2PtParams(C.Structure):
                 ("allowMatchAlreadyMatchedGlobalPoints", C.c_int32),
                 ("bounding_box_intersection_check_epsilon", C.c_double),
                 ("local_index_offset", C.c_uint64), ("initial_radius_cells", C.c_float),
-                ("queries_per_wave", C.c_uint32), ("group_radius_factor", C.c_float)]
+                ("queries_per_wave", C.c_uint32), ("group_radius_factor", C.c_float),
+                ("cell_budget", C.c_uint32), ("defer_radius_cells", C.c_float)]
 
 
 class Pt2PlParams(C.Structure):
@@ -68,14 +69,18 @@ class GNResult(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("ms_nn", C.c_double), ("ms_compact", C.c_double), ("ms_gn", C.c_double),
+    _fields_ = [("ms_nn", C.c_double), ("ms_nn_tile", C.c_double), ("ms_nn_single", C.c_double),
+                ("ms_compact", C.c_double), ("ms_gn", C.c_double),
                 ("nn_tiles", C.c_uint64), ("nn_passes", C.c_uint64),
                 ("nn_cells_visited", C.c_uint64), ("nn_candidates_tested", C.c_uint64),
                 ("nn_points_staged", C.c_uint64), ("nn_queries", C.c_uint64),
                 ("nn_unresolved_after_first_pass", C.c_uint64),
                 ("nn_max_candidates_one_tile", C.c_uint64), ("nn_max_passes_one_tile", C.c_uint64),
                 ("nn_tile_ticks_sum", C.c_uint64), ("nn_tile_ticks_max", C.c_uint64),
-                ("nn_coop_passes", C.c_uint64), ("nn_tile_ticks_hist", C.c_uint64 * 24)]
+                ("nn_coop_passes", C.c_uint64), ("nn_single_queries", C.c_uint64),
+                ("nn_single_passes", C.c_uint64), ("nn_single_cells", C.c_uint64),
+                ("nn_single_candidates", C.c_uint64), ("nn_single_max_candidates", C.c_uint64),
+                ("nn_tile_ticks_hist", C.c_uint64 * 24)]
 
 
 _P = C.c_void_p

@@ -129,6 +129,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release();
     ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release();
     ctx->aos_stage.release(), ctx->pl_slots.release();
+    ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -408,9 +409,7 @@ int mp2p_hip_gn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const doub
     // convergence test (:365) or the cost test (:344) has fired are no-ops on the device
     for (uint32_t it = 0; it < prm->maxInnerLoopIterations; it++)
     {
-        rc = gn_accumulate(ctx);
-        if (rc) return rc;
-        rc = gn_step(ctx);
+        rc = gn_iterate_fused(ctx);
         if (rc) return rc;
     }
     rc = gn_end(ctx, out);
@@ -443,6 +442,9 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
     {
         float ms_nn = 0, ms_cp = 0;
         MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_nn, ctx->ev[0], ctx->ev[1]));
+        float ms_tile = 0;
+        MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_tile, ctx->ev[0], ctx->ev[6]));
+        ctx->stats.ms_nn_tile = ms_tile, ctx->stats.ms_nn_single = ms_nn - ms_tile;
         MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_cp, ctx->ev[2], ctx->ev[3]));
         ctx->stats.ms_nn = ms_nn, ctx->stats.ms_compact = ms_cp;
         if (ctx->pending_match >= 2)
@@ -450,7 +452,10 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
             unsigned long long c[64];
             MP2P_TRY_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));
             ctx->stats.nn_tile_ticks_sum = c[7], ctx->stats.nn_tile_ticks_max = c[8];
-            ctx->stats.nn_coop_passes = c[9];
+            ctx->stats.nn_coop_passes = c[9];  // queries deferred to the one-per-wave kernel
+            ctx->stats.nn_single_queries = c[10], ctx->stats.nn_single_passes = c[11];
+            ctx->stats.nn_single_cells = c[12], ctx->stats.nn_single_candidates = c[13];
+            ctx->stats.nn_single_max_candidates = c[14];
             for (int i = 0; i < 24; i++) ctx->stats.nn_tile_ticks_hist[i] = c[16 + i];
             ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1];
             ctx->stats.nn_cells_visited = c[2], ctx->stats.nn_candidates_tested = c[3];

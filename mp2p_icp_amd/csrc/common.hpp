@@ -87,7 +87,7 @@ struct mp2p_hip_ctx
     bool        own_stream = false;
     std::string err;
     int         profiling = 0;  // 0 off, 1 hipEvent timing, 2 + device counters
-    hipEvent_t  ev[6]     = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t  ev[7]     = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int         pending_match = 0, pending_gn = 0;
     size_t      pending_map_n = 0;
     mp2p_hip_stats stats{};
@@ -97,6 +97,7 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<uint32_t>           nn_spos;      // [n_local] by ORIGINAL local index
     mp2p::DevBuf<float>              nn_d2;        // [n_local]
     mp2p::DevBuf<float>              tile_bbox;    // [n_tiles][6]
+    mp2p::DevBuf<float>              tile_bbox2;   // [64][6] second reduction level
     mp2p::DevBuf<float>              local_bbox;   // [6] min xyz, max xyz of transformed local
     mp2p::DevBuf<uint32_t>           block_counts; // compaction
     mp2p::DevBuf<unsigned long long> counters;     // profiling counters
@@ -105,6 +106,8 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<double>             gn_state;     // pose(12) H(36) g(6) cost(1) iters(1) done(1)
     mp2p::DevBuf<unsigned char>      aos_stage;    // download staging
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
+    mp2p::DevBuf<uint4>              work;         // deferred queries of the NN search
+    mp2p::DevBuf<uint32_t>           work_spos;    //   (+ counter in the last word)
     mp2p::GnState                    gn;
     uint32_t last_n_tiles = 0;
     uint32_t last_q       = 64;

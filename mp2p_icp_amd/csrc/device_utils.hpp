@@ -44,6 +44,17 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, float px, f
     return fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz));
 }
 
+// two candidates per instruction (v_pk_add_f32 / v_pk_mul_f32), same roundings as dist2()
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f dist2_pk(v2f qx, v2f qy, v2f qz, v2f px, v2f py, v2f pz)
+{
+#pragma clang fp contract(off)
+    const v2f dx = qx - px, dy = qy - py, dz = qz - pz;
+    const v2f xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const v2f s  = xx + yy;
+    return s + zz;
+}
+
 // CPose3D::composePoint in fp64, left to right, narrowed once (Matcher_Points_Base.cpp:216-217)
 struct PoseRt
 {
@@ -74,18 +85,43 @@ __device__ __host__ __forceinline__ float ord2f(uint32_t u)
     return f;
 }
 
-// ---- wave64 collectives --------------------------------------------------------------------
+// ---- wave64 collectives ---------------------------------------------------------------------
+// Reductions run on the DPP cross-lane path (row rotations inside each 16-lane row, then four
+// v_readlane to combine the rows): ~12 issue slots and no LDS round trip, instead of the
+// 6 x ds_bpermute (~100 cycles each) a __shfl_xor butterfly costs.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u0(uint32_t v)  // out-of-row source lanes read 0
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+
 __device__ __forceinline__ float wave_min(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fminf(v, dpp_f<DPP_ROW_ROR1>(v));
+    v = fminf(v, dpp_f<DPP_ROW_ROR2>(v));
+    v = fminf(v, dpp_f<DPP_ROW_ROR4>(v));
+    v = fminf(v, dpp_f<DPP_ROW_ROR8>(v));
+    return fminf(fminf(readlane_f(v, 0), readlane_f(v, 16)), fminf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<DPP_ROW_ROR1>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_ROR2>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_ROR4>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_ROR8>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
@@ -99,16 +135,48 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-// inclusive prefix sum across the 64 lanes
+// inclusive prefix sum across the 64 lanes: Hillis-Steele inside each 16-lane row on DPP
+// (row_shr with zero fill), then the three row carries through v_readlane
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
+    v += dpp_u0<DPP_ROW_SHR1>(v);
+    v += dpp_u0<DPP_ROW_SHR2>(v);
+    v += dpp_u0<DPP_ROW_SHR4>(v);
+    v += dpp_u0<DPP_ROW_SHR8>(v);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const int      row = lane >> 4;
+    return v + (row > 0 ? t0 : 0u) + (row > 1 ? t1 : 0u) + (row > 2 ? t2 : 0u);
+}
+// inclusive prefix MAX across the 64 lanes (values >= 0; 0 = "nothing yet")
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, int lane)
+{
+    v = max(v, dpp_u0<DPP_ROW_SHR1>(v));
+    v = max(v, dpp_u0<DPP_ROW_SHR2>(v));
+    v = max(v, dpp_u0<DPP_ROW_SHR4>(v));
+    v = max(v, dpp_u0<DPP_ROW_SHR8>(v));
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+    const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const int      row = lane >> 4;
+    uint32_t       c   = 0;
+    if (row > 0) c = t0;
+    if (row > 1) c = max(c, t1);
+    if (row > 2) c = max(c, t2);
+    return max(v, c);
+}
+// lexicographic arg-min of (d2, idx) over the wave; the winner's triple is returned uniformly
+__device__ __forceinline__ void wave_argmin(float& d, uint32_t& i, uint32_t& s)
+{
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1)
+    for (int off = 32; off > 0; off >>= 1)
     {
-        const uint32_t t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
+        const float    od = __shfl_xor(d, off, 64);
+        const uint32_t oi = __shfl_xor(i, off, 64);
+        const uint32_t os = __shfl_xor(s, off, 64);
+        if (od < d || (od == d && oi < i)) d = od, i = oi, s = os;
     }
-    return v;
 }
 
 // ---- voxel addressing: THE cell function, used identically by the index build and by the
@@ -145,12 +213,12 @@ __device__ __host__ __forceinline__ unsigned long long cell_key(uint32_t level, 
 }
 __device__ __host__ __forceinline__ uint64_t hash_key(unsigned long long k)
 {
-    k ^= k >> 33;
-    k *= 0xff51afd7ed558ccdull;
-    k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ull;
-    k ^= k >> 33;
-    return k;
+    // 32-bit multiplicative mix of the two key halves (a handful of VALU ops per lookup)
+    uint32_t h = (uint32_t)k * 0x9E3779B1u ^ ((uint32_t)(k >> 32) * 0x85EBCA77u);
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h;
 }
 
 // returns true and [start,end) when the voxel is occupied

@@ -19,7 +19,7 @@
 
 namespace mp2p
 {
-constexpr int GN_BLOCKS  = 512;
+constexpr int GN_BLOCKS  = 256;
 constexpr int GN_THREADS = 256;
 constexpr int NS         = MP2P_HIP_GN_NSUMS;  // 48
 constexpr int NS_PT      = 17;
@@ -178,23 +178,34 @@ __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pl_kernel(
     block_reduce_store<NS_PL>(acc, partials + (size_t)blockIdx.x * NS + NS_PT);
 }
 
-// fixed-order sum of the block partials -> sums[48]
-__global__ __launch_bounds__(256) void gn_sums_kernel(const double* __restrict__ partials,
-                                                      const double* __restrict__ state,
-                                                      int use_pt, int use_pl,
-                                                      double* __restrict__ sums)
+// fixed-order sum of the block partials -> sums[48] (16 interleaved partial sums per quantity,
+// combined as a fixed tree: deterministic run to run)
+__device__ __forceinline__ void gn_sums_body(const double* __restrict__ partials, bool done,
+                                             int use_pt, int use_pl, double* __restrict__ sums)
 {
-    // 4 partial sums per quantity (blocks b%4), combined in fixed order
-    __shared__ double s[4][NS];
+    __shared__ double s[16][NS];
     const int         q = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const bool        done = state[ST_DONE] != 0.0;
     double            t = 0;
-    const bool        mine = q < NS && ((q < NS_PT && use_pt) || (q >= NS_PT && q < NS_PT + NS_PL && use_pl));
+    const bool mine = q < NS && ((q < NS_PT && use_pt) || (q >= NS_PT && q < NS_PT + NS_PL && use_pl));
     if (mine && !done)
-        for (int b = part; b < GN_BLOCKS; b += 4) t += partials[(size_t)b * NS + q];
+        for (int b = part; b < GN_BLOCKS; b += 16) t += partials[(size_t)b * NS + q];
     if (q < NS) s[part][q] = t;
     __syncthreads();
-    if (threadIdx.x < NS) sums[threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    if (threadIdx.x < NS)
+    {
+        const int i = threadIdx.x;
+        double    r[8];
+        for (int k = 0; k < 8; k++) r[k] = s[2 * k][i] + s[2 * k + 1][i];
+        sums[i] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    }
+}
+
+__global__ __launch_bounds__(1024) void gn_sums_kernel(const double* __restrict__ partials,
+                                                       const double* __restrict__ state,
+                                                       int use_pt, int use_pl,
+                                                       double* __restrict__ sums)
+{
+    gn_sums_body(partials, state[ST_DONE] != 0.0, use_pt, use_pl, sums);
 }
 
 // ---- small dense helpers (single thread) -----------------------------------------------------
@@ -370,10 +381,9 @@ struct GnStepPrm
 };
 
 // ---- K8: assemble H,g from the sums, prior, solve, retract (one thread) -----------------------
-__global__ void gn_step_kernel(const double* __restrict__ sums, double* __restrict__ state,
-                               const GnStepPrm prm)
+__device__ void gn_step_body(const double* __restrict__ sums, double* __restrict__ state,
+                             const GnStepPrm& prm)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (state[ST_DONE] != 0.0) return;
     double T[12];
     for (int i = 0; i < 12; i++) T[i] = state[ST_POSE + i];
@@ -483,6 +493,34 @@ __global__ void gn_step_kernel(const double* __restrict__ sums, double* __restri
     if (sqrt(nrm) < prm.minDelta) state[ST_DONE] = 1.0;  // :365
 }
 
+__global__ void gn_step_kernel(const double* __restrict__ sums, double* __restrict__ state,
+                               const GnStepPrm prm)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) gn_step_body(sums, state, prm);
+}
+
+// single-GPU form: final reduction and the 6x6 step in one launch (no all-reduce in between)
+__global__ __launch_bounds__(1024) void gn_sums_step_kernel(const double* __restrict__ partials,
+                                                            double* __restrict__ state, int use_pt,
+                                                            int use_pl, double* __restrict__ sums,
+                                                            const GnStepPrm prm)
+{
+    gn_sums_body(partials, state[ST_DONE] != 0.0, use_pt, use_pl, sums);
+    __syncthreads();  // sums[] written by this block are visible to its thread 0
+    if (threadIdx.x == 0) gn_step_body(sums, state, prm);
+}
+
+struct GnInit
+{
+    double pose[12];
+};
+// the linearisation point travels as a kernel argument: no H2D copy, no host synchronisation
+__global__ void gn_init_kernel(double* __restrict__ state, const GnInit init)
+{
+    const int i = threadIdx.x;
+    if (i < ST_SIZE) state[i] = (i < 12) ? init.pose[i] : 0.0;
+}
+
 static GnKernelPrm make_kernel_prm(const mp2p_hip_gn_params& p)
 {
     GnKernelPrm k;
@@ -510,12 +548,9 @@ int gn_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[
     MP2P_TRY_HIP(ctx, ctx->gn_partials.ensure((size_t)GN_BLOCKS * NS));
     MP2P_TRY_HIP(ctx, ctx->gn_sums.ensure(NS));
     MP2P_TRY_HIP(ctx, ctx->gn_state.ensure(ST_SIZE));
-    double st[ST_SIZE];
-    memset(st, 0, sizeof(st));
-    for (int i = 0; i < 12; i++) st[ST_POSE + i] = pose0[i];
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->gn_state.p, st, sizeof(st), hipMemcpyHostToDevice, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));  // 'st' is a stack buffer
-    MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->gn_partials.p, 0, (size_t)GN_BLOCKS * NS * sizeof(double), ctx->stream));
+    GnInit init;
+    for (int i = 0; i < 12; i++) init.pose[i] = pose0[i];
+    hipLaunchKernelGGL(gn_init_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->gn_state.p, init);
     ctx->gn.pairs  = pairs;
     ctx->gn.prm    = *prm;
     ctx->gn.active = true;
@@ -523,12 +558,23 @@ int gn_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[
     return MP2P_HIP_OK;
 }
 
-int gn_accumulate(mp2p_hip_ctx* ctx)
+static GnStepPrm make_step_prm(mp2p_hip_ctx* ctx)
 {
-    MP2P_REQUIRE(ctx, ctx->gn.active, "gn_accumulate without gn_begin");
+    const mp2p_hip_gn_params& p = ctx->gn.prm;
+    GnStepPrm                 s;
+    memset(&s, 0, sizeof(s));
+    s.minDelta = p.minDelta, s.maxCost = p.maxCost, s.has_prior = p.has_prior;
+    memcpy(s.prior_mean, p.prior_mean, sizeof(s.prior_mean));
+    memcpy(s.prior_cov_inv, p.prior_cov_inv, sizeof(s.prior_cov_inv));
+    s.use_pt = ctx->gn.pairs->cap_pt2pt > 0, s.use_pl = ctx->gn.pairs->cap_pt2pl > 0;
+    return s;
+}
+
+static void launch_partials(mp2p_hip_ctx* ctx, int& use_pt, int& use_pl)
+{
     const mp2p_hip_pairs* P = ctx->gn.pairs;
     const GnKernelPrm     k = make_kernel_prm(ctx->gn.prm);
-    const int use_pt = P->cap_pt2pt > 0, use_pl = P->cap_pt2pl > 0;
+    use_pt = P->cap_pt2pt > 0, use_pl = P->cap_pt2pl > 0;
     if (use_pt)
         hipLaunchKernelGGL(gn_accum_pt2pt_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
                            P->lx.p, P->ly.p, P->lz.p, P->gx.p, P->gy.p, P->gz.p, P->counts.p,
@@ -537,7 +583,14 @@ int gn_accumulate(mp2p_hip_ctx* ctx)
         hipLaunchKernelGGL(gn_accum_pt2pl_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
                            P->pl_coef.p, P->pl_lx.p, P->pl_ly.p, P->pl_lz.p, P->counts.p,
                            ctx->gn_state.p, k, ctx->gn_partials.p);
-    hipLaunchKernelGGL(gn_sums_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->gn_partials.p,
+}
+
+int gn_accumulate(mp2p_hip_ctx* ctx)
+{
+    MP2P_REQUIRE(ctx, ctx->gn.active, "gn_accumulate without gn_begin");
+    int use_pt, use_pl;
+    launch_partials(ctx, use_pt, use_pl);
+    hipLaunchKernelGGL(gn_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->gn_partials.p,
                        ctx->gn_state.p, use_pt, use_pl, ctx->gn_sums.p);
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
@@ -546,15 +599,21 @@ int gn_accumulate(mp2p_hip_ctx* ctx)
 int gn_step(mp2p_hip_ctx* ctx)
 {
     MP2P_REQUIRE(ctx, ctx->gn.active, "gn_step without gn_begin");
-    const mp2p_hip_gn_params& p = ctx->gn.prm;
-    GnStepPrm                 s;
-    memset(&s, 0, sizeof(s));
-    s.minDelta = p.minDelta, s.maxCost = p.maxCost, s.has_prior = p.has_prior;
-    memcpy(s.prior_mean, p.prior_mean, sizeof(s.prior_mean));
-    memcpy(s.prior_cov_inv, p.prior_cov_inv, sizeof(s.prior_cov_inv));
-    s.use_pt = ctx->gn.pairs->cap_pt2pt > 0, s.use_pl = ctx->gn.pairs->cap_pt2pl > 0;
     hipLaunchKernelGGL(gn_step_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->gn_sums.p,
-                       ctx->gn_state.p, s);
+                       ctx->gn_state.p, make_step_prm(ctx));
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
+}
+
+// accumulate ; reduce ; step  without the all-reduce seam (one GPU)
+int gn_iterate_fused(mp2p_hip_ctx* ctx)
+{
+    MP2P_REQUIRE(ctx, ctx->gn.active, "gn_iterate_fused without gn_begin");
+    int use_pt, use_pl;
+    launch_partials(ctx, use_pt, use_pl);
+    hipLaunchKernelGGL(gn_sums_step_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                       ctx->gn_partials.p, ctx->gn_state.p, use_pt, use_pl, ctx->gn_sums.p,
+                       make_step_prm(ctx));
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
 }

@@ -331,7 +331,7 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
     g.shift0 = shift0, g.n_levels = n_levels;
     for (int d = 0; d < 3; d++) g.bbmin[d] = mn[d], g.bbmax[d] = mx[d];
     // 8 ulp of the largest coordinate magnitude (see nn_query.hip for how it is used)
-    g.slack = std::max(maxabs, ext) * (1.0f / 1048576.0f);
+    g.slack = std::max(std::max(maxabs, ext) * (1.0f / 1048576.0f), 1e-30f);
 
     mp2p_hip_map_info& info = map->info;
     for (int d = 0; d < 3; d++) info.bbox_min[d] = mn[d], info.bbox_max[d] = mx[d];

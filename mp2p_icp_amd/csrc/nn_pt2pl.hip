@@ -460,8 +460,10 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     else if (K <= 8) launch_k<8>(a, n_tiles, ctx->stream);
     else if (K <= 12) launch_k<12>(a, n_tiles, ctx->stream);
     else launch_k<16>(a, n_tiles, ctx->stream);
-    hipLaunchKernelGGL(tile_bbox_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream,
-                       ctx->tile_bbox.p, n_tiles, ctx->local_bbox.p);
+    {
+        const int rc = launch_bbox_reduce(ctx, n_tiles);
+        if (rc) return rc;
+    }
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
 
     const uint32_t n_blocks = (uint32_t)((n_l + PC_TILE - 1) / PC_TILE);

@@ -6,26 +6,33 @@
 //   the threshold rule                   :252-259
 //   the "global point already paired"    :94-121 (claims; resolved in pairs.hip)
 //
-// Mapping onto CDNA4 (one wave64 = one workgroup = one TILE of Q Morton-consecutive queries):
-//   * lane = (query slot, candidate slice): Q query slots x S=64/Q slices.  Every lane keeps
-//     its query in registers; the wave stages the candidate points of all voxels overlapping
-//     the tile's search box into LDS with coalesced 16-byte loads, then every lane scans the
-//     staged bucket (its slice of it) with broadcast ds_read_b128 -- each HBM/L2 byte is
-//     fetched once per tile and reused by Q queries.
-//   * argmin is lexicographic on (fp32 d2, original global index), so the result does not
-//     depend on traversal order and ties resolve to the lowest index (the repo's policy).
-//   * exactness without an unbounded search: a query is final when its best distance is
-//     below the radius its visited voxels are guaranteed to cover, or when that radius has
-//     reached r_max = sqrt(threshold rule) beyond which the reference discards the pair
-//     anyway.  Otherwise the radius grows (to the best distance found, else x2) and the tile
-//     repeats at a coarser voxel level.
+// Two kernels, both one wave64 per workgroup:
+//
+//  nn_tile_kernel  -- a TILE of Q Morton-consecutive queries per wave.  lane = (query slot,
+//     candidate slice).  Every lane keeps its query in registers; the wave stages the points of
+//     all voxels overlapping the search box of the current GROUP of queries into LDS (SoA) with
+//     coalesced 16-byte loads, then every lane scans the staged bucket against its own query,
+//     8 candidates per step (ds_read_b128 broadcasts).  Each HBM/L2 byte is fetched once per
+//     tile and reused by up to 64 queries.  Queries that are spatially isolated inside their
+//     tile (sparse far-range returns, tiles straddling a jump of the Morton curve) would make
+//     the shared box dwarf their search balls; they are DEFERRED to
+//
+//  nn_single_kernel -- one query per wave: the 64 lanes split the candidates (one coalesced
+//     16-byte load each, no LDS staging), and a wave arg-min merges them.  Deferred queries
+//     are spread over the whole chip instead of serialising inside one tile's wave.
+//
+// Exactness: argmin is lexicographic on (fp32 d2, original global index) -> independent of the
+// traversal order, ties resolve to the lowest index.  A query is final when its best distance
+// is below the radius its visited voxels are guaranteed to cover, or when that radius has
+// reached r_max = sqrt(threshold rule), beyond which the reference discards the pair anyway
+// (so bounding the unbounded nn_single_search there is result-equivalent).  Otherwise the
+// radius grows (to the best distance found, else x2) and the search repeats at a coarser level.
 #include "device_utils.hpp"
 
 namespace mp2p
 {
-constexpr int      NN_CAP         = 512;   // staged candidates per round (LDS: 5 x 2 KB)
-constexpr uint32_t NN_CELL_BUDGET = 2048;  // voxels of the search box per pass (<=32 lookups/lane)
-constexpr int      NN_COOP_MAX    = 4;     // group size up to which the scan is cooperative
+constexpr int NN_CAP      = 256;  // staged candidates per round (LDS: 5 x 1 KB)
+constexpr int NN_COOP_MAX = 4;    // groups of up to this many queries are deferred
 
 struct NNArgs
 {
@@ -36,6 +43,8 @@ struct NNArgs
     float         maxDistSq, angSq;  // Matcher_Points_DistanceThreshold.cpp:82-83
     float         r0;                // first search radius [m]
     float         grp_factor;        // group extent in units of the seed's radius
+    float         r_defer;           // radius beyond which a query leaves its tile
+    uint32_t      cell_budget;       // voxels of a search box per pass
     const unsigned char* local_taken;   // by original local index, or null
     const unsigned char* global_taken;  // by original global index, or null
     unsigned long long*  claims;        // by sorted global position, or null
@@ -44,21 +53,166 @@ struct NNArgs
     uint32_t*            out_spos;      // [n_l] by original local index
     float*               out_d2;
     float*               tile_bbox;  // [n_tiles][6]
-    unsigned long long*  counters;   // profiling, or null
-    unsigned char*       touched;    // profiling: [n_g] by sorted position, or null
+    uint4*               work;       // deferred queries {sorted idx, r, best_d2, best_idx}
+    uint32_t*            work_spos;  //   + best_spos
+    uint32_t*            work_count;
+    unsigned long long*  counters;  // profiling, or null
+    unsigned char*       touched;   // profiling: [n_g] by sorted position, or null
 };
 
+// ---- geometry of one search pass (all values wave-uniform) -----------------------------------
+struct PassBox
+{
+    uint32_t nx, ny, nz, cx0, cy0, cz0, s, lev;
+    unsigned long long ncell;
+    float hs, inv_nx, inv_ny;
+};
+
+__device__ __forceinline__ PassBox choose_level(const GridView& g, float lox, float loy, float loz,
+                                                float hix, float hiy, float hiz, uint32_t budget)
+{
+    PassBox b;
+    b.nx = b.ny = b.nz = b.cx0 = b.cy0 = b.cz0 = 0, b.s = g.shift0, b.lev = 0, b.ncell = 0;
+    // clip to the layer's bounding box; disjoint -> nothing to visit
+    lox = fmaxf(lox, g.bbmin[0]), loy = fmaxf(loy, g.bbmin[1]), loz = fmaxf(loz, g.bbmin[2]);
+    hix = fminf(hix, g.bbmax[0]), hiy = fminf(hiy, g.bbmax[1]), hiz = fminf(hiz, g.bbmax[2]);
+    if (!((lox > hix) || (loy > hiy) || (loz > hiz)))
+    {
+        const uint32_t flx = cell_fine(lox, g.ox, g.inv_hf), fhx = cell_fine(hix, g.ox, g.inv_hf);
+        const uint32_t fly = cell_fine(loy, g.oy, g.inv_hf), fhy = cell_fine(hiy, g.oy, g.inv_hf);
+        const uint32_t flz = cell_fine(loz, g.oz, g.inv_hf), fhz = cell_fine(hiz, g.oz, g.inv_hf);
+        for (;;)
+        {
+            b.cx0 = flx >> b.s, b.cy0 = fly >> b.s, b.cz0 = flz >> b.s;
+            b.nx = (fhx >> b.s) - b.cx0 + 1, b.ny = (fhy >> b.s) - b.cy0 + 1,
+            b.nz = (fhz >> b.s) - b.cz0 + 1;
+            b.ncell = (unsigned long long)b.nx * b.ny * b.nz;
+            if (b.ncell <= budget || b.lev + 1 >= g.n_levels) break;
+            b.s++, b.lev++;
+        }
+    }
+    b.hs = g.hf * (float)(1u << b.s);  // voxel edge at this level
+    b.inv_nx = 1.0f / (float)max(b.nx, 1u), b.inv_ny = 1.0f / (float)max(b.ny, 1u);
+    return b;
+}
+
+// lane `lane` resolves voxel number cb+lane of the box: occupied range [start, start+cnt)
+__device__ __forceinline__ void lookup_voxel(const GridView& g, const PassBox& b,
+                                             unsigned long long cid, float qlx, float qly,
+                                             float qlz, float qhx, float qhy, float qhz,
+                                             float prune2, uint32_t& start, uint32_t& cnt,
+                                             float& md2)
+{
+    start = 0, cnt = 0, md2 = INFINITY;
+    if (cid >= b.ncell) return;
+    uint32_t ix, iy, iz;
+    if (b.ncell <= 65536ull)
+    {
+        // exact for these sizes: (c + 0.5) / n is at least 0.5/n away from an integer
+        const uint32_t c32 = (uint32_t)cid;
+        const uint32_t row = (uint32_t)(((float)c32 + 0.5f) * b.inv_nx);
+        ix = c32 - row * b.nx;
+        iz = (uint32_t)(((float)row + 0.5f) * b.inv_ny);
+        iy = row - iz * b.ny;
+    }
+    else if (b.ncell <= 0xFFFFFFFFull)
+    {
+        const uint32_t c32 = (uint32_t)cid, row = c32 / b.nx;
+        ix = c32 - row * b.nx, iz = row / b.ny, iy = row - iz * b.ny;
+    }
+    else
+    {
+        ix = (uint32_t)(cid % b.nx), iy = (uint32_t)((cid / b.nx) % b.ny);
+        iz = (uint32_t)(cid / ((unsigned long long)b.nx * b.ny));
+    }
+    const uint32_t cx = b.cx0 + ix, cy = b.cy0 + iy, cz = b.cz0 + iz;
+    // voxel box vs bounding box of the queries served by this pass
+    const float vx0 = g.ox + (float)cx * b.hs, vy0 = g.oy + (float)cy * b.hs,
+                vz0 = g.oz + (float)cz * b.hs;
+    const float dx = fmaxf(0.f, fmaxf(vx0 - qhx, qlx - (vx0 + b.hs)));
+    const float dy = fmaxf(0.f, fmaxf(vy0 - qhy, qly - (vy0 + b.hs)));
+    const float dz = fmaxf(0.f, fmaxf(vz0 - qhz, qlz - (vz0 + b.hs)));
+    md2 = dx * dx + dy * dy + dz * dz;
+    if (md2 <= prune2)
+    {
+        uint32_t e = 0;
+        if (cell_lookup(g, cell_key(b.lev, cx, cy, cz), start, e)) cnt = e - start;
+    }
+}
+
+// which voxel of the current batch holds candidate number gt (s_coff = exclusive offsets)
+__device__ __forceinline__ uint32_t locate_candidate(const uint32_t* s_cstart,
+                                                     const uint32_t* s_coff, uint32_t gt)
+{
+    int lo = 0, hi = 63;
+#pragma unroll
+    for (int it = 0; it < 6; it++)
+    {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_coff[mid] <= gt) lo = mid;
+        else hi = mid - 1;
+    }
+    return s_cstart[lo] + (gt - s_coff[lo]);
+}
+
+// next radius of an unresolved query (grows strictly; capped at r_max)
+__device__ __forceinline__ float next_radius(float r, float rmax, float best_d2, bool have,
+                                             float slack)
+{
+    const float rn = have ? sqrtf(best_d2) * (1.0f + 1.0f / 512.0f) + 4.f * slack : 2.0f * r;
+    return fminf(fmaxf(rn, r * 1.0009765625f), rmax);
+}
+// the visited voxels cover the whole cube of half-edge r around the query
+__device__ __forceinline__ bool is_final(float r, float rmax, float best_d2, float slack)
+{
+    const float gr = r * (1.0f - 1.0f / 1024.0f) - slack;
+    return r >= rmax || (gr > 0.f && best_d2 < gr * gr);
+}
+
+__device__ __forceinline__ void emit_result(const NNArgs& a, uint32_t orig, bool active, float thr,
+                                            float best_d2, uint32_t best_idx, uint32_t best_spos)
+{
+    bool acc = active && best_idx != NONE_U32 && best_d2 < thr;  // :259
+    if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;  // :98-101
+    a.out_spos[orig] = acc ? best_spos : NONE_U32;
+    a.out_d2[orig]   = best_d2;
+    if (acc && a.claims) atomicMin(&a.claims[best_spos], a.claim_hi | (a.local_offset + orig));
+}
+
+// push the lanes of `mask` (one entry per query slot) onto the deferred-query list
 template <int Q>
+__device__ __forceinline__ uint32_t defer_lanes(const NNArgs& a, bool mine, unsigned long long mask,
+                                                int lane, int slice, uint32_t qi, float r,
+                                                float best_d2, uint32_t best_idx, uint32_t best_spos)
+{
+    const unsigned long long slot_mask = (Q < 64) ? ((1ull << (Q & 63)) - 1ull) : ~0ull;
+    const unsigned long long push      = mask & slot_mask;
+    const int                npush     = __popcll(push);
+    uint32_t                 base_slot = 0;
+    if (lane == 0) base_slot = atomicAdd(a.work_count, (uint32_t)npush);
+    base_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_slot);
+    if (mine && slice == 0)
+    {
+        const uint32_t slot = base_slot + (uint32_t)__popcll(push & ((1ull << lane) - 1ull));
+        a.work[slot]      = make_uint4(qi, __float_as_uint(r), __float_as_uint(best_d2), best_idx);
+        a.work_spos[slot] = best_spos;
+    }
+    return (uint32_t)npush;
+}
+
+// ================================================================================================
+template <int Q, bool INSTR>
 __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
 {
     constexpr int S = 64 / Q;
     __shared__ __attribute__((aligned(16))) float s_x[NN_CAP];
     __shared__ __attribute__((aligned(16))) float s_y[NN_CAP];
     __shared__ __attribute__((aligned(16))) float s_z[NN_CAP];
-    __shared__ uint32_t s_idx[NN_CAP];
-    __shared__ uint32_t s_spos[NN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_idx[NN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_spos[NN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_owner[NN_CAP];
     __shared__ uint32_t s_cstart[64];
-    __shared__ uint32_t s_coff[65];
+    __shared__ uint32_t s_coff[64];
 
     const GridView& g     = a.g;
     const int       lane  = threadIdx.x;
@@ -100,247 +254,160 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
 
     float    r        = fminf(a.r0, rmax);
     bool     done     = !active;
+    bool     deferred = false;
     float    best_d2  = INFINITY;
     uint32_t best_idx = NONE_U32, best_spos = NONE_U32;
 
-    uint32_t st_pass = 0, st_cells = 0, st_cand = 0, st_maxcand = 0, st_coop = 0;
-    const long long t_start = a.counters ? (long long)wall_clock64() : 0;
+    uint32_t        st_pass = 0, st_cells = 0, st_cand = 0, st_defer = 0;
+    const long long t_start = INSTR ? (long long)wall_clock64() : 0;
 
     while (true)
     {
         const unsigned long long pend = __ballot(!done);
         if (pend == 0ull) break;
-        st_pass++;
 
         // ---- this pass serves a GROUP of pending queries: those within grp_factor radii of
         //      the first pending one (and of comparable radius).  A Morton-consecutive tile is
-        //      normally one group; a tile straddling a jump of the curve (or holding far-range
-        //      returns) is split so that the search box never dwarfs the search balls.  The
-        //      other pending lanes still test the staged points (every candidate is a valid
-        //      upper bound) but only group members may conclude. -------------------------------
+        //      normally one group.  The other pending lanes still test the staged points (every
+        //      candidate is a valid upper bound) but only group members may conclude. ----------
         const int   seed = __ffsll((long long)pend) - 1;
-        const float sx = __shfl(qx, seed, 64), sy = __shfl(qy, seed, 64), sz = __shfl(qz, seed, 64);
-        const float sr = __shfl(r, seed, 64);
+        const float sx = readlane_f(qx, seed), sy = readlane_f(qy, seed), sz = readlane_f(qz, seed);
+        const float sr = readlane_f(r, seed);
         const float G  = a.grp_factor * sr;
         const bool  grp = !done && fabsf(qx - sx) <= G && fabsf(qy - sy) <= G &&
                          fabsf(qz - sz) <= G && r <= 2.0f * sr;
+        const unsigned long long gmask = __ballot(grp);
+
+        // ---- a group of a few isolated queries goes to the one-query-per-wave kernel -----------
+        if (__popcll(gmask) <= NN_COOP_MAX * S)
+        {
+            st_defer += defer_lanes<Q>(a, grp, gmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
+            if (grp) done = true, deferred = true;
+            continue;
+        }
+        st_pass++;
 
         // ---- search box = union of the group's cubes ---------------------------------------
-        float lox = wave_min(grp ? qx - r : INFINITY), loy = wave_min(grp ? qy - r : INFINITY),
-              loz = wave_min(grp ? qz - r : INFINITY);
-        float hix = wave_max(grp ? qx + r : -INFINITY), hiy = wave_max(grp ? qy + r : -INFINITY),
-              hiz = wave_max(grp ? qz + r : -INFINITY);
+        const float lox = wave_min(grp ? qx - r : INFINITY), loy = wave_min(grp ? qy - r : INFINITY),
+                    loz = wave_min(grp ? qz - r : INFINITY);
+        const float hix = wave_max(grp ? qx + r : -INFINITY), hiy = wave_max(grp ? qy + r : -INFINITY),
+                    hiz = wave_max(grp ? qz + r : -INFINITY);
         const float rmin_t = wave_min(grp ? r : INFINITY);
         const float rmax_t = wave_max(grp ? r : 0.f);
         // conservative bounding box of the group's queries themselves
         const float qlx = lox + rmin_t, qly = loy + rmin_t, qlz = loz + rmin_t;
         const float qhx = hix - rmin_t, qhy = hiy - rmin_t, qhz = hiz - rmin_t;
+        const PassBox box    = choose_level(g, lox, loy, loz, hix, hiy, hiz, a.cell_budget);
+        const float   prune  = rmax_t + 4.f * g.slack;
+        const float   prune2 = prune * prune;
 
-        // clip to the layer's bounding box; disjoint -> nothing to visit
-        lox = fmaxf(lox, g.bbmin[0]), loy = fmaxf(loy, g.bbmin[1]), loz = fmaxf(loz, g.bbmin[2]);
-        hix = fminf(hix, g.bbmax[0]), hiy = fminf(hiy, g.bbmax[1]), hiz = fminf(hiz, g.bbmax[2]);
-        const bool empty_box = (lox > hix) || (loy > hiy) || (loz > hiz);
-
-        uint32_t           nx = 0, ny = 0, nz = 0, cx0 = 0, cy0 = 0, cz0 = 0, s = g.shift0, lev = 0;
-        unsigned long long ncell = 0;
-        if (!empty_box)
+        const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        for (unsigned long long cb = 0; cb < box.ncell; cb += 64)
         {
-            const uint32_t flx = cell_fine(lox, g.ox, g.inv_hf), fhx = cell_fine(hix, g.ox, g.inv_hf);
-            const uint32_t fly = cell_fine(loy, g.oy, g.inv_hf), fhy = cell_fine(hiy, g.oy, g.inv_hf);
-            const uint32_t flz = cell_fine(loz, g.oz, g.inv_hf), fhz = cell_fine(hiz, g.oz, g.inv_hf);
-            for (;;)
-            {
-                cx0 = flx >> s, cy0 = fly >> s, cz0 = flz >> s;
-                nx = (fhx >> s) - cx0 + 1, ny = (fhy >> s) - cy0 + 1, nz = (fhz >> s) - cz0 + 1;
-                ncell = (unsigned long long)nx * ny * nz;
-                if (ncell <= NN_CELL_BUDGET || lev + 1 >= g.n_levels) break;
-                s++, lev++;
-            }
-        }
-        const float hs     = g.hf * (float)(1u << s);  // voxel edge at this level
-        const float prune  = rmax_t + 4.f * g.slack;
-        const float prune2 = prune * prune;
-
-        // ---- small group: switch to the COOPERATIVE scan (lanes split the candidates of up
-        //      to 4 member queries and a wave arg-min merges them): a sparse far-range return
-        //      then costs 1/64 of the per-lane scan ------------------------------------------
-        const unsigned long long gmask = __ballot(grp);
-        const int                k_grp = __popcll(gmask);
-        const bool               coop  = (S == 1) && (k_grp <= NN_COOP_MAX);
-        st_coop += coop ? 1u : 0u;
-        float    mqx[NN_COOP_MAX], mqy[NN_COOP_MAX], mqz[NN_COOP_MAX];
-        float    pb_d2[NN_COOP_MAX];
-        uint32_t pb_idx[NN_COOP_MAX], pb_spos[NN_COOP_MAX];
-        int      mlane[NN_COOP_MAX];
-        {
-            unsigned long long tmp = gmask;
-#pragma unroll
-            for (int t = 0; t < NN_COOP_MAX; t++)
-            {
-                mlane[t] = tmp ? (__ffsll((long long)tmp) - 1) : 0;
-                tmp &= tmp - 1;
-                mqx[t] = __shfl(qx, mlane[t], 64), mqy[t] = __shfl(qy, mlane[t], 64),
-                mqz[t] = __shfl(qz, mlane[t], 64);
-                pb_d2[t] = INFINITY, pb_idx[t] = NONE_U32, pb_spos[t] = NONE_U32;
-            }
-        }
-
-        const bool small_grid = ncell <= 0xFFFFFFFFull;
-        for (unsigned long long cb = 0; cb < ncell; cb += 64)
-        {
-            const unsigned long long cid = cb + lane;
-            uint32_t                 cnt = 0, start = 0;
-            if (cid < ncell)
-            {
-                uint32_t ix, iy, iz;
-                if (small_grid)
-                {
-                    const uint32_t c32 = (uint32_t)cid, row = c32 / nx;
-                    ix = c32 - row * nx, iz = row / ny, iy = row - iz * ny;
-                }
-                else
-                {
-                    ix = (uint32_t)(cid % nx), iy = (uint32_t)((cid / nx) % ny);
-                    iz = (uint32_t)(cid / ((unsigned long long)nx * ny));
-                }
-                const uint32_t cx = cx0 + ix, cy = cy0 + iy, cz = cz0 + iz;
-                // voxel box vs bounding box of the group's queries
-                const float vx0 = g.ox + (float)cx * hs, vy0 = g.oy + (float)cy * hs,
-                            vz0 = g.oz + (float)cz * hs;
-                const float dx = fmaxf(0.f, fmaxf(vx0 - qhx, qlx - (vx0 + hs)));
-                const float dy = fmaxf(0.f, fmaxf(vy0 - qhy, qly - (vy0 + hs)));
-                const float dz = fmaxf(0.f, fmaxf(vz0 - qhz, qlz - (vz0 + hs)));
-                if (dx * dx + dy * dy + dz * dz <= prune2)
-                {
-                    uint32_t e = 0;
-                    if (cell_lookup(g, cell_key(lev, cx, cy, cz), start, e)) cnt = e - start;
-                }
-            }
+            uint32_t cnt, start;
+            float    md2_unused;
+            lookup_voxel(g, box, cb + lane, qlx, qly, qlz, qhx, qhy, qhz, prune2, start, cnt, md2_unused);
             const uint32_t incl  = wave_incl_scan(cnt, lane);
-            const uint32_t total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63, 64));
-            st_cells += (uint32_t)min((unsigned long long)64, ncell - cb);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            st_cells += (uint32_t)min((unsigned long long)64, box.ncell - cb);
             if (total == 0) continue;  // uniform: no occupied voxel in this batch
+            const uint32_t off = incl - cnt;
             s_cstart[lane] = start;
-            s_coff[lane]   = incl - cnt;
-            if (lane == 63) s_coff[64] = total;
-            __syncthreads();
+            s_coff[lane]   = off;
             st_cand += total;
-            st_maxcand = max(st_maxcand, total);
 
             for (uint32_t base = 0; base < total; base += NN_CAP)
             {
                 const uint32_t m     = min((uint32_t)NN_CAP, total - base);
                 const uint32_t m_pad = (m + 31u) & ~31u;
-                // ---- stage: coalesced 16-byte loads, lane t <- t-th candidate of the round,
-                //      stored as SoA so that the scan reads 4 candidates per ds_read_b128
-                for (uint32_t t = lane; t < m_pad; t += 64)
+                // ---- stage.  Lane l fills slots 4l..4l+3 of the round.  Which voxel a slot
+                //      belongs to comes from a segmented broadcast: every occupied voxel drops
+                //      its id at its first slot, a prefix-max carries it to the following slots.
+                *reinterpret_cast<uint4*>(&s_owner[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+                __syncthreads();
+                if (cnt > 0)
                 {
-                    float4   c   = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
-                    uint32_t src = NONE_U32;
-                    if (t < m)
-                    {
-                        const uint32_t gt = base + t;
-                        int            lo = 0, hi = 63;
-                        while (lo < hi)
-                        {
-                            const int mid = (lo + hi + 1) >> 1;
-                            if (s_coff[mid] <= gt) lo = mid;
-                            else hi = mid - 1;
-                        }
-                        src = s_cstart[lo] + (gt - s_coff[lo]);
-                        c   = g.pts[src];
-                        if (a.touched) a.touched[src] = 1;
-                    }
-                    s_x[t] = c.x, s_y[t] = c.y, s_z[t] = c.z;
-                    s_idx[t]  = __float_as_uint(c.w);
-                    s_spos[t] = src;
+                    if (off >= base && off < base + NN_CAP) s_owner[off - base] = (uint32_t)lane + 1u;
+                    else if (off < base && off + cnt > base) s_owner[0] = (uint32_t)lane + 1u;
                 }
                 __syncthreads();
-                if (coop)
                 {
-                    for (uint32_t j = lane; j < m; j += 64)
-                    {
-                        const float    cx = s_x[j], cy = s_y[j], cz = s_z[j];
-                        const uint32_t ci = s_idx[j];
+                    const uint4    o4 = *reinterpret_cast<const uint4*>(&s_owner[4 * lane]);
+                    const uint32_t p0 = o4.x, p1 = max(p0, o4.y), p2 = max(p1, o4.z), p3 = max(p2, o4.w);
+                    const uint32_t in = wave_incl_max(p3, lane);
+                    uint32_t       ex = __shfl_up(in, 1, 64);
+                    if (lane == 0) ex = 0u;
+                    const uint32_t ow[4] = {max(ex, p0), max(ex, p1), max(ex, p2), max(ex, p3)};
+                    const uint32_t t0    = 4u * (uint32_t)lane;
+                    uint32_t       src[4];
+                    float4         c4[4];
 #pragma unroll
-                        for (int t = 0; t < NN_COOP_MAX; t++)
+                    for (int k = 0; k < 4; k++)
+                    {
+                        src[k] = NONE_U32;
+                        if (t0 + k < m)
                         {
-                            if (t < k_grp)
-                            {
-                                const float d2 = dist2(mqx[t], mqy[t], mqz[t], cx, cy, cz);
-                                if (d2 < pb_d2[t] || (d2 == pb_d2[t] && ci < pb_idx[t]))
-                                    pb_d2[t] = d2, pb_idx[t] = ci, pb_spos[t] = s_spos[j];
-                            }
+                            const uint32_t v = ow[k] - 1u;
+                            src[k]           = s_cstart[v] + (base + t0 + k - s_coff[v]);
                         }
                     }
-                }
-                else
-                {
-                    // ---- scan: every lane tests (its slice of) the bucket against its query,
-                    //      8 candidates per step; the update path is rare after the first few
-                    for (uint32_t jb = (uint32_t)slice * 8u; jb < m_pad; jb += 8u * S)
-                    {
-                        const float4 xa = *reinterpret_cast<const float4*>(&s_x[jb]);
-                        const float4 xb = *reinterpret_cast<const float4*>(&s_x[jb + 4]);
-                        const float4 ya = *reinterpret_cast<const float4*>(&s_y[jb]);
-                        const float4 yb = *reinterpret_cast<const float4*>(&s_y[jb + 4]);
-                        const float4 za = *reinterpret_cast<const float4*>(&s_z[jb]);
-                        const float4 zb = *reinterpret_cast<const float4*>(&s_z[jb + 4]);
-                        float        d[8];
-                        d[0] = dist2(qx, qy, qz, xa.x, ya.x, za.x);
-                        d[1] = dist2(qx, qy, qz, xa.y, ya.y, za.y);
-                        d[2] = dist2(qx, qy, qz, xa.z, ya.z, za.z);
-                        d[3] = dist2(qx, qy, qz, xa.w, ya.w, za.w);
-                        d[4] = dist2(qx, qy, qz, xb.x, yb.x, zb.x);
-                        d[5] = dist2(qx, qy, qz, xb.y, yb.y, zb.y);
-                        d[6] = dist2(qx, qy, qz, xb.z, yb.z, zb.z);
-                        d[7] = dist2(qx, qy, qz, xb.w, yb.w, zb.w);
-                        const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])),
-                                               fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
-                        if (!done && mn <= best_d2)
-                        {
 #pragma unroll
-                            for (int k = 0; k < 8; k++)
+                    for (int k = 0; k < 4; k++)
+                    {
+                        c4[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
+                        if (t0 + k < m) c4[k] = g.pts[src[k]];
+                    }
+                    *reinterpret_cast<float4*>(&s_x[t0]) = make_float4(c4[0].x, c4[1].x, c4[2].x, c4[3].x);
+                    *reinterpret_cast<float4*>(&s_y[t0]) = make_float4(c4[0].y, c4[1].y, c4[2].y, c4[3].y);
+                    *reinterpret_cast<float4*>(&s_z[t0]) = make_float4(c4[0].z, c4[1].z, c4[2].z, c4[3].z);
+                    *reinterpret_cast<uint4*>(&s_idx[t0]) =
+                        make_uint4(__float_as_uint(c4[0].w), __float_as_uint(c4[1].w),
+                                   __float_as_uint(c4[2].w), __float_as_uint(c4[3].w));
+                    *reinterpret_cast<uint4*>(&s_spos[t0]) = make_uint4(src[0], src[1], src[2], src[3]);
+                    if (INSTR)
+                    {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (t0 + k < m) a.touched[src[k]] = 1;
+                    }
+                }
+                __syncthreads();
+                // ---- scan: every lane tests (its slice of) the bucket against its query, 8
+                //      candidates per step on the packed-fp32 path; the update is rare
+                for (uint32_t jb = (uint32_t)slice * 8u; jb < m_pad; jb += 8u * S)
+                {
+                    const float4 xa = *reinterpret_cast<const float4*>(&s_x[jb]);
+                    const float4 xb = *reinterpret_cast<const float4*>(&s_x[jb + 4]);
+                    const float4 ya = *reinterpret_cast<const float4*>(&s_y[jb]);
+                    const float4 yb = *reinterpret_cast<const float4*>(&s_y[jb + 4]);
+                    const float4 za = *reinterpret_cast<const float4*>(&s_z[jb]);
+                    const float4 zb = *reinterpret_cast<const float4*>(&s_z[jb + 4]);
+                    const v2f d01 = dist2_pk(qx2, qy2, qz2, v2f{xa.x, xa.y}, v2f{ya.x, ya.y}, v2f{za.x, za.y});
+                    const v2f d23 = dist2_pk(qx2, qy2, qz2, v2f{xa.z, xa.w}, v2f{ya.z, ya.w}, v2f{za.z, za.w});
+                    const v2f d45 = dist2_pk(qx2, qy2, qz2, v2f{xb.x, xb.y}, v2f{yb.x, yb.y}, v2f{zb.x, zb.y});
+                    const v2f d67 = dist2_pk(qx2, qy2, qz2, v2f{xb.z, xb.w}, v2f{yb.z, yb.w}, v2f{zb.z, zb.w});
+                    const float d[8] = {d01.x, d01.y, d23.x, d23.y, d45.x, d45.y, d67.x, d67.y};
+                    const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])),
+                                           fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+                    if (!done && mn <= best_d2)
+                    {
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                        {
+                            if (d[k] <= best_d2)
                             {
-                                if (d[k] <= best_d2)
+                                const uint32_t ci = s_idx[jb + k];
+                                if (d[k] < best_d2 || ci < best_idx)
                                 {
-                                    const uint32_t ci = s_idx[jb + k];
-                                    if (d[k] < best_d2 || ci < best_idx)
-                                    {
-                                        best_d2   = d[k];
-                                        best_idx  = ci;
-                                        best_spos = s_spos[jb + k];
-                                    }
+                                    best_d2   = d[k];
+                                    best_idx  = ci;
+                                    best_spos = s_spos[jb + k];
                                 }
                             }
                         }
                     }
                 }
                 __syncthreads();
-            }
-        }
-
-        if (coop)
-        {
-            // wave arg-min per member, merged into the member's own lane
-#pragma unroll
-            for (int t = 0; t < NN_COOP_MAX; t++)
-            {
-                if (t < k_grp)
-                {
-                    float    bd = pb_d2[t];
-                    uint32_t bi = pb_idx[t], bs = pb_spos[t];
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1)
-                    {
-                        const float    od = __shfl_xor(bd, off, 64);
-                        const uint32_t oi = __shfl_xor(bi, off, 64);
-                        const uint32_t os = __shfl_xor(bs, off, 64);
-                        if (od < bd || (od == bd && oi < bi)) bd = od, bi = oi, bs = os;
-                    }
-                    if (lane == mlane[t] && (bd < best_d2 || (bd == best_d2 && bi < best_idx)))
-                        best_d2 = bd, best_idx = bi, best_spos = bs;
-                }
             }
         }
 
@@ -358,33 +425,31 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
             }
         }
 
-        // ---- final?  (visited voxels cover the whole cube of half-edge r around the query)
+        bool too_wide = false;
         if (grp)
         {
-            const float gr = r * (1.0f - 1.0f / 1024.0f) - g.slack;
-            if (r >= rmax || (gr > 0.f && best_d2 < gr * gr))
-                done = true;
+            if (is_final(r, rmax, best_d2, g.slack)) done = true;
             else
             {
-                const float rn = (best_idx != NONE_U32)
-                                     ? sqrtf(best_d2) * (1.0f + 1.0f / 512.0f) + 4.f * g.slack
-                                     : 2.0f * r;
-                r = fminf(fmaxf(rn, r * 1.0009765625f), rmax);
+                r = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
+                // a query whose radius outgrows the voxels would drag the shared box with it:
+                // it continues alone, with the whole wave on its own candidates
+                too_wide = r > a.r_defer;
             }
+        }
+        const unsigned long long wmask = __ballot(too_wide);
+        if (wmask)
+        {
+            st_defer += defer_lanes<Q>(a, too_wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
+            if (too_wide) done = true, deferred = true;
         }
     }
 
     // ---- output (original local order) + claim of the global point --------------------------
-    if (valid && slice == 0)
-    {
-        bool acc = active && best_idx != NONE_U32 && best_d2 < thr;  // :259
-        if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;  // :98-101
-        a.out_spos[orig] = acc ? best_spos : NONE_U32;
-        a.out_d2[orig]   = best_d2;
-        if (acc && a.claims)
-            atomicMin(&a.claims[best_spos], a.claim_hi | (a.local_offset + orig));
-    }
-    if (a.counters && lane == 0)
+    if (valid && slice == 0 && !deferred)
+        emit_result(a, orig, active, thr, best_d2, best_idx, best_spos);
+
+    if (INSTR && lane == 0)
     {
         atomicAdd(&a.counters[0], 1ull);
         atomicAdd(&a.counters[1], (unsigned long long)st_pass);
@@ -396,21 +461,151 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
         const unsigned long long dt = (unsigned long long)((long long)wall_clock64() - t_start);
         atomicAdd(&a.counters[7], dt);
         atomicMax(&a.counters[8], dt);
-        atomicAdd(&a.counters[9], (unsigned long long)st_coop);
-        // histogram of per-tile wall time, log2 bins of 100 MHz ticks
-        int b = 63 - __clzll((long long)(dt | 1ull));
+        atomicAdd(&a.counters[9], (unsigned long long)st_defer);
+        int b = 63 - __clzll((long long)(dt | 1ull));  // log2 bins of 100 MHz ticks
         if (b > 23) b = 23;
         atomicAdd(&a.counters[16 + b], 1ull);
     }
 }
 
-// reduce the per-tile boxes to the layer box {min xyz, max xyz}
+// ================================================================================================
+// one deferred query per wave
+template <bool INSTR>
+__global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
+{
+    __shared__ uint32_t s_cstart[64];
+    __shared__ uint32_t s_coff[64];
+    const GridView& g      = a.g;
+    const int       lane   = threadIdx.x;
+    const uint32_t  n_work = *a.work_count;
+
+    for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x)
+    {
+        const uint4    w    = a.work[item];
+        const uint32_t qi   = w.x;
+        const float4   lp   = a.lpts[qi];
+        const uint32_t orig = __float_as_uint(lp.w);
+        float          qx, qy, qz;
+        compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
+        const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));
+        const float thr    = fadd(a.maxDistSq, fmul(a.angSq, normSq));
+        const float rmax   = sqrtf(thr) * 1.002f + g.slack;
+        float       r      = __uint_as_float(w.y);
+        // wave-uniform running best (carried over from the tile kernel)
+        float    best_d2  = __uint_as_float(w.z);
+        uint32_t best_idx = w.w, best_spos = a.work_spos[item];
+        uint32_t st_pass = 0, st_cand = 0, st_cells = 0;
+
+        for (;;)
+        {
+            st_pass++;
+            const PassBox box = choose_level(g, qx - r, qy - r, qz - r, qx + r, qy + r, qz + r,
+                                             a.cell_budget);
+            const float prune  = r + 4.f * g.slack;
+            const float prune2 = prune * prune;
+            // per-lane partial best over the candidates this lane tests
+            float    pd = INFINITY;
+            uint32_t pi = NONE_U32, ps = NONE_U32;
+            float    bound = best_d2;  // wave-uniform upper bound of the answer (prunes voxels)
+            for (unsigned long long cb = 0; cb < box.ncell; cb += 64)
+            {
+                uint32_t cnt, start;
+                float    md2;
+                lookup_voxel(g, box, cb + lane, qx, qy, qz, qx, qy, qz, prune2, start, cnt, md2);
+                st_cells += (uint32_t)min((unsigned long long)64, box.ncell - cb);
+                // ---- closest voxel first (its points give a tight bound), then every voxel the
+                //      bound cannot exclude, flattened over the lanes with 4 loads in flight
+                const unsigned long long occ = __ballot(cnt > 0);
+                if (occ == 0ull) continue;
+                {
+                    const float kmin = wave_min(cnt > 0 ? md2 : INFINITY);
+                    const float lim  = bound * 1.000001f + g.slack * (2.f * sqrtf(bound) + g.slack);
+                    if (!(kmin <= lim)) continue;  // nothing in this batch can matter
+                    const int      lc = __ffsll((long long)__ballot(cnt > 0 && md2 == kmin)) - 1;
+                    const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)start, lc);
+                    const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, lc);
+                    st_cand += cc;
+                    for (uint32_t j = lane; j < cc; j += 64)
+                    {
+                        const uint32_t sa = cs + j;
+                        const float4   ca = g.pts[sa];
+                        const float    da = dist2(qx, qy, qz, ca.x, ca.y, ca.z);
+                        const uint32_t ia = __float_as_uint(ca.w);
+                        if (da < pd || (da == pd && ia < pi)) pd = da, pi = ia, ps = sa;
+                        if (INSTR) a.touched[sa] = 1;
+                    }
+                    bound = fminf(bound, wave_min(pd));
+                    if (lane == lc) cnt = 0;  // done
+                }
+                {
+                    // conservative: a voxel is skipped only if even its nearest corner is farther
+                    // than the bound (fp32 slack on the voxel box included); ties must be seen
+                    const float    lim  = bound * 1.000001f + g.slack * (2.f * sqrtf(bound) + g.slack);
+                    const uint32_t c2   = (cnt > 0 && md2 <= lim) ? cnt : 0u;
+                    const uint32_t incl = wave_incl_scan(c2, lane);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (total == 0) continue;
+                    s_cstart[lane] = start;
+                    s_coff[lane]   = incl - c2;
+                    __syncthreads();
+                    st_cand += total;
+                    for (uint32_t t0 = 0; t0 < total; t0 += 256)
+                    {
+                        uint32_t sa[4];
+                        float4   ca[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                            const uint32_t t = t0 + 64u * k + lane;
+                            sa[k] = (t < total) ? locate_candidate(s_cstart, s_coff, t) : 0u;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                            const uint32_t t = t0 + 64u * k + lane;
+                            ca[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
+                            if (t < total) ca[k] = g.pts[sa[k]];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                            const uint32_t t  = t0 + 64u * k + lane;
+                            const float    da = dist2(qx, qy, qz, ca[k].x, ca[k].y, ca[k].z);
+                            const uint32_t ia = __float_as_uint(ca[k].w);
+                            if (t < total && (da < pd || (da == pd && ia < pi))) pd = da, pi = ia, ps = sa[k];
+                            if (INSTR && t < total) a.touched[sa[k]] = 1;
+                        }
+                    }
+                    __syncthreads();
+                    bound = fminf(bound, wave_min(pd));
+                }
+            }
+            wave_argmin(pd, pi, ps);
+            if (pd < best_d2 || (pd == best_d2 && pi < best_idx)) best_d2 = pd, best_idx = pi, best_spos = ps;
+            if (is_final(r, rmax, best_d2, g.slack)) break;
+            r = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
+        }
+        if (lane == 0) emit_result(a, orig, true, thr, best_d2, best_idx, best_spos);
+        if (INSTR && lane == 0)
+        {
+            atomicAdd(&a.counters[10], 1ull);
+            atomicAdd(&a.counters[11], (unsigned long long)st_pass);
+            atomicAdd(&a.counters[12], (unsigned long long)st_cells);
+            atomicAdd(&a.counters[13], (unsigned long long)st_cand);
+            atomicMax(&a.counters[14], (unsigned long long)st_cand);
+        }
+    }
+}
+
+__global__ void zero_u32_kernel(uint32_t* p) { *p = 0; }
+
+// reduce the per-tile boxes to the layer box {min xyz, max xyz}: [n_in][6] -> [gridDim.x][6]
 __global__ __launch_bounds__(256) void tile_bbox_reduce_kernel(const float* __restrict__ tb,
-                                                               uint32_t n_tiles,
-                                                               float* __restrict__ out6)
+                                                               uint32_t n_in,
+                                                               float* __restrict__ out)
 {
     float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = threadIdx.x; i < n_tiles; i += blockDim.x)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x)
     {
         const float* p = tb + (size_t)i * 6;
         for (int d = 0; d < 3; d++) v[d] = fminf(v[d], p[d]), v[3 + d] = fmaxf(v[3 + d], p[3 + d]);
@@ -426,8 +621,19 @@ __global__ __launch_bounds__(256) void tile_bbox_reduce_kernel(const float* __re
         const int d = threadIdx.x;
         float     r = s[0][d];
         for (int k = 1; k < 4; k++) r = d < 3 ? fminf(r, s[k][d]) : fmaxf(r, s[k][d]);
-        out6[d] = r;
+        out[(size_t)blockIdx.x * 6 + d] = r;
     }
+}
+
+int launch_bbox_reduce(mp2p_hip_ctx* ctx, uint32_t n_tiles)
+{
+    constexpr uint32_t NB = 64;
+    MP2P_TRY_HIP(ctx, ctx->tile_bbox2.ensure(NB * 6));
+    hipLaunchKernelGGL(tile_bbox_reduce_kernel, dim3(NB), dim3(256), 0, ctx->stream,
+                       ctx->tile_bbox.p, n_tiles, ctx->tile_bbox2.p);
+    hipLaunchKernelGGL(tile_bbox_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream,
+                       ctx->tile_bbox2.p, NB, ctx->local_bbox.p);
+    return MP2P_HIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -435,14 +641,16 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
                     const double pose[12], const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms)
 {
     const size_t n_l = cloud->n;
-    uint32_t     Q   = prm->queries_per_wave ? prm->queries_per_wave : 64;
-    MP2P_REQUIRE(ctx, Q == 64 || Q == 16, "queries_per_wave must be 64 or 16");
+    uint32_t     Q   = prm->queries_per_wave ? prm->queries_per_wave : 32;
+    MP2P_REQUIRE(ctx, Q == 64 || Q == 32 || Q == 16, "queries_per_wave must be 64, 32 or 16");
     const uint32_t n_tiles = (uint32_t)((n_l + Q - 1) / Q);
 
     MP2P_TRY_HIP(ctx, ctx->nn_spos.ensure(n_l));
     MP2P_TRY_HIP(ctx, ctx->nn_d2.ensure(n_l));
     MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_tiles * 6));
     MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
+    MP2P_TRY_HIP(ctx, ctx->work.ensure(n_l));
+    MP2P_TRY_HIP(ctx, ctx->work_spos.ensure(n_l + 1));  // last word = counter
     ctx->last_n_tiles = n_tiles;
     ctx->last_q       = Q;
 
@@ -458,8 +666,10 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     const double angRad = prm->thresholdAngularDeg * 3.14159265358979323846 / 180.0;
     a.angSq             = (float)(angRad * angRad);
     const float cell0   = map->view.hf * (float)(1u << map->view.shift0);
-    a.r0 = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 1.0f);
-    a.grp_factor = prm->group_radius_factor > 0 ? prm->group_radius_factor : 4.0f;
+    a.r0          = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 1.0f);
+    a.grp_factor  = prm->group_radius_factor > 0 ? prm->group_radius_factor : 4.0f;
+    a.cell_budget = prm->cell_budget > 0 ? prm->cell_budget : 512u;
+    a.r_defer     = cell0 * (prm->defer_radius_cells > 0 ? prm->defer_radius_cells : 3.0f);
     a.local_taken =
         (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
     a.global_taken =
@@ -471,6 +681,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.out_spos     = ctx->nn_spos.p;
     a.out_d2       = ctx->nn_d2.p;
     a.tile_bbox    = ctx->tile_bbox.p;
+    a.work         = ctx->work.p;
+    a.work_spos    = ctx->work_spos.p;
+    a.work_count   = ctx->work_spos.p + n_l;
     a.counters     = nullptr;
     a.touched      = nullptr;
     if (ctx->profiling >= 2)
@@ -482,19 +695,32 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->pl_slots.p, 0, map->n, ctx->stream));
         a.touched = ctx->pl_slots.p;
     }
+    hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, ctx->stream, a.work_count);
+    // ev[0]..ev[1] brackets exactly the two search kernels (the roofline kernels of bench.py)
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (n_tiles)
     {
-        switch (Q)
-        {
-            case 64: hipLaunchKernelGGL(nn_tile_kernel<64>, dim3(n_tiles), dim3(64), 0, ctx->stream, a); break;
-            default: hipLaunchKernelGGL(nn_tile_kernel<16>, dim3(n_tiles), dim3(64), 0, ctx->stream, a); break;
-        }
+        const bool     instr         = a.counters != nullptr;
+        const uint32_t single_blocks = (uint32_t)std::min<size_t>(n_l, 256u * 32u);
+#define MP2P_LAUNCH_TILE(QQ)                                                                       \
+    do                                                                                             \
+    {                                                                                              \
+        if (instr) hipLaunchKernelGGL((nn_tile_kernel<QQ, true>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);  \
+        else hipLaunchKernelGGL((nn_tile_kernel<QQ, false>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);      \
+    } while (0)
+        if (Q == 64) MP2P_LAUNCH_TILE(64);
+        else if (Q == 32) MP2P_LAUNCH_TILE(32);
+        else MP2P_LAUNCH_TILE(16);
+#undef MP2P_LAUNCH_TILE
+        if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        // deferred queries: the count lives on the device; a fixed grid strides over it
+        if (instr) hipLaunchKernelGGL(nn_single_kernel<true>, dim3(single_blocks), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(nn_single_kernel<false>, dim3(single_blocks), dim3(64), 0, ctx->stream, a);
     }
-    // ev[0]..ev[1] brackets exactly the search kernel (the roofline kernel of bench.py)
+    else if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    hipLaunchKernelGGL(tile_bbox_reduce_kernel, dim3(1), dim3(256), 0, ctx->stream,
-                       ctx->tile_bbox.p, n_tiles, ctx->local_bbox.p);
+    int rc = launch_bbox_reduce(ctx, n_tiles);
+    if (rc) return rc;
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
 }

@@ -89,6 +89,11 @@ class HipBackend:
         _lib.check(self.ctx._L.mp2p_hip_gn_end(self.ctx.handle, C.byref(res)), self.ctx.handle)
         return np.array(res.pose), int(res.iterations)
 
+    def gn_solve_fused(self, pose):
+        from . import core
+        res = core.gn_solve(self.ctx, self.pairs, pose, self.gn_prm)
+        return np.array(res.pose), int(res.iterations)
+
     def n_pairs(self):
         return self.pairs.counts()[0]
 
@@ -123,6 +128,8 @@ class ShardedRegistration:
 
     def solve(self, pose):
         b = self.b
+        if self.world == 1 and hasattr(b, "gn_solve_fused"):
+            return b.gn_solve_fused(pose)  # no all-reduce seam: one launch per inner iteration less
         b.gn_begin(pose)
         for _ in range(b.max_inner):
             b.gn_accumulate()

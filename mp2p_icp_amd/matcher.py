@@ -197,6 +197,8 @@ class Matcher_Points_Base(Matcher):
         self.initial_radius_cells = 0.0
         self.queries_per_wave = 0
         self.group_radius_factor = 0.0
+        self.cell_budget = 0
+        self.defer_radius_cells = 0.0
 
     def initialize(self, params):
         super().initialize(params)
@@ -225,6 +227,8 @@ class Matcher_Points_Base(Matcher):
         self.initial_radius_cells = float(params.get("hip_initial_radius_cells", 0.0))
         self.queries_per_wave = int(params.get("hip_queries_per_wave", 0))
         self.group_radius_factor = float(params.get("hip_group_radius_factor", 0.0))
+        self.cell_budget = int(params.get("hip_cell_budget", 0))
+        self.defer_radius_cells = float(params.get("hip_defer_radius_cells", 0.0))
         if self.maxLocalPointsPerLayer_:
             raise NotImplementedError(
                 "maxLocalPointsPerLayer (random sub-sampling, Matcher_Points_Base.cpp:207-245) "
@@ -301,7 +305,8 @@ class Matcher_Points_DistanceThreshold(Matcher_Points_Base):
             int(self.allowMatchAlreadyMatchedGlobalPoints_),
             float(self.bounding_box_intersection_check_epsilon_), int(local_index_offset),
             float(self.initial_radius_cells), int(self.queries_per_wave),
-            float(self.group_radius_factor))
+            float(self.group_radius_factor), int(self.cell_budget),
+            float(self.defer_radius_cells))
 
     def implMatchOneLayer(self, ctx, gLayer, lLayer, localPose, ms, glName, lcName, out):
         self.checkAllParametersAreRealized()

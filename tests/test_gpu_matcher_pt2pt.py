@@ -77,7 +77,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("n_g,n_l,thr,ang,seed,kw", CASES)
-@pytest.mark.parametrize("q", [64, 16])
+@pytest.mark.parametrize("q", [64, 32, 16])
 def test_random_parity_vs_oracle(amd, oracle, n_g, n_l, thr, ang, seed, kw, q):
     from mp2p_icp_amd import synthetic
     d = synthetic.random_cloud_pair(n_l, n_g, seed, outlier_frac=0.1)

@@ -16,7 +16,7 @@ ctx = amd.Context(0)
 g, l = d["glob"], d["local"]
 cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
 pairs = core.DevicePairs(ctx, n_l, 0)
-configs = [dict(), dict(q=16), dict(r0=2.0), dict(grp=8.0), dict(grp=2.0), dict(tpc=3.0), dict(tpc=12.0), dict(tpc=24.0)]
+configs = [dict(), dict(q=32), dict(q=16), dict(q=16, defer=4.0), dict(q=32, grp=3.0), dict(q=16, r0=1.5), dict(q=16, tpc=4.0)]
 if len(sys.argv) > 3:
     configs = json.loads(sys.argv[3])
 maps = {}
@@ -26,7 +26,7 @@ for cfg in configs:
     if key not in maps:
         maps[key] = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2], cell_size=cell, target_per_cell=tpc)
     gmap = maps[key]
-    prm = _lib.Pt2PtParams(2.0, 0.0, 1, 0, 0, 0.20, 0, cfg.get("r0", 0.0), cfg.get("q", 0), cfg.get("grp", 0.0))
+    prm = _lib.Pt2PtParams(2.0, 0.0, 1, 0, 0, 0.20, 0, cfg.get("r0", 0.0), cfg.get("q", 0), cfg.get("grp", 0.0), cfg.get("budget", 0), cfg.get("defer", 0.0))
     for name, pose in (("init", d["T_init"]), ("gt", d["T_gt"])):
         ctx.set_profiling(1)
         ts = []
@@ -42,7 +42,7 @@ for cfg in configs:
         hist = st["nn_tile_ticks_hist"]
         nt = max(1, st["nn_tiles"])
         print(json.dumps(dict(cfg=cfg, pose=name, cell=round(gmap.info()["cell_size"], 3), ms_nn=round(float(np.median(ts)), 3),
-              tiles=st["nn_tiles"], passes_per_tile=round(st["nn_passes"] / nt, 2), coop_passes=st["nn_coop_passes"],
+              tiles=st["nn_tiles"], passes_per_tile=round(st["nn_passes"] / nt, 2), deferred=st["nn_coop_passes"], single=dict(q=st["nn_single_queries"], passes=st["nn_single_passes"], cells=st["nn_single_cells"], cand=st["nn_single_candidates"], maxcand=st["nn_single_max_candidates"]),
               cand_per_tile=round(st["nn_candidates_tested"] / nt, 1), cells_per_tile=round(st["nn_cells_visited"] / nt, 1),
               touched=st["nn_points_staged"], max_cand=st["nn_max_candidates_one_tile"], max_pass=st["nn_max_passes_one_tile"],
               tile_us_avg=round(st["nn_tile_ticks_sum"] / nt / 100.0, 2), tile_us_max=round(st["nn_tile_ticks_max"] / 100.0, 1),

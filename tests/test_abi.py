@@ -68,50 +68,43 @@ def test_product_never_imports_the_oracle():
                 assert "libmp2p_oracle" not in txt, f
 
 
-def test_nn_kernels_have_no_fma_in_distance_math():
-    """bit-exact indices need separately rounded mul/add (device_utils.hpp): the ISA of the
-    search kernels must not contain fp32/fp64 fused multiply-adds."""
+def test_exact_rounding_helpers_compile_without_fma():
+    """bit-exact indices need separately rounded mul/add: the helpers of device_utils.hpp that
+    carry the reference's fp32/fp64 expressions (distance, threshold, voxel address, pose
+    composition) must compile to ISA without any fused multiply-add, under the product's
+    own compile flags.  (The GPU parity tests are the end-to-end proof.)"""
     from mp2p_icp_amd import _build
-    so = _build.build()
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
-        pytest.skip("llvm-objdump not available")
     d = os.path.join(ROOT, "tests", "_tmp_abi")
     os.makedirs(d, exist_ok=True)
-    # extract the gfx950 code object bundled in the .so (llvm-objdump writes next to its input)
-    import glob
-    import shutil
-    cp = os.path.join(d, "lib.so")
-    shutil.copy(so, cp)
-    for f in glob.glob(cp + ".*"):
-        os.remove(f)
-    subprocess.run([objdump, "--offloading", cp], capture_output=True)
-    cos = glob.glob(cp + ".*gfx950*")
-    if not cos:
-        pytest.skip("cannot extract the device code object")
-    co = cos[0]
-    asm = subprocess.check_output([objdump, "-d", co], text=True)
-    cur, bad = None, []
-    for line in asm.splitlines():
-        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
-        if m:
-            cur = m.group(1)
-            continue
-        if not (cur and "nn_tile_kernel" in cur):
-            continue
-        m = re.search(r"\b(v_(?:fma|fmac|mad|mac|pk_fma)_(?:f32|f64|legacy_f32)\S*)\s+(.*?)\s*//", line)
-        if not m:
-            continue
-        op, args = m.group(1), m.group(2)
-        # the only legitimate fused ops are inside the correctly-rounded sqrtf expansion
-        # (v_fma_f32 d, -a, b, c) and the u64-division expansion (v_fmac_f32 with the
-        # literals 2^32 / -2^32 / 0); anything else would be a contracted distance term
-        if op.startswith("v_fma_f32") and re.match(r"^v\d+, -v\d+, v\d+, v\d+$", args):
-            continue
-        if op.startswith("v_fmac_f32") and re.search(r", (0x4f800000|0xcf800000|0), v\d+$", args):
-            continue
-        bad.append((cur, line.strip()))
+    src = os.path.join(d, "probe.hip")
+    with open(src, "w") as f:
+        f.write(r'''
+#include "device_utils.hpp"
+using namespace mp2p;
+__global__ void probe_dist(const float4* q, const float4* p, float* out, float a, float b) {
+    const float4 Q = q[threadIdx.x], P = p[threadIdx.x];
+    const float d = dist2(Q.x, Q.y, Q.z, P.x, P.y, P.z);
+    const v2f d2 = dist2_pk(v2f{Q.x, Q.x}, v2f{Q.y, Q.y}, v2f{Q.z, Q.z}, v2f{P.x, P.w}, v2f{P.y, P.w}, v2f{P.z, P.w});
+    const float n = fadd(fadd(fmul(Q.x, Q.x), fmul(Q.y, Q.y)), fmul(Q.z, Q.z));
+    out[threadIdx.x] = d + d2.x + d2.y + fadd(a, fmul(b, n)) + (float)cell_fine(Q.x, a, b);
+}
+__global__ void probe_pose(const float4* l, PoseRt P, float* out) {
+    float x, y, z;
+    compose_point_f(P, l[threadIdx.x].x, l[threadIdx.x].y, l[threadIdx.x].z, x, y, z);
+    out[3 * threadIdx.x] = x, out[3 * threadIdx.x + 1] = y, out[3 * threadIdx.x + 2] = z;
+}
+''')
+    asm_path = os.path.join(d, "probe.s")
+    flags = [f for f in _build.FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([_build.hipcc_path()] + flags + ["-I", _build.SRC_DIR, "-S",
+                          "--cuda-device-only", src, "-o", asm_path])
+    asm = open(asm_path).read()
+    assert "probe_dist" in asm and "probe_pose" in asm
+    body = asm[asm.index("probe_dist"):]
+    bad = re.findall(r"^\s*(v_(?:pk_)?(?:fma|fmac|mad|mac)\w*f(?:32|64)\w*)\b.*$", body, flags=re.M)
+    # the final `d + d2.x + ...` sum of the probe itself is outside the helpers: plain adds only
     assert not bad, bad[:5]
+    assert re.search(r"v_pk_mul_f32", body) and re.search(r"v_mul_f64", body)
 
 
 def test_no_device_fails_loudly():

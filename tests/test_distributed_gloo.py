@@ -1,0 +1,198 @@
+"""N>1 path on CPU: two processes, torch.distributed backend gloo, rendezvous on 127.0.0.1.
+
+The exchange logic of mp2p_icp_amd.distributed.ShardedRegistration (bbox MIN/MAX, claim MIN,
+normal-equation SUM) is exercised with a CPU stand-in for this rank's GPU work: OracleBackend
+below computes each shard with the CPU oracle (tests may use the oracle; the product's only
+backend is HipBackend).  The sharded result must equal the unsharded oracle: identical
+correspondence list (concatenated by rank) and the same pose to 1e-9.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+WORLD = 2
+
+
+class OracleBackend:
+    """mirror of HipBackend's protocol on CPU tensors"""
+
+    def __init__(self, orc, torch, g, l_shard, offset, thr, gn_iters, kernel, kparam, uses_claims=True):
+        self.o, self.torch = orc, torch
+        self.g, self.l, self.offset = g, l_shard, offset
+        self.thr, self.iters, self.kernel, self.kparam = thr, gn_iters, kernel, kparam
+        self.tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
+        self.claims = torch.full((g.shape[0],), np.iinfo(np.int64).max, dtype=torch.int64)
+        self.bbox = torch.zeros(6, dtype=torch.float32)
+        self.sums = torch.zeros(48, dtype=torch.float64)
+        self.uses_claims = uses_claims
+        self.max_inner = gn_iters
+        self.pairs = None
+
+    def phase1(self, pose):
+        o, l = self.o, self.l
+        tx, ty, tz, bmin, bmax = o.transform_local_to_global(l[:, 0], l[:, 1], l[:, 2], pose)
+        self.bbox[:3] = self.torch.from_numpy(bmin)
+        self.bbox[3:] = self.torch.from_numpy(bmax)
+        self.claims.fill_(np.iinfo(np.int64).max)
+        n = l.shape[0]
+        self.nn = np.full(n, -1, np.int64)
+        self.d2 = np.zeros(n, np.float32)
+        maxd = np.float32(self.thr * self.thr)
+        cl = self.claims.numpy()
+        for i in range(n):
+            idx, d2 = self.tree.knn((tx[i], ty[i], tz[i]), 1)
+            if len(idx) and d2[0] < maxd:
+                self.nn[i], self.d2[i] = int(idx[0]), d2[0]
+                cl[idx[0]] = min(cl[idx[0]], self.offset + i)
+
+    def phase2(self):
+        o = self.o
+        gmin, gmax = self.g.min(0), self.g.max(0)
+        b = self.bbox.numpy()
+        eps = np.float32(self.thr + 0.2)
+        ok = all(b[d] - eps <= gmax[d] and b[3 + d] + eps >= gmin[d] for d in range(3))
+        cl = self.claims.numpy()
+        rows = []
+        if ok:
+            for i, gi in enumerate(self.nn):
+                if gi >= 0 and (not self.uses_claims or cl[gi] == self.offset + i):
+                    rows.append((gi, self.offset + i, *self.g[gi], *self.l[i], self.d2[i]))
+        self.pairs = np.array(rows, dtype=o.PAIR_PT2PT) if rows else np.zeros(0, o.PAIR_PT2PT)
+
+    # -- Gauss-Newton, closed-form sums of csrc/gn_solver.hip restated in numpy ----------------
+    def gn_begin(self, pose):
+        self.pose = np.array(pose, dtype=np.float64)
+        self.it = 0
+        self.done = False
+
+    def gn_accumulate(self):
+        s = np.zeros(48)
+        if not self.done and len(self.pairs):
+            p = self.pairs
+            R, t = self.pose[:9].reshape(3, 3), self.pose[9:]
+            l = np.stack([p["lx"], p["ly"], p["lz"]], 1).astype(np.float64)
+            g = np.stack([p["gx"], p["gy"], p["gz"]], 1).astype(np.float64)
+            e = l @ R.T + t - g
+            esq = (e * e).sum(1)
+            w = np.array([self.o.robust_weight(self.kernel, self.kparam, v) for v in esq])
+            ep = e @ R  # R^T e
+            s[0] = w.sum()
+            s[1:4] = (w[:, None] * l).sum(0)
+            ll = np.stack([l[:, 0] * l[:, 0], l[:, 0] * l[:, 1], l[:, 0] * l[:, 2], l[:, 1] * l[:, 1],
+                           l[:, 1] * l[:, 2], l[:, 2] * l[:, 2]], 1)
+            s[4:10] = (w[:, None] * ll).sum(0)
+            s[10:13] = (w[:, None] * ep).sum(0)
+            s[13:16] = (w[:, None] * np.cross(l, ep)).sum(0)
+            s[16] = (w * esq).sum()
+        self.sums.copy_(self.torch.from_numpy(s))
+
+    def gn_step(self):
+        if self.done:
+            return
+        s = self.sums.numpy()
+        sw, sl = s[0], s[1:4]
+        xx, xy, xz, yy, yz, zz = s[4:10]
+        K = np.array([[0, -sl[2], sl[1]], [sl[2], 0, -sl[0]], [-sl[1], sl[0], 0]])
+        H = np.zeros((6, 6))
+        H[:3, :3] = sw * np.eye(3)
+        H[:3, 3:] = -K
+        H[3:, :3] = -K.T
+        S = np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]])
+        H[3:, 3:] = np.trace(S) * np.eye(3) - S
+        gvec = s[10:16]
+        self.it += 1
+        if np.sqrt(s[16]) <= 0.0:
+            self.done = True
+            return
+        delta = -np.linalg.solve(H, gvec)
+        self.pose = self.o.pose_compose(self.pose, self.o.se3_exp(delta))
+        if np.linalg.norm(delta) < 1e-7:
+            self.done = True
+
+    def gn_end(self):
+        return self.pose, self.it
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle as orc
+        from mp2p_icp_amd import synthetic
+        from mp2p_icp_amd.distributed import ShardedRegistration, shard_range
+
+        d = synthetic.random_cloud_pair(600, 3000, 5, outlier_frac=0.05)
+        g, l = d["glob"], d["local"]
+        b, e = shard_range(l.shape[0], rank, world)
+        be = OracleBackend(orc, torch, g, l[b:e], b, 0.8, 3, orc.KERNEL_CAUCHY, 0.3)
+        reg = ShardedRegistration(be, dist)
+        pose = d["T_init"].copy()
+        all_pairs = []
+        for it in range(3):
+            reg.match(pose)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, be.pairs)
+            all_pairs.append(np.concatenate(gathered))
+            pose, _ = reg.solve(pose)
+        # unsharded oracle
+        tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
+        pose_o = d["T_init"].copy()
+        prm = orc.make_gn_params(3, kernel=orc.KERNEL_CAUCHY, kernelParam=0.3)
+        ok = True
+        msg = ""
+        for it in range(3):
+            want, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose_o, 0.8, 0.0, tree=tree)
+            got = all_pairs[it]
+            if not (len(got) == len(want) and np.array_equal(got["localIdx"], want["localIdx"])
+                    and np.array_equal(got["globalIdx"], want["globalIdx"])):
+                ok, msg = False, f"pairs differ at iteration {it}: {len(got)} vs {len(want)}"
+                break
+            pose_o, *_ = orc.optimal_tf_gauss_newton(want, None, None, pose_o, prm)
+        if ok:
+            dt, dr = orc.pose_err_split(pose, pose_o)
+            if not (dt < 1e-9 and dr < 1e-9):
+                ok, msg = False, f"pose differs: {dt} {dr}"
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok, msg))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc() + str(ex)))
+
+
+def test_shard_range_partitions():
+    from mp2p_icp_amd.distributed import shard_range
+    for n in (0, 1, 7, 1000, 1_000_003):
+        for w in (1, 2, 3, 8):
+            edges = [shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+
+
+@pytest.mark.timeout(300)
+def test_sharded_registration_gloo_world2():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(WORLD)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"

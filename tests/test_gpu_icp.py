@@ -1,0 +1,84 @@
+"""End-to-end: the ICP::align-shaped driver over the HIP matcher + solver
+(tests/test-mp2p_icp_algos.cpp:52-233: bunny decimated x10, random pose within +-15 % bbox /
++-10 deg, threshold = 0.40*max_dim, thresholdAngularDeg = 0, 100 iterations, |log SE3 err| < 0.1),
+and iteration-by-iteration agreement with the same loop run on the CPU oracle."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _bunny():
+    pts = np.loadtxt(gzip.open(os.path.join(HERE, "golden", "bunny_decim.xyz.gz"))).astype(np.float32)
+    return pts[::10].copy()  # decimation 10 (test-mp2p_icp_algos.cpp:62-72)
+
+
+@pytest.mark.parametrize("solver_name", ["GaussNewton", "Horn"])
+def test_bunny_icp_converges(oracle, solver_name):
+    import mp2p_icp_amd as amd
+    pts = _bunny()
+    max_dim = float((pts.max(0) - pts.min(0)).max())
+    rng = np.random.default_rng(1234)
+    for rep in range(5):
+        t = rng.uniform(-0.15, 0.15, 3) * max_dim
+        r = np.deg2rad(rng.uniform(-10, 10, 3))
+        gt = amd.se3.from_xyzypr(*t, *r)
+        R, tt = amd.se3.Rt(gt)
+        # global = gt (+) local  => pose of local w.r.t. global is gt
+        glob = (pts.astype(np.float64) @ R.T + tt).astype(np.float32)
+        pcG = amd.metric_map_t({"raw": amd.PointLayer(glob)})
+        pcL = amd.metric_map_t({"raw": amd.PointLayer(pts)})
+        m = amd.Matcher_Points_DistanceThreshold()
+        m.initialize({"threshold": 0.40 * max_dim, "thresholdAngularDeg": 0.0})
+        if solver_name == "GaussNewton":
+            s = amd.Solver_GaussNewton()
+            s.initialize({"maxIterations": 10})
+        else:
+            s = amd.Solver_Horn()
+            s.initialize({})
+        icp = amd.ICP()
+        icp.set_matchers([m])
+        icp.set_solvers([s])
+        res = icp.align(pcL, pcG, amd.se3.identity(), amd.Parameters(maxIterations=100))
+        err = float(np.linalg.norm(amd.se3.log(amd.se3.inverse_compose(res.optimal_tf, gt))))
+        assert err < 0.1, (rep, err, res.nIterations)
+        assert res.terminationReason in (amd.IterTermReason.Stalled, amd.IterTermReason.MaxIterations)
+
+
+def test_icp_iterations_track_the_oracle(oracle):
+    """same outer loop on the oracle: identical pair lists and poses (1e-5) at every iteration"""
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import synthetic
+    d = synthetic.make_pair(8000, 80000, 42, max_t=0.2, max_r_deg=1.0)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g)})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    m = amd.Matcher_Points_DistanceThreshold()
+    m.initialize({"threshold": 1.0, "thresholdAngularDeg": 0.0})
+    s = amd.Solver_GaussNewton()
+    s.initialize({"maxIterations": 3, "robustKernel": "RobustKernel::GemanMcClure", "robustKernelParam": 0.15})
+    pose_h = d["T_init"].copy()
+    pose_o = d["T_init"].copy()
+    prm = oracle.make_gn_params(3, kernel=oracle.KERNEL_GEMANMCCLURE, kernelParam=0.15)
+    for it in range(8):
+        pairs = amd.run_matchers([m], pcG, pcL, pose_h, amd.MatchContext(it))
+        want, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose_o, 1.0, 0.0, tree=tree)
+        got = pairs.paired_pt2pt
+        # poses agree to ~1e-12, far below fp32 resolution of the transformed points: the
+        # correspondence lists stay identical along the whole chain
+        assert np.array_equal(got["localIdx"], want["localIdx"]), it
+        assert np.array_equal(got["globalIdx"], want["globalIdx"]), it
+        sc = amd.SolverContext()
+        sc.guessRelativePose = pose_h
+        sc.icpIteration = it
+        out = amd.OptimalTF_Result()
+        assert s.optimal_pose(pairs, out, sc)
+        pose_h = out.optimalPose
+        pose_o, *_ = oracle.optimal_tf_gauss_newton(want, None, None, pose_o, prm)
+        dt, dr = oracle.pose_err_split(pose_h, pose_o)
+        assert dt < 1e-5 and dr < 1e-5, (it, dt, dr)

@@ -1,0 +1,149 @@
+"""GPU parity of Matcher_Point2Plane (K5) against the CPU oracle's declared nn_search_pt2pl
+semantics, the committed golden vectors and the expectations of the reference's (disabled)
+tests/test-mp2p_matcher_pt2pl.cpp.  Which local points are paired must match exactly; plane
+coefficients / centroids to 1e-9 (fp64 eigen-solver on both sides)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import mp2p_icp_amd
+    return mp2p_icp_amd
+
+
+def _match(amd, g, l, pose, params, ms=None, layer_kw=None):
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g, **(layer_kw or {}))})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    m = amd.Matcher_Point2Plane()
+    m.initialize(params)
+    pairs = amd.Pairings()
+    ms = ms or amd.MatchState(pcG, pcL)
+    assert m.match(pcG, pcL, pose, amd.MatchContext(), ms, pairs)
+    return pairs, ms
+
+
+def _check(pairs, want_pl, want_idx):
+    got, gidx = pairs.paired_pt2pl, pairs.paired_pt2pl_local_idx
+    assert len(got) == len(want_pl), (len(got), len(want_pl))
+    assert np.array_equal(gidx, want_idx)
+    if len(got):
+        assert np.allclose(got["plane"], want_pl["plane"], rtol=0, atol=1e-9)
+        assert np.allclose(got["centroid"], want_pl["centroid"], rtol=0, atol=1e-9)
+        want_l = np.stack([want_pl["lx"], want_pl["ly"], want_pl["lz"]], 1)
+        assert np.array_equal(got["pt_local"], want_l)
+
+
+def test_reference_pt2pl_expectations(amd):
+    """tests/test-mp2p_matcher_pt2pl.cpp:75-131"""
+    from test_oracle_kat import PT2PL_MATCH_PRM, _kat_local, pt2pl_kat_global
+    g, l = pt2pl_kat_global(), _kat_local()
+    P = dict(PT2PL_MATCH_PRM)
+
+    def run(p6):
+        pairs, _ = _match(amd, g, l, amd.se3.from_xyzypr(*p6), P)
+        return pairs
+
+    assert run((0, 0, 0, 0, 0, 0)).empty()
+    assert len(run((0, 5, 0, 0, 0, 0)).paired_pt2pl) == 1
+    p = run((8.04, 0, 0, 0, 0, 0)).paired_pt2pl
+    assert len(p) == 1
+    assert np.allclose(p[0]["pt_local"], (2, 0, 0), atol=1e-3)
+    assert np.allclose(p[0]["centroid"], (10, 0, 0), atol=0.01)
+    assert np.allclose(p[0]["plane"], (1, 0, 0, -10), atol=1e-3)
+    assert len(run((18.053, 0.05, 0.03, 0, 0, 0)).paired_pt2pl) == 0
+
+
+def test_golden_pt2pl(amd):
+    gold = np.load(os.path.join(HERE, "golden", "golden_v1.npz"))
+    dt, sr, knn, mpp, pet = gold["pt2pl_params"]
+    pairs, _ = _match(amd, gold["pt2pl_glob"], gold["pt2pl_local"], amd.se3.identity(),
+                      dict(distanceThreshold=float(dt), searchRadius=float(sr), knn=int(knn),
+                           minimumPlanePoints=int(mpp), planeEigenThreshold=float(pet)))
+    _check(pairs, gold["pt2pl_pairs"], gold["pt2pl_local_idx"])
+    assert pairs.potential_pairings == gold["pt2pl_potential"][0]
+
+
+@pytest.mark.parametrize("knn,minpts,radius,eig", [(5, 5, 0.4, 0.05), (8, 6, 0.6, 0.02),
+                                                   (12, 5, 0.3, 0.1), (16, 10, 0.8, 0.05)])
+def test_random_parity_vs_oracle(amd, oracle, knn, minpts, radius, eig):
+    from mp2p_icp_amd import synthetic
+    d = synthetic.make_pair(6000, 60000, 77 + knn)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    for pose in (d["T_gt"], d["T_init"]):
+        want, widx, pot = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2],
+                                             pose, 0.25, radius, knn, minpts, eig, tree=tree)
+        pairs, _ = _match(amd, g, l, pose, dict(distanceThreshold=0.25, searchRadius=radius, knn=knn,
+                                                minimumPlanePoints=minpts, planeEigenThreshold=eig))
+        _check(pairs, want, widx)
+        assert pairs.potential_pairings == pot
+
+
+def test_local_taken_and_state(amd, oracle):
+    from mp2p_icp_amd import synthetic
+    d = synthetic.make_pair(3000, 40000, 5)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    rng = np.random.default_rng(1)
+    lt0 = (rng.random(l.shape[0]) < 0.4).astype(np.uint8)
+    P = dict(distanceThreshold=0.3, searchRadius=0.5, knn=6, minimumPlanePoints=5, planeEigenThreshold=0.05)
+    for allow in (False, True):
+        lt = lt0.copy()
+        want, widx, _ = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2],
+                                           d["T_gt"], tree=tree, local_taken=lt,
+                                           allowMatchAlreadyMatchedPoints=allow, **P)
+        pcG = amd.metric_map_t({"raw": amd.PointLayer(g)})
+        pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+        ms = amd.MatchState(pcG, pcL)
+        ms.for_layers("raw", "raw").upload(None, lt0)
+        m = amd.Matcher_Point2Plane()
+        m.initialize(dict(P, allowMatchAlreadyMatchedPoints=allow))
+        pairs = amd.Pairings()
+        m.match(pcG, pcL, d["T_gt"], amd.MatchContext(), ms, pairs)
+        _check(pairs, want, widx)
+        _, l_after = ms.for_layers("raw", "raw").download()
+        assert np.array_equal(l_after, lt)
+
+
+def test_pt2pl_then_pt2pt_pipeline_and_gn(amd, oracle):
+    """run_matchers with both matchers (tests/test-mp2p_matcher_pt2pl.cpp:136-167) and a GN solve
+    over the mixed pairings."""
+    from mp2p_icp_amd import synthetic
+    d = synthetic.make_pair(5000, 50000, 9)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    P = dict(distanceThreshold=0.3, searchRadius=0.6, knn=6, minimumPlanePoints=5, planeEigenThreshold=0.05)
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g)})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    for allow in (True, False):
+        mpl = amd.Matcher_Point2Plane()
+        mpl.initialize(P)
+        mpt = amd.Matcher_Points_DistanceThreshold()
+        mpt.initialize({"threshold": 0.3, "thresholdAngularDeg": 0.0, "allowMatchAlreadyMatchedPoints": allow})
+        pairs = amd.run_matchers([mpl, mpt], pcG, pcL, d["T_init"])
+        lt = np.zeros(l.shape[0], np.uint8)
+        gt = np.zeros(g.shape[0], np.uint8)
+        wpl, widx, _ = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2],
+                                          d["T_init"], tree=tree, local_taken=lt, **P)
+        wpt, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], d["T_init"],
+                                    0.3, 0.0, tree=tree, allowMatchAlreadyMatchedPoints=allow,
+                                    local_taken=lt, global_taken=gt)
+        _check(pairs, wpl, widx)
+        got = pairs.paired_pt2pt
+        assert np.array_equal(got["localIdx"], wpt["localIdx"]) and np.array_equal(got["globalIdx"], wpt["globalIdx"])
+        s = amd.Solver_GaussNewton()
+        s.initialize({"maxIterations": 4, "robustKernel": "RobustKernel::Cauchy", "robustKernelParam": 0.2})
+        sc = amd.SolverContext()
+        sc.guessRelativePose = d["T_init"]
+        out = amd.OptimalTF_Result()
+        assert s.optimal_pose(pairs, out, sc)
+        To, *_ = oracle.optimal_tf_gauss_newton(wpt, wpl, None, d["T_init"],
+                                                oracle.make_gn_params(4, kernel=oracle.KERNEL_CAUCHY, kernelParam=0.2))
+        dt, dr = oracle.pose_err_split(out.optimalPose, To)
+        assert dt < 1e-5 and dr < 1e-5

@@ -134,6 +134,9 @@ int  mp2p_hip_pairs_create(mp2p_hip_ctx* ctx, size_t cap_pt2pt, size_t cap_pt2pl
                            mp2p_hip_pairs** out);
 void mp2p_hip_pairs_free(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p);
 int  mp2p_hip_pairs_clear(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p); /* out = Pairings() */
+/* grow the capacities, keeping the content (std::vector::reserve) */
+int  mp2p_hip_pairs_reserve(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p, size_t cap_pt2pt,
+                            size_t cap_pt2pl);
 /* counts (synchronises the stream; 24 B read back) */
 int  mp2p_hip_pairs_counts(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, uint64_t* n_pt2pt,
                            uint64_t* n_pt2pl, uint64_t* potential_pairings);

@@ -183,6 +183,12 @@ class DevicePairs:
     def clear(self):
         check(self.ctx._L.mp2p_hip_pairs_clear(self.ctx.handle, self._h), self.ctx.handle)
 
+    def reserve(self, cap_pt2pt, cap_pt2pl):
+        check(self.ctx._L.mp2p_hip_pairs_reserve(self.ctx.handle, self._h, int(cap_pt2pt),
+                                                 int(cap_pt2pl)), self.ctx.handle)
+        self.cap_pt2pt = max(self.cap_pt2pt, int(cap_pt2pt))
+        self.cap_pt2pl = max(self.cap_pt2pl, int(cap_pt2pl))
+
     def counts(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(self.ctx._L.mp2p_hip_pairs_counts(self.ctx.handle, self._h, C.byref(a), C.byref(b),

@@ -29,6 +29,7 @@ struct PlArgs
     float         radSq, rad, distThr, r0;
     double        eigThr;
     uint32_t      minPts;
+    uint32_t      knn;  // <= K (template capacity of the register k-list)
     const unsigned char* local_taken;
     unsigned char*       out_flag;  // [n_l] by original local index
     double*              out_rec;   // [n_l][7] plane(4) + centroid(3)
@@ -89,6 +90,17 @@ __device__ void jacobi3(const double* Ain, double* eval, double* evec0)
             }
     for (int k = 0; k < 3; k++) eval[k] = A[order[k] * n + order[k]];
     for (int i = 0; i < 3; i++) evec0[i] = Q[i * n + order[0]];
+}
+
+// distance of the knn-th neighbour held so far (static indexing only: no scratch)
+template <int K>
+__device__ __forceinline__ float kth_d2(const float (&kd2)[K], uint32_t knn)
+{
+    float v = INFINITY;
+#pragma unroll
+    for (int q = 0; q < K; q++)
+        if (q == (int)knn - 1) v = kd2[q];
+    return v;
 }
 
 template <int K>
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
                 {
                     const float4 c  = s_cand[j];
                     const float  d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
-                    if (!done && d2 <= kd2[K - 1] && d2 <= a.radSq)
+                    if (!done && d2 <= kth_d2(kd2, a.knn) && d2 <= a.radSq)
                     {
                         float    cd = d2;
                         uint32_t ci = __float_as_uint(c.w), cs = s_spos[j];
@@ -238,6 +250,9 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
                                 cd = td, ci = ti, cs = ts;
                             }
                         }
+#pragma unroll
+                        for (int q = 0; q < K; q++)  // only the knn nearest are kept
+                            if (q >= (int)a.knn) kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
                     }
                 }
                 __syncthreads();
@@ -245,13 +260,14 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
         }
         if (!done)
         {
-            const float gr = r * (1.0f - 1.0f / 1024.0f) - g.slack;
-            if (r >= rmax || (gr > 0.f && kd2[K - 1] < gr * gr))
+            const float gr  = r * (1.0f - 1.0f / 1024.0f) - g.slack;
+            const float kth = kth_d2(kd2, a.knn);  // INFINITY while fewer than knn are known
+            if (r >= rmax || (gr > 0.f && kth < gr * gr))
                 done = true;
             else
             {
-                const float rn = (kidx[K - 1] != NONE_U32)
-                                     ? sqrtf(kd2[K - 1]) * (1.0f + 1.0f / 512.0f) + 4.f * g.slack
+                const float rn = (kth < INFINITY)
+                                     ? sqrtf(kth) * (1.0f + 1.0f / 512.0f) + 4.f * g.slack
                                      : 2.0f * r;
                 r = fminf(fmaxf(rn, r * 1.0009765625f), rmax);
             }
@@ -451,6 +467,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     a.r0     = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 2.0f);
     a.eigThr = prm->planeEigenThreshold;
     a.minPts = prm->minimumPlanePoints;
+    a.knn    = prm->knn;
     a.local_taken = (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
     a.out_flag = flag, a.out_rec = rec, a.tile_bbox = ctx->tile_bbox.p;
 

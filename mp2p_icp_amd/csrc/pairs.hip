@@ -281,6 +281,18 @@ __global__ __launch_bounds__(256) void unpack_pt2pl_kernel(const mp2p_hip_pair_p
     lidx[i] = i;
 }
 
+template <class T>
+static int grow_buf(mp2p_hip_ctx* ctx, DevBuf<T>& b, size_t new_count, size_t keep)
+{
+    DevBuf<T> nb;
+    MP2P_TRY_HIP(ctx, nb.alloc(new_count));
+    if (keep) MP2P_TRY_HIP(ctx, hipMemcpyAsync(nb.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    b.release();
+    b = nb;
+    return MP2P_HIP_OK;
+}
+
 }  // namespace mp2p
 
 using namespace mp2p;
@@ -327,6 +339,46 @@ void mp2p_hip_pairs_free(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p)
     p->pl_lx.release(), p->pl_ly.release(), p->pl_lz.release();
     p->counts.release();
     delete p;
+}
+
+int mp2p_hip_pairs_reserve(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p, size_t cap_pt2pt, size_t cap_pt2pl)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    if (cap_pt2pt <= p->cap_pt2pt && cap_pt2pl <= p->cap_pt2pl) return MP2P_HIP_OK;
+    uint64_t n1 = 0, n2 = 0;
+    int      rc = mp2p_hip_pairs_counts(ctx, p, &n1, &n2, nullptr);
+    if (rc) return rc;
+#define MP2P_GROW(buf, cnt, keep)                         \
+    do                                                    \
+    {                                                     \
+        rc = grow_buf(ctx, p->buf, (cnt), (keep));        \
+        if (rc) return rc;                                \
+    } while (0)
+    if (cap_pt2pt > p->cap_pt2pt)
+    {
+        MP2P_GROW(lidx, cap_pt2pt, n1);
+        MP2P_GROW(gidx, cap_pt2pt, n1);
+        MP2P_GROW(lx, cap_pt2pt, n1);
+        MP2P_GROW(ly, cap_pt2pt, n1);
+        MP2P_GROW(lz, cap_pt2pt, n1);
+        MP2P_GROW(gx, cap_pt2pt, n1);
+        MP2P_GROW(gy, cap_pt2pt, n1);
+        MP2P_GROW(gz, cap_pt2pt, n1);
+        MP2P_GROW(err, cap_pt2pt, n1);
+        p->cap_pt2pt = cap_pt2pt;
+    }
+    if (cap_pt2pl > p->cap_pt2pl)
+    {
+        MP2P_GROW(pl_lidx, cap_pt2pl, n2);
+        MP2P_GROW(pl_coef, cap_pt2pl * 4, n2 * 4);
+        MP2P_GROW(pl_cen, cap_pt2pl * 3, n2 * 3);
+        MP2P_GROW(pl_lx, cap_pt2pl, n2);
+        MP2P_GROW(pl_ly, cap_pt2pl, n2);
+        MP2P_GROW(pl_lz, cap_pt2pl, n2);
+        p->cap_pt2pl = cap_pt2pl;
+    }
+#undef MP2P_GROW
+    return MP2P_HIP_OK;
 }
 
 int mp2p_hip_pairs_clear(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p)

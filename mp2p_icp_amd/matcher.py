@@ -35,22 +35,12 @@ class Pairings:
 
     # -- device side -----------------------------------------------------------------------
     def _ensure_dev(self, ctx, cap_pt2pt, cap_pt2pl):
-        if (self._dev is None or self._dev.cap_pt2pt < cap_pt2pt or self._dev.cap_pt2pl < cap_pt2pl
-                or self.ctx is not ctx):
-            old = self._dev
-            n1 = n2 = pot = 0
-            a = b = None
-            if old is not None:
-                n1, n2, pot = old.counts()
-                if n1:
-                    a = old.download_pt2pt()
-                if n2:
-                    b, _ = old.download_pt2pl()
+        if self._dev is None or self.ctx is not ctx:
             self.ctx = ctx
             self._dev = core.DevicePairs(ctx, max(cap_pt2pt, self._cap[0], 1),
                                          max(cap_pt2pl, self._cap[1], 0))
-            if n1 or n2:
-                self._dev.upload(a, b)
+        elif self._dev.cap_pt2pt < cap_pt2pt or self._dev.cap_pt2pl < cap_pt2pl:
+            self._dev.reserve(max(cap_pt2pt, self._dev.cap_pt2pt), max(cap_pt2pl, self._dev.cap_pt2pl))
         self._invalidate()
         return self._dev
 

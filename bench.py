@@ -294,6 +294,20 @@ def main():
             "traffic": None,
         },
     }
+    # HBM traffic of the search kernels from the committed rocprofv3 PMC passes of this same
+    # command (FETCH_SIZE x2 correction for gfx950 + WRITE_SIZE, MI355X_MICROARCH.md "HBM")
+    try:
+        import csv
+        t = 0.0
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc.csv"))):
+            if r["kernel"].strip('"') in ("void mp2p::nn_tile_kernel<32, false>",
+                                          "void mp2p::nn_single_kernel<false>"):
+                t += float(r["fetch_bytes_avg_corrected_x2"]) + float(r["write_bytes_avg"])
+        if t > 0 and args.n_local == 1_000_000 and args.n_global == 10_000_000 and world == 1:
+            out["roofline"]["traffic"] = t
+            out["roofline"]["traffic_source"] = "profiles/r01_bench_hbm_pmc.csv (rocprofv3 --pmc)"
+    except Exception:
+        pass
     if not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
         t0 = time.time()

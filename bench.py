@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--q", type=int, default=0, help="queries per wave (tuning)")
     ap.add_argument("--r0", type=float, default=0.0, help="initial radius in cells (tuning)")
     ap.add_argument("--grp", type=float, default=0.0, help="group radius factor (tuning)")
+    ap.add_argument("--cold", action="store_true", help="disable the warm start from the previous iteration")
     ap.add_argument("--defer", type=float, default=0.0, help="defer radius in cells (tuning)")
     ap.add_argument("--budget", type=int, default=0, help="voxel budget per search box (tuning)")
     ap.add_argument("--cell", type=float, default=0.0, help="voxel edge [m] (0 = automatic)")
@@ -153,7 +154,7 @@ def main():
         f"{info['build_ms']:.1f} ms (upload+build {t_index * 1e3:.0f} ms); cloud {t_cloud * 1e3:.0f} ms")
 
     n_l = l.shape[0]
-    prm = _lib.Pt2PtParams(args.threshold, 0.0, 1, 0, 0, 0.20, rank * n_l, args.r0, args.q, args.grp, args.budget, args.defer)
+    prm = _lib.Pt2PtParams(args.threshold, 0.0, 1, 0, 0, 0.20, rank * n_l, args.r0, args.q, args.grp, args.budget, args.defer, int(args.cold))
     gnp = _lib.GNParams()
     gnp.maxInnerLoopIterations = args.gn_iters
     gnp.minDelta, gnp.maxCost = 1e-7, 0.0
@@ -194,6 +195,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(0)
+    log(f"[bench r{rank}] per-step kernel ms (chain position = (warmup + i) % {CYCLE}): tile="
+        f"{[round(v, 3) for v in nn_tile_ms]} single={[round(v, 3) for v in nn_single_ms]} "
+        f"gn={[round(v, 3) for v in gn_ms]}")
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

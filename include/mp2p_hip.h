@@ -176,6 +176,9 @@ typedef struct
                                      used; 0 = 512 */
     float    defer_radius_cells;  /* a query whose search radius exceeds this many cells leaves
                                      its tile for the one-query-per-wave kernel; 0 = 3 */
+    int32_t  disable_warm_start;  /* by default a call on the same (map, cloud) as the previous
+                                     call of this context seeds every query with its previous
+                                     nearest neighbour (exactness is unaffected) */
 } mp2p_hip_pt2pt_params;
 
 /* ms may be NULL (fresh MatchState with nothing marked, marks discarded). */
@@ -287,6 +290,8 @@ typedef struct
     uint64_t nn_single_queries, nn_single_passes, nn_single_cells, nn_single_candidates;
     uint64_t nn_single_max_candidates;
     uint64_t nn_tile_ticks_hist[24]; /* log2 bins */
+    uint64_t nn_single_ticks_sum, nn_single_ticks_max; /* 100 MHz ticks per deferred query */
+    uint64_t nn_single_max_passes, nn_single_max_cells;
 } mp2p_hip_stats;
 /* 0 = off; 1 = bracket the kernels with hipEvents (ms_* fields; each call then ends with a
  * stream synchronisation); 2 = additionally collect the device counters (nn_* fields, slower). */

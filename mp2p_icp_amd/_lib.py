@@ -42,7 +42,8 @@ class Pt2PtParams(C.Structure):
                 ("bounding_box_intersection_check_epsilon", C.c_double),
                 ("local_index_offset", C.c_uint64), ("initial_radius_cells", C.c_float),
                 ("queries_per_wave", C.c_uint32), ("group_radius_factor", C.c_float),
-                ("cell_budget", C.c_uint32), ("defer_radius_cells", C.c_float)]
+                ("cell_budget", C.c_uint32), ("defer_radius_cells", C.c_float),
+                ("disable_warm_start", C.c_int32)]
 
 
 class Pt2PlParams(C.Structure):
@@ -80,7 +81,9 @@ class Stats(C.Structure):
                 ("nn_coop_passes", C.c_uint64), ("nn_single_queries", C.c_uint64),
                 ("nn_single_passes", C.c_uint64), ("nn_single_cells", C.c_uint64),
                 ("nn_single_candidates", C.c_uint64), ("nn_single_max_candidates", C.c_uint64),
-                ("nn_tile_ticks_hist", C.c_uint64 * 24)]
+                ("nn_tile_ticks_hist", C.c_uint64 * 24),
+                ("nn_single_ticks_sum", C.c_uint64), ("nn_single_ticks_max", C.c_uint64),
+                ("nn_single_max_passes", C.c_uint64), ("nn_single_max_cells", C.c_uint64)]
 
 
 _P = C.c_void_p

@@ -129,7 +129,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release();
     ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release();
     ctx->aos_stage.release(), ctx->pl_slots.release();
-    ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release();
+    ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release(), ctx->hint.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -179,6 +179,7 @@ int mp2p_hip_map_upload_device(mp2p_hip_ctx* ctx, const float* d_x, const float*
 void mp2p_hip_map_free(mp2p_hip_ctx* ctx, mp2p_hip_map* map)
 {
     if (!map) return;
+    if (ctx && ctx->hint_map == map) ctx->hint_map = nullptr;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     map->pts.release(), map->table.release(), map->claims.release();
     delete map;
@@ -227,6 +228,7 @@ int mp2p_hip_cloud_upload_device(mp2p_hip_ctx* ctx, const float* d_x, const floa
 void mp2p_hip_cloud_free(mp2p_hip_ctx* ctx, mp2p_hip_cloud* c)
 {
     if (!c) return;
+    if (ctx && ctx->hint_cloud == c) ctx->hint_cloud = nullptr;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     c->sorted.release(), c->x.release(), c->y.release(), c->z.release();
     delete c;
@@ -456,6 +458,8 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
             ctx->stats.nn_single_queries = c[10], ctx->stats.nn_single_passes = c[11];
             ctx->stats.nn_single_cells = c[12], ctx->stats.nn_single_candidates = c[13];
             ctx->stats.nn_single_max_candidates = c[14];
+            ctx->stats.nn_single_ticks_sum = c[40], ctx->stats.nn_single_ticks_max = c[15];
+            ctx->stats.nn_single_max_passes = c[41], ctx->stats.nn_single_max_cells = c[42];
             for (int i = 0; i < 24; i++) ctx->stats.nn_tile_ticks_hist[i] = c[16 + i];
             ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1];
             ctx->stats.nn_cells_visited = c[2], ctx->stats.nn_candidates_tested = c[3];

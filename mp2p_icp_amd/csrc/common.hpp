@@ -108,6 +108,11 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
     mp2p::DevBuf<uint4>              work;         // deferred queries of the NN search
     mp2p::DevBuf<uint32_t>           work_spos;    //   (+ counter in the last word)
+    mp2p::DevBuf<uint2>              hint;         // warm start: previous NN + distance bound per local point
+    double                           hint_pose[12] = {};
+    const void*                      hint_map   = nullptr;
+    const void*                      hint_cloud = nullptr;
+    size_t                           hint_n     = 0;
     mp2p::GnState                    gn;
     uint32_t last_n_tiles = 0;
     uint32_t last_q       = 64;

@@ -262,7 +262,7 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
     for (int d = 0; d < 3; d++) maxabs = std::max(maxabs, std::max(std::fabs(mn[d]), std::fabs(mx[d])));
 
     const bool  user_cell = prm && prm->cell_size > 0;
-    const float target    = (prm && prm->target_per_cell > 0) ? prm->target_per_cell : 6.0f;
+    const float target    = (prm && prm->target_per_cell > 0) ? std::max(prm->target_per_cell, 1.25f) : 6.0f;
     // fine voxel: the user's cell, or the finest 20-bit subdivision of the bounding cube
     float hf = user_cell ? prm->cell_size : std::max(ext * (1.0f / 1048000.0f), 1e-6f);
     if (user_cell && ext / hf > 1048000.0f) hf = ext / 1048000.0f;  // keep 20-bit coordinates

@@ -56,6 +56,12 @@ struct NNArgs
     uint4*               work;       // deferred queries {sorted idx, r, best_d2, best_idx}
     uint32_t*            work_spos;  //   + best_spos
     uint32_t*            work_count;
+    // warm start, [n_l] by original local index: {sorted position of the nearest neighbour found by
+    // the previous call on the same (map, cloud) pair or NONE, lower bound on the SQUARED distance
+    // to every map point at that call's pose}; read at entry, rewritten at exit
+    uint2*               hint;
+    int                  use_hint;
+    PoseRt               prev_pose;
     unsigned long long*  counters;  // profiling, or null
     unsigned char*       touched;   // profiling: [n_g] by sorted position, or null
 };
@@ -159,7 +165,9 @@ __device__ __forceinline__ uint32_t locate_candidate(const uint32_t* s_cstart,
 __device__ __forceinline__ float next_radius(float r, float rmax, float best_d2, bool have,
                                              float slack)
 {
-    const float rn = have ? sqrtf(best_d2) * (1.0f + 1.0f / 512.0f) + 4.f * slack : 2.0f * r;
+    // the radius certain to conclude (the best candidate so far), but never more than doubling: a
+    // far candidate (a stale warm start) must not blow the box up
+    const float rn = have ? fminf(sqrtf(best_d2) * (1.0f + 1.0f / 512.0f) + 4.f * slack, 2.0f * r) : 2.0f * r;
     return fminf(fmaxf(rn, r * 1.0009765625f), rmax);
 }
 // the visited voxels cover the whole cube of half-edge r around the query
@@ -170,12 +178,18 @@ __device__ __forceinline__ bool is_final(float r, float rmax, float best_d2, flo
 }
 
 __device__ __forceinline__ void emit_result(const NNArgs& a, uint32_t orig, bool active, float thr,
-                                            float best_d2, uint32_t best_idx, uint32_t best_spos)
+                                            float best_d2, uint32_t best_idx, uint32_t best_spos,
+                                            float lb2_keep = 0.f)
 {
     bool acc = active && best_idx != NONE_U32 && best_d2 < thr;  // :259
     if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;  // :98-101
     a.out_spos[orig] = acc ? best_spos : NONE_U32;
     a.out_d2[orig]   = best_d2;
+    // next call's warm start: the raw nearest neighbour (even if rejected) and what this search
+    // proved: no map point is nearer than min(best, threshold) (every point that could pass the
+    // threshold was examined), or than the bound that let the search be skipped
+    const float lb2 = active ? fmaxf(fminf(best_d2, thr), lb2_keep) : 0.f;
+    a.hint[orig]    = make_uint2(best_spos, __float_as_uint(lb2));
     if (acc && a.claims) atomicMin(&a.claims[best_spos], a.claim_hi | (a.local_offset + orig));
 }
 
@@ -257,6 +271,54 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
     bool     deferred = false;
     float    best_d2  = INFINITY;
     uint32_t best_idx = NONE_U32, best_spos = NONE_U32;
+
+    // ---- warm start from the previous call on the same map and cloud (the previous ICP
+    //      iteration).  Two facts survive a pose change: (1) the previous nearest neighbour is
+    //      still a map point, so its distance now is an upper bound; (2) every map point was at
+    //      least lb away then and this query moved by disp, so every map point is at least
+    //      lb - disp away now.  (2) proves radii below that bound useless and lets a query with
+    //      nothing within the threshold finish without a search; (1) gives the radius that is
+    //      certain to conclude.  The ball that decides the result is still searched completely,
+    //      so the result is the cold result. ---------------------------------------------------
+    float lb2_keep = 0.f;
+    if (a.use_hint && active)
+    {
+        const uint2 h = a.hint[orig];
+        float       ox, oy, oz;
+        compose_point_f(a.prev_pose, lp.x, lp.y, lp.z, ox, oy, oz);
+        const float disp = sqrtf(dist2(qx, qy, qz, ox, oy, oz));
+        float       lb   = sqrtf(__uint_as_float(h.y)) * 0.99999f - disp * 1.00001f - 4.f * g.slack;
+        if (!(lb > 0.f)) lb = 0.f;  // also catches NaN
+        float hr = 0.f;
+        if (h.x < g.n)
+        {
+            const float4 hp = g.pts[h.x];
+            const float  hd = dist2(qx, qy, qz, hp.x, hp.y, hp.z);
+            if (hd < INFINITY)
+            {
+                best_d2 = hd, best_idx = __float_as_uint(hp.w), best_spos = h.x;
+                hr = sqrtf(hd) * (1.0f + 1.0f / 512.0f) + 4.f * g.slack;
+            }
+        }
+        if (lb * 0.999f > sqrtf(thr))
+        {  // fl(d2) >= thr for every map point: nothing to pair, nothing to search
+            done     = true;
+            lb2_keep = (lb * 0.9999f) * (lb * 0.9999f);
+        }
+        else if (lb > r * (1.0f - 1.0f / 1024.0f) - g.slack)
+            r = fminf(fmaxf(hr > 0.f ? fminf(hr, 2.0f * lb) : 2.0f * lb, r), rmax);
+    }
+    // a query whose radius already exceeds what a tile should carry goes straight to the
+    // one-query-per-wave kernel
+    {
+        const bool               wide  = !done && r > a.r_defer;
+        const unsigned long long wmask = __ballot(wide);
+        if (wmask)
+        {
+            defer_lanes<Q>(a, wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
+            if (wide) done = true, deferred = true;
+        }
+    }
 
     uint32_t        st_pass = 0, st_cells = 0, st_cand = 0, st_defer = 0;
     const long long t_start = INSTR ? (long long)wall_clock64() : 0;
@@ -447,7 +509,7 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
 
     // ---- output (original local order) + claim of the global point --------------------------
     if (valid && slice == 0 && !deferred)
-        emit_result(a, orig, active, thr, best_d2, best_idx, best_spos);
+        emit_result(a, orig, active, thr, best_d2, best_idx, best_spos, lb2_keep);
 
     if (INSTR && lane == 0)
     {
@@ -495,6 +557,7 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
         float    best_d2  = __uint_as_float(w.z);
         uint32_t best_idx = w.w, best_spos = a.work_spos[item];
         uint32_t st_pass = 0, st_cand = 0, st_cells = 0;
+        const long long t_start = INSTR ? (long long)wall_clock64() : 0;
 
         for (;;)
         {
@@ -593,6 +656,11 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
             atomicAdd(&a.counters[12], (unsigned long long)st_cells);
             atomicAdd(&a.counters[13], (unsigned long long)st_cand);
             atomicMax(&a.counters[14], (unsigned long long)st_cand);
+            const unsigned long long dt = (unsigned long long)((long long)wall_clock64() - t_start);
+            atomicAdd(&a.counters[40], dt);
+            atomicMax(&a.counters[15], dt);
+            atomicMax(&a.counters[41], (unsigned long long)st_pass);
+            atomicMax(&a.counters[42], (unsigned long long)st_cells);
         }
     }
 }
@@ -684,6 +752,13 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.work         = ctx->work.p;
     a.work_spos    = ctx->work_spos.p;
     a.work_count   = ctx->work_spos.p + n_l;
+    MP2P_TRY_HIP(ctx, ctx->hint.ensure(n_l));
+    a.hint     = ctx->hint.p;
+    for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->hint_pose[i];
+    for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->hint_pose[9 + i];
+    a.use_hint = (ctx->hint_map == map && ctx->hint_cloud == cloud && ctx->hint_n == n_l && !prm->disable_warm_start) ? 1 : 0;
+    ctx->hint_map = map, ctx->hint_cloud = cloud, ctx->hint_n = n_l;
+    for (int i = 0; i < 12; i++) ctx->hint_pose[i] = pose[i];
     a.counters     = nullptr;
     a.touched      = nullptr;
     if (ctx->profiling >= 2)

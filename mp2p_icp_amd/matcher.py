@@ -189,6 +189,7 @@ class Matcher_Points_Base(Matcher):
         self.group_radius_factor = 0.0
         self.cell_budget = 0
         self.defer_radius_cells = 0.0
+        self.disable_warm_start = False
 
     def initialize(self, params):
         super().initialize(params)
@@ -219,6 +220,7 @@ class Matcher_Points_Base(Matcher):
         self.group_radius_factor = float(params.get("hip_group_radius_factor", 0.0))
         self.cell_budget = int(params.get("hip_cell_budget", 0))
         self.defer_radius_cells = float(params.get("hip_defer_radius_cells", 0.0))
+        self.disable_warm_start = bool(params.get("hip_disable_warm_start", False))
         if self.maxLocalPointsPerLayer_:
             raise NotImplementedError(
                 "maxLocalPointsPerLayer (random sub-sampling, Matcher_Points_Base.cpp:207-245) "
@@ -296,7 +298,7 @@ class Matcher_Points_DistanceThreshold(Matcher_Points_Base):
             float(self.bounding_box_intersection_check_epsilon_), int(local_index_offset),
             float(self.initial_radius_cells), int(self.queries_per_wave),
             float(self.group_radius_factor), int(self.cell_budget),
-            float(self.defer_radius_cells))
+            float(self.defer_radius_cells), int(self.disable_warm_start))
 
     def implMatchOneLayer(self, ctx, gLayer, lLayer, localPose, ms, glName, lcName, out):
         self.checkAllParametersAreRealized()

@@ -203,3 +203,33 @@ def test_kitti_shape_c2_parity(amd, oracle):
                                      2.0, 0.0, tree=tree, threads=8)
         pairs, _ = _hip_match(amd, pcG, pcL, pose, {"threshold": 2.0, "thresholdAngularDeg": 0.0})
         _assert_same_pairs(pairs.paired_pt2pt, want)
+
+
+def test_warm_start_pose_sequence(amd, oracle):
+    """Repeated calls on the same (map, cloud) seed every query with its previous nearest
+    neighbour.  The lists must stay bit-exact for any pose sequence (small steps, big jumps,
+    back again) and identical to a cold call."""
+    from mp2p_icp_amd import synthetic
+    d = synthetic.make_pair(20_000, 100_000, 77)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG, pcL = _maps(amd, g, l)
+    rng = np.random.default_rng(5)
+    poses = [d["T_init"], d["T_gt"]]
+    for _ in range(4):
+        xi = np.concatenate([rng.normal(0, 0.4, 3), rng.normal(0, 0.05, 3)])
+        poses.append(amd.se3.compose(d["T_gt"], amd.se3.exp(xi)))
+    poses += [amd.se3.compose(d["T_gt"], amd.se3.from_xyzypr(30.0, -20.0, 1.0, 1.0, 0, 0)),  # far away
+              d["T_gt"], d["T_init"]]
+    ms_w = amd.Matcher_Points_DistanceThreshold()
+    ms_w.initialize({"threshold": 1.5, "thresholdAngularDeg": 0.05})
+    ms_c = amd.Matcher_Points_DistanceThreshold()
+    ms_c.initialize({"threshold": 1.5, "thresholdAngularDeg": 0.05, "hip_disable_warm_start": True})
+    for pose in poses:
+        want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose,
+                                       1.5, 0.05, tree=tree, threads=8)
+        for m in (ms_w, ms_c):
+            pairs = amd.Pairings()
+            m.match(pcG, pcL, pose, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+            _assert_same_pairs(pairs.paired_pt2pt, want)
+            assert pairs.potential_pairings == pot

@@ -18,7 +18,7 @@ def test_split_equals_fused_and_buffers_are_torch_visible(oracle):
     ctx = amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])
     cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
-    prm = _lib.Pt2PtParams(0.7, 0.0, 1, 0, 0, 0.20, 0, 0.0, 0, 0.0, 0, 0.0)
+    prm = _lib.Pt2PtParams(0.7, 0.0, 1, 0, 0, 0.20, 0, 0.0, 0, 0.0, 0, 0.0, 0)
     gnp = _lib.GNParams()
     gnp.maxInnerLoopIterations = 4
     gnp.minDelta, gnp.maxCost = 1e-7, 0.0

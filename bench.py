@@ -137,8 +137,11 @@ def main():
     log(f"[bench r{rank}] inputs ready in {time.time() - t0:.1f}s: local {d['local'].shape}, "
         f"global {d['glob'].shape}")
 
-    # one HIP stream shared with torch so that RCCL collectives are ordered with our kernels
-    stream = torch.cuda.current_stream().cuda_stream
+    # one HIP stream shared with torch so that RCCL collectives are ordered with our kernels: a
+    # dedicated torch stream made current (torch's default stream is the null stream, raw value 0)
+    tstream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
     ctx = amd.Context(local_rank, stream=stream)
     g, l = d["glob"], d["local"]
     t0 = time.time()

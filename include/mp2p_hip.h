@@ -50,7 +50,8 @@ typedef struct mp2p_hip_mstate mp2p_hip_mstate; /* device-resident MatchState bi
 /* ---- context ------------------------------------------------------------------------ */
 int  mp2p_hip_abi_version(void);
 int  mp2p_hip_device_count(void);
-/* stream: a hipStream_t to enqueue on (e.g. torch's current stream) or NULL to create one. */
+/* stream: a hipStream_t to enqueue on (e.g. the host framework's current stream) or NULL to
+ * create a private non-blocking one.  To share the null stream pass hipStreamLegacy, not 0. */
 int  mp2p_hip_ctx_create(int device_id, void* hip_stream, mp2p_hip_ctx** out);
 void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx);
 const char* mp2p_hip_last_error(const mp2p_hip_ctx* ctx); /* ctx may be NULL (global text) */
@@ -186,20 +187,38 @@ int mp2p_hip_match_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
                          const double pose[12], const mp2p_hip_pt2pt_params* prm,
                          mp2p_hip_mstate* ms, mp2p_hip_pairs* out);
 
-/* split form for a local layer sharded over several GPUs: phase1 = search + claims,
- * then the caller min-all-reduces the claim words (int64 MIN, RCCL), then phase2 =
- * winner check + ordered compaction.  mp2p_hip_match_pt2pt == phase1 ; phase2. */
+/* Split form for a local layer sharded over several GPUs (the map replicated, every rank passing
+ * its shard's whole-layer offset in local_index_offset).  mp2p_hip_match_pt2pt == phase1 ; phase2.
+ * Between the phases the ranks agree on two things the sequential loop of
+ * Matcher_Points_DistanceThreshold.cpp:73-75, 94-121 sees globally: the bounding box of ALL
+ * transformed local points and, per global point, the lowest whole-layer local index claiming it:
+ *
+ *   phase1                      search + this rank's claims
+ *   exchange_pack               -> exch = double[8] {-min xyz, max xyz, #records, 0} and the list of
+ *                                  this rank's surviving claim records (uint64: sorted global
+ *                                  position << 32 | whole-layer local index; padded with ~0)
+ *   all-reduce MAX of exch      (RCCL; 64 bytes)
+ *   all-gather of list[0 .. max #records)   (skipped when global re-use is allowed)
+ *   exchange_unpack(gathered)   box from exch, foreign claims applied
+ *   phase2                      winner check + ordered compaction                              */
 int mp2p_hip_match_pt2pt_phase1(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
                                 const mp2p_hip_cloud* cloud, const double pose[12],
                                 const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms);
 int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
                                 const mp2p_hip_cloud* cloud, const mp2p_hip_pt2pt_params* prm,
                                 mp2p_hip_mstate* ms, mp2p_hip_pairs* out);
-/* device pointer / element count of the claim words (int64, one per global point) */
+/* exch_dev: device double[8]; list_dev: device uint64[cloud size] (valid until the next call on
+ * this context).  Either out-pointer may be NULL. */
+int mp2p_hip_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                           const mp2p_hip_pt2pt_params* prm, void** exch_dev, void** list_dev);
+/* gathered_dev: n_records uint64 records of all ranks (device; NULL/0 = none) */
+int mp2p_hip_exchange_unpack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const void* gathered_dev,
+                             size_t n_records);
+/* device pointer / element count of the claim words (int64, one per global point): the dense
+ * alternative to the record exchange (all-reduce MIN) */
 void*  mp2p_hip_map_claims_ptr(const mp2p_hip_map* map);
 size_t mp2p_hip_map_claims_count(const mp2p_hip_map* map);
-/* transformed-local bounding box of the last phase1 on this ctx (6 floats min,max; device)
- * -- to be min/max all-reduced across ranks before phase2 */
+/* transformed-local bounding box of the last phase1 on this ctx (6 floats min,max; device) */
 void* mp2p_hip_ctx_local_bbox_ptr(mp2p_hip_ctx* ctx);
 
 /* ---- Matcher_Point2Plane::implMatchOneLayer (Matcher_Point2Plane.cpp:41-114) with the

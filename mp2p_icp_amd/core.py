@@ -25,13 +25,20 @@ def _pose(T):
 
 
 class Context:
-    """One HIP stream on one device.  `stream` may be a raw hipStream_t (int), e.g.
-    torch.cuda.current_stream().cuda_stream, to share ordering with torch.distributed."""
+    """One HIP stream on one device.  stream=None: the context creates its own (non-blocking)
+    stream.  Otherwise `stream` is a raw hipStream_t (int), e.g.
+    torch.cuda.current_stream().cuda_stream, so that torch ops and torch.distributed collectives
+    are ordered with the library's kernels.  torch's DEFAULT stream has the raw value 0 (the
+    null stream): it is passed on as hipStreamLegacy, never silently replaced by a private
+    stream -- that would race with torch."""
+    HIP_STREAM_LEGACY = 1  # hip_runtime_api.h: #define hipStreamLegacy ((hipStream_t)1)
 
     def __init__(self, device=0, stream=None):
         self._L = _lib.load()
         h = C.c_void_p()
-        check(self._L.mp2p_hip_ctx_create(int(device), C.c_void_p(stream) if stream else None,
+        if stream is not None and int(stream) == 0:
+            stream = self.HIP_STREAM_LEGACY
+        check(self._L.mp2p_hip_ctx_create(int(device), C.c_void_p(int(stream)) if stream is not None else None,
                                           C.byref(h)))
         self._h = h
         self.device = int(device)
@@ -243,6 +250,18 @@ def match_pt2pt_phase2(ctx, gmap, cloud, prm, mstate, pairs):
     check(ctx._L.mp2p_hip_match_pt2pt_phase2(ctx.handle, gmap.handle, cloud.handle, C.byref(prm),
                                              mstate.handle if mstate is not None else None,
                                              pairs.handle), ctx.handle)
+
+
+def exchange_pack(ctx, gmap, cloud, prm):
+    """-> (device pointer of exch double[8], device pointer of the claim record list uint64[n_l])"""
+    e, l = C.c_void_p(), C.c_void_p()
+    check(ctx._L.mp2p_hip_exchange_pack(ctx.handle, gmap.handle, cloud.handle, C.byref(prm),
+                                        C.byref(e), C.byref(l)), ctx.handle)
+    return e.value, l.value
+
+
+def exchange_unpack(ctx, gmap, gathered_ptr, n_records):
+    check(ctx._L.mp2p_hip_exchange_unpack(ctx.handle, gmap.handle, gathered_ptr, n_records), ctx.handle)
 
 
 def match_pt2pl(ctx, gmap, cloud, pose, prm, mstate, pairs):

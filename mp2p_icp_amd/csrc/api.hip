@@ -129,7 +129,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release();
     ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release();
     ctx->aos_stage.release(), ctx->pl_slots.release();
-    ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release(), ctx->hint.release();
+    ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release(), ctx->hint.release(), ctx->exch.release(), ctx->claim_list.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -360,6 +360,30 @@ int mp2p_hip_match_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     rc = mp2p_hip_match_pt2pt_phase2(ctx, map, cloud, prm, ms, out);
     if (rc) return rc;
     return MP2P_HIP_OK;
+}
+
+int mp2p_hip_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                           const mp2p_hip_pt2pt_params* prm, void** exch_dev, void** list_dev)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, map && cloud && prm, "null argument");
+    MP2P_REQUIRE(ctx, map->ctx == ctx && cloud->ctx == ctx, "handle belongs to another context");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = launch_exchange_pack(ctx, map, cloud, prm);
+    if (rc) return rc;
+    if (exch_dev) *exch_dev = ctx->exch.p;
+    if (list_dev) *list_dev = ctx->claim_list.p;
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_exchange_unpack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const void* gathered_dev,
+                             size_t n_records)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, map && map->ctx == ctx, "bad map handle");
+    MP2P_REQUIRE(ctx, ctx->exch.p, "exchange_unpack without exchange_pack");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_exchange_unpack(ctx, map, (const unsigned long long*)gathered_dev, n_records);
 }
 
 void* mp2p_hip_ctx_local_bbox_ptr(mp2p_hip_ctx* ctx)

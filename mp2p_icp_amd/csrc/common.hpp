@@ -99,6 +99,8 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<float>              tile_bbox;    // [n_tiles][6]
     mp2p::DevBuf<float>              tile_bbox2;   // [64][6] second reduction level
     mp2p::DevBuf<float>              local_bbox;   // [6] min xyz, max xyz of transformed local
+    mp2p::DevBuf<double>             exch;         // [8] what a sharded layer all-reduces (pairs.hip)
+    mp2p::DevBuf<unsigned long long> claim_list;   // [n_l + 1] claim records + their count
     mp2p::DevBuf<uint32_t>           block_counts; // compaction
     mp2p::DevBuf<unsigned long long> counters;     // profiling counters
     mp2p::DevBuf<double>             gn_partials;  // [GN_BLOCKS][NSUMS]

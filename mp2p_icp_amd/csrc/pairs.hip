@@ -155,7 +155,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
         {
             const float4   gp = a.gpts[sp[k]];
             const uint32_t gi = __float_as_uint(gp.w);
-            a.o_lidx[dst] = i, a.o_gidx[dst] = gi;
+            a.o_lidx[dst] = (uint32_t)(a.local_offset + i), a.o_gidx[dst] = gi;  // whole-layer index
             a.o_lx[dst] = a.lx[i], a.o_ly[dst] = a.ly[i], a.o_lz[dst] = a.lz[i];  // UNtransformed
             a.o_gx[dst] = gp.x, a.o_gy[dst] = gp.y, a.o_gz[dst] = gp.z;
             a.o_err[dst] = a.nn_d2[i];
@@ -205,6 +205,106 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     if (n_blocks)
         hipLaunchKernelGGL(compact_write_kernel, dim3(n_blocks), dim3(CP_THREADS), 0, ctx->stream, a);
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
+}
+
+// ---- sharded local layer: what the ranks exchange between phase 1 and phase 2 -----------------
+// exch = double[8]: {-min xyz, +max xyz of this rank's transformed local points, number of claim
+// records, 0}: ONE all-reduce MAX gives every rank the whole layer's box (negation is exact) and
+// the longest record list.  A claim record = (sorted global position << 32 | whole-layer local
+// index) of a local point that survived this rank's own unique-global filter: only these can
+// win across ranks, and there are at most as many as distinct global points hit (a few per cent
+// of the map), so the ranks all-gather records instead of reducing one word per global point.
+__global__ __launch_bounds__(256) void claims_export_kernel(const uint32_t* __restrict__ nn_spos,
+                                                            uint32_t n_l,
+                                                            const unsigned long long* claims,
+                                                            unsigned long long claim_hi,
+                                                            unsigned long long local_offset,
+                                                            unsigned long long* list,
+                                                            unsigned long long* counter)
+{
+    const uint32_t i    = blockIdx.x * blockDim.x + threadIdx.x;
+    const int      lane = threadIdx.x & 63;
+    uint32_t       spos = NONE_U32;
+    if (i < n_l) spos = nn_spos[i];
+    const bool mine = spos != NONE_U32 && claims[spos] == (claim_hi | (local_offset + i));
+    const unsigned long long m = __ballot(mine);
+    if (m == 0ull) return;
+    unsigned long long base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (mine)
+        list[base + __popcll(m & ((1ull << lane) - 1ull))] =
+            ((unsigned long long)spos << 32) | (unsigned long long)(uint32_t)(local_offset + i);
+}
+
+__global__ void exchange_pack_kernel(const float* bbox, int have_bbox, const unsigned long long* counter,
+                                     double* exch)
+{
+    for (int d = 0; d < 3; d++)
+    {
+        exch[d]     = have_bbox ? -(double)bbox[d] : -(double)INFINITY;
+        exch[3 + d] = have_bbox ? (double)bbox[3 + d] : -(double)INFINITY;
+    }
+    exch[6] = counter ? (double)*counter : 0.0;
+    exch[7] = 0.0;
+}
+
+__global__ void exchange_unpack_kernel(const double* exch, float* bbox)
+{
+    for (int d = 0; d < 3; d++) bbox[d] = (float)(-exch[d]), bbox[3 + d] = (float)exch[3 + d];
+}
+
+__global__ __launch_bounds__(256) void claims_import_kernel(const unsigned long long* __restrict__ list,
+                                                            size_t n, unsigned long long* claims,
+                                                            size_t n_g, unsigned long long claim_hi)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long rec = list[i];
+    if (rec == ~0ull) return;  // padding
+    const unsigned long long spos = rec >> 32;
+    if (spos < n_g) atomicMin(&claims[spos], claim_hi | (rec & 0xFFFFFFFFull));
+}
+
+int launch_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                         const mp2p_hip_pt2pt_params* prm)
+{
+    const size_t n_l      = cloud->n;
+    const bool   searched = map->n > 0 && n_l > 0;  // phase 1 ran (it returns early otherwise)
+    const bool   claims   = !prm->allowMatchAlreadyMatchedGlobalPoints;
+    MP2P_TRY_HIP(ctx, ctx->exch.ensure(8));
+    MP2P_TRY_HIP(ctx, ctx->claim_list.ensure(n_l + 1));  // [n_l] records + the counter
+    unsigned long long* counter = ctx->claim_list.p + n_l;
+    if (claims)
+    {
+        // padding first: the tail of the list beyond this rank's count travels in the all-gather
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->claim_list.p, 0xFF, n_l * sizeof(unsigned long long), ctx->stream));
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+        if (searched)
+            hipLaunchKernelGGL(claims_export_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0,
+                               ctx->stream, ctx->nn_spos.p, (uint32_t)n_l, map->claims.p,
+                               (~(unsigned long long)ctx->epoch) << 32,
+                               (unsigned long long)prm->local_index_offset, ctx->claim_list.p, counter);
+    }
+    MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
+    hipLaunchKernelGGL(exchange_pack_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->local_bbox.p,
+                       searched ? 1 : 0, claims ? counter : nullptr, ctx->exch.p);
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
+}
+
+int launch_exchange_unpack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const unsigned long long* gathered,
+                           size_t n_records)
+{
+    MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
+    hipLaunchKernelGGL(exchange_unpack_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->exch.p,
+                       ctx->local_bbox.p);
+    if (gathered && n_records && map->n)
+        hipLaunchKernelGGL(claims_import_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0,
+                           ctx->stream, gathered, n_records, map->claims.p, map->n,
+                           (~(unsigned long long)ctx->epoch) << 32);
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
 }

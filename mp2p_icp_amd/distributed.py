@@ -3,10 +3,14 @@ torch.distributed process group (one process per GPU, backend "nccl" = RCCL over
 global layer and its index replicated on every GPU (10 M points = 160 MB of 288 GB).
 
 Exchange steps per outer ICP iteration:
-  1. bounding box of the transformed local layer : all-reduce MIN/MAX of 3+3 floats
-  2. unique-global filter                         : all-reduce MIN of the claim words
-     (int64, one per global point; "lowest whole-layer local index wins" across ranks),
-     skipped when allowMatchAlreadyMatchedGlobalPoints is set
+  1. all-reduce MAX of 8 doubles {-min xyz, max xyz of the transformed local layer, number of
+     claim records, 0}: the whole layer's bounding box and the longest record list in one go
+  2. unique-global filter: all-gather of the claim RECORDS (uint64 = sorted global position <<
+     32 | whole-layer local index) of the local points that survived their own rank's filter;
+     every rank applies the foreign records with atomicMin ("lowest whole-layer local index
+     wins").  Records number at most the distinct global points a rank hits (about a tenth of
+     its shard on the bench scene), so this moves ~1 MB per rank where an all-reduce MIN of one
+     word per global point would move 80 MB.  Skipped when allowMatchAlreadyMatchedGlobalPoints.
   3. per Gauss-Newton inner iteration             : all-reduce SUM of 48 doubles
      (17 pt2pt + 28 pt2pl normal-equation sums); every rank then solves the same 6x6 system
      and retracts redundantly -- no broadcast.
@@ -44,16 +48,40 @@ class HipBackend:
         self.torch = torch
         self.ctx, self.gmap, self.cloud, self.pairs = ctx, gmap, cloud, pairs
         self.prm, self.gn_prm = pt2pt_params, gn_params
-        dev = torch.device("cuda", ctx.device)
-        self.claims = torch.as_tensor(_DevArray(gmap.claims_ptr(), gmap.n, "<i8"), device=dev)
-        self.bbox = torch.as_tensor(_DevArray(ctx.local_bbox_ptr(), 6, "<f4"), device=dev)
+        self.dev = torch.device("cuda", ctx.device)
         self._sums = None
+        self._gather = None
+        self._views = None
         self.uses_claims = not bool(pt2pt_params.allowMatchAlreadyMatchedGlobalPoints)
 
     def phase1(self, pose):
         from . import core
         self.pairs.clear()
         core.match_pt2pt_phase1(self.ctx, self.gmap, self.cloud, pose, self.prm, None)
+
+    def exchange_pack(self):
+        """-> (exch: f64[8] device tensor, records: i64[n_l] device tensor padded with -1)"""
+        from . import core
+        e, l = core.exchange_pack(self.ctx, self.gmap, self.cloud, self.prm)
+        key = (e, l, self.cloud.n)
+        if self._views is None or self._views[0] != key:  # the buffers only move when they grow
+            torch = self.torch
+            exch = torch.as_tensor(_DevArray(e, 8, "<f8"), device=self.dev)
+            recs = torch.as_tensor(_DevArray(l, max(1, self.cloud.n), "<i8"), device=self.dev)
+            self._views = (key, exch, recs[:self.cloud.n])
+        return self._views[1], self._views[2]
+
+    def gather_buffer(self, n):
+        if self._gather is None or self._gather.numel() < n:
+            self._gather = self.torch.empty(max(n, 1), dtype=self.torch.int64, device=self.dev)
+        return self._gather[:n]
+
+    def exchange_unpack(self, gathered):
+        from . import core
+        if gathered is None:
+            core.exchange_unpack(self.ctx, self.gmap, None, 0)
+        else:
+            core.exchange_unpack(self.ctx, self.gmap, gathered.data_ptr(), gathered.numel())
 
     def phase2(self):
         from . import core
@@ -119,11 +147,22 @@ class ShardedRegistration:
         b = self.b
         b.phase1(pose)
         if self.world > 1:
-            R = self.dist.ReduceOp
-            self._allreduce(b.bbox[:3], R.MIN)
-            self._allreduce(b.bbox[3:], R.MAX)
+            exch, recs = b.exchange_pack()
+            self._allreduce(exch, self.dist.ReduceOp.MAX)
+            gathered = None
             if b.uses_claims:
-                self._allreduce(b.claims, R.MIN)
+                # the one host round trip of the exchange: how long the longest list is
+                n_max = int(exch[6].item())
+                if n_max > 0:
+                    cap = -(-n_max // 1024) * 1024
+                    send = recs[:cap]
+                    if send.numel() < cap:  # a shorter shard than the longest list: pad
+                        pad = recs.new_full((cap,), -1)
+                        pad[:send.numel()] = send
+                        send = pad
+                    gathered = b.gather_buffer(self.world * cap)
+                    self.dist.all_gather_into_tensor(gathered, send, group=self.group)
+            b.exchange_unpack(gathered)
         b.phase2()
 
     def solve(self, pose):

@@ -1,7 +1,7 @@
 """N>1 path on CPU: two processes, torch.distributed backend gloo, rendezvous on 127.0.0.1.
 
-The exchange logic of mp2p_icp_amd.distributed.ShardedRegistration (bbox MIN/MAX, claim MIN,
-normal-equation SUM) is exercised with a CPU stand-in for this rank's GPU work: OracleBackend
+The exchange logic of mp2p_icp_amd.distributed.ShardedRegistration (one MAX all-reduce for the
+bounding box and the record count, all-gather of the claim records, normal-equation SUM) is exercised with a CPU stand-in for this rank's GPU work: OracleBackend
 below computes each shard with the CPU oracle (tests may use the oracle; the product's only
 backend is HipBackend).  The sharded result must equal the unsharded oracle: identical
 correspondence list (concatenated by rank) and the same pose to 1e-9.
@@ -23,8 +23,8 @@ class OracleBackend:
         self.g, self.l, self.offset = g, l_shard, offset
         self.thr, self.iters, self.kernel, self.kparam = thr, gn_iters, kernel, kparam
         self.tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
-        self.claims = torch.full((g.shape[0],), np.iinfo(np.int64).max, dtype=torch.int64)
-        self.bbox = torch.zeros(6, dtype=torch.float32)
+        self.exch = torch.zeros(8, dtype=torch.float64)
+        self.bbox = np.zeros(6, np.float32)
         self.sums = torch.zeros(48, dtype=torch.float64)
         self.uses_claims = uses_claims
         self.max_inner = gn_iters
@@ -33,27 +33,51 @@ class OracleBackend:
     def phase1(self, pose):
         o, l = self.o, self.l
         tx, ty, tz, bmin, bmax = o.transform_local_to_global(l[:, 0], l[:, 1], l[:, 2], pose)
-        self.bbox[:3] = self.torch.from_numpy(bmin)
-        self.bbox[3:] = self.torch.from_numpy(bmax)
-        self.claims.fill_(np.iinfo(np.int64).max)
+        self.bbox[:3], self.bbox[3:] = bmin, bmax
         n = l.shape[0]
         self.nn = np.full(n, -1, np.int64)
         self.d2 = np.zeros(n, np.float32)
         maxd = np.float32(self.thr * self.thr)
-        cl = self.claims.numpy()
+        self.cl = np.full(self.g.shape[0], np.iinfo(np.int64).max, np.int64)
         for i in range(n):
             idx, d2 = self.tree.knn((tx[i], ty[i], tz[i]), 1)
             if len(idx) and d2[0] < maxd:
                 self.nn[i], self.d2[i] = int(idx[0]), d2[0]
-                cl[idx[0]] = min(cl[idx[0]], self.offset + i)
+                self.cl[idx[0]] = min(self.cl[idx[0]], self.offset + i)
+
+    def exchange_pack(self):
+        n = self.l.shape[0]
+        recs = np.full(n, -1, np.int64)
+        k = 0
+        if self.uses_claims:
+            for i, gi in enumerate(self.nn):
+                if gi >= 0 and self.cl[gi] == self.offset + i:
+                    recs[k] = (int(gi) << 32) | (self.offset + i)
+                    k += 1
+        self.exch[:3] = self.torch.from_numpy(-self.bbox[:3].astype(np.float64))
+        self.exch[3:6] = self.torch.from_numpy(self.bbox[3:].astype(np.float64))
+        self.exch[6], self.exch[7] = float(k), 0.0
+        return self.exch, self.torch.from_numpy(recs)
+
+    def gather_buffer(self, n):
+        return self.torch.empty(n, dtype=self.torch.int64)
+
+    def exchange_unpack(self, gathered):
+        e = self.exch.numpy()
+        self.bbox[:3], self.bbox[3:] = (-e[:3]).astype(np.float32), e[3:6].astype(np.float32)
+        if gathered is not None:
+            for rec in gathered.numpy():
+                if rec != -1:
+                    gi, w = int(rec) >> 32, int(rec) & 0xFFFFFFFF
+                    self.cl[gi] = min(self.cl[gi], w)
 
     def phase2(self):
         o = self.o
         gmin, gmax = self.g.min(0), self.g.max(0)
-        b = self.bbox.numpy()
+        b = self.bbox
         eps = np.float32(self.thr + 0.2)
         ok = all(b[d] - eps <= gmax[d] and b[3 + d] + eps >= gmin[d] for d in range(3))
-        cl = self.claims.numpy()
+        cl = self.cl
         rows = []
         if ok:
             for i, gi in enumerate(self.nn):

@@ -101,6 +101,14 @@ int  mp2p_hip_cloud_upload_device(mp2p_hip_ctx* ctx, const float* d_x, const flo
                                   const float* d_z, size_t n, mp2p_hip_cloud** out);
 void mp2p_hip_cloud_free(mp2p_hip_ctx* ctx, mp2p_hip_cloud* cloud);
 size_t mp2p_hip_cloud_size(const mp2p_hip_cloud* cloud);
+/* maxLocalPointsPerLayer (Matcher_Points_Base.cpp:222-246): the matchers visit only order[0..n)
+ * (host array of distinct original indices), IN THAT ORDER -- it decides the bounding box, which
+ * claimant of a contested global point wins and the order of the output.  The reference builds
+ * the list with mrpt::random::partial_shuffle over iota(0..maxLocalPoints); the caller passes
+ * that list here (the shuffle itself lives in un-vendored MRPT).  order == NULL or n == 0: all
+ * points in ascending index (the default).  Stays attached to the cloud until changed. */
+int mp2p_hip_cloud_set_visit_order(mp2p_hip_ctx* ctx, mp2p_hip_cloud* cloud, const uint32_t* order,
+                                   size_t n);
 
 /* ---- MatchState (Matcher.h:44-70): one byte per point, 0/1 ---------------------------- */
 int  mp2p_hip_mstate_create(mp2p_hip_ctx* ctx, size_t n_global, size_t n_local,
@@ -207,10 +215,12 @@ int mp2p_hip_match_pt2pt_phase1(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
 int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
                                 const mp2p_hip_cloud* cloud, const mp2p_hip_pt2pt_params* prm,
                                 mp2p_hip_mstate* ms, mp2p_hip_pairs* out);
-/* exch_dev: device double[8]; list_dev: device uint64[cloud size] (valid until the next call on
- * this context).  Either out-pointer may be NULL. */
+/* exch_dev: device double[8]; list_dev: device uint64[*list_len] with *list_len = visited local
+ * points x pairingsPerPoint (valid until the next call on this context).  Any out-pointer may
+ * be NULL. */
 int mp2p_hip_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
-                           const mp2p_hip_pt2pt_params* prm, void** exch_dev, void** list_dev);
+                           const mp2p_hip_pt2pt_params* prm, void** exch_dev, void** list_dev,
+                           size_t* list_len);
 /* gathered_dev: n_records uint64 records of all ranks (device; NULL/0 = none) */
 int mp2p_hip_exchange_unpack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const void* gathered_dev,
                              size_t n_records);

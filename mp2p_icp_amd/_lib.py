@@ -127,7 +127,9 @@ SIGNATURES = {
     "mp2p_hip_match_pt2pt": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PtParams), _P, _P]),
     "mp2p_hip_match_pt2pt_phase1": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PtParams), _P]),
     "mp2p_hip_match_pt2pt_phase2": (C.c_int, [_P, _P, _P, C.POINTER(Pt2PtParams), _P, _P]),
-    "mp2p_hip_exchange_pack": (C.c_int, [_P, _P, _P, C.POINTER(Pt2PtParams), C.POINTER(_P), C.POINTER(_P)]),
+    "mp2p_hip_exchange_pack": (C.c_int, [_P, _P, _P, C.POINTER(Pt2PtParams), C.POINTER(_P), C.POINTER(_P),
+                                         C.POINTER(C.c_size_t)]),
+    "mp2p_hip_cloud_set_visit_order": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "mp2p_hip_exchange_unpack": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "mp2p_hip_map_claims_ptr": (_P, [_P]),
     "mp2p_hip_map_claims_count": (C.c_size_t, [_P]),

@@ -139,6 +139,18 @@ class LocalCloud:
     def handle(self):
         return self._h
 
+    def set_visit_order(self, order):
+        """order: distinct original indices, visited in that order (None/empty: all, ascending)"""
+        if order is None or len(order) == 0:
+            check(self.ctx._L.mp2p_hip_cloud_set_visit_order(self.ctx.handle, self._h, None, 0),
+                  self.ctx.handle)
+            self.n_visit = 0
+            return
+        o = np.ascontiguousarray(order, dtype=np.uint32)
+        check(self.ctx._L.mp2p_hip_cloud_set_visit_order(self.ctx.handle, self._h, o.ctypes.data, o.size),
+              self.ctx.handle)
+        self.n_visit = int(o.size)
+
 
 class DeviceMatchState:
     def __init__(self, ctx, n_global, n_local):
@@ -253,11 +265,11 @@ def match_pt2pt_phase2(ctx, gmap, cloud, prm, mstate, pairs):
 
 
 def exchange_pack(ctx, gmap, cloud, prm):
-    """-> (device pointer of exch double[8], device pointer of the claim record list uint64[n_l])"""
-    e, l = C.c_void_p(), C.c_void_p()
+    """-> (device pointer of exch double[8], device pointer of the claim record list, its length)"""
+    e, l, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
     check(ctx._L.mp2p_hip_exchange_pack(ctx.handle, gmap.handle, cloud.handle, C.byref(prm),
-                                        C.byref(e), C.byref(l)), ctx.handle)
-    return e.value, l.value
+                                        C.byref(e), C.byref(l), C.byref(n)), ctx.handle)
+    return e.value, l.value, n.value
 
 
 def exchange_unpack(ctx, gmap, gathered_ptr, n_records):

@@ -231,10 +231,40 @@ void mp2p_hip_cloud_free(mp2p_hip_ctx* ctx, mp2p_hip_cloud* c)
     if (ctx && ctx->hint_cloud == c) ctx->hint_cloud = nullptr;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     c->sorted.release(), c->x.release(), c->y.release(), c->z.release();
+    c->order.release(), c->rank.release();
     delete c;
 }
 
 size_t mp2p_hip_cloud_size(const mp2p_hip_cloud* c) { return c ? c->n : 0; }
+
+int mp2p_hip_cloud_set_visit_order(mp2p_hip_ctx* ctx, mp2p_hip_cloud* c, const uint32_t* order,
+                                   size_t n)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, c && c->ctx == ctx, "bad cloud handle");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (!order || n == 0)
+    {
+        c->n_visit = 0;  // all points, ascending index
+        return MP2P_HIP_OK;
+    }
+    MP2P_REQUIRE(ctx, n <= c->n, "visit order longer than the cloud");
+    std::vector<uint32_t> rank(c->n ? c->n : 1, 0xFFFFFFFFu);
+    for (size_t r = 0; r < n; r++)
+    {
+        MP2P_REQUIRE(ctx, order[r] < c->n, "visit order: index out of range");
+        MP2P_REQUIRE(ctx, rank[order[r]] == 0xFFFFFFFFu, "visit order: index listed twice");
+        rank[order[r]] = (uint32_t)r;
+    }
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a previous match may still read the old lists
+    MP2P_TRY_HIP(ctx, c->order.ensure(n));
+    MP2P_TRY_HIP(ctx, c->rank.ensure(c->n));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(c->order.p, order, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(c->rank.p, rank.data(), c->n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `rank` is a host temporary
+    c->n_visit = n;
+    return MP2P_HIP_OK;
+}
 
 // ---- MatchState -----------------------------------------------------------------------------
 int mp2p_hip_mstate_create(mp2p_hip_ctx* ctx, size_t n_global, size_t n_local,
@@ -306,9 +336,9 @@ static int check_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     MP2P_REQUIRE(ctx, prm->pairingsPerPoint >= 1, "pairingsPerPoint must be >= 1");
     MP2P_REQUIRE(ctx, prm->threshold > 0.0, "threshold must be > 0");
     MP2P_REQUIRE(ctx, prm->thresholdAngularDeg >= 0.0, "thresholdAngularDeg must be >= 0");
-    MP2P_REQUIRE(ctx, prm->pairingsPerPoint == 1, "pairingsPerPoint > 1 is not implemented yet");
-    MP2P_REQUIRE(ctx, prm->local_index_offset + cloud->n <= 0xFFFFFFFFull,
-                 "whole-layer local index must fit 32 bits");
+    MP2P_REQUIRE(ctx, prm->pairingsPerPoint <= 16, "pairingsPerPoint > 16 is not supported");
+    MP2P_REQUIRE(ctx, (prm->local_index_offset + cloud->n) * prm->pairingsPerPoint <= 0xFFFFFFFFull,
+                 "whole-layer (local index x pairingsPerPoint) must fit 32 bits");
     if (ms)
     {
         MP2P_REQUIRE(ctx, ms->global_taken.n >= std::max<size_t>(map->n, 1), "MatchState too small (global)");
@@ -327,6 +357,7 @@ int mp2p_hip_match_pt2pt_phase1(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
     MP2P_REQUIRE(ctx, pose, "null pose");
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     if (map->n == 0 || cloud->n == 0) return MP2P_HIP_OK;  // :67
+    if (prm->pairingsPerPoint > 1) return launch_nn_pt2pt_knn(ctx, map, cloud, pose, prm, ms);  // :242-248
     return launch_nn_pt2pt(ctx, map, cloud, pose, prm, ms);
 }
 
@@ -340,7 +371,8 @@ int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
     MP2P_REQUIRE(ctx, out && out->ctx == ctx, "bad Pairings handle");
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     if (map->n == 0 || cloud->n == 0)  // potential_pairings is added BEFORE the early-out (:64-67)
-        return launch_add_potential(ctx, out, (unsigned long long)cloud->n * prm->pairingsPerPoint);
+        return launch_add_potential(ctx, out, (unsigned long long)(cloud->n_visit ? cloud->n_visit : cloud->n) *
+                                                  prm->pairingsPerPoint);
     rc = launch_compact_pt2pt(ctx, map, cloud, prm, ms, out);
     if (!rc && ctx->profiling)
     {
@@ -363,7 +395,8 @@ int mp2p_hip_match_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
 }
 
 int mp2p_hip_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
-                           const mp2p_hip_pt2pt_params* prm, void** exch_dev, void** list_dev)
+                           const mp2p_hip_pt2pt_params* prm, void** exch_dev, void** list_dev,
+                           size_t* list_len)
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;
     MP2P_REQUIRE(ctx, map && cloud && prm, "null argument");
@@ -373,6 +406,7 @@ int mp2p_hip_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2
     if (rc) return rc;
     if (exch_dev) *exch_dev = ctx->exch.p;
     if (list_dev) *list_dev = ctx->claim_list.p;
+    if (list_len) *list_len = (cloud->n_visit ? cloud->n_visit : cloud->n) * prm->pairingsPerPoint;
     return MP2P_HIP_OK;
 }
 
@@ -407,7 +441,7 @@ int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     MP2P_REQUIRE(ctx, prm->knn >= 3 && prm->knn <= 16, "knn must be in [3,16]");
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     if (map->n == 0 || cloud->n == 0)  // Matcher_Point2Plane.cpp:54-57
-        return launch_add_potential(ctx, out, (unsigned long long)cloud->n);
+        return launch_add_potential(ctx, out, (unsigned long long)(cloud->n_visit ? cloud->n_visit : cloud->n));
     return launch_match_pt2pl(ctx, map, cloud, pose, prm, ms, out);
 }
 

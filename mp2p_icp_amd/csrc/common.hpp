@@ -137,6 +137,10 @@ struct mp2p_hip_cloud
     size_t               n   = 0;
     mp2p::DevBuf<float4> sorted;  // Morton-sorted (own frame) {x,y,z,idx}
     mp2p::DevBuf<float>  x, y, z; // original order (pair output)
+    // optional visit order (mp2p_hip_cloud_set_visit_order): order[r] = original index visited
+    // r-th, rank = its inverse (NONE for points that are not visited); n_visit == 0: all, ascending
+    size_t                 n_visit = 0;
+    mp2p::DevBuf<uint32_t> order, rank;
 };
 
 struct mp2p_hip_mstate

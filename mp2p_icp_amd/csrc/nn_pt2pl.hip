@@ -31,6 +31,7 @@ struct PlArgs
     uint32_t      minPts;
     uint32_t      knn;  // <= K (template capacity of the register k-list)
     const unsigned char* local_taken;
+    const uint32_t*      rank;      // visit rank per original local index (NONE = not visited) or null
     unsigned char*       out_flag;  // [n_l] by original local index
     double*              out_rec;   // [n_l][7] plane(4) + centroid(3)
     float*               tile_bbox;
@@ -103,45 +104,19 @@ __device__ __forceinline__ float kth_d2(const float (&kd2)[K], uint32_t knn)
     return v;
 }
 
-template <int K>
-__global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
+// Exact k nearest neighbours (fp32 metric, (d2, idx) order) of one query per lane, restricted to
+// d2 <= lim2 (STRICT: d2 < lim2); rmax = a radius that covers every such point.  All lanes scan
+// the staged voxel buckets of the wave's common search box; each lane keeps its sorted k-list in
+// registers.  Uniform control flow: must be called by the whole wave.
+template <int K, bool STRICT>
+__device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx, float qy, float qz,
+                                           bool active, float lim2, float rmax, float r0, uint32_t knn,
+                                           float4* s_cand, uint32_t* s_spos, uint32_t* s_cstart,
+                                           uint32_t* s_coff, float (&kd2)[K], uint32_t (&kidx)[K],
+                                           uint32_t (&kspos)[K])
 {
-    __shared__ float4   s_cand[PL_CAP];
-    __shared__ uint32_t s_spos[PL_CAP];
-    __shared__ uint32_t s_cstart[64];
-    __shared__ uint32_t s_coff[65];
-
-    const GridView& g     = a.g;
-    const int       lane  = threadIdx.x;
-    const uint32_t  tile  = blockIdx.x;
-    const uint32_t  qi    = tile * 64 + lane;
-    const bool      valid = qi < a.n_l;
-    float4          lp    = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) lp = a.lpts[qi];
-    const uint32_t orig = __float_as_uint(lp.w);
-    float          qx, qy, qz;
-    compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
-    {
-        const float bx0 = wave_min(valid ? qx : INFINITY), by0 = wave_min(valid ? qy : INFINITY),
-                    bz0 = wave_min(valid ? qz : INFINITY);
-        const float bx1 = wave_max(valid ? qx : -INFINITY), by1 = wave_max(valid ? qy : -INFINITY),
-                    bz1 = wave_max(valid ? qz : -INFINITY);
-        if (lane == 0)
-        {
-            float* o = a.tile_bbox + (size_t)tile * 6;
-            o[0] = bx0, o[1] = by0, o[2] = bz0, o[3] = bx1, o[4] = by1, o[5] = bz1;
-        }
-    }
-    const float fin    = fadd(fadd(qx, qy), qz);
-    bool        active = valid && (fin - fin == 0.0f);
-    if (active && a.local_taken && a.local_taken[orig]) active = false;  // Matcher_Point2Plane.cpp:83-85
-
-    const float rmax = a.rad * 1.002f + g.slack;
-    float       r    = fminf(a.r0, rmax);
-    bool        done = !active;
-
-    float    kd2[K];
-    uint32_t kidx[K], kspos[K];
+    float r    = fminf(r0, rmax);
+    bool  done = !active;
 #pragma unroll
     for (int j = 0; j < K; j++) kd2[j] = INFINITY, kidx[j] = NONE_U32, kspos[j] = NONE_U32;
 
@@ -234,7 +209,8 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
                 {
                     const float4 c  = s_cand[j];
                     const float  d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
-                    if (!done && d2 <= kth_d2(kd2, a.knn) && d2 <= a.radSq)
+                    const bool   in = STRICT ? (d2 < lim2) : (d2 <= lim2);
+                    if (!done && d2 <= kth_d2(kd2, knn) && in)
                     {
                         float    cd = d2;
                         uint32_t ci = __float_as_uint(c.w), cs = s_spos[j];
@@ -252,7 +228,7 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
                         }
 #pragma unroll
                         for (int q = 0; q < K; q++)  // only the knn nearest are kept
-                            if (q >= (int)a.knn) kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
+                            if (q >= (int)knn) kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
                     }
                 }
                 __syncthreads();
@@ -261,7 +237,7 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
         if (!done)
         {
             const float gr  = r * (1.0f - 1.0f / 1024.0f) - g.slack;
-            const float kth = kth_d2(kd2, a.knn);  // INFINITY while fewer than knn are known
+            const float kth = kth_d2(kd2, knn);  // INFINITY while fewer than knn are known
             if (r >= rmax || (gr > 0.f && kth < gr * gr))
                 done = true;
             else
@@ -273,6 +249,57 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
             }
         }
     }
+}
+
+// transform one local point per lane and publish the tile's bounding box of the visited points
+__device__ __forceinline__ void transform_tile(const PoseRt& pose, const float4* lpts, uint32_t n_l,
+                                               const uint32_t* rank, float* tile_bbox, int lane,
+                                               bool& valid, bool& visited, uint32_t& orig,
+                                               uint32_t& vrank, float& qx, float& qy, float& qz)
+{
+    const uint32_t tile = blockIdx.x;
+    const uint32_t qi   = tile * 64 + lane;
+    valid               = qi < n_l;
+    float4 lp           = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) lp = lpts[qi];
+    orig    = __float_as_uint(lp.w);
+    vrank   = orig;
+    visited = valid;
+    if (rank && valid) vrank = rank[orig], visited = vrank != NONE_U32;
+    compose_point_f(pose, lp.x, lp.y, lp.z, qx, qy, qz);
+    const float bx0 = wave_min(visited ? qx : INFINITY), by0 = wave_min(visited ? qy : INFINITY),
+                bz0 = wave_min(visited ? qz : INFINITY);
+    const float bx1 = wave_max(visited ? qx : -INFINITY), by1 = wave_max(visited ? qy : -INFINITY),
+                bz1 = wave_max(visited ? qz : -INFINITY);
+    if (lane == 0)
+    {
+        float* o = tile_bbox + (size_t)tile * 6;
+        o[0] = bx0, o[1] = by0, o[2] = bz0, o[3] = bx1, o[4] = by1, o[5] = bz1;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
+{
+    __shared__ float4   s_cand[PL_CAP];
+    __shared__ uint32_t s_spos[PL_CAP];
+    __shared__ uint32_t s_cstart[64];
+    __shared__ uint32_t s_coff[65];
+
+    const GridView& g    = a.g;
+    const int       lane = threadIdx.x;
+    bool            valid, visited;
+    uint32_t        orig, vrank;
+    float           qx, qy, qz;
+    transform_tile(a.pose, a.lpts, a.n_l, a.rank, a.tile_bbox, lane, valid, visited, orig, vrank, qx, qy, qz);
+    const float fin    = fadd(fadd(qx, qy), qz);
+    bool        active = visited && (fin - fin == 0.0f);
+    if (active && a.local_taken && a.local_taken[orig]) active = false;  // Matcher_Point2Plane.cpp:83-85
+
+    float    kd2[K];
+    uint32_t kidx[K], kspos[K];
+    knn_search<K, false>(g, lane, qx, qy, qz, active, a.radSq, a.rad * 1.002f + g.slack, a.r0, a.knn,
+                         s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
 
     // ---- plane fit (per lane) ------------------------------------------------------------------
     if (!valid) return;
@@ -345,6 +372,66 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
     a.out_flag[orig] = flag;
 }
 
+// ---- Matcher_Points_DistanceThreshold with pairingsPerPoint > 1 ----------------------------------
+// (Matcher_Points_DistanceThreshold.cpp:242-265): the k nearest in ascending d2, cut at the first
+// d2 >= thr, a neighbour whose global point is already marked skipped.  Searching only d2 < thr
+// gives the same list.  Slot (i, k) claims its global point with the word (visit rank * K + k):
+// the sequential loop's "first claimant wins" (pairs.hip).
+struct KnnArgs
+{
+    GridView      g;
+    const float4* lpts;
+    uint32_t      n_l;
+    PoseRt        pose;
+    float         maxDistSq, angSq, r0;
+    uint32_t      knn;
+    const unsigned char *local_taken, *global_taken;
+    const uint32_t*      rank;
+    unsigned long long*  claims;
+    unsigned long long   claim_hi, local_offset;
+    uint32_t*            out_spos;  // [n_l][knn] by original local index
+    float*               out_d2;
+    float*               tile_bbox;
+};
+
+template <int K>
+__global__ __launch_bounds__(64) void pt2pt_knn_kernel(const KnnArgs a)
+{
+    __shared__ float4   s_cand[PL_CAP];
+    __shared__ uint32_t s_spos[PL_CAP];
+    __shared__ uint32_t s_cstart[64];
+    __shared__ uint32_t s_coff[65];
+
+    const GridView& g    = a.g;
+    const int       lane = threadIdx.x;
+    bool            valid, visited;
+    uint32_t        orig, vrank;
+    float           qx, qy, qz;
+    transform_tile(a.pose, a.lpts, a.n_l, a.rank, a.tile_bbox, lane, valid, visited, orig, vrank, qx, qy, qz);
+    const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));  // :223-225
+    const float thr    = fadd(a.maxDistSq, fmul(a.angSq, normSq));              // :256-257
+    bool        active = visited && (normSq < INFINITY);
+    if (active && a.local_taken && a.local_taken[orig]) active = false;  // :218-220
+
+    float    kd2[K];
+    uint32_t kidx[K], kspos[K];
+    knn_search<K, true>(g, lane, qx, qy, qz, active, thr, sqrtf(thr) * 1.002f + g.slack, a.r0, a.knn,
+                        s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
+    if (!valid) return;
+#pragma unroll
+    for (int k = 0; k < K; k++)
+    {
+        if (k >= (int)a.knn) continue;
+        bool acc = active && kidx[k] != NONE_U32;                             // d2 < thr by construction
+        if (acc && a.global_taken && a.global_taken[kidx[k]]) acc = false;   // :98-101
+        const size_t slot = (size_t)orig * a.knn + k;
+        a.out_spos[slot]  = acc ? kspos[k] : NONE_U32;
+        a.out_d2[slot]    = kd2[k];
+        if (acc && a.claims)
+            atomicMin(&a.claims[kspos[k]], a.claim_hi | ((a.local_offset + vrank) * a.knn + (unsigned)k));
+    }
+}
+
 // ---- ordered compaction of the per-query plane slots ---------------------------------------------
 constexpr int PC_THREADS = 256, PC_ITEMS = 4, PC_TILE = PC_THREADS * PC_ITEMS;
 
@@ -352,7 +439,9 @@ struct PlCompactArgs
 {
     const unsigned char* flag;
     const double*        rec;
-    uint32_t             n_l;
+    uint32_t             n_l;      // slots = visited local points, in visiting order
+    const uint32_t*      order;    // slot -> original local index (null: identity)
+    unsigned long long   local_offset;
     const float*         local_bbox;
     float                gbb[6];
     float                margin;
@@ -385,7 +474,7 @@ __global__ __launch_bounds__(PC_THREADS) void pl_count_kernel(const PlCompactArg
         const uint32_t base = blockIdx.x * PC_TILE + threadIdx.x * PC_ITEMS;
 #pragma unroll
         for (int k = 0; k < PC_ITEMS; k++)
-            if (base + k < a.n_l && a.flag[base + k]) c++;
+            if (base + k < a.n_l && a.flag[a.order ? a.order[base + k] : base + k]) c++;
     }
     c = wave_sum_u32(c);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
@@ -408,7 +497,7 @@ __global__ __launch_bounds__(PC_THREADS) void pl_write_kernel(const PlCompactArg
 #pragma unroll
     for (int k = 0; k < PC_ITEMS; k++)
     {
-        f[k] = (base + k < a.n_l) && a.flag[base + k];
+        f[k] = (base + k < a.n_l) && a.flag[a.order ? a.order[base + k] : base + k];
         c += f[k] ? 1u : 0u;
     }
     const int      lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -422,13 +511,13 @@ __global__ __launch_bounds__(PC_THREADS) void pl_write_kernel(const PlCompactArg
     for (int k = 0; k < PC_ITEMS; k++)
     {
         if (!f[k]) continue;
-        const uint32_t i = base + k;
+        const uint32_t i = a.order ? a.order[base + k] : base + k;
         if (dst < a.cap)
         {
             const double* r = a.rec + (size_t)i * 7;
             for (int q = 0; q < 4; q++) a.o_coef[dst * 4 + q] = r[q];
             for (int q = 0; q < 3; q++) a.o_cen[dst * 3 + q] = r[4 + q];
-            a.o_lidx[dst] = i;
+            a.o_lidx[dst] = (uint32_t)(a.local_offset + i);
             a.o_lx[dst] = a.lx[i], a.o_ly[dst] = a.ly[i], a.o_lz[dst] = a.lz[i];
             if (a.ms_local) a.ms_local[i] = 1;  // Matcher_Point2Plane.cpp:109
         }
@@ -469,6 +558,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     a.minPts = prm->minimumPlanePoints;
     a.knn    = prm->knn;
     a.local_taken = (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
+    a.rank     = cloud->n_visit ? cloud->rank.p : nullptr;
     a.out_flag = flag, a.out_rec = rec, a.tile_bbox = ctx->tile_bbox.p;
 
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -483,11 +573,13 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     }
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
 
-    const uint32_t n_blocks = (uint32_t)((n_l + PC_TILE - 1) / PC_TILE);
+    const size_t   n_slots  = cloud->n_visit ? cloud->n_visit : n_l;
+    const uint32_t n_blocks = (uint32_t)((n_slots + PC_TILE - 1) / PC_TILE);
     MP2P_TRY_HIP(ctx, ctx->block_counts.ensure(n_blocks ? n_blocks : 1));
     PlCompactArgs c;
     memset(&c, 0, sizeof(c));
-    c.flag = flag, c.rec = rec, c.n_l = (uint32_t)n_l, c.local_bbox = ctx->local_bbox.p;
+    c.flag = flag, c.rec = rec, c.n_l = (uint32_t)n_slots, c.local_bbox = ctx->local_bbox.p;
+    c.order = cloud->n_visit ? cloud->order.p : nullptr;
     for (int d = 0; d < 3; d++) c.gbb[d] = map->view.bbmin[d], c.gbb[3 + d] = map->view.bbmax[d];
     c.margin = (float)(prm->distanceThreshold + prm->bounding_box_intersection_check_epsilon);
     c.lx = cloud->x.p, c.ly = cloud->y.p, c.lz = cloud->z.p;
@@ -499,9 +591,61 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     hipLaunchKernelGGL(pl_count_kernel, dim3(n_blocks), dim3(PC_THREADS), 0, ctx->stream, c);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream,
                        ctx->block_counts.p, n_blocks, out->counts.p, c.cap,
-                       (unsigned long long)n_l, 1);
+                       (unsigned long long)n_slots, 1);
     hipLaunchKernelGGL(pl_write_kernel, dim3(n_blocks), dim3(PC_THREADS), 0, ctx->stream, c);
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
+}
+
+template <int K>
+static void launch_knn_k(const KnnArgs& a, uint32_t n_tiles, hipStream_t st)
+{
+    hipLaunchKernelGGL(pt2pt_knn_kernel<K>, dim3(n_tiles), dim3(64), 0, st, a);
+}
+
+// phase 1 of Matcher_Points_DistanceThreshold for pairingsPerPoint > 1 (<= 16)
+int launch_nn_pt2pt_knn(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                        const double pose[12], const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms)
+{
+    const size_t   n_l     = cloud->n;
+    const uint32_t K       = prm->pairingsPerPoint;
+    const uint32_t n_tiles = (uint32_t)((n_l + 63) / 64);
+    MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_tiles * 6));
+    MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
+    MP2P_TRY_HIP(ctx, ctx->nn_spos.ensure(n_l * K));
+    MP2P_TRY_HIP(ctx, ctx->nn_d2.ensure(n_l * K));
+    KnnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = map->view, a.lpts = cloud->sorted.p, a.n_l = (uint32_t)n_l;
+    for (int i = 0; i < 9; i++) a.pose.r[i] = pose[i];
+    for (int i = 0; i < 3; i++) a.pose.t[i] = pose[9 + i];
+    a.maxDistSq = (float)(prm->threshold * prm->threshold);                 // :82
+    const double ang = prm->thresholdAngularDeg * 3.14159265358979323846 / 180.0;
+    a.angSq          = (float)(ang * ang);                                  // :83
+    const float cell0 = map->view.hf * (float)(1u << map->view.shift0);
+    a.r0  = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 1.5f);
+    a.knn = K;
+    a.local_taken  = (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
+    a.global_taken = (ms && !prm->allowMatchAlreadyMatchedGlobalPoints) ? ms->global_taken.p : nullptr;
+    a.rank         = cloud->n_visit ? cloud->rank.p : nullptr;
+    a.claims       = prm->allowMatchAlreadyMatchedGlobalPoints ? nullptr : map->claims.p;
+    ctx->epoch++;
+    a.claim_hi     = (~(unsigned long long)ctx->epoch) << 32;
+    a.local_offset = prm->local_index_offset;
+    a.out_spos = ctx->nn_spos.p, a.out_d2 = ctx->nn_d2.p, a.tile_bbox = ctx->tile_bbox.p;
+    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (K <= 5) launch_knn_k<5>(a, n_tiles, ctx->stream);
+    else if (K <= 8) launch_knn_k<8>(a, n_tiles, ctx->stream);
+    else if (K <= 12) launch_knn_k<12>(a, n_tiles, ctx->stream);
+    else launch_knn_k<16>(a, n_tiles, ctx->stream);
+    if (ctx->profiling)
+    {
+        MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    }
+    const int rc = launch_bbox_reduce(ctx, n_tiles);
+    if (rc) return rc;
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
 }

@@ -60,6 +60,7 @@ struct NNArgs
     // the previous call on the same (map, cloud) pair or NONE, lower bound on the SQUARED distance
     // to every map point at that call's pose}; read at entry, rewritten at exit
     uint2*               hint;
+    const uint32_t*      rank;  // visit rank per original local index (NONE = not visited) or null
     int                  use_hint;
     PoseRt               prev_pose;
     unsigned long long*  counters;  // profiling, or null
@@ -190,7 +191,11 @@ __device__ __forceinline__ void emit_result(const NNArgs& a, uint32_t orig, bool
     // threshold was examined), or than the bound that let the search be skipped
     const float lb2 = active ? fmaxf(fminf(best_d2, thr), lb2_keep) : 0.f;
     a.hint[orig]    = make_uint2(best_spos, __float_as_uint(lb2));
-    if (acc && a.claims) atomicMin(&a.claims[best_spos], a.claim_hi | (a.local_offset + orig));
+    if (acc && a.claims)
+    {
+        const uint32_t vrank = a.rank ? a.rank[orig] : orig;  // the order the sequential loop visits
+        atomicMin(&a.claims[best_spos], a.claim_hi | (a.local_offset + vrank));
+    }
 }
 
 // push the lanes of `mask` (one entry per query slot) onto the deferred-query list
@@ -239,6 +244,10 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
     float4 lp = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) lp = a.lpts[qi];
     const uint32_t orig = __float_as_uint(lp.w);
+    // a visit order on the cloud (maxLocalPointsPerLayer, Matcher_Points_Base.cpp:222-246): only
+    // the listed points are transformed, boxed and matched
+    bool visited = valid;
+    if (a.rank && valid) visited = a.rank[orig] != NONE_U32;
 
     // ---- K1: transform (fp64 compose, one narrowing) ------------------------------------
     float qx, qy, qz;
@@ -246,10 +255,10 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
 
     // bounding box of ALL transformed local points of the tile (Matcher_Points_Base.cpp:186-196)
     {
-        const float bx0 = wave_min(valid ? qx : INFINITY), by0 = wave_min(valid ? qy : INFINITY),
-                    bz0 = wave_min(valid ? qz : INFINITY);
-        const float bx1 = wave_max(valid ? qx : -INFINITY), by1 = wave_max(valid ? qy : -INFINITY),
-                    bz1 = wave_max(valid ? qz : -INFINITY);
+        const float bx0 = wave_min(visited ? qx : INFINITY), by0 = wave_min(visited ? qy : INFINITY),
+                    bz0 = wave_min(visited ? qz : INFINITY);
+        const float bx1 = wave_max(visited ? qx : -INFINITY), by1 = wave_max(visited ? qy : -INFINITY),
+                    bz1 = wave_max(visited ? qz : -INFINITY);
         if (lane == 0)
         {
             float* o = a.tile_bbox + (size_t)tile * 6;
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
     // every point with fl(d2) < thr lies within r_max of the query
     const float rmax = sqrtf(thr) * 1.002f + g.slack;
 
-    bool active = valid && (normSq < INFINITY);  // non-finite query: nothing to pair
+    bool active = visited && (normSq < INFINITY);  // non-finite query: nothing to pair
     if (active && a.local_taken && a.local_taken[orig]) active = false;  // :218-220
 
     float    r        = fminf(a.r0, rmax);
@@ -746,6 +755,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     ctx->epoch++;
     a.claim_hi     = (~(unsigned long long)ctx->epoch) << 32;
     a.local_offset = prm->local_index_offset;
+    a.rank         = cloud->n_visit ? cloud->rank.p : nullptr;
     a.out_spos     = ctx->nn_spos.p;
     a.out_d2       = ctx->nn_d2.p;
     a.tile_bbox    = ctx->tile_bbox.p;

@@ -16,9 +16,11 @@ constexpr int CP_TILE    = CP_THREADS * CP_ITEMS;
 
 struct CompactArgs
 {
-    const uint32_t*           nn_spos;  // [n_l] by original local index
+    const uint32_t*           nn_spos;  // [n_l][K] by original local index
     const float*              nn_d2;
-    uint32_t                  n_l;
+    uint32_t                  n_l;      // number of SLOTS = visited local points x K, in visiting order
+    uint32_t                  K;        // pairingsPerPoint
+    const uint32_t*           order;    // visit position -> original local index (null: identity)
     const unsigned long long* claims;  // null when global re-use is allowed
     unsigned long long        claim_hi, local_offset;
     const float*              local_bbox;  // device [6]
@@ -48,11 +50,18 @@ __device__ __forceinline__ bool bbox_overlap(const float* g, const float* l, flo
     return true;
 }
 
-__device__ __forceinline__ bool pair_flag(const CompactArgs& a, uint32_t i, uint32_t& spos)
+// slot t = (visit position r, neighbour k): does it produce a pair?  i = original local index,
+// src = its place in nn_spos / nn_d2
+__device__ __forceinline__ bool pair_flag(const CompactArgs& a, uint32_t t, uint32_t& spos,
+                                          uint32_t& i, size_t& src)
 {
-    spos = a.nn_spos[i];
+    const uint32_t r = (a.K == 1) ? t : t / a.K;
+    const uint32_t k = (a.K == 1) ? 0u : t - r * a.K;
+    i                = a.order ? a.order[r] : r;
+    src              = (size_t)i * a.K + k;
+    spos             = a.nn_spos[src];
     if (spos == NONE_U32) return false;
-    if (a.claims && a.claims[spos] != (a.claim_hi | (a.local_offset + i))) return false;
+    if (a.claims && a.claims[spos] != (a.claim_hi | ((a.local_offset + r) * a.K + k))) return false;
     return true;
 }
 
@@ -66,8 +75,9 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const Compact
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; k++)
         {
-            uint32_t sp;
-            if (base + k < a.n_l && pair_flag(a, base + k, sp)) c++;
+            uint32_t sp, i;
+            size_t   src;
+            if (base + k < a.n_l && pair_flag(a, base + k, sp, i, src)) c++;
         }
     }
     c = wave_sum_u32(c);
@@ -130,13 +140,14 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
     __shared__ uint32_t s_w[CP_THREADS / 64];
     if (!bbox_overlap(a.gbb, a.local_bbox, a.margin)) return;
     const uint32_t base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
-    uint32_t       sp[CP_ITEMS];
+    uint32_t       sp[CP_ITEMS], li[CP_ITEMS];
+    size_t         src[CP_ITEMS];
     bool           f[CP_ITEMS];
     uint32_t       c = 0;
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; k++)
     {
-        f[k] = (base + k < a.n_l) && pair_flag(a, base + k, sp[k]);
+        f[k] = (base + k < a.n_l) && pair_flag(a, base + k, sp[k], li[k], src[k]);
         c += f[k] ? 1u : 0u;
     }
     const int      lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
     for (int k = 0; k < CP_ITEMS; k++)
     {
         if (!f[k]) continue;
-        const uint32_t i = base + k;
+        const uint32_t i = li[k];
         if (dst < a.cap)
         {
             const float4   gp = a.gpts[sp[k]];
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
             a.o_lidx[dst] = (uint32_t)(a.local_offset + i), a.o_gidx[dst] = gi;  // whole-layer index
             a.o_lx[dst] = a.lx[i], a.o_ly[dst] = a.ly[i], a.o_lz[dst] = a.lz[i];  // UNtransformed
             a.o_gx[dst] = gp.x, a.o_gy[dst] = gp.y, a.o_gz[dst] = gp.z;
-            a.o_err[dst] = a.nn_d2[i];
+            a.o_err[dst] = a.nn_d2[src[k]];
             if (a.claims)
             {  // marks are only left when global re-use is forbidden (:116-120)
                 if (a.ms_local) a.ms_local[i] = 1;
@@ -173,12 +184,14 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
                          const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms,
                          mp2p_hip_pairs* out)
 {
-    const size_t   n_l      = cloud->n;
+    const size_t   n_visit  = cloud->n_visit ? cloud->n_visit : cloud->n;
+    const size_t   n_l      = n_visit * prm->pairingsPerPoint;  // slots
     const uint32_t n_blocks = (uint32_t)((n_l + CP_TILE - 1) / CP_TILE);
     MP2P_TRY_HIP(ctx, ctx->block_counts.ensure(n_blocks ? n_blocks : 1));
     CompactArgs a;
     memset(&a, 0, sizeof(a));
     a.nn_spos = ctx->nn_spos.p, a.nn_d2 = ctx->nn_d2.p, a.n_l = (uint32_t)n_l;
+    a.K = prm->pairingsPerPoint, a.order = cloud->n_visit ? cloud->order.p : nullptr;
     a.claims       = prm->allowMatchAlreadyMatchedGlobalPoints ? nullptr : map->claims.p;
     a.claim_hi     = (~(unsigned long long)ctx->epoch) << 32;
     a.local_offset = prm->local_index_offset;
@@ -190,7 +203,7 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     a.block_counts  = ctx->block_counts.p;
     a.counts        = out->counts.p;
     a.cap           = out->cap_pt2pt;
-    a.potential_add = (unsigned long long)n_l * prm->pairingsPerPoint;
+    a.potential_add = (unsigned long long)n_l;  // visited points x pairingsPerPoint (:64)
     a.o_lidx = out->lidx.p, a.o_gidx = out->gidx.p;
     a.o_lx = out->lx.p, a.o_ly = out->ly.p, a.o_lz = out->lz.p;
     a.o_gx = out->gx.p, a.o_gy = out->gy.p, a.o_gz = out->gz.p, a.o_err = out->err.p;
@@ -217,26 +230,33 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
 // win across ranks, and there are at most as many as distinct global points hit (a few per cent
 // of the map), so the ranks all-gather records instead of reducing one word per global point.
 __global__ __launch_bounds__(256) void claims_export_kernel(const uint32_t* __restrict__ nn_spos,
-                                                            uint32_t n_l,
+                                                            uint32_t n_slots, uint32_t K,
+                                                            const uint32_t* order,
                                                             const unsigned long long* claims,
                                                             unsigned long long claim_hi,
                                                             unsigned long long local_offset,
                                                             unsigned long long* list,
                                                             unsigned long long* counter)
 {
-    const uint32_t i    = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t    = blockIdx.x * blockDim.x + threadIdx.x;
     const int      lane = threadIdx.x & 63;
     uint32_t       spos = NONE_U32;
-    if (i < n_l) spos = nn_spos[i];
-    const bool mine = spos != NONE_U32 && claims[spos] == (claim_hi | (local_offset + i));
+    unsigned long long id = 0;
+    if (t < n_slots)
+    {
+        const uint32_t r = t / K, k = t - r * K;
+        const uint32_t i = order ? order[r] : r;
+        spos             = nn_spos[(size_t)i * K + k];
+        id               = (local_offset + r) * K + k;
+    }
+    const bool mine = spos != NONE_U32 && claims[spos] == (claim_hi | id);
     const unsigned long long m = __ballot(mine);
     if (m == 0ull) return;
     unsigned long long base = 0;
     if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(m));
     base = __shfl(base, __ffsll((long long)m) - 1);
     if (mine)
-        list[base + __popcll(m & ((1ull << lane) - 1ull))] =
-            ((unsigned long long)spos << 32) | (unsigned long long)(uint32_t)(local_offset + i);
+        list[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)spos << 32) | (id & 0xFFFFFFFFull);
 }
 
 __global__ void exchange_pack_kernel(const float* bbox, int have_bbox, const unsigned long long* counter,
@@ -271,8 +291,9 @@ __global__ __launch_bounds__(256) void claims_import_kernel(const unsigned long 
 int launch_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
                          const mp2p_hip_pt2pt_params* prm)
 {
-    const size_t n_l      = cloud->n;
-    const bool   searched = map->n > 0 && n_l > 0;  // phase 1 ran (it returns early otherwise)
+    const uint32_t K      = prm->pairingsPerPoint;
+    const size_t n_l      = (cloud->n_visit ? cloud->n_visit : cloud->n) * K;  // slots
+    const bool   searched = map->n > 0 && cloud->n > 0;  // phase 1 ran (it returns early otherwise)
     const bool   claims   = !prm->allowMatchAlreadyMatchedGlobalPoints;
     MP2P_TRY_HIP(ctx, ctx->exch.ensure(8));
     MP2P_TRY_HIP(ctx, ctx->claim_list.ensure(n_l + 1));  // [n_l] records + the counter
@@ -284,7 +305,8 @@ int launch_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
         MP2P_TRY_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
         if (searched)
             hipLaunchKernelGGL(claims_export_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0,
-                               ctx->stream, ctx->nn_spos.p, (uint32_t)n_l, map->claims.p,
+                               ctx->stream, ctx->nn_spos.p, (uint32_t)n_l, K,
+                               cloud->n_visit ? cloud->order.p : nullptr, map->claims.p,
                                (~(unsigned long long)ctx->epoch) << 32,
                                (unsigned long long)prm->local_index_offset, ctx->claim_list.p, counter);
     }

@@ -62,13 +62,13 @@ class HipBackend:
     def exchange_pack(self):
         """-> (exch: f64[8] device tensor, records: i64[n_l] device tensor padded with -1)"""
         from . import core
-        e, l = core.exchange_pack(self.ctx, self.gmap, self.cloud, self.prm)
-        key = (e, l, self.cloud.n)
+        e, l, n = core.exchange_pack(self.ctx, self.gmap, self.cloud, self.prm)
+        key = (e, l, n)
         if self._views is None or self._views[0] != key:  # the buffers only move when they grow
             torch = self.torch
             exch = torch.as_tensor(_DevArray(e, 8, "<f8"), device=self.dev)
-            recs = torch.as_tensor(_DevArray(l, max(1, self.cloud.n), "<i8"), device=self.dev)
-            self._views = (key, exch, recs[:self.cloud.n])
+            recs = torch.as_tensor(_DevArray(l, max(1, n), "<i8"), device=self.dev)
+            self._views = (key, exch, recs[:n])
         return self._views[1], self._views[2]
 
     def gather_buffer(self, n):

@@ -221,10 +221,35 @@ class Matcher_Points_Base(Matcher):
         self.cell_budget = int(params.get("hip_cell_budget", 0))
         self.defer_radius_cells = float(params.get("hip_defer_radius_cells", 0.0))
         self.disable_warm_start = bool(params.get("hip_disable_warm_start", False))
-        if self.maxLocalPointsPerLayer_:
-            raise NotImplementedError(
-                "maxLocalPointsPerLayer (random sub-sampling, Matcher_Points_Base.cpp:207-245) "
-                "is not implemented on the HIP path yet")
+
+    # maxLocalPointsPerLayer (Matcher_Points_Base.cpp:222-246): when the local layer is larger,
+    # only idxs[0..maxLocalPoints) are visited, where idxs = iota(0..maxLocalPoints) shuffled by
+    # mrpt::random::partial_shuffle with std::default_random_engine(seed) (seed 0 = the clock).
+    # The result is a permutation of the FIRST maxLocalPoints indices: it changes the visiting
+    # order (hence which claimant of a contested global point wins and the output order), not
+    # the set.  MRPT's shuffle is not in the reference tree, so this mirror draws its own
+    # permutation (numpy PCG64) -- "parity unpinned" for the order; set `visit_order_fn` to a
+    # callable (n_local, max_points, seed) -> indices to plug the exact list in (the C++ adapter
+    # passes MRPT's own list to mp2p_hip_cloud_set_visit_order).
+    visit_order_fn = None
+
+    def _visit_order(self, n_local):
+        m = int(self.maxLocalPointsPerLayer_)
+        if m == 0 or n_local <= m:
+            return None
+        seed = int(self.localPointsSampleSeed_)
+        if self.visit_order_fn is not None:
+            return np.asarray(self.visit_order_fn(n_local, m, seed), dtype=np.uint32)
+        rng = np.random.default_rng(seed if seed != 0 else None)
+        return rng.permutation(m).astype(np.uint32)
+
+    def _apply_visit_order(self, lLayer, cloud):
+        order = self._visit_order(lLayer.size())
+        key = None if order is None else order.tobytes()
+        if getattr(cloud, "_order_key", None) != key:
+            cloud.set_visit_order(order)
+            cloud._order_key = key
+        return lLayer.size() if order is None else int(order.size)
 
     def impl_match(self, pcGlobal, pcLocal, localPose, mc, ms, out):
         out._reset(ms.ctx)  # out = Pairings()  (:37)
@@ -304,7 +329,8 @@ class Matcher_Points_DistanceThreshold(Matcher_Points_Base):
         self.checkAllParametersAreRealized()
         prm = self._params()
         gmap, cloud = gLayer.as_global(ctx), lLayer.as_local(ctx)
-        out._ub[0] += lLayer.size() * int(self.pairingsPerPoint)
+        n_visit = self._apply_visit_order(lLayer, cloud)
+        out._ub[0] += n_visit * int(self.pairingsPerPoint)
         dev = out._ensure_dev(ctx, out._ub[0], out._ub[1])
         core.match_pt2pt(ctx, gmap, cloud, localPose, prm, ms.for_layers(glName, lcName), dev)
         ms._sync_shared(glName, lcName)
@@ -341,7 +367,7 @@ class Matcher_Point2Plane(Matcher_Points_Base):
                                float(self.bounding_box_intersection_check_epsilon_),
                                float(self.initial_radius_cells), int(self.queries_per_wave))
         gmap, cloud = gLayer.as_global(ctx), lLayer.as_local(ctx)
-        out._ub[1] += lLayer.size()
+        out._ub[1] += self._apply_visit_order(lLayer, cloud)
         dev = out._ensure_dev(ctx, out._ub[0], out._ub[1])
         core.match_pt2pl(ctx, gmap, cloud, localPose, prm, ms.for_layers(glName, lcName), dev)
         ms._sync_shared(glName, lcName)

@@ -1065,6 +1065,76 @@ size_t orc_match_pt2pl(const orc_kdtree* tree, const float* gx, const float* gy,
     return n_out;
 }
 
+/* ---- maxLocalPointsPerLayer: the matchers visit a LIST of local points ------------------------
+ * Matcher_Points_Base.cpp:222-246 transforms only x_locals[ri] = T * l[idxs[ri]] (the bounding
+ * box is theirs alone) and both matchers then run their loop over ri with
+ * localIdx = idxs[ri] (Matcher_Points_DistanceThreshold.cpp:216, Matcher_Point2Plane.cpp:81).
+ * That is the plain matcher on the gathered cloud with indices and MatchState marks mapped back.
+ * The list itself comes from mrpt::random::partial_shuffle (un-vendored MRPT): an input here. */
+size_t orc_match_pt2pt_subset(const orc_kdtree* tree, const float* gx, const float* gy,
+                              const float* gz, size_t n_g, const float* lx, const float* ly,
+                              const float* lz, size_t n_l, const uint32_t* idxs, size_t n_idxs,
+                              const double T[12], const orc_pt2pt_params* prm,
+                              uint8_t* local_taken, uint8_t* global_taken, orc_pair_pt2pt* out,
+                              uint64_t* potential_pairings)
+{
+    if (!idxs)
+        return orc_match_pt2pt(tree, gx, gy, gz, n_g, lx, ly, lz, n_l, T, prm, local_taken,
+                               global_taken, out, potential_pairings);
+    float*   sx = (float*)malloc((n_idxs + 1) * sizeof(float));
+    float*   sy = (float*)malloc((n_idxs + 1) * sizeof(float));
+    float*   sz = (float*)malloc((n_idxs + 1) * sizeof(float));
+    uint8_t* st = local_taken ? (uint8_t*)malloc(n_idxs + 1) : NULL;
+    for (size_t r = 0; r < n_idxs; r++)
+    {
+        const uint32_t i = idxs[r];
+        sx[r] = lx[i], sy[r] = ly[i], sz[r] = lz[i];
+        if (st) st[r] = local_taken[i];
+    }
+    const size_t n = orc_match_pt2pt(tree, gx, gy, gz, n_g, sx, sy, sz, n_idxs, T, prm, st,
+                                     global_taken, out, potential_pairings);
+    for (size_t k = 0; k < n; k++) out[k].localIdx = idxs[out[k].localIdx]; /* :216 */
+    if (st)
+        for (size_t r = 0; r < n_idxs; r++)
+            if (st[r]) local_taken[idxs[r]] = 1;
+    free(sx), free(sy), free(sz), free(st);
+    (void)n_l;
+    return n;
+}
+
+size_t orc_match_pt2pl_subset(const orc_kdtree* tree, const float* gx, const float* gy,
+                              const float* gz, size_t n_g, const float* lx, const float* ly,
+                              const float* lz, size_t n_l, const uint32_t* idxs, size_t n_idxs,
+                              const double T[12], const orc_pt2pl_params* prm,
+                              uint8_t* local_taken, orc_pair_pt2pl* out, uint32_t* out_local_idx,
+                              uint64_t* potential_pairings)
+{
+    if (!idxs)
+        return orc_match_pt2pl(tree, gx, gy, gz, n_g, lx, ly, lz, n_l, T, prm, local_taken, out,
+                               out_local_idx, potential_pairings);
+    float*    sx = (float*)malloc((n_idxs + 1) * sizeof(float));
+    float*    sy = (float*)malloc((n_idxs + 1) * sizeof(float));
+    float*    sz = (float*)malloc((n_idxs + 1) * sizeof(float));
+    uint8_t*  st = local_taken ? (uint8_t*)malloc(n_idxs + 1) : NULL;
+    uint32_t* oi = (uint32_t*)malloc((n_idxs + 1) * sizeof(uint32_t));
+    for (size_t r = 0; r < n_idxs; r++)
+    {
+        const uint32_t i = idxs[r];
+        sx[r] = lx[i], sy[r] = ly[i], sz[r] = lz[i];
+        if (st) st[r] = local_taken[i];
+    }
+    const size_t n = orc_match_pt2pl(tree, gx, gy, gz, n_g, sx, sy, sz, n_idxs, T, prm, st, out, oi,
+                                     potential_pairings);
+    if (out_local_idx)
+        for (size_t k = 0; k < n; k++) out_local_idx[k] = idxs[oi[k]]; /* :81 */
+    if (st)
+        for (size_t r = 0; r < n_idxs; r++)
+            if (st[r]) local_taken[idxs[r]] = 1;
+    free(sx), free(sy), free(sz), free(st), free(oi);
+    (void)n_l;
+    return n;
+}
+
 /* ======================================================================================
  *  a10: optimal_tf_gauss_newton (optimal_tf_gauss_newton.cpp:36-372)
  *  Sequential summation order; H and g reset at the top of every inner iteration (the

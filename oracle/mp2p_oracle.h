@@ -184,6 +184,21 @@ size_t orc_match_pt2pl(const orc_kdtree* tree, const float* gx, const float* gy,
                        orc_pair_pt2pl* out, uint32_t* out_local_idx,
                        uint64_t* potential_pairings);
 
+/* maxLocalPointsPerLayer (Matcher_Points_Base.cpp:222-246): visit only idxs[0..n_idxs) in that
+ * order; idxs == NULL -> the plain functions above.  Capacity of out >= n_idxs * K. */
+size_t orc_match_pt2pt_subset(const orc_kdtree* tree, const float* gx, const float* gy,
+                              const float* gz, size_t n_g, const float* lx, const float* ly,
+                              const float* lz, size_t n_l, const uint32_t* idxs, size_t n_idxs,
+                              const double T[12], const orc_pt2pt_params* prm,
+                              uint8_t* local_taken, uint8_t* global_taken, orc_pair_pt2pt* out,
+                              uint64_t* potential_pairings);
+size_t orc_match_pt2pl_subset(const orc_kdtree* tree, const float* gx, const float* gy,
+                              const float* gz, size_t n_g, const float* lx, const float* ly,
+                              const float* lz, size_t n_l, const uint32_t* idxs, size_t n_idxs,
+                              const double T[12], const orc_pt2pl_params* prm,
+                              uint8_t* local_taken, orc_pair_pt2pl* out, uint32_t* out_local_idx,
+                              uint64_t* potential_pairings);
+
 /* estimate_points_eigen (estimate_points_eigen.cpp:27-123): fp32 mean, fp64 covariance,
  * eigenvalues ascending with eigenvectors as rows of evec[3][3]. */
 void orc_estimate_points_eigen(const float* xs, const float* ys, const float* zs, size_t n,

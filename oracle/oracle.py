@@ -116,6 +116,14 @@ def _declare(L):
                                   C.c_size_t, _dp, C.POINTER(Pt2PlParams), _u8p, C.c_void_p,
                                   _u32p, C.POINTER(C.c_uint64)]
     L.orc_match_pt2pl.restype = C.c_size_t
+    L.orc_match_pt2pt_subset.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp,
+                                         C.c_size_t, _u32p, C.c_size_t, _dp, C.POINTER(Pt2PtParams),
+                                         _u8p, _u8p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.orc_match_pt2pt_subset.restype = C.c_size_t
+    L.orc_match_pt2pl_subset.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp,
+                                         C.c_size_t, _u32p, C.c_size_t, _dp, C.POINTER(Pt2PlParams),
+                                         _u8p, C.c_void_p, _u32p, C.POINTER(C.c_uint64)]
+    L.orc_match_pt2pl_subset.restype = C.c_size_t
     L.orc_estimate_points_eigen.argtypes = [_fp, _fp, _fp, C.c_size_t, _fp, _dp, _dp, _dp]
     L.orc_optimal_tf_gauss_newton.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                               C.c_void_p, C.c_size_t, _dp,
@@ -283,8 +291,9 @@ def brute_knn(x, y, z, q, k=1, max_d2=-1.0):
 def match_pt2pt(gx, gy, gz, lx, ly, lz, T, threshold, thresholdAngularDeg, pairingsPerPoint=1,
                 allowMatchAlreadyMatchedPoints=False, allowMatchAlreadyMatchedGlobalPoints=False,
                 bbox_eps=0.20, tree=None, local_taken=None, global_taken=None,
-                multi_search_radius_mode=0, threads=0):
-    """Matcher_Points_DistanceThreshold::implMatchOneLayer.  Returns (pairs, potential)."""
+                multi_search_radius_mode=0, threads=0, idxs=None):
+    """Matcher_Points_DistanceThreshold::implMatchOneLayer.  Returns (pairs, potential).
+    idxs: the visit list of maxLocalPointsPerLayer (Matcher_Points_Base.cpp:222-246) or None."""
     gx, gy, gz, lx, ly, lz = map(_f32, (gx, gy, gz, lx, ly, lz))
     T = np.ascontiguousarray(T, dtype=np.float64)
     prm = Pt2PtParams(threshold, thresholdAngularDeg, pairingsPerPoint,
@@ -301,6 +310,12 @@ def match_pt2pt(gx, gy, gz, lx, ly, lz, T, threshold, thresholdAngularDeg, pairi
         return out[:n].copy(), lx.size * pairingsPerPoint
     lt = local_taken.ctypes.data_as(_u8p) if local_taken is not None else None
     gt = global_taken.ctypes.data_as(_u8p) if global_taken is not None else None
+    if idxs is not None:
+        ii = np.ascontiguousarray(idxs, dtype=np.uint32)
+        n = lib().orc_match_pt2pt_subset(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
+                                         lx.size, ii.ctypes.data_as(_u32p), ii.size,
+                                         _d(T), C.byref(prm), lt, gt, out.ctypes.data, C.byref(pot))
+        return out[:n].copy(), pot.value
     n = lib().orc_match_pt2pt(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
                               lx.size, _d(T), C.byref(prm), lt, gt, out.ctypes.data,
                               C.byref(pot))
@@ -309,7 +324,7 @@ def match_pt2pt(gx, gy, gz, lx, ly, lz, T, threshold, thresholdAngularDeg, pairi
 
 def match_pt2pl(gx, gy, gz, lx, ly, lz, T, distanceThreshold, searchRadius, knn,
                 minimumPlanePoints, planeEigenThreshold, allowMatchAlreadyMatchedPoints=False,
-                bbox_eps=0.20, tree=None, local_taken=None):
+                bbox_eps=0.20, tree=None, local_taken=None, idxs=None):
     """Matcher_Point2Plane::implMatchOneLayer with the declared nn_search_pt2pl.
     Returns (pairs, local_idx, potential)."""
     gx, gy, gz, lx, ly, lz = map(_f32, (gx, gy, gz, lx, ly, lz))
@@ -321,6 +336,13 @@ def match_pt2pl(gx, gy, gz, lx, ly, lz, T, distanceThreshold, searchRadius, knn,
     pot = C.c_uint64(0)
     th = tree._h if tree is not None else None
     lt = local_taken.ctypes.data_as(_u8p) if local_taken is not None else None
+    if idxs is not None:
+        ii = np.ascontiguousarray(idxs, dtype=np.uint32)
+        n = lib().orc_match_pt2pl_subset(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
+                                         lx.size, ii.ctypes.data_as(_u32p), ii.size, _d(T),
+                                         C.byref(prm), lt, out.ctypes.data,
+                                         oidx.ctypes.data_as(_u32p), C.byref(pot))
+        return out[:n].copy(), oidx[:n].copy(), pot.value
     n = lib().orc_match_pt2pl(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
                               lx.size, _d(T), C.byref(prm), lt, out.ctypes.data,
                               oidx.ctypes.data_as(_u32p), C.byref(pot))

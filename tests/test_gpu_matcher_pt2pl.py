@@ -147,3 +147,24 @@ def test_pt2pl_then_pt2pt_pipeline_and_gn(amd, oracle):
                                                 oracle.make_gn_params(4, kernel=oracle.KERNEL_CAUCHY, kernelParam=0.2))
         dt, dr = oracle.pose_err_split(out.optimalPose, To)
         assert dt < 1e-5 and dr < 1e-5
+
+
+def test_pt2pl_max_local_points_visit_order(amd, oracle):
+    """Matcher_Point2Plane.cpp:58-59, 81: the same visit list as the point matcher"""
+    from mp2p_icp_amd import synthetic
+    d = synthetic.make_pair(5000, 50000, 19)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    order = np.random.default_rng(2).permutation(3000).astype(np.uint32)
+    P = dict(distanceThreshold=0.3, searchRadius=0.5, knn=6, minimumPlanePoints=5, planeEigenThreshold=0.05)
+    want, widx, pot = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2],
+                                         d["T_gt"], tree=tree, idxs=order, **P)
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g)})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    m = amd.Matcher_Point2Plane()
+    m.initialize(dict(P, maxLocalPointsPerLayer=3000, localPointsSampleSeed=1))
+    m.visit_order_fn = lambda n, mx, seed: order
+    pairs = amd.Pairings()
+    assert m.match(pcG, pcL, d["T_gt"], amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+    _check(pairs, want, widx)
+    assert pairs.potential_pairings == pot == 3000

@@ -233,3 +233,81 @@ def test_warm_start_pose_sequence(amd, oracle):
             m.match(pcG, pcL, pose, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
             _assert_same_pairs(pairs.paired_pt2pt, want)
             assert pairs.potential_pairings == pot
+
+
+@pytest.mark.parametrize("K", [2, 3, 5, 8, 13, 16])
+@pytest.mark.parametrize("allow_global", [False, True])
+def test_pairings_per_point(amd, oracle, K, allow_global):
+    """pairingsPerPoint > 1 (Matcher_Points_DistanceThreshold.cpp:242-265): the k nearest in
+    ascending d2 up to the threshold, first claimant of a global point wins."""
+    from mp2p_icp_amd import synthetic
+    d = synthetic.random_cloud_pair(3000, 12000, 40 + K, outlier_frac=0.1)
+    g, l = d["glob"], d["local"]
+    g[200:230] = g[0:30]  # duplicated global points: ties inside a k-list
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG, pcL = _maps(amd, g, l)
+    for pose in (d["T_gt"], d["T_init"]):
+        want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose,
+                                       0.6, 0.2, pairingsPerPoint=K, tree=tree,
+                                       allowMatchAlreadyMatchedGlobalPoints=allow_global)
+        pairs, _ = _hip_match(amd, pcG, pcL, pose,
+                              {"threshold": 0.6, "thresholdAngularDeg": 0.2, "pairingsPerPoint": K,
+                               "allowMatchAlreadyMatchedGlobalPoints": allow_global})
+        _assert_same_pairs(pairs.paired_pt2pt, want)
+        assert pairs.potential_pairings == pot == l.shape[0] * K
+
+
+def test_pairings_per_point_with_match_state(amd, oracle):
+    from mp2p_icp_amd import synthetic
+    d = synthetic.random_cloud_pair(2000, 8000, 77, outlier_frac=0.05)
+    g, l = d["glob"], d["local"]
+    rng = np.random.default_rng(3)
+    lt = (rng.random(l.shape[0]) < 0.2).astype(np.uint8)
+    gt = (rng.random(g.shape[0]) < 0.2).astype(np.uint8)
+    lt_o, gt_o = lt.copy(), gt.copy()
+    want, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], d["T_gt"], 0.5, 0.0,
+                                 pairingsPerPoint=4, local_taken=lt_o, global_taken=gt_o)
+    pcG, pcL = _maps(amd, g, l)
+    ms = amd.MatchState(pcG, pcL)
+    ms.for_layers("raw", "raw").upload(gt, lt)
+    pairs, ms = _hip_match(amd, pcG, pcL, d["T_gt"], {"threshold": 0.5, "thresholdAngularDeg": 0.0,
+                                                      "pairingsPerPoint": 4}, ms=ms)
+    _assert_same_pairs(pairs.paired_pt2pt, want)
+    g_after, l_after = ms.for_layers("raw", "raw").download()
+    assert np.array_equal(g_after, gt_o) and np.array_equal(l_after, lt_o)
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_max_local_points_visit_order(amd, oracle, K):
+    """maxLocalPointsPerLayer (Matcher_Points_Base.cpp:222-246): a shuffled list of the first
+    maxLocalPoints indices is visited in list order; box, winners and output order follow it."""
+    from mp2p_icp_amd import synthetic
+    d = synthetic.random_cloud_pair(4000, 9000, 90 + K, outlier_frac=0.1)
+    g, l = d["glob"], d["local"]
+    l[3000:] += 50.0  # far-away tail: must not enter the bounding box of the visited points
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG, pcL = _maps(amd, g, l)
+    order = np.random.default_rng(8).permutation(2500).astype(np.uint32)
+    m = amd.Matcher_Points_DistanceThreshold()
+    m.initialize({"threshold": 0.8, "thresholdAngularDeg": 0.0, "pairingsPerPoint": K,
+                  "maxLocalPointsPerLayer": 2500, "localPointsSampleSeed": 5})
+    m.visit_order_fn = lambda n, mx, seed: order
+    for pose in (d["T_gt"], d["T_init"]):
+        want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose,
+                                       0.8, 0.0, pairingsPerPoint=K, tree=tree, idxs=order)
+        pairs = amd.Pairings()
+        m.match(pcG, pcL, pose, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+        _assert_same_pairs(pairs.paired_pt2pt, want)
+        assert pairs.potential_pairings == pot == 2500 * K
+    # a later matcher without the limit sees the whole layer again
+    want, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], d["T_gt"],
+                                 0.8, 0.0, tree=tree)
+    pairs, _ = _hip_match(amd, pcG, pcL, d["T_gt"], {"threshold": 0.8, "thresholdAngularDeg": 0.0})
+    _assert_same_pairs(pairs.paired_pt2pt, want)
+    # the mirror's own permutation: seeded -> reproducible, a permutation of the first 2500
+    m2 = amd.Matcher_Points_DistanceThreshold()
+    m2.initialize({"threshold": 0.8, "thresholdAngularDeg": 0.0, "maxLocalPointsPerLayer": 2500,
+                   "localPointsSampleSeed": 5})
+    o1, o2 = m2._visit_order(4000), m2._visit_order(4000)
+    assert np.array_equal(o1, o2) and sorted(o1.tolist()) == list(range(2500))
+    assert m2._visit_order(2500) is None

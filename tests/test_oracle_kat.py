@@ -279,3 +279,34 @@ def test_matcher_pt2pl_kat(oracle):
     assert np.allclose(p0["plane"], (1, 0, 0, -10), atol=1e-3)         # :118-121
     pairs, idx, _ = run((18.053, 0.05, 0.03, 0, 0, 0))
     assert len(pairs) == 0                                 # :129-130 (cube: not a plane)
+
+
+def test_oracle_visit_list_and_pairings_per_point(oracle):
+    """maxLocalPointsPerLayer visit list (Matcher_Points_Base.cpp:222-246) and pairingsPerPoint>1
+    (Matcher_Points_DistanceThreshold.cpp:242-265): KD-tree path == brute-force definition, and
+    the visit list == the plain matcher on the gathered cloud with indices mapped back."""
+    rng = np.random.default_rng(12)
+    g = rng.uniform(-3, 3, (800, 3)).astype(np.float32)
+    l = (g[:400] + rng.normal(0, 0.03, (400, 3))).astype(np.float32)
+    T = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0.01, -0.02, 0.0])
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    for K in (1, 2, 4):
+        a, pa = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, 0.5, 0.1,
+                                   pairingsPerPoint=K, tree=tree)
+        b, pb = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, 0.5, 0.1,
+                                   pairingsPerPoint=K, tree=None)
+        assert np.array_equal(a, b) and pa == pb == 400 * K
+        assert len(set(a["globalIdx"].tolist())) == len(a)  # unique-global filter
+        order = rng.permutation(250).astype(np.uint32)
+        c, pc = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, 0.5, 0.1,
+                                   pairingsPerPoint=K, tree=tree, idxs=order)
+        ls = l[order]
+        e, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], ls[:, 0], ls[:, 1], ls[:, 2], T, 0.5, 0.1,
+                                  pairingsPerPoint=K, tree=tree)
+        assert pc == 250 * K and len(c) == len(e)
+        assert np.array_equal(c["localIdx"], order[e["localIdx"]])
+        assert np.array_equal(c["globalIdx"], e["globalIdx"])
+        # visiting order = output order
+        pos = {int(v): i for i, v in enumerate(order)}
+        ranks = [pos[int(v)] for v in c["localIdx"]]
+        assert ranks == sorted(ranks)

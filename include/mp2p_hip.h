@@ -139,6 +139,19 @@ typedef struct
     float  _pad;
 } mp2p_hip_pair_pt2pl; /* = mp2p_icp::point_plane_pair_t, 72 B */
 
+typedef struct
+{
+    double ln_base[3];     /* TLine3D::pBase    */
+    double ln_director[3]; /* TLine3D::director */
+    double pt_local[3];    /* TPoint3D (double) */
+} mp2p_hip_pair_pt2ln; /* = mp2p_icp::point_line_pair_t (Pairings.h:61-73), 72 B */
+
+typedef struct
+{
+    double pl_global[4], c_global[3]; /* plane_patch_t p_global: TPlane coefs, centroid */
+    double pl_local[4], c_local[3];   /* plane_patch_t p_local                          */
+} mp2p_hip_pair_pl2pl; /* = mp2p_icp::matched_plane_t (Pairings.h:37-48), 112 B */
+
 int  mp2p_hip_pairs_create(mp2p_hip_ctx* ctx, size_t cap_pt2pt, size_t cap_pt2pl,
                            mp2p_hip_pairs** out);
 void mp2p_hip_pairs_free(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p);
@@ -155,6 +168,15 @@ int  mp2p_hip_pairs_download_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
 int  mp2p_hip_pairs_download_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
                                    mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx,
                                    size_t capacity, size_t* n_out);
+/* paired_pt2ln / paired_pl2pl: produced on the host by Matcher_Point2Line /
+ * Matcher_Planes_Normals (not on this path), consumed by the Gauss-Newton solver
+ * (optimal_tf_gauss_newton.cpp:184-202, 289-308).  Replaces both lists (n = 0 empties one);
+ * mp2p_hip_pairs_clear empties them too.  paired_ln2ln is not supported. */
+int  mp2p_hip_pairs_upload_lines_planes(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p,
+                                        const mp2p_hip_pair_pt2ln* pt2ln, size_t n_pt2ln,
+                                        const mp2p_hip_pair_pl2pl* pl2pl, size_t n_pl2pl);
+int  mp2p_hip_pairs_counts_lines_planes(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
+                                        uint64_t* n_pt2ln, uint64_t* n_pl2pl);
 /* a solver handed host Pairings it did not produce uploads them first */
 int  mp2p_hip_pairs_upload(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p, const mp2p_hip_pair_pt2pt* pt2pt,
                            size_t n_pt2pt, const mp2p_hip_pair_pt2pl* pt2pl, size_t n_pt2pl);
@@ -278,6 +300,7 @@ typedef struct
     uint32_t n_weight_blocks;
     uint64_t weight_block_count[8];
     double   weight_block_w[8];
+    double   w_pt2ln, w_pl2pl;       /* PairWeights, for the host-produced lists */
 } mp2p_hip_gn_params;
 
 typedef struct

@@ -13,6 +13,9 @@ from . import _build
 PAIR_PT2PT = np.dtype(
     [("globalIdx", "<u4"), ("localIdx", "<u4"), ("global", "<f4", (3,)), ("local", "<f4", (3,)),
      ("errorSquareAfterTransformation", "<f4")])
+PAIR_PT2LN = np.dtype([("ln_base", "<f8", (3,)), ("ln_director", "<f8", (3,)), ("pt_local", "<f8", (3,))])
+PAIR_PL2PL = np.dtype([("pl_global", "<f8", (4,)), ("c_global", "<f8", (3,)), ("pl_local", "<f8", (4,)),
+                       ("c_local", "<f8", (3,))])
 PAIR_PT2PL = np.dtype(
     [("plane", "<f8", (4,)), ("centroid", "<f8", (3,)), ("pt_local", "<f4", (3,)), ("_pad", "<f4")])
 assert PAIR_PT2PT.itemsize == 36 and PAIR_PT2PL.itemsize == 72
@@ -61,7 +64,14 @@ class GNParams(C.Structure):
                 ("w_pt2pt", C.c_double), ("w_pt2pl", C.c_double), ("has_prior", C.c_int32),
                 ("prior_mean", C.c_double * 12), ("prior_cov_inv", C.c_double * 36),
                 ("n_weight_blocks", C.c_uint32), ("weight_block_count", C.c_uint64 * 8),
-                ("weight_block_w", C.c_double * 8)]
+                ("weight_block_w", C.c_double * 8), ("w_pt2ln", C.c_double), ("w_pl2pl", C.c_double)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        if "w_pt2ln" not in k and len(a) < 14:
+            self.w_pt2ln = 1.0   # PairWeights defaults (PairWeights.h)
+        if "w_pl2pl" not in k and len(a) < 15:
+            self.w_pl2pl = 1.0
 
 
 class GNResult(C.Structure):
@@ -123,6 +133,8 @@ SIGNATURES = {
     "mp2p_hip_pairs_download_pt2pt": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mp2p_hip_pairs_download_pt2pl": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint32), C.c_size_t,
                                                 C.POINTER(C.c_size_t)]),
+    "mp2p_hip_pairs_upload_lines_planes": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_size_t]),
+    "mp2p_hip_pairs_counts_lines_planes": (C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mp2p_hip_pairs_upload": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_size_t]),
     "mp2p_hip_match_pt2pt": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PtParams), _P, _P]),
     "mp2p_hip_match_pt2pt_phase1": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PtParams), _P]),

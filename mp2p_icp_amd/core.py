@@ -241,6 +241,27 @@ class DevicePairs:
               self.ctx.handle)
 
 
+def _pairs_upload_lines_planes(self, pt2ln=None, pl2pl=None):
+    """paired_pt2ln / paired_pl2pl (host-produced) for the Gauss-Newton solver; replaces both"""
+    a = np.ascontiguousarray(pt2ln, _lib.PAIR_PT2LN) if pt2ln is not None else np.zeros(0, _lib.PAIR_PT2LN)
+    b = np.ascontiguousarray(pl2pl, _lib.PAIR_PL2PL) if pl2pl is not None else np.zeros(0, _lib.PAIR_PL2PL)
+    check(self.ctx._L.mp2p_hip_pairs_upload_lines_planes(self.ctx.handle, self._h,
+                                                         a.ctypes.data if a.size else None, a.size,
+                                                         b.ctypes.data if b.size else None, b.size),
+          self.ctx.handle)
+
+
+def _pairs_counts_lines_planes(self):
+    a, b = C.c_uint64(), C.c_uint64()
+    check(self.ctx._L.mp2p_hip_pairs_counts_lines_planes(self.ctx.handle, self._h, C.byref(a), C.byref(b)),
+          self.ctx.handle)
+    return a.value, b.value
+
+
+DevicePairs.upload_lines_planes = _pairs_upload_lines_planes
+DevicePairs.counts_lines_planes = _pairs_counts_lines_planes
+
+
 def match_pt2pt(ctx, gmap, cloud, pose, prm, mstate, pairs):
     T = _pose(pose)
     check(ctx._L.mp2p_hip_match_pt2pt(ctx.handle, gmap.handle, cloud.handle,

@@ -161,8 +161,11 @@ struct mp2p_hip_pairs
     mp2p::DevBuf<double>   pl_coef;  // [cap][4]  a,b,c,d
     mp2p::DevBuf<double>   pl_cen;   // [cap][3]
     mp2p::DevBuf<float>    pl_lx, pl_ly, pl_lz;
+    // host-produced lists kept as uploaded (AoS): paired_pt2ln, paired_pl2pl
+    mp2p::DevBuf<mp2p_hip_pair_pt2ln> ln;
+    mp2p::DevBuf<mp2p_hip_pair_pl2pl> pp;
     // counts: [0]=n_pt2pt [1]=n_pt2pl [2]=potential_pairings [3]=write base scratch
-    // [4]=overflow flag
+    // [4]=overflow flag [5]=n_pt2ln [6]=n_pl2pl
     mp2p::DevBuf<unsigned long long> counts;
 };
 

@@ -8,7 +8,9 @@
 //   pt2pt : 17 fp64 sums  {Sw, Sw*l (3), Sw*l l^T (6), Sw*e' (3), Sw*(l x e') (3), Sw*|e|^2}
 //           with e' = R^T e, independent of R in the Hessian part;
 //   pt2pl : 28 fp64 sums  {Sw*a a^T (21 upper), Sw*a*r (6), Sw*r^2}, a = [n' ; l x n'],
-//           n' = R^T n/|n|, r = signed point-plane distance.
+//           n' = R^T n/|n|, r = signed point-plane distance;
+//   pt2ln / pl2pl (host-produced lists, small): the same 28 sums {H upper, g, cost} with
+//           Ji = (I - u u^T)[R | -R [l]x]  resp.  Ji = [0 | -R [n_l]x], added by the same kernel.
 // The kernels stream the pair arrays once per inner iteration (HBM-bound: 24 B / pt2pt pair,
 // 44 B / pt2pl pair), reduce per lane -> wave (shuffles) -> block (LDS) -> fixed-order final
 // sum (deterministic, no fp64 atomics).  The 6x6 solve, the prior term and the retraction
@@ -33,7 +35,7 @@ struct GnKernelPrm
 {
     int    kernel;
     double c, c2;
-    double w_pt2pt, w_pt2pl;
+    double w_pt2pt, w_pt2pl, w_pt2ln, w_pl2pl;
     uint32_t           n_blocks;  // weight blocks
     unsigned long long blk_end[8];
     double             blk_w[8];
@@ -125,16 +127,31 @@ __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pt_kernel(
 }
 
 // ---- K7: point-to-plane (errorTerms.cpp:115-161 + optimal_tf_gauss_newton.cpp:229-259) ------
+// one 3-row term: H(upper) += w Ji^T Ji, g += w Ji^T e     (Ji row-major 3x6)
+__device__ __forceinline__ void accum_rows3(double (&acc)[28], const double (&J)[18], const double (&e)[3],
+                                            double w)
+{
+    int k = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++)
+#pragma unroll
+        for (int q = p; q < 6; q++)
+            acc[k++] += w * (J[p] * J[q] + J[6 + p] * J[6 + q] + J[12 + p] * J[12 + q]);
+#pragma unroll
+    for (int p = 0; p < 6; p++) acc[21 + p] += w * (J[p] * e[0] + J[6 + p] * e[1] + J[12 + p] * e[2]);
+}
+
 __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pl_kernel(
     const double* __restrict__ coef, const float* __restrict__ lx, const float* __restrict__ ly,
-    const float* __restrict__ lz, const unsigned long long* __restrict__ counts,
+    const float* __restrict__ lz, const mp2p_hip_pair_pt2ln* __restrict__ lines,
+    const mp2p_hip_pair_pl2pl* __restrict__ planes, const unsigned long long* __restrict__ counts,
     const double* __restrict__ state, const GnKernelPrm prm, double* __restrict__ partials)
 {
     double acc[NS_PL];
 #pragma unroll
     for (int k = 0; k < NS_PL; k++) acc[k] = 0;
     const bool done = state[ST_DONE] != 0.0;
-    const unsigned long long n = done ? 0ull : counts[1];
+    const unsigned long long n = (done || !coef) ? 0ull : counts[1];
     double R[9], t[3];
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = state[ST_POSE + k];
@@ -174,6 +191,64 @@ __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pl_kernel(
 #pragma unroll
         for (int p = 0; p < 6; p++) acc[21 + p] += w * a[p] * r;
         acc[27] += w * r * r;
+    }
+
+    // ---- point-to-line (errorTerms.cpp:68-112 + optimal_tf_gauss_newton.cpp:184-202) ---------
+    const unsigned long long n_ln = (done || !lines) ? 0ull : counts[5];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * GN_THREADS + threadIdx.x; i < n_ln;
+         i += (unsigned long long)GN_BLOCKS * GN_THREADS)
+    {
+        const mp2p_hip_pair_pt2ln P = lines[i];
+        const double l[3] = {P.pt_local[0], P.pt_local[1], P.pt_local[2]};
+        const double* u   = P.ln_director;  // not assumed unit (:77-84)
+        double q[3];
+        for (int r = 0; r < 3; r++)
+            q[r] = R[r * 3] * l[0] + R[r * 3 + 1] * l[1] + R[r * 3 + 2] * l[2] + t[r] - P.ln_base[r];
+        const double uq   = u[0] * q[0] + u[1] * q[1] + u[2] * q[2];
+        const double e[3] = {q[0] - u[0] * uq, q[1] - u[1] * uq, q[2] - u[2] * uq};
+        const double esq  = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        const double w    = prm.w_pt2ln * robust_w(prm, esq);
+        // A = [R | -R [l]x]: column 3+j = R (e_j x l);  Ji = (I - u u^T) A
+        double A[18];
+        const double c[3][3] = {{0, -l[2], l[1]}, {l[2], 0, -l[0]}, {-l[1], l[0], 0}};  // e_j x l
+        for (int r = 0; r < 3; r++)
+        {
+            for (int j = 0; j < 3; j++) A[r * 6 + j] = R[r * 3 + j];
+            for (int j = 0; j < 3; j++)
+                A[r * 6 + 3 + j] = R[r * 3] * c[j][0] + R[r * 3 + 1] * c[j][1] + R[r * 3 + 2] * c[j][2];
+        }
+        double J[18];
+        for (int col = 0; col < 6; col++)
+        {
+            const double uA = u[0] * A[col] + u[1] * A[6 + col] + u[2] * A[12 + col];
+            for (int r = 0; r < 3; r++) J[r * 6 + col] = A[r * 6 + col] - u[r] * uA;
+        }
+        accum_rows3(acc, J, e, w);
+        acc[27] += w * w * esq;  // :198 (the weight enters squared here, unlike :175)
+    }
+
+    // ---- plane-to-plane, normals only (errorTerms.cpp:325-363 + ...gauss_newton.cpp:289-308) --
+    const unsigned long long n_pp = (done || !planes) ? 0ull : counts[6];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * GN_THREADS + threadIdx.x; i < n_pp;
+         i += (unsigned long long)GN_BLOCKS * GN_THREADS)
+    {
+        const mp2p_hip_pair_pl2pl P = planes[i];
+        const double* nl = P.pl_local;
+        double e[3];
+        for (int r = 0; r < 3; r++)
+            e[r] = R[r * 3] * nl[0] + R[r * 3 + 1] * nl[1] + R[r * 3 + 2] * nl[2] - P.pl_global[r];
+        const double esq = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+        const double w   = prm.w_pl2pl * robust_w(prm, esq);
+        const double c[3][3] = {{0, -nl[2], nl[1]}, {nl[2], 0, -nl[0]}, {-nl[1], nl[0], 0}};  // e_j x n_l
+        double J[18];
+        for (int r = 0; r < 3; r++)
+        {
+            for (int j = 0; j < 3; j++) J[r * 6 + j] = 0.0;  // insensitive to translation
+            for (int j = 0; j < 3; j++)
+                J[r * 6 + 3 + j] = R[r * 3] * c[j][0] + R[r * 3 + 1] * c[j][1] + R[r * 3 + 2] * c[j][2];
+        }
+        accum_rows3(acc, J, e, w);
+        acc[27] += w * w * esq;  // :303
     }
     block_reduce_store<NS_PL>(acc, partials + (size_t)blockIdx.x * NS + NS_PT);
 }
@@ -529,6 +604,7 @@ static GnKernelPrm make_kernel_prm(const mp2p_hip_gn_params& p)
     k.c       = p.kernelParam;
     k.c2      = p.kernelParam * p.kernelParam;
     k.w_pt2pt = p.w_pt2pt, k.w_pt2pl = p.w_pt2pl;
+    k.w_pt2ln = p.w_pt2ln, k.w_pl2pl = p.w_pl2pl;
     k.n_blocks = p.n_weight_blocks;
     unsigned long long end = 0;
     for (uint32_t b = 0; b < p.n_weight_blocks && b < 8; b++)
@@ -566,7 +642,8 @@ static GnStepPrm make_step_prm(mp2p_hip_ctx* ctx)
     s.minDelta = p.minDelta, s.maxCost = p.maxCost, s.has_prior = p.has_prior;
     memcpy(s.prior_mean, p.prior_mean, sizeof(s.prior_mean));
     memcpy(s.prior_cov_inv, p.prior_cov_inv, sizeof(s.prior_cov_inv));
-    s.use_pt = ctx->gn.pairs->cap_pt2pt > 0, s.use_pl = ctx->gn.pairs->cap_pt2pl > 0;
+    s.use_pt = ctx->gn.pairs->cap_pt2pt > 0;
+    s.use_pl = ctx->gn.pairs->cap_pt2pl > 0 || ctx->gn.pairs->ln.p || ctx->gn.pairs->pp.p;
     return s;
 }
 
@@ -574,15 +651,15 @@ static void launch_partials(mp2p_hip_ctx* ctx, int& use_pt, int& use_pl)
 {
     const mp2p_hip_pairs* P = ctx->gn.pairs;
     const GnKernelPrm     k = make_kernel_prm(ctx->gn.prm);
-    use_pt = P->cap_pt2pt > 0, use_pl = P->cap_pt2pl > 0;
+    use_pt = P->cap_pt2pt > 0, use_pl = P->cap_pt2pl > 0 || P->ln.p || P->pp.p;
     if (use_pt)
         hipLaunchKernelGGL(gn_accum_pt2pt_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
                            P->lx.p, P->ly.p, P->lz.p, P->gx.p, P->gy.p, P->gz.p, P->counts.p,
                            ctx->gn_state.p, k, ctx->gn_partials.p);
     if (use_pl)
         hipLaunchKernelGGL(gn_accum_pt2pl_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
-                           P->pl_coef.p, P->pl_lx.p, P->pl_ly.p, P->pl_lz.p, P->counts.p,
-                           ctx->gn_state.p, k, ctx->gn_partials.p);
+                           P->cap_pt2pl > 0 ? P->pl_coef.p : nullptr, P->pl_lx.p, P->pl_ly.p, P->pl_lz.p,
+                           P->ln.p, P->pp.p, P->counts.p, ctx->gn_state.p, k, ctx->gn_partials.p);
 }
 
 int gn_accumulate(mp2p_hip_ctx* ctx)

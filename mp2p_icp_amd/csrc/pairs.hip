@@ -459,6 +459,7 @@ void mp2p_hip_pairs_free(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p)
     p->gx.release(), p->gy.release(), p->gz.release(), p->err.release();
     p->pl_lidx.release(), p->pl_coef.release(), p->pl_cen.release();
     p->pl_lx.release(), p->pl_ly.release(), p->pl_lz.release();
+    p->ln.release(), p->pp.release();
     p->counts.release();
     delete p;
 }
@@ -605,9 +606,45 @@ int mp2p_hip_pairs_upload(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p, const mp2p_hip_p
                            (uint32_t)n_pt2pl, p->pl_coef.p, p->pl_cen.p, p->pl_lx.p, p->pl_ly.p,
                            p->pl_lz.p, p->pl_lidx.p);
     }
-    unsigned long long h[8] = {n_pt2pt, n_pt2pl, 0, 0, 0, 0, 0, 0};
+    unsigned long long h[5] = {n_pt2pt, n_pt2pl, 0, 0, 0};  // [5],[6] (lines, planes) are kept
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(p->counts.p, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
     MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_upload_lines_planes(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p,
+                                       const mp2p_hip_pair_pt2ln* pt2ln, size_t n_pt2ln,
+                                       const mp2p_hip_pair_pl2pl* pl2pl, size_t n_pl2pl)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, p->ctx == ctx, "bad Pairings handle");
+    MP2P_REQUIRE(ctx, (pt2ln || !n_pt2ln) && (pl2pl || !n_pl2pl), "null list with a non-zero count");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_pt2ln)
+    {
+        MP2P_TRY_HIP(ctx, p->ln.ensure(n_pt2ln));
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(p->ln.p, pt2ln, n_pt2ln * sizeof(*pt2ln), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (n_pl2pl)
+    {
+        MP2P_TRY_HIP(ctx, p->pp.ensure(n_pl2pl));
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(p->pp.p, pl2pl, n_pl2pl * sizeof(*pl2pl), hipMemcpyHostToDevice, ctx->stream));
+    }
+    const unsigned long long h[2] = {n_pt2ln, n_pl2pl};
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(p->counts.p + 5, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the sources are caller memory
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_counts_lines_planes(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, uint64_t* n_pt2ln,
+                                       uint64_t* n_pl2pl)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    unsigned long long h[2] = {0, 0};
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(h, p->counts.p + 5, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_pt2ln) *n_pt2ln = h[0];
+    if (n_pl2pl) *n_pl2pl = h[1];
     return MP2P_HIP_OK;
 }
 

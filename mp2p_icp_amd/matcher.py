@@ -32,6 +32,11 @@ class Pairings:
         self._host_pt2pl = None
         self._host_pl_idx = None
         self._ub = [0, 0]  # host-side upper bounds of the list lengths (no sync needed)
+        # lists no matcher of this path produces (Pairings.h:94-99); the Gauss-Newton solver
+        # uploads paired_pt2ln / paired_pl2pl, paired_ln2ln is not supported
+        self.paired_pt2ln = np.zeros(0, _lib.PAIR_PT2LN)
+        self.paired_pl2pl = np.zeros(0, _lib.PAIR_PL2PL)
+        self.paired_ln2ln = []
 
     # -- device side -----------------------------------------------------------------------
     def _ensure_dev(self, ctx, cap_pt2pt, cap_pt2pl):
@@ -78,11 +83,12 @@ class Pairings:
     def potential_pairings(self):
         return self._dev.counts()[2] if self._dev is not None else 0
 
-    def size(self):
+    def size(self):  # Pairings.cpp:143-147
+        n = len(self.paired_pt2ln) + len(self.paired_pl2pl) + len(self.paired_ln2ln)
         if self._dev is None:
-            return 0
+            return n
         a, b, _ = self._dev.counts()
-        return a + b
+        return a + b + n
 
     def empty(self):
         return self.size() == 0
@@ -92,7 +98,7 @@ class Pairings:
         return f"{a} point-point, {b} point-plane" if (a or b) else "none"
 
     @staticmethod
-    def from_host(ctx, pt2pt=None, pt2pl=None, point_weights=None):
+    def from_host(ctx, pt2pt=None, pt2pl=None, point_weights=None, pt2ln=None, pl2pl=None):
         """Build a Pairings from host lists (a solver handed pairings it did not produce)."""
         n1 = 0 if pt2pt is None else len(pt2pt)
         n2 = 0 if pt2pl is None else len(pt2pl)
@@ -101,6 +107,10 @@ class Pairings:
         p._ub = [n1, n2]
         p._dev.upload(pt2pt, pt2pl)
         p.point_weights = list(point_weights or [])
+        if pt2ln is not None:
+            p.paired_pt2ln = np.ascontiguousarray(pt2ln, _lib.PAIR_PT2LN)
+        if pl2pl is not None:
+            p.paired_pl2pl = np.ascontiguousarray(pl2pl, _lib.PAIR_PL2PL)
         return p
 
 
@@ -284,6 +294,9 @@ class Matcher_Points_Base(Matcher):
 def _pairings_reset(self, ctx):
     self.ctx = ctx
     self.point_weights = []
+    self.paired_pt2ln = np.zeros(0, _lib.PAIR_PT2LN)
+    self.paired_pl2pl = np.zeros(0, _lib.PAIR_PL2PL)
+    self.paired_ln2ln = []
     self._ub = [0, 0]
     if self._dev is not None:
         self._dev.clear()

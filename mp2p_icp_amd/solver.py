@@ -119,6 +119,7 @@ class Solver_GaussNewton(Solver):
         p.minDelta, p.maxCost = 1e-7, 0.0  # optimal_tf_gauss_newton.h:46-58
         p.kernel, p.kernelParam = self.robustKernel, float(self.robustKernelParam)
         p.w_pt2pt, p.w_pt2pl = self.pairWeights.pt2pt, self.pairWeights.pt2pl
+        p.w_pt2ln, p.w_pl2pl = self.pairWeights.pt2ln, self.pairWeights.pl2pl
         p.has_prior = 0
         if sc.prior is not None:
             p.has_prior = 1
@@ -142,6 +143,12 @@ class Solver_GaussNewton(Solver):
         dev = pairings.device
         if dev is None:
             dev = pairings._ensure_dev(ctx, 1, 0)
+        if len(pairings.paired_ln2ln):
+            raise NotImplementedError("paired_ln2ln (optimal_tf_gauss_newton.cpp:204-225) is not supported")
+        n_ln, n_pp = len(pairings.paired_pt2ln), len(pairings.paired_pl2pl)
+        if n_ln or n_pp or getattr(dev, "_has_lines_planes", False):
+            dev.upload_lines_planes(pairings.paired_pt2ln, pairings.paired_pl2pl)
+            dev._has_lines_planes = bool(n_ln or n_pp)
         res = core.gn_solve(ctx, dev, sc.guessRelativePose, self.gn_params(sc, pairings.point_weights))
         out.__init__()
         out.optimalPose = np.array(res.pose)

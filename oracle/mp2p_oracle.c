@@ -441,6 +441,22 @@ void orc_error_point2line(const orc_pair_pt2ln* p, const double T[12], double e[
     }
 }
 
+/* errorTerms.cpp:325-363: e = R*n_local - n_global (normals = the first three TPlane coefs, not
+ * re-normalised); J1 = d(R n_l)/d[R t] with the translation block zero */
+void orc_error_plane2plane(const orc_pair_pl2pl* p, const double T[12], double e[3], double J1[36])
+{
+    const double* nl = p->pl_local;
+    const double* ng = p->pl_global;
+    for (int i = 0; i < 3; i++)
+        e[i] = T[i * 3 + 0] * nl[0] + T[i * 3 + 1] * nl[1] + T[i * 3 + 2] * nl[2] - ng[i]; /* rotateVector */
+    if (J1)
+    {
+        memset(J1, 0, 36 * sizeof(double));
+        for (int i = 0; i < 3; i++)
+            for (int c = 0; c < 3; c++) J1[i * 12 + c * 3 + i] = nl[c]; /* :350-354 */
+    }
+}
+
 /* robust_kernels.h:57-94: weight functor on the SQUARED error */
 double orc_robust_weight(int32_t kernel, double c, double errSq)
 {
@@ -1210,6 +1226,7 @@ static void prior_term(const double T[12], const orc_gn_params* prm, double* H, 
 int orc_optimal_tf_gauss_newton(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
                                 const orc_pair_pt2pl* pt2pl, size_t n_pt2pl,
                                 const orc_pair_pt2ln* pt2ln, size_t n_pt2ln,
+                                const orc_pair_pl2pl* pl2pl, size_t n_pl2pl,
                                 const double T0[12], const orc_gn_params* prm, double T_out[12],
                                 double* H_out, double* g_out)
 {
@@ -1273,6 +1290,16 @@ int orc_optimal_tf_gauss_newton(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
             const double esq = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
             if (prm->kernel != ORC_KERNEL_NONE) w *= orc_robust_weight(prm->kernel, prm->kernelParam, esq);
             errNormSqr += w * esq; /* :249 */
+            accum_term(e, J1, dD, w, H, g);
+        }
+        for (size_t i = 0; i < n_pl2pl; i++) /* :289-308 */
+        {
+            double e[3], J1[36];
+            orc_error_plane2plane(&pl2pl[i], T, e, J1);
+            double       w   = prm->w_pl2pl;
+            const double esq = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+            if (prm->kernel != ORC_KERNEL_NONE) w *= orc_robust_weight(prm->kernel, prm->kernelParam, esq);
+            errNormSqr += w * w * esq; /* :303 */
             accum_term(e, J1, dD, w, H, g);
         }
         if (prm->has_prior) prior_term(T, prm, H, g); /* :311-341 */

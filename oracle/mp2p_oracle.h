@@ -58,14 +58,21 @@ typedef struct
     float  _pad;
 } orc_pair_pt2pl; /* 72 bytes */
 
-/* mp2p_icp::point_line_pair_t: TLine3D{pBase,director} + pt_local */
+/* mp2p_icp::point_line_pair_t (Pairings.h:61-73): TLine3D{pBase,director} + TPoint3D pt_local
+ * (a DOUBLE point, unlike the float point of point_plane_pair_t) */
 typedef struct
 {
     double pbase[3];
     double director[3];
-    float  lx, ly, lz;
-    float  _pad;
-} orc_pair_pt2ln; /* 64 bytes */
+    double lx, ly, lz;
+} orc_pair_pt2ln; /* 72 bytes */
+
+/* mp2p_icp::matched_plane_t (Pairings.h:37-48): two plane_patch_t {TPlane coefs, centroid} */
+typedef struct
+{
+    double pl_global[4], c_global[3];
+    double pl_local[4], c_local[3];
+} orc_pair_pl2pl; /* 112 bytes */
 
 enum
 {
@@ -106,7 +113,7 @@ typedef struct
     double   maxCost;                /* 0    */
     int32_t  kernel;                 /* ORC_KERNEL_*  */
     double   kernelParam;
-    double   w_pt2pt, w_pt2pl, w_pt2ln; /* PairWeights */
+    double   w_pt2pt, w_pt2pl, w_pt2ln, w_pl2pl; /* PairWeights */
     int32_t  has_prior;
     double   prior_mean[12];    /* pose                               */
     double   prior_cov_inv[36]; /* 6x6 row-major information matrix   */
@@ -136,6 +143,8 @@ void orc_jacob_dDexpe_de(const double T[12], double J[72]); /* 12x6 row-major */
 void orc_error_point2point(const orc_pair_pt2pt* p, const double T[12], double e[3],
                            double J1[36] /* 3x12 row-major, may be NULL */);
 void orc_error_point2plane(const orc_pair_pt2pl* p, const double T[12], double e[3],
+                           double J1[36]);
+void orc_error_plane2plane(const orc_pair_pl2pl* p, const double T[12], double e[3],
                            double J1[36]);
 void orc_error_point2line(const orc_pair_pt2ln* p, const double T[12], double e[3],
                           double J1[36]);
@@ -210,6 +219,7 @@ void orc_estimate_points_eigen(const float* xs, const float* ys, const float* zs
 int orc_optimal_tf_gauss_newton(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
                                 const orc_pair_pt2pl* pt2pl, size_t n_pt2pl,
                                 const orc_pair_pt2ln* pt2ln, size_t n_pt2ln,
+                                const orc_pair_pl2pl* pl2pl, size_t n_pl2pl,
                                 const double T0[12], const orc_gn_params* prm, double T_out[12],
                                 double* H_out, double* g_out);
 /* multi-threaded accumulation, CPU baseline only */

@@ -19,9 +19,12 @@ PAIR_PT2PL = np.dtype(
     [("plane", "<f8", (4,)), ("centroid", "<f8", (3,)), ("lx", "<f4"), ("ly", "<f4"),
      ("lz", "<f4"), ("_pad", "<f4")])
 PAIR_PT2LN = np.dtype(
-    [("pbase", "<f8", (3,)), ("director", "<f8", (3,)), ("lx", "<f4"), ("ly", "<f4"),
-     ("lz", "<f4"), ("_pad", "<f4")])
-assert PAIR_PT2PT.itemsize == 36 and PAIR_PT2PL.itemsize == 72 and PAIR_PT2LN.itemsize == 64
+    [("pbase", "<f8", (3,)), ("director", "<f8", (3,)), ("lx", "<f8"), ("ly", "<f8"), ("lz", "<f8")])
+PAIR_PL2PL = np.dtype(
+    [("pl_global", "<f8", (4,)), ("c_global", "<f8", (3,)), ("pl_local", "<f8", (4,)),
+     ("c_local", "<f8", (3,))])
+assert PAIR_PT2PT.itemsize == 36 and PAIR_PT2PL.itemsize == 72 and PAIR_PT2LN.itemsize == 72
+assert PAIR_PL2PL.itemsize == 112
 
 KERNEL_NONE, KERNEL_GEMANMCCLURE, KERNEL_CAUCHY = 0, 1, 2
 
@@ -45,7 +48,7 @@ class GNParams(C.Structure):
     _fields_ = [("maxInnerLoopIterations", C.c_uint32), ("minDelta", C.c_double),
                 ("maxCost", C.c_double), ("kernel", C.c_int32), ("kernelParam", C.c_double),
                 ("w_pt2pt", C.c_double), ("w_pt2pl", C.c_double), ("w_pt2ln", C.c_double),
-                ("has_prior", C.c_int32), ("prior_mean", C.c_double * 12),
+                ("w_pl2pl", C.c_double), ("has_prior", C.c_int32), ("prior_mean", C.c_double * 12),
                 ("prior_cov_inv", C.c_double * 36), ("n_weight_blocks", C.c_uint32),
                 ("weight_block_count", C.POINTER(C.c_size_t)),
                 ("weight_block_w", C.POINTER(C.c_double)),
@@ -89,7 +92,8 @@ def _declare(L):
     L.orc_se3_exp.argtypes = [_dp, _dp]
     L.orc_se3_log.argtypes = [_dp, _dp]
     L.orc_jacob_dDexpe_de.argtypes = [_dp, _dp]
-    for n in ("orc_error_point2point", "orc_error_point2plane", "orc_error_point2line"):
+    for n in ("orc_error_point2point", "orc_error_point2plane", "orc_error_point2line",
+              "orc_error_plane2plane"):
         getattr(L, n).argtypes = [C.c_void_p, _dp, _dp, _dp]
     L.orc_robust_weight.argtypes = [C.c_int32, C.c_double, C.c_double]
     L.orc_robust_weight.restype = C.c_double
@@ -126,7 +130,7 @@ def _declare(L):
     L.orc_match_pt2pl_subset.restype = C.c_size_t
     L.orc_estimate_points_eigen.argtypes = [_fp, _fp, _fp, C.c_size_t, _fp, _dp, _dp, _dp]
     L.orc_optimal_tf_gauss_newton.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                                              C.c_void_p, C.c_size_t, _dp,
+                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _dp,
                                               C.POINTER(GNParams), _dp, _dp, _dp]
     L.orc_optimal_tf_gauss_newton.restype = C.c_int
     L.orc_optimal_tf_gauss_newton_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
@@ -241,6 +245,10 @@ def error_point2plane(pair, T):
 
 def error_point2line(pair, T):
     return _err_term("orc_error_point2line", pair, T)
+
+
+def error_plane2plane(pair, T):
+    return _err_term("orc_error_plane2plane", pair, T)
 
 
 def robust_weight(kernel, c, esq):
@@ -360,12 +368,12 @@ def estimate_points_eigen(xs, ys, zs):
 
 def make_gn_params(maxIterations, kernel=KERNEL_NONE, kernelParam=1.0, w_pt2pt=1.0, w_pt2pl=1.0,
                    w_pt2ln=1.0, prior_mean=None, prior_cov_inv=None, minDelta=1e-7, maxCost=0.0,
-                   weight_blocks=None, reset_weight_cursor_each_iter=0):
+                   weight_blocks=None, reset_weight_cursor_each_iter=0, w_pl2pl=1.0):
     p = GNParams()
     p.maxInnerLoopIterations = maxIterations
     p.minDelta, p.maxCost = minDelta, maxCost
     p.kernel, p.kernelParam = kernel, kernelParam
-    p.w_pt2pt, p.w_pt2pl, p.w_pt2ln = w_pt2pt, w_pt2pl, w_pt2ln
+    p.w_pt2pt, p.w_pt2pl, p.w_pt2ln, p.w_pl2pl = w_pt2pt, w_pt2pl, w_pt2ln, w_pl2pl
     p.has_prior = 0
     keep = []
     if prior_mean is not None:
@@ -385,8 +393,9 @@ def make_gn_params(maxIterations, kernel=KERNEL_NONE, kernelParam=1.0, w_pt2pt=1
     return p
 
 
-def optimal_tf_gauss_newton(pt2pt, pt2pl, pt2ln, T0, prm, threads=0):
+def optimal_tf_gauss_newton(pt2pt, pt2pl, pt2ln, T0, prm, threads=0, pl2pl=None):
     """Returns (T, iters, H, g)."""
+    pl2pl = np.ascontiguousarray(pl2pl if pl2pl is not None else np.zeros(0, PAIR_PL2PL))
     T0 = np.ascontiguousarray(T0, dtype=np.float64)
     pt2pt = np.ascontiguousarray(pt2pt if pt2pt is not None else np.zeros(0, PAIR_PT2PT))
     pt2pl = np.ascontiguousarray(pt2pl if pt2pl is not None else np.zeros(0, PAIR_PT2PL))
@@ -399,7 +408,8 @@ def optimal_tf_gauss_newton(pt2pt, pt2pl, pt2ln, T0, prm, threads=0):
                                                   C.byref(prm), _d(T), threads)
         return T, it, None, None
     it = lib().orc_optimal_tf_gauss_newton(pt2pt.ctypes.data, pt2pt.size, pt2pl.ctypes.data,
-                                           pt2pl.size, pt2ln.ctypes.data, pt2ln.size, _d(T0),
+                                           pt2pl.size, pt2ln.ctypes.data, pt2ln.size,
+                                           pl2pl.ctypes.data, pl2pl.size, _d(T0),
                                            C.byref(prm), _d(T), _d(H), _d(g))
     return T, it, H.reshape(6, 6), g
 

@@ -205,3 +205,105 @@ def test_horn_parity(amd, oracle):
     assert s.optimal_pose(p, out, amd.SolverContext())
     To, ok = oracle.optimal_tf_horn(pt)
     assert ok and _close(oracle, out.optimalPose, To)
+
+
+# ---- paired_pt2ln / paired_pl2pl in the solver ---------------------------------------------------
+def _to_hip_pt2ln(o):
+    from mp2p_icp_amd import _lib
+    h = np.zeros(len(o), _lib.PAIR_PT2LN)
+    h["ln_base"], h["ln_director"] = o["pbase"], o["director"]
+    h["pt_local"] = np.stack([o["lx"], o["ly"], o["lz"]], 1)
+    return h
+
+
+def _to_hip_pl2pl(o):
+    from mp2p_icp_amd import _lib
+    h = np.zeros(len(o), _lib.PAIR_PL2PL)
+    for k in ("pl_global", "c_global", "pl_local", "c_local"):
+        h[k] = o[k]
+    return h
+
+
+def _solve_all(amd, pt, pl, ln, pp, T0, solver_params):
+    ctx = amd.default_context()
+    p = amd.Pairings.from_host(ctx, _to_hip_pt2pt(amd, pt) if pt is not None else None,
+                               _to_hip_pt2pl(amd, pl) if pl is not None else None,
+                               pt2ln=_to_hip_pt2ln(ln) if ln is not None else None,
+                               pl2pl=_to_hip_pl2pl(pp) if pp is not None else None)
+    s = amd.Solver_GaussNewton()
+    s.initialize(solver_params)
+    sc = amd.SolverContext()
+    sc.guessRelativePose = T0
+    out = amd.OptimalTF_Result()
+    assert s.optimal_pose(p, out, sc)
+    return out, p
+
+
+def test_optimize_pt2ln_kat(amd, oracle):
+    """tests/test-mp2p_optimize_pt2ln.cpp:25-76 through the HIP solver"""
+    from test_oracle_kat import PT2PL_POSES
+    for pose in PT2PL_POSES:
+        gt = oracle.pose_from_xyzypr(*pose)
+        ln = np.zeros(3, oracle.PAIR_PT2LN)
+        specs = [((1, 0, 0), (0.5, 0, 0)), ((0, 1, 0), (0, 0.4, 0)), ((0, 0, 1), (0, 0, 0.2))]
+        for i, (d, gp) in enumerate(specs):
+            ln[i]["pbase"] = (0, 0, 0)
+            ln[i]["director"] = d
+            ln[i]["lx"], ln[i]["ly"], ln[i]["lz"] = oracle.pose_inverse_compose_point(gt, gp)
+        out, _ = _solve_all(amd, None, None, ln, None, oracle.pose_identity(), {"maxIterations": 25})
+        assert oracle.pose_err(out.optimalPose, gt) < 1e-3, pose          # reference assertion
+        To, it, *_ = oracle.optimal_tf_gauss_newton(None, None, ln, oracle.pose_identity(),
+                                                    oracle.make_gn_params(25))
+        assert _close(oracle, out.optimalPose, To), pose
+        assert out.gn["iterations"] == it
+
+
+@pytest.mark.parametrize("kname,kid,kparam", KERNELS)
+def test_all_term_kinds_parity(amd, oracle, kname, kid, kparam):
+    """pt2pt + pt2pl + pt2ln + pl2pl together, non-unit directors / normals, pair weights"""
+    from test_oracle_kat import _random_pt_pl_pairs
+    rng = np.random.default_rng(123)
+    gt = oracle.pose_from_xyzypr(0.2, -0.1, 0.05, 1.5 * DEG, -2 * DEG, 1 * DEG)
+    R, t = gt[:9].reshape(3, 3), gt[9:]
+    pt, pp = _random_pt_pl_pairs(oracle, rng, gt, 3000, 500, noise=0.01)
+    pt["lx"], pt["ly"], pt["lz"] = [pt[k].astype(np.float32) for k in ("lx", "ly", "lz")]
+    pp["pl_local"][:, :3] += rng.normal(0, 0.01, (500, 3))              # noisy, non-unit normals
+    pp["pl_global"] *= rng.uniform(0.5, 1.5, (500, 1))
+    n_ln = 800
+    ln = np.zeros(n_ln, oracle.PAIR_PT2LN)
+    base = rng.uniform(-10, 10, (n_ln, 3))
+    u = rng.normal(size=(n_ln, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    on_line = base + u * rng.uniform(-5, 5, (n_ln, 1))
+    loc = (on_line - t) @ R + rng.normal(0, 0.01, (n_ln, 3))
+    ln["pbase"], ln["director"] = base, u * rng.uniform(0.9, 1.1, (n_ln, 1))
+    ln["lx"], ln["ly"], ln["lz"] = loc.T
+    n_pl = 700
+    l2 = rng.uniform(-10, 10, (n_pl, 3))
+    nrm = rng.normal(size=(n_pl, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    w2 = l2 @ R.T + t
+    pl = np.zeros(n_pl, oracle.PAIR_PT2PL)
+    pl["plane"] = np.concatenate([nrm, -(nrm * (w2 + rng.normal(0, 0.01, (n_pl, 3)))).sum(1)[:, None]], 1)
+    pl["centroid"] = w2
+    pl["lx"], pl["ly"], pl["lz"] = l2.T.astype(np.float32)
+    weights = {"pt2pt": 1.2, "pt2pl": 0.8, "pt2ln": 1.5, "ln2ln": 1.0, "pl2pl": 2.5}
+    T0 = oracle.pose_identity()
+    for iters in (1, 5):
+        sp = {"maxIterations": iters, "robustKernel": kname, "robustKernelParam": kparam,
+              "pair_weights": weights}
+        out, p = _solve_all(amd, pt, pl, ln, pp, T0, sp)
+        To, it, H, g = oracle.optimal_tf_gauss_newton(
+            pt, pl, ln, T0, oracle.make_gn_params(iters, kernel=kid, kernelParam=kparam, w_pt2pt=1.2,
+                                                  w_pt2pl=0.8, w_pt2ln=1.5, w_pl2pl=2.5), pl2pl=pp)
+        assert _close(oracle, out.optimalPose, To), oracle.pose_err_split(out.optimalPose, To)
+        assert out.gn["iterations"] == it
+        if iters == 1:
+            assert np.allclose(out.gn["H"], H, rtol=1e-9, atol=1e-9 * np.abs(H).max())
+            assert np.allclose(out.gn["g"], g, rtol=1e-9, atol=1e-9 * np.abs(g).max())
+    assert p.size() == 3000 + n_pl + n_ln + 500
+    assert p.device.counts_lines_planes() == (n_ln, 500)
+    # lines and planes alone (no point lists at all)
+    out, _ = _solve_all(amd, None, None, ln, pp, T0, {"maxIterations": 6})
+    To, *_ = oracle.optimal_tf_gauss_newton(None, None, ln, T0, oracle.make_gn_params(6), pl2pl=pp)
+    assert _close(oracle, out.optimalPose, To)

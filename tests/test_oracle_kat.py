@@ -157,7 +157,7 @@ def _numeric_jac(fn, T, oracle, h=1e-6):
     return J
 
 
-@pytest.mark.parametrize("kind", ["pt2pt", "pt2pl", "pt2ln"])
+@pytest.mark.parametrize("kind", ["pt2pt", "pt2pl", "pt2ln", "pl2pl"])
 def test_error_term_jacobians(oracle, kind):
     rng = np.random.default_rng(1234)
     for _ in range(200):
@@ -172,13 +172,19 @@ def test_error_term_jacobians(oracle, kind):
             n = rng.normal(size=3)
             pair[0]["plane"] = _plane_from_point_normal(rng.uniform(-5, 5, 3), n) * rng.uniform(0.5, 2)
             f = oracle.error_point2plane
+        elif kind == "pl2pl":
+            pair = np.zeros(1, oracle.PAIR_PL2PL)
+            pair[0]["pl_global"] = _plane_from_point_normal(rng.uniform(-5, 5, 3), rng.normal(size=3))
+            pair[0]["pl_local"] = _plane_from_point_normal(rng.uniform(-5, 5, 3), rng.normal(size=3))
+            f = oracle.error_plane2plane
         else:
             pair = np.zeros(1, oracle.PAIR_PT2LN)
             d = rng.normal(size=3)
             pair[0]["director"] = d / np.linalg.norm(d)
             pair[0]["pbase"] = rng.uniform(-5, 5, 3)
             f = oracle.error_point2line
-        pair[0]["lx"], pair[0]["ly"], pair[0]["lz"] = rng.uniform(-10, 10, 3)
+        if kind != "pl2pl":
+            pair[0]["lx"], pair[0]["ly"], pair[0]["lz"] = rng.uniform(-10, 10, 3)
         e, J1 = f(pair, T)
         Ja = J1 @ oracle.jacob_dDexpe_de(T)
         Jn = _numeric_jac(lambda TT: f(pair, TT)[0], T, oracle)
@@ -310,3 +316,46 @@ def test_oracle_visit_list_and_pairings_per_point(oracle):
         pos = {int(v): i for i, v in enumerate(order)}
         ranks = [pos[int(v)] for v in c["localIdx"]]
         assert ranks == sorted(ranks)
+
+
+def _random_pt_pl_pairs(oracle, rng, gt, n_pts, n_planes, noise=0.0):
+    """tests/test-mp2p_optimal_tf_algos.cpp:100-257 (transform_points_planes): global points /
+    planes, local = inverse-transformed (+ noise); own RNG (MRPT's stream is not reproducible)"""
+    R, t = gt[:9].reshape(3, 3), gt[9:]
+    pt = np.zeros(n_pts, oracle.PAIR_PT2PT)
+    for i in range(n_pts):
+        g = rng.uniform(-10, 10, 3)
+        l = R.T @ (g - t) + rng.normal(0, noise, 3)
+        pt[i]["gx"], pt[i]["gy"], pt[i]["gz"] = g
+        pt[i]["lx"], pt[i]["ly"], pt[i]["lz"] = l
+        pt[i]["globalIdx"] = pt[i]["localIdx"] = i
+    pl = np.zeros(n_planes, oracle.PAIR_PL2PL)
+    for i in range(n_planes):
+        cg = rng.uniform(-10, 10, 3)
+        ng = rng.normal(size=3)
+        ng /= np.linalg.norm(ng)
+        cl = R.T @ (cg - t)
+        nl = R.T @ ng
+        pl[i]["pl_global"] = (*ng, -ng @ cg)
+        pl[i]["c_global"] = cg
+        pl[i]["pl_local"] = (*nl, -nl @ cl)
+        pl[i]["c_local"] = cl
+    return pt, pl
+
+
+def test_optimize_points_and_planes(oracle):
+    """tests/test-mp2p_optimal_tf_algos.cpp:300-460: point pairs + plane-normal pairs in the
+    Gauss-Newton solver recover the ground-truth pose (noise-free: to 1e-6)."""
+    rng = np.random.default_rng(99)
+    for rep in range(20):
+        gt = oracle.pose_from_xyzypr(*rng.uniform(-4, 4, 3), *rng.uniform(-0.5, 0.5, 3))
+        pt, pl = _random_pt_pl_pairs(oracle, rng, gt, 10, 10)
+        prm = oracle.make_gn_params(maxIterations=40)
+        T, *_ = oracle.optimal_tf_gauss_newton(pt, None, None, oracle.pose_identity(), prm, pl2pl=pl)
+        assert oracle.pose_err(T, gt) < 1e-6
+    # plane normals alone fix the rotation; the translation then stays at the guess
+    gt = oracle.pose_from_xyzypr(0, 0, 0, 0.3, -0.2, 0.1)
+    _, pl = _random_pt_pl_pairs(oracle, rng, gt, 0, 12)
+    T, *_ = oracle.optimal_tf_gauss_newton(None, None, None, oracle.pose_identity(),
+                                           oracle.make_gn_params(maxIterations=40), pl2pl=pl)
+    assert np.allclose(T[:9], gt[:9], atol=1e-6)

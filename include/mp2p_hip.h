@@ -346,7 +346,8 @@ typedef struct
     uint64_t nn_single_max_passes, nn_single_max_cells;
 } mp2p_hip_stats;
 /* 0 = off; 1 = bracket the kernels with hipEvents (ms_* fields; each call then ends with a
- * stream synchronisation); 2 = additionally collect the device counters (nn_* fields, slower). */
+ * stream synchronisation); 2 = additionally collect the device counters (nn_* fields, slower);
+ * 3 = only the two events around the search kernels (ms_nn; the cheapest timing). */
 int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable);
 int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out);
 

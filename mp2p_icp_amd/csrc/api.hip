@@ -490,7 +490,7 @@ int mp2p_hip_horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, double w
 int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable)
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;
-    ctx->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    ctx->profiling = enable < 0 ? 0 : (enable > 3 ? 3 : enable);
     return MP2P_HIP_OK;
 }
 
@@ -502,12 +502,16 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
     {
         float ms_nn = 0, ms_cp = 0;
         MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_nn, ctx->ev[0], ctx->ev[1]));
-        float ms_tile = 0;
-        MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_tile, ctx->ev[0], ctx->ev[6]));
-        ctx->stats.ms_nn_tile = ms_tile, ctx->stats.ms_nn_single = ms_nn - ms_tile;
-        MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_cp, ctx->ev[2], ctx->ev[3]));
-        ctx->stats.ms_nn = ms_nn, ctx->stats.ms_compact = ms_cp;
-        if (ctx->pending_match >= 2)
+        ctx->stats.ms_nn = ms_nn;
+        if (ctx->pending_match != 3)
+        {
+            float ms_tile = 0;
+            MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_tile, ctx->ev[0], ctx->ev[6]));
+            ctx->stats.ms_nn_tile = ms_tile, ctx->stats.ms_nn_single = ms_nn - ms_tile;
+            MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_cp, ctx->ev[2], ctx->ev[3]));
+            ctx->stats.ms_compact = ms_cp;
+        }
+        if (ctx->pending_match == 2)
         {
             unsigned long long c[64];
             MP2P_TRY_HIP(ctx, hipMemcpy(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost));

@@ -86,7 +86,9 @@ struct mp2p_hip_ctx
     hipStream_t stream     = nullptr;
     bool        own_stream = false;
     std::string err;
-    int         profiling = 0;  // 0 off, 1 hipEvent timing, 2 + device counters
+    int         profiling = 0;  // 0 off, 1 hipEvent timing of every stage, 2 + device counters,
+                                // 3 only the two events around the search kernels
+    bool        prof_all() const { return profiling == 1 || profiling == 2; }
     hipEvent_t  ev[7]     = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int         pending_match = 0, pending_gn = 0;
     size_t      pending_map_n = 0;

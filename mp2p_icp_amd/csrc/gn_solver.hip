@@ -630,7 +630,7 @@ int gn_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[
     ctx->gn.pairs  = pairs;
     ctx->gn.prm    = *prm;
     ctx->gn.active = true;
-    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     return MP2P_HIP_OK;
 }
 
@@ -699,7 +699,7 @@ int gn_end(mp2p_hip_ctx* ctx, mp2p_hip_gn_result* out)
 {
     MP2P_REQUIRE(ctx, ctx->gn.active, "gn_end without gn_begin");
     double st[ST_SIZE];
-    if (ctx->profiling)
+    if (ctx->prof_all())
     {
         MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
         ctx->pending_gn = 1;

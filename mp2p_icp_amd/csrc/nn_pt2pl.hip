@@ -587,13 +587,13 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     c.o_lidx = out->pl_lidx.p, c.o_coef = out->pl_coef.p, c.o_cen = out->pl_cen.p;
     c.o_lx = out->pl_lx.p, c.o_ly = out->pl_ly.p, c.o_lz = out->pl_lz.p;
     c.ms_local = ms ? ms->local_taken.p : nullptr;
-    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     hipLaunchKernelGGL(pl_count_kernel, dim3(n_blocks), dim3(PC_THREADS), 0, ctx->stream, c);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream,
                        ctx->block_counts.p, n_blocks, out->counts.p, c.cap,
                        (unsigned long long)n_slots, 1);
     hipLaunchKernelGGL(pl_write_kernel, dim3(n_blocks), dim3(PC_THREADS), 0, ctx->stream, c);
-    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
 }
@@ -639,11 +639,8 @@ int launch_nn_pt2pt_knn(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_h
     else if (K <= 8) launch_knn_k<8>(a, n_tiles, ctx->stream);
     else if (K <= 12) launch_knn_k<12>(a, n_tiles, ctx->stream);
     else launch_knn_k<16>(a, n_tiles, ctx->stream);
-    if (ctx->profiling)
-    {
-        MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-        MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    }
+    if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     const int rc = launch_bbox_reduce(ctx, n_tiles);
     if (rc) return rc;
     MP2P_TRY_HIP(ctx, hipGetLastError());

@@ -771,7 +771,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     for (int i = 0; i < 12; i++) ctx->hint_pose[i] = pose[i];
     a.counters     = nullptr;
     a.touched      = nullptr;
-    if (ctx->profiling >= 2)
+    if (ctx->profiling == 2)
     {
         MP2P_TRY_HIP(ctx, ctx->counters.ensure(64));
         MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64 * sizeof(unsigned long long), ctx->stream));
@@ -797,12 +797,12 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         else if (Q == 32) MP2P_LAUNCH_TILE(32);
         else MP2P_LAUNCH_TILE(16);
 #undef MP2P_LAUNCH_TILE
-        if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         // deferred queries: the count lives on the device; a fixed grid strides over it
         if (instr) hipLaunchKernelGGL(nn_single_kernel<true>, dim3(single_blocks), dim3(64), 0, ctx->stream, a);
         else hipLaunchKernelGGL(nn_single_kernel<false>, dim3(single_blocks), dim3(64), 0, ctx->stream, a);
     }
-    else if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    else if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     int rc = launch_bbox_reduce(ctx, n_tiles);
     if (rc) return rc;

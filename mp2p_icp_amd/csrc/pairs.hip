@@ -210,14 +210,14 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     a.ms_local  = ms ? ms->local_taken.p : nullptr;
     a.ms_global = ms ? ms->global_taken.p : nullptr;
 
-    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (n_blocks)
         hipLaunchKernelGGL(compact_count_kernel, dim3(n_blocks), dim3(CP_THREADS), 0, ctx->stream, a);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream,
                        ctx->block_counts.p, n_blocks, out->counts.p, a.cap, a.potential_add, 0);
     if (n_blocks)
         hipLaunchKernelGGL(compact_write_kernel, dim3(n_blocks), dim3(CP_THREADS), 0, ctx->stream, a);
-    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
 }

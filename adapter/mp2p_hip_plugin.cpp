@@ -30,9 +30,13 @@
 #include <mp2p_icp/metricmap.h>
 #include <mrpt/core/initializer.h>
 #include <mrpt/maps/CPointsMap.h>
+#include <mrpt/random/random_shuffle.h>
 #include <mrpt/rtti/CObject.h>
 
+#include <chrono>
 #include <cstring>
+#include <numeric>
+#include <random>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -68,6 +72,7 @@ struct Runtime
     mp2p_hip_pairs* dev_pairs = nullptr;
     size_t          dev_cap_pt = 0, dev_cap_pl = 0;
     size_t          token_n_pt = 0, token_n_pl = 0;
+    bool            has_lines_planes = false;
     uint32_t        token_first = 0, token_last = 0;
 
     static Runtime& get()
@@ -168,14 +173,28 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base
         ASSERT_(pairingsPerPoint >= 1);
         ASSERT_GT_(threshold, .0);
         ASSERT_GE_(thresholdAngularDeg, .0);
-        if (maxLocalPointsPerLayer_ != 0 && pcLocal.size() > maxLocalPointsPerLayer_)
-            THROW_EXCEPTION("maxLocalPointsPerLayer is not supported by the HIP matcher");
+        ASSERT_LE_(pairingsPerPoint, 16u);
         const auto* gl = mp2p_icp::MapToPointsMap(pcGlobal);
         if (!gl) THROW_EXCEPTION("HIP matcher: the global layer must be a CPointsMap");
 
         auto& rt = Runtime::get();
-        out.potential_pairings += pcLocal.size() * pairingsPerPoint;  // :64 (the library adds the
-        if (pcGlobal.isEmpty() || pcLocal.empty()) return;           //  same amount on its side)
+        // maxLocalPointsPerLayer: the SAME list the reference would visit (Matcher_Points_Base.cpp:
+        // 222-232), drawn here with MRPT's own shuffle and handed to the library
+        std::vector<uint32_t> visit;
+        if (maxLocalPointsPerLayer_ != 0 && pcLocal.size() > maxLocalPointsPerLayer_)
+        {
+            std::vector<std::size_t> idxs(maxLocalPointsPerLayer_);
+            std::iota(idxs.begin(), idxs.end(), 0);
+            const unsigned int seed = localPointsSampleSeed_ != 0
+                                          ? localPointsSampleSeed_
+                                          : std::chrono::system_clock::now().time_since_epoch().count();
+            mrpt::random::partial_shuffle(idxs.begin(), idxs.end(), std::default_random_engine(seed),
+                                          maxLocalPointsPerLayer_);
+            visit.assign(idxs.begin(), idxs.end());
+        }
+        const size_t nVisited = visit.empty() ? pcLocal.size() : visit.size();
+        out.potential_pairings += nVisited * pairingsPerPoint;  // :64 (the library adds the
+        if (pcGlobal.isEmpty() || pcLocal.empty()) return;     //  same amount on its side)
 
         mp2p_hip_pt2pt_params prm;
         std::memset(&prm, 0, sizeof(prm));
@@ -205,7 +224,9 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base
 
         mp2p_hip_pairs* dp = rt.pairs(out.paired_pt2pt.size() + pcLocal.size() * pairingsPerPoint, rt.dev_cap_pl);
         if (out.paired_pt2pt.empty() && out.paired_pt2pl.empty()) rt.check(mp2p_hip_pairs_clear(rt.ctx, dp));
-        const int rc = mp2p_hip_match_pt2pt(rt.ctx, rt.global_layer(*gl), rt.local_layer(pcLocal), T, &prm, dms, dp);
+        mp2p_hip_cloud* dl = rt.local_layer(pcLocal);
+        rt.check(mp2p_hip_cloud_set_visit_order(rt.ctx, dl, visit.empty() ? nullptr : visit.data(), visit.size()));
+        const int rc = mp2p_hip_match_pt2pt(rt.ctx, rt.global_layer(*gl), dl, T, &prm, dms, dp);
         if (rc)
         {
             mp2p_hip_mstate_free(rt.ctx, dms);
@@ -261,8 +282,8 @@ class Solver_GaussNewton : public mp2p_icp::Solver
         checkAllParametersAreRealized();
         out = mp2p_icp::OptimalTF_Result();
         ASSERT_(sc.guessRelativePose.has_value());
-        if (!pairings.paired_pt2ln.empty() || !pairings.paired_ln2ln.empty() || !pairings.paired_pl2pl.empty())
-            THROW_EXCEPTION("HIP Gauss-Newton: only pt2pt and pt2pl pairings are implemented");
+        if (!pairings.paired_ln2ln.empty())
+            THROW_EXCEPTION("HIP Gauss-Newton: paired_ln2ln is not supported");
         auto& rt = Runtime::get();
 
         const size_t n1 = pairings.paired_pt2pt.size(), n2 = pairings.paired_pt2pl.size();
@@ -288,6 +309,29 @@ class Solver_GaussNewton : public mp2p_icp::Solver
             rt.token_n_pt = 0;
         }
 
+        {  // paired_pt2ln / paired_pl2pl always come from host matchers: (re)upload, also when empty
+            std::vector<mp2p_hip_pair_pt2ln> ln(pairings.paired_pt2ln.size());
+            for (size_t i = 0; i < ln.size(); i++)
+            {
+                const auto& q = pairings.paired_pt2ln[i];
+                for (int k = 0; k < 3; k++)
+                    ln[i].ln_base[k] = q.ln_global.pBase[k], ln[i].ln_director[k] = q.ln_global.director[k],
+                    ln[i].pt_local[k] = q.pt_local[k];
+            }
+            std::vector<mp2p_hip_pair_pl2pl> pp(pairings.paired_pl2pl.size());
+            for (size_t i = 0; i < pp.size(); i++)
+            {
+                const auto& q = pairings.paired_pl2pl[i];
+                for (int k = 0; k < 4; k++)
+                    pp[i].pl_global[k] = q.p_global.plane.coefs[k], pp[i].pl_local[k] = q.p_local.plane.coefs[k];
+                for (int k = 0; k < 3; k++)
+                    pp[i].c_global[k] = q.p_global.centroid[k], pp[i].c_local[k] = q.p_local.centroid[k];
+            }
+            if (!ln.empty() || !pp.empty() || rt.has_lines_planes)
+                rt.check(mp2p_hip_pairs_upload_lines_planes(rt.ctx, dp, ln.data(), ln.size(), pp.data(), pp.size()));
+            rt.has_lines_planes = !ln.empty() || !pp.empty();
+        }
+
         mp2p_hip_gn_params p;
         std::memset(&p, 0, sizeof(p));
         p.maxInnerLoopIterations = maxIterations;
@@ -295,6 +339,7 @@ class Solver_GaussNewton : public mp2p_icp::Solver
         p.kernel      = static_cast<int32_t>(robustKernel);
         p.kernelParam = robustKernelParam;
         p.w_pt2pt = pairWeights.pt2pt, p.w_pt2pl = pairWeights.pt2pl;
+        p.w_pt2ln = pairWeights.pt2ln, p.w_pl2pl = pairWeights.pl2pl;
         ASSERT_(pairings.point_weights.size() <= 8);
         p.n_weight_blocks = static_cast<uint32_t>(pairings.point_weights.size());
         for (size_t i = 0; i < pairings.point_weights.size(); i++)

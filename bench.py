@@ -318,8 +318,8 @@ def main():
         import csv
         t = 0.0
         for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc.csv"))):
-            if r["kernel"].strip('"') in ("void mp2p::nn_tile_kernel<32, false>",
-                                          "void mp2p::nn_single_kernel<false>"):
+            if r["kernel"].strip('"').startswith(("void mp2p::nn_tile_kernel<32, false>",
+                                                   "void mp2p::nn_single_kernel<false>")):
                 t += float(r["fetch_bytes_avg_corrected_x2"]) + float(r["write_bytes_avg"])
         if t > 0 and args.n_local == 1_000_000 and args.n_global == 10_000_000 and world == 1:
             out["roofline"]["traffic"] = t

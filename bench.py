@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--q", type=int, default=0, help="queries per wave (tuning)")
     ap.add_argument("--r0", type=float, default=0.0, help="initial radius in cells (tuning)")
     ap.add_argument("--grp", type=float, default=0.0, help="group radius factor (tuning)")
+    ap.add_argument("--no-bitmap", action="store_true", help="build the map without occupancy bitmaps")
     ap.add_argument("--no-events", action="store_true", help="timed loop without hipEvents (overhead probe)")
     ap.add_argument("--cold", action="store_true", help="disable the warm start from the previous iteration")
     ap.add_argument("--defer", type=float, default=0.0, help="defer radius in cells (tuning)")
@@ -147,7 +148,7 @@ def main():
     g, l = d["glob"], d["local"]
     t0 = time.time()
     gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2], cell_size=args.cell,
-                          target_per_cell=args.target_per_cell)
+                          target_per_cell=args.target_per_cell, no_occupancy_bitmap=args.no_bitmap)
     info = gmap.info()
     t_index = time.time() - t0
     t0 = time.time()

@@ -66,6 +66,7 @@ typedef struct
     float    cell_size;       /* finest voxel edge [m]; <=0 = choose from the point density   */
     float    target_per_cell; /* density target for the automatic choice (<=0 -> 6)           */
     uint32_t max_levels;      /* 0 -> default (12)                                            */
+    uint32_t no_occupancy_bitmap; /* 1 = do not build the dense occupancy bitmaps (probe only) */
 } mp2p_hip_map_params;
 
 typedef struct

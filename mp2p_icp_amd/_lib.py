@@ -27,7 +27,7 @@ GN_NSUMS = 48
 
 class MapParams(C.Structure):
     _fields_ = [("cell_size", C.c_float), ("target_per_cell", C.c_float),
-                ("max_levels", C.c_uint32)]
+                ("max_levels", C.c_uint32), ("no_occupancy_bitmap", C.c_uint32)]
 
 
 class MapInfo(C.Structure):

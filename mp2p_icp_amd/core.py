@@ -81,10 +81,10 @@ class GlobalMap:
     """NN index of one global point layer (replaces the layer's NearestNeighborsCapable)."""
 
     def __init__(self, ctx, x, y, z, cell_size=0.0, target_per_cell=0.0, max_levels=0,
-                 device_ptrs=False):
+                 device_ptrs=False, no_occupancy_bitmap=False):
         self.ctx = ctx
         L = ctx._L
-        prm = _lib.MapParams(cell_size, target_per_cell, max_levels)
+        prm = _lib.MapParams(cell_size, target_per_cell, max_levels, int(no_occupancy_bitmap))
         h = C.c_void_p()
         if device_ptrs:
             n = int(device_ptrs)

@@ -38,7 +38,14 @@ struct GridView
     uint32_t      n_levels;        // level j uses shift0+j
     float         bbmin[3], bbmax[3];
     float         slack;           // fp32 rounding slack for conservative geometric tests [m]
+    // dense occupancy bitmaps, one per level, in 4x4x4 bricks (one u64 per brick, x fastest):
+    // tested before a hash probe, because most voxels of a search box are empty and an
+    // unsuccessful probe is a random 16-byte read of a table that does not fit any cache
+    const unsigned long long* occ;          // all levels in one allocation, or null
+    uint32_t                  occ_off[16];  // first word of level l, OCC_NONE = no bitmap for it
+    uint32_t                  occ_bx[16], occ_by[16], occ_bz[16];  // bricks per axis
 };
+constexpr uint32_t OCC_NONE = 0xFFFFFFFFu;
 
 // ---------------------------------------------------------------------------------------
 // host-side objects behind the opaque C handles
@@ -129,6 +136,7 @@ struct mp2p_hip_map
     mp2p::DevBuf<float4>             pts;     // Morton-sorted {x,y,z,idx}
     mp2p::DevBuf<mp2p::Cell>         table;
     mp2p::DevBuf<unsigned long long> claims;  // [n] indexed by SORTED position
+    mp2p::DevBuf<unsigned long long> occ;     // occupancy bitmaps of all levels
     mp2p::GridView                   view{};
     mp2p_hip_map_info                info{};
 };

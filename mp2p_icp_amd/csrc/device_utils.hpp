@@ -221,6 +221,18 @@ __device__ __host__ __forceinline__ uint64_t hash_key(unsigned long long k)
     return h;
 }
 
+// false = the voxel is certainly empty (no probe needed); true = occupied, or no bitmap to tell
+__device__ __forceinline__ bool occ_maybe(const GridView& g, uint32_t lev, uint32_t cx, uint32_t cy,
+                                          uint32_t cz)
+{
+    const uint32_t off = g.occ_off[lev];
+    if (off == OCC_NONE) return true;
+    const uint32_t bx = cx >> 2, by = cy >> 2, bz = cz >> 2;
+    if (bx >= g.occ_bx[lev] || by >= g.occ_by[lev] || bz >= g.occ_bz[lev]) return false;
+    const unsigned long long w = g.occ[(size_t)off + ((size_t)bz * g.occ_by[lev] + by) * g.occ_bx[lev] + bx];
+    return (w >> (((cz & 3u) << 4) | ((cy & 3u) << 2) | (cx & 3u))) & 1ull;
+}
+
 // returns true and [start,end) when the voxel is occupied
 __device__ __forceinline__ bool cell_lookup(const GridView& g, unsigned long long key,
                                             uint32_t& start, uint32_t& end)

@@ -146,12 +146,19 @@ __device__ __forceinline__ void hash_set_end(Cell* table, uint64_t mask, unsigne
 }
 
 // pass 0: voxel heads -> insert {key,start}; pass 1: voxel tails -> set end
+struct OccBuild
+{
+    unsigned long long* words;
+    uint32_t            off[16], bx[16], by[16];
+};
+
 template <int PASS>
 __global__ __launch_bounds__(256) void cells_kernel(const unsigned long long* __restrict__ keys,
                                                     const float4* __restrict__ pts, uint32_t n,
                                                     float ox, float oy, float oz, float inv_hf,
                                                     uint32_t shift0, uint32_t n_levels,
-                                                    Cell* __restrict__ table, uint64_t mask)
+                                                    Cell* __restrict__ table, uint64_t mask,
+                                                    const OccBuild occ)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (PASS == 0)
@@ -164,8 +171,13 @@ __global__ __launch_bounds__(256) void cells_kernel(const unsigned long long* __
                        fz = cell_fine(p.z, oz, inv_hf);
         for (uint32_t l = 0; l < n_levels && (int)(shift0 + l) <= g; l++)
         {
-            const uint32_t s = shift0 + l;
-            hash_insert(table, mask, cell_key(l, fx >> s, fy >> s, fz >> s), i);
+            const uint32_t s  = shift0 + l;
+            const uint32_t cx = fx >> s, cy = fy >> s, cz = fz >> s;
+            hash_insert(table, mask, cell_key(l, cx, cy, cz), i);
+            if (occ.words && occ.off[l] != OCC_NONE)  // one bit per occupied voxel (this is its head)
+                atomicOr(&occ.words[(size_t)occ.off[l] +
+                                    ((size_t)(cz >> 2) * occ.by[l] + (cy >> 2)) * occ.bx[l] + (cx >> 2)],
+                         1ull << (((cz & 3u) << 4) | ((cy & 3u) << 2) | (cx & 3u)));
         }
     }
     else
@@ -313,12 +325,42 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
     while (cap < 2 * total_cells) cap <<= 1;
     MP2P_TRY_HIP(ctx, map->table.alloc(cap));
     MP2P_TRY_HIP(ctx, hipMemsetAsync(map->table.p, 0xFF, cap * sizeof(Cell), ctx->stream));
+    // occupancy bitmaps: level l has ((max fine cell >> s) + 1) voxels per axis, in 4x4x4 bricks;
+    // a level whose bitmap would not fit the budget simply has none (the probe decides alone)
+    OccBuild ob;
+    memset(&ob, 0, sizeof(ob));
+    {
+        const unsigned long long budget = (prm && prm->no_occupancy_bitmap) ? 0ull : (1ull << 27);  // words = 1 GB
+        unsigned long long       total  = 0;
+        uint32_t nf[3];
+        for (int d = 0; d < 3; d++)
+            nf[d] = (uint32_t)std::min<double>(1048575.0, std::floor((double)(mx[d] - mn[d]) * (double)inv_hf) + 2.0) + 1u;
+        for (int l = (int)n_levels - 1; l >= 0; l--)  // coarse levels first: they are tiny
+        {
+            const uint32_t s = shift0 + (uint32_t)l;
+            const unsigned long long bx = (((nf[0] - 1) >> s) + 4) / 4, by = (((nf[1] - 1) >> s) + 4) / 4,
+                                     bz = (((nf[2] - 1) >> s) + 4) / 4;
+            const unsigned long long w = bx * by * bz;
+            g.occ_bx[l] = (uint32_t)bx, g.occ_by[l] = (uint32_t)by, g.occ_bz[l] = (uint32_t)bz;
+            if (total + w > budget || total + w >= OCC_NONE) { g.occ_off[l] = OCC_NONE; continue; }
+            g.occ_off[l] = (uint32_t)total;
+            total += w;
+        }
+        for (uint32_t l = n_levels; l < 16; l++) g.occ_off[l] = OCC_NONE, g.occ_bx[l] = g.occ_by[l] = g.occ_bz[l] = 0;
+        if (total)
+        {
+            MP2P_TRY_HIP(ctx, map->occ.alloc(total));
+            MP2P_TRY_HIP(ctx, hipMemsetAsync(map->occ.p, 0, total * sizeof(unsigned long long), ctx->stream));
+        }
+        ob.words = map->occ.p;
+        for (int l = 0; l < 16; l++) ob.off[l] = g.occ_off[l], ob.bx[l] = g.occ_bx[l], ob.by[l] = g.occ_by[l];
+    }
     hipLaunchKernelGGL(cells_kernel<0>, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, keys.p,
                        map->pts.p, (uint32_t)n, mn[0], mn[1], mn[2], inv_hf, shift0, n_levels,
-                       map->table.p, cap - 1);
+                       map->table.p, cap - 1, ob);
     hipLaunchKernelGGL(cells_kernel<1>, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, keys.p,
                        map->pts.p, (uint32_t)n, mn[0], mn[1], mn[2], inv_hf, shift0, n_levels,
-                       map->table.p, cap - 1);
+                       map->table.p, cap - 1, ob);
     MP2P_TRY_HIP(ctx, map->claims.alloc(n));
     MP2P_TRY_HIP(ctx, hipMemsetAsync(map->claims.p, 0xFF, n * sizeof(unsigned long long), ctx->stream));
     MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -326,6 +368,7 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
 
     g.pts = map->pts.p, g.n = (uint32_t)n;
     g.table = map->table.p, g.mask = cap - 1;
+    g.occ   = map->occ.p;
     g.ox = mn[0], g.oy = mn[1], g.oz = mn[2];
     g.hf = hf, g.inv_hf = inv_hf;
     g.shift0 = shift0, g.n_levels = n_levels;
@@ -340,7 +383,7 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
     info.n_cells_total  = total_cells;
     info.n_cells_level0 = cells[shift0];
     info.hash_capacity  = cap;
-    info.device_bytes   = map->pts.bytes() + map->table.bytes() + map->claims.bytes();
+    info.device_bytes   = map->pts.bytes() + map->table.bytes() + map->claims.bytes() + map->occ.bytes();
     info.build_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MP2P_HIP_OK;

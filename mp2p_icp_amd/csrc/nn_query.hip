@@ -140,7 +140,7 @@ __device__ __forceinline__ void lookup_voxel(const GridView& g, const PassBox& b
     const float dy = fmaxf(0.f, fmaxf(vy0 - qhy, qly - (vy0 + b.hs)));
     const float dz = fmaxf(0.f, fmaxf(vz0 - qhz, qlz - (vz0 + b.hs)));
     md2 = dx * dx + dy * dy + dz * dz;
-    if (md2 <= prune2)
+    if (md2 <= prune2 && occ_maybe(g, b.lev, cx, cy, cz))
     {
         uint32_t e = 0;
         if (cell_lookup(g, cell_key(b.lev, cx, cy, cz), start, e)) cnt = e - start;

@@ -18,7 +18,7 @@ class PointLayer:
     """A point-cloud layer.  Device objects (NN index as a global layer, sorted copy as a local
     layer) are created lazily and cached until the layer is modified."""
 
-    def __init__(self, x, y=None, z=None, cell_size=0.0, target_per_cell=0.0):
+    def __init__(self, x, y=None, z=None, cell_size=0.0, target_per_cell=0.0, no_occupancy_bitmap=False):
         if y is None:
             pts = np.asarray(x, dtype=np.float32)
             x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
@@ -28,6 +28,7 @@ class PointLayer:
         assert self.x.size == self.y.size == self.z.size
         self.cell_size = cell_size
         self.target_per_cell = target_per_cell
+        self.no_occupancy_bitmap = no_occupancy_bitmap
         self.uid = next(_uid)
         self._version = 0
         self._cache = {}
@@ -46,7 +47,8 @@ class PointLayer:
         key = ("g", id(ctx))
         if key not in self._cache:
             self._cache[key] = core.GlobalMap(ctx, self.x, self.y, self.z, self.cell_size,
-                                              self.target_per_cell)
+                                              self.target_per_cell,
+                                              no_occupancy_bitmap=self.no_occupancy_bitmap)
         return self._cache[key]
 
     def as_local(self, ctx):

@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--q", type=int, default=0, help="queries per wave (tuning)")
     ap.add_argument("--r0", type=float, default=0.0, help="initial radius in cells (tuning)")
     ap.add_argument("--grp", type=float, default=0.0, help="group radius factor (tuning)")
+    ap.add_argument("--bricks", type=int, default=0, help="brick budget of the deferred-query kernel (0 = default)")
     ap.add_argument("--no-bitmap", action="store_true", help="build the map without occupancy bitmaps")
     ap.add_argument("--no-events", action="store_true", help="timed loop without hipEvents (overhead probe)")
     ap.add_argument("--cold", action="store_true", help="disable the warm start from the previous iteration")
@@ -159,7 +160,7 @@ def main():
         f"{info['build_ms']:.1f} ms (upload+build {t_index * 1e3:.0f} ms); cloud {t_cloud * 1e3:.0f} ms")
 
     n_l = l.shape[0]
-    prm = _lib.Pt2PtParams(args.threshold, 0.0, 1, 0, 0, 0.20, rank * n_l, args.r0, args.q, args.grp, args.budget, args.defer, int(args.cold))
+    prm = _lib.Pt2PtParams(args.threshold, 0.0, 1, 0, 0, 0.20, rank * n_l, args.r0, args.q, args.grp, args.budget, args.defer, int(args.cold), args.bricks)
     gnp = _lib.GNParams()
     gnp.maxInnerLoopIterations = args.gn_iters
     gnp.minDelta, gnp.maxCost = 1e-7, 0.0

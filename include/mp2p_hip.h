@@ -211,6 +211,8 @@ typedef struct
     int32_t  disable_warm_start;  /* by default a call on the same (map, cloud) as the previous
                                      call of this context seeds every query with its previous
                                      nearest neighbour (exactness is unaffected) */
+    uint32_t brick_budget;        /* 4x4x4-voxel bricks of the occupancy bitmap a deferred query
+                                     enumerates per pass before it moves to a coarser level; 0 = 128 */
 } mp2p_hip_pt2pt_params;
 
 /* ms may be NULL (fresh MatchState with nothing marked, marks discarded). */

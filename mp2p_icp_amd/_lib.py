@@ -46,7 +46,7 @@ class Pt2PtParams(C.Structure):
                 ("local_index_offset", C.c_uint64), ("initial_radius_cells", C.c_float),
                 ("queries_per_wave", C.c_uint32), ("group_radius_factor", C.c_float),
                 ("cell_budget", C.c_uint32), ("defer_radius_cells", C.c_float),
-                ("disable_warm_start", C.c_int32)]
+                ("disable_warm_start", C.c_int32), ("brick_budget", C.c_uint32)]
 
 
 class Pt2PlParams(C.Structure):

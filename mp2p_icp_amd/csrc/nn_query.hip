@@ -45,6 +45,7 @@ struct NNArgs
     float         grp_factor;        // group extent in units of the seed's radius
     float         r_defer;           // radius beyond which a query leaves its tile
     uint32_t      cell_budget;       // voxels of a search box per pass
+    uint32_t      brick_budget;      // 4x4x4 bricks per pass of the one-query-per-wave kernel
     const unsigned char* local_taken;   // by original local index, or null
     const unsigned char* global_taken;  // by original global index, or null
     unsigned long long*  claims;        // by sorted global position, or null
@@ -160,6 +161,13 @@ __device__ __forceinline__ uint32_t locate_candidate(const uint32_t* s_cstart,
         else hi = mid - 1;
     }
     return s_cstart[lo] + (gt - s_coff[lo]);
+}
+
+// a voxel whose nearest corner is farther than this cannot hold the answer or a tie of it
+// (fp32 slack on the voxel box included)
+__device__ __forceinline__ float voxel_limit(float bound, float slack)
+{
+    return bound * 1.000001f + slack * (2.f * sqrtf(bound) + slack);
 }
 
 // next radius of an unresolved query (grows strictly; capped at r_max)
@@ -540,12 +548,111 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
 }
 
 // ================================================================================================
-// one deferred query per wave
+// One deferred query per wave.  Such a query is far from its tile mates or far from the map: its
+// box holds hundreds of voxels, most of them empty.
+//
+// scan_batch: one batch of <= 64 resolved voxels (lane = voxel: start, cnt, squared distance of
+// the voxel box from the query).  The closest voxel first when no bound is known yet (its points
+// give one), then every voxel the bound cannot exclude as one flat candidate list, 4 loads in
+// flight per lane.  pd/pi/ps = this lane's partial best, bound = wave-uniform upper bound.
+template <bool INSTR>
+__device__ __forceinline__ void scan_batch(const NNArgs& a, const GridView& g, int lane, float qx,
+                                           float qy, float qz, uint32_t start, uint32_t cnt, float md2,
+                                           uint32_t* s_cstart, uint32_t* s_coff, float& pd,
+                                           uint32_t& pi, uint32_t& ps, float& bound, uint32_t& st_cand)
+{
+    const unsigned long long occ = __ballot(cnt > 0);
+    if (occ == 0ull) return;
+    {
+        const float kmin = wave_min(cnt > 0 ? md2 : INFINITY);
+        const float lim  = bound * 1.000001f + g.slack * (2.f * sqrtf(bound) + g.slack);
+        if (!(kmin <= lim)) return;  // nothing in this batch can matter
+        if (!(bound < INFINITY))
+        {
+            const int      lc = __ffsll((long long)__ballot(cnt > 0 && md2 == kmin)) - 1;
+            const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)start, lc);
+            const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, lc);
+            st_cand += cc;
+            for (uint32_t j = lane; j < cc; j += 64)
+            {
+                const uint32_t sa = cs + j;
+                const float4   ca = g.pts[sa];
+                const float    da = dist2(qx, qy, qz, ca.x, ca.y, ca.z);
+                const uint32_t ia = __float_as_uint(ca.w);
+                if (da < pd || (da == pd && ia < pi)) pd = da, pi = ia, ps = sa;
+                if (INSTR) a.touched[sa] = 1;
+            }
+            bound = fminf(bound, wave_min(pd));
+            if (lane == lc) cnt = 0;  // done
+        }
+    }
+    // conservative: a voxel is skipped only if even its nearest corner is farther than the bound
+    // (fp32 slack on the voxel box included); ties must be seen
+    const float    lim   = bound * 1.000001f + g.slack * (2.f * sqrtf(bound) + g.slack);
+    const uint32_t c2    = (cnt > 0 && md2 <= lim) ? cnt : 0u;
+    const uint32_t incl  = wave_incl_scan(c2, lane);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total == 0) return;
+    s_cstart[lane] = start;
+    s_coff[lane]   = incl - c2;
+    __syncthreads();
+    st_cand += total;
+    for (uint32_t t0 = 0; t0 < total; t0 += 256)
+    {
+        uint32_t sa[4];
+        float4   ca[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const uint32_t t = t0 + 64u * k + lane;
+            sa[k] = (t < total) ? locate_candidate(s_cstart, s_coff, t) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const uint32_t t = t0 + 64u * k + lane;
+            ca[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
+            if (t < total) ca[k] = g.pts[sa[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const uint32_t t  = t0 + 64u * k + lane;
+            const float    da = dist2(qx, qy, qz, ca[k].x, ca[k].y, ca[k].z);
+            const uint32_t ia = __float_as_uint(ca[k].w);
+            if (t < total && (da < pd || (da == pd && ia < pi))) pd = da, pi = ia, ps = sa[k];
+            if (INSTR && t < total) a.touched[sa[k]] = 1;
+        }
+    }
+    __syncthreads();
+    bound = fminf(bound, wave_min(pd));
+}
+
+// squared distance of the axis-aligned box [v0, v0+h]^3 from the point q
+__device__ __forceinline__ float box_dist2(float vx0, float vy0, float vz0, float h, float qx,
+                                           float qy, float qz)
+{
+    const float dx = fmaxf(0.f, fmaxf(vx0 - qx, qx - (vx0 + h)));
+    const float dy = fmaxf(0.f, fmaxf(vy0 - qy, qy - (vy0 + h)));
+    const float dz = fmaxf(0.f, fmaxf(vz0 - qz, qz - (vz0 + h)));
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// 4-bit mask of the positions lo..hi (clamped to the brick [b*4, b*4+3]) along one axis
+__device__ __forceinline__ uint32_t axis_mask(uint32_t b, uint32_t c0, uint32_t c1)
+{
+    const uint32_t lo = max(c0, b * 4u) - b * 4u, hi = min(c1, b * 4u + 3u) - b * 4u;
+    return ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+}
+
+constexpr int NN_VLIST = 1024;  // occupied voxels listed per round (LDS)
+
 template <bool INSTR>
 __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
 {
     __shared__ uint32_t s_cstart[64];
     __shared__ uint32_t s_coff[64];
+    __shared__ uint32_t s_vox[NN_VLIST];
     const GridView& g      = a.g;
     const int       lane   = threadIdx.x;
     const uint32_t  n_work = *a.work_count;
@@ -571,85 +678,132 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
         for (;;)
         {
             st_pass++;
-            const PassBox box = choose_level(g, qx - r, qy - r, qz - r, qx + r, qy + r, qz + r,
-                                             a.cell_budget);
             const float prune  = r + 4.f * g.slack;
             const float prune2 = prune * prune;
             // per-lane partial best over the candidates this lane tests
             float    pd = INFINITY;
             uint32_t pi = NONE_U32, ps = NONE_U32;
             float    bound = best_d2;  // wave-uniform upper bound of the answer (prunes voxels)
-            for (unsigned long long cb = 0; cb < box.ncell; cb += 64)
+
+            // ---- voxel enumeration through the occupancy bitmaps: one lane = one 4x4x4 brick,
+            //      an empty brick dismisses 64 voxels with one 8-byte load; the occupied voxels
+            //      are listed in LDS and only they are probed (always successfully) -------------
+            float lox = fmaxf(qx - r, g.bbmin[0]), loy = fmaxf(qy - r, g.bbmin[1]), loz = fmaxf(qz - r, g.bbmin[2]);
+            float hix = fminf(qx + r, g.bbmax[0]), hiy = fminf(qy + r, g.bbmax[1]), hiz = fminf(qz + r, g.bbmax[2]);
+            const bool empty_box = (lox > hix) || (loy > hiy) || (loz > hiz);
+            uint32_t   lev = 0, s = g.shift0, cx0 = 0, cy0 = 0, cz0 = 0, cx1 = 0, cy1 = 0, cz1 = 0;
+            uint32_t   nbx = 0, nby = 0, nbz = 0;
+            bool       bricks = !empty_box;
+            if (bricks)
             {
-                uint32_t cnt, start;
-                float    md2;
-                lookup_voxel(g, box, cb + lane, qx, qy, qz, qx, qy, qz, prune2, start, cnt, md2);
-                st_cells += (uint32_t)min((unsigned long long)64, box.ncell - cb);
-                // ---- closest voxel first (its points give a tight bound), then every voxel the
-                //      bound cannot exclude, flattened over the lanes with 4 loads in flight
-                const unsigned long long occ = __ballot(cnt > 0);
-                if (occ == 0ull) continue;
+                const uint32_t flx = cell_fine(lox, g.ox, g.inv_hf), fhx = cell_fine(hix, g.ox, g.inv_hf);
+                const uint32_t fly = cell_fine(loy, g.oy, g.inv_hf), fhy = cell_fine(hiy, g.oy, g.inv_hf);
+                const uint32_t flz = cell_fine(loz, g.oz, g.inv_hf), fhz = cell_fine(hiz, g.oz, g.inv_hf);
+                for (;;)
                 {
-                    const float kmin = wave_min(cnt > 0 ? md2 : INFINITY);
-                    const float lim  = bound * 1.000001f + g.slack * (2.f * sqrtf(bound) + g.slack);
-                    if (!(kmin <= lim)) continue;  // nothing in this batch can matter
-                    const int      lc = __ffsll((long long)__ballot(cnt > 0 && md2 == kmin)) - 1;
-                    const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)start, lc);
-                    const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)cnt, lc);
-                    st_cand += cc;
-                    for (uint32_t j = lane; j < cc; j += 64)
-                    {
-                        const uint32_t sa = cs + j;
-                        const float4   ca = g.pts[sa];
-                        const float    da = dist2(qx, qy, qz, ca.x, ca.y, ca.z);
-                        const uint32_t ia = __float_as_uint(ca.w);
-                        if (da < pd || (da == pd && ia < pi)) pd = da, pi = ia, ps = sa;
-                        if (INSTR) a.touched[sa] = 1;
-                    }
-                    bound = fminf(bound, wave_min(pd));
-                    if (lane == lc) cnt = 0;  // done
+                    cx0 = flx >> s, cy0 = fly >> s, cz0 = flz >> s;
+                    cx1 = fhx >> s, cy1 = fhy >> s, cz1 = fhz >> s;
+                    nbx = (cx1 >> 2) - (cx0 >> 2) + 1, nby = (cy1 >> 2) - (cy0 >> 2) + 1,
+                    nbz = (cz1 >> 2) - (cz0 >> 2) + 1;
+                    if ((unsigned long long)nbx * nby * nbz <= a.brick_budget || lev + 1 >= g.n_levels) break;
+                    s++, lev++;
                 }
+                bricks = g.occ_off[lev] != OCC_NONE && (unsigned long long)nbx * nby * nbz <= 65536ull &&
+                         (cx1 - cx0) < 1024u && (cy1 - cy0) < 1024u && (cz1 - cz0) < 1024u;
+            }
+            if (bricks)
+            {
+                const float    hs   = g.hf * (float)(1u << s);
+                const uint32_t nb   = nbx * nby * nbz;
+                const float    inbx = 1.0f / (float)nbx, inby = 1.0f / (float)nby;
+                for (uint32_t b0 = 0; b0 < nb; b0 += 64)
                 {
-                    // conservative: a voxel is skipped only if even its nearest corner is farther
-                    // than the bound (fp32 slack on the voxel box included); ties must be seen
-                    const float    lim  = bound * 1.000001f + g.slack * (2.f * sqrtf(bound) + g.slack);
-                    const uint32_t c2   = (cnt > 0 && md2 <= lim) ? cnt : 0u;
-                    const uint32_t incl = wave_incl_scan(c2, lane);
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    if (total == 0) continue;
-                    s_cstart[lane] = start;
-                    s_coff[lane]   = incl - c2;
-                    __syncthreads();
-                    st_cand += total;
-                    for (uint32_t t0 = 0; t0 < total; t0 += 256)
+                    const uint32_t id = b0 + lane;
+                    st_cells += min(64u, nb - b0);
+                    unsigned long long m = 0ull;
+                    uint32_t Bx = 0, By = 0, Bz = 0;
+                    if (id < nb)
                     {
-                        uint32_t sa[4];
-                        float4   ca[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
+                        // exact for these sizes: (c + 0.5) / n is at least 0.5/n away from an integer
+                        const uint32_t row = (uint32_t)(((float)id + 0.5f) * inbx);
+                        const uint32_t ix = id - row * nbx, iz = (uint32_t)(((float)row + 0.5f) * inby),
+                                       iy = row - iz * nby;
+                        Bx = (cx0 >> 2) + ix, By = (cy0 >> 2) + iy, Bz = (cz0 >> 2) + iz;
+                        const float lim0 = fminf(prune2, voxel_limit(bound, g.slack));
+                        const float bd2  = box_dist2(g.ox + (float)(Bx * 4u) * hs, g.oy + (float)(By * 4u) * hs,
+                                                     g.oz + (float)(Bz * 4u) * hs, 4.f * hs, qx, qy, qz);
+                        if (bd2 <= lim0 && Bx < g.occ_bx[lev] && By < g.occ_by[lev] && Bz < g.occ_bz[lev])
                         {
-                            const uint32_t t = t0 + 64u * k + lane;
-                            sa[k] = (t < total) ? locate_candidate(s_cstart, s_coff, t) : 0u;
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
-                        {
-                            const uint32_t t = t0 + 64u * k + lane;
-                            ca[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
-                            if (t < total) ca[k] = g.pts[sa[k]];
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
-                        {
-                            const uint32_t t  = t0 + 64u * k + lane;
-                            const float    da = dist2(qx, qy, qz, ca[k].x, ca[k].y, ca[k].z);
-                            const uint32_t ia = __float_as_uint(ca[k].w);
-                            if (t < total && (da < pd || (da == pd && ia < pi))) pd = da, pi = ia, ps = sa[k];
-                            if (INSTR && t < total) a.touched[sa[k]] = 1;
+                            const unsigned long long word =
+                                g.occ[(size_t)g.occ_off[lev] + ((size_t)Bz * g.occ_by[lev] + By) * g.occ_bx[lev] + Bx];
+                            const unsigned long long mx = axis_mask(Bx, cx0, cx1) * 0x1111111111111111ull;
+                            const uint32_t           y4 = axis_mask(By, cy0, cy1), z4 = axis_mask(Bz, cz0, cz1);
+                            const unsigned long long my16 = ((y4 & 1u) ? 0x000Full : 0) | ((y4 & 2u) ? 0x00F0ull : 0) |
+                                                            ((y4 & 4u) ? 0x0F00ull : 0) | ((y4 & 8u) ? 0xF000ull : 0);
+                            const unsigned long long my = my16 * 0x0001000100010001ull;
+                            const unsigned long long mz = ((z4 & 1u) ? 0x000000000000FFFFull : 0) |
+                                                          ((z4 & 2u) ? 0x00000000FFFF0000ull : 0) |
+                                                          ((z4 & 4u) ? 0x0000FFFF00000000ull : 0) |
+                                                          ((z4 & 8u) ? 0xFFFF000000000000ull : 0);
+                            m = word & mx & my & mz;
                         }
                     }
-                    __syncthreads();
-                    bound = fminf(bound, wave_min(pd));
+                    const uint32_t c     = (uint32_t)__popcll(m);
+                    const uint32_t incl  = wave_incl_scan(c, lane);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    for (uint32_t r0 = 0; r0 < total; r0 += NN_VLIST)
+                    {
+                        uint32_t           rank = incl - c;
+                        unsigned long long mm   = m;
+                        while (mm)
+                        {
+                            const uint32_t bit = (uint32_t)__ffsll((long long)mm) - 1u;
+                            mm &= mm - 1ull;
+                            if (rank >= r0 && rank < r0 + NN_VLIST)
+                                s_vox[rank - r0] = ((Bz * 4u + (bit >> 4)) - cz0) << 20 |
+                                                   ((By * 4u + ((bit >> 2) & 3u)) - cy0) << 10 |
+                                                   ((Bx * 4u + (bit & 3u)) - cx0);
+                            rank++;
+                        }
+                        __syncthreads();
+                        const uint32_t nlist = min((uint32_t)NN_VLIST, total - r0);
+                        for (uint32_t v0 = 0; v0 < nlist; v0 += 64)
+                        {
+                            uint32_t cnt = 0, start = 0;
+                            float    md2 = INFINITY;
+                            if (v0 + lane < nlist)
+                            {
+                                const uint32_t pk = s_vox[v0 + lane];
+                                const uint32_t cx = cx0 + (pk & 1023u), cy = cy0 + ((pk >> 10) & 1023u),
+                                               cz = cz0 + (pk >> 20);
+                                md2 = box_dist2(g.ox + (float)cx * hs, g.oy + (float)cy * hs, g.oz + (float)cz * hs,
+                                                hs, qx, qy, qz);
+                                if (md2 <= fminf(prune2, voxel_limit(bound, g.slack)))
+                                {
+                                    uint32_t e = 0;
+                                    if (cell_lookup(g, cell_key(lev, cx, cy, cz), start, e)) cnt = e - start;
+                                }
+                            }
+                            scan_batch<INSTR>(a, g, lane, qx, qy, qz, start, cnt, md2, s_cstart, s_coff, pd, pi,
+                                              ps, bound, st_cand);
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+            else
+            {
+                // no bitmap at a usable level: every voxel of the box is probed
+                const PassBox box = choose_level(g, qx - r, qy - r, qz - r, qx + r, qy + r, qz + r,
+                                                 a.cell_budget);
+                for (unsigned long long cb = 0; cb < box.ncell; cb += 64)
+                {
+                    uint32_t cnt, start;
+                    float    md2;
+                    lookup_voxel(g, box, cb + lane, qx, qy, qz, qx, qy, qz, prune2, start, cnt, md2);
+                    st_cells += (uint32_t)min((unsigned long long)64, box.ncell - cb);
+                    scan_batch<INSTR>(a, g, lane, qx, qy, qz, start, cnt, md2, s_cstart, s_coff, pd, pi, ps, bound,
+                                      st_cand);
                 }
             }
             wave_argmin(pd, pi, ps);
@@ -746,6 +900,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.r0          = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 1.0f);
     a.grp_factor  = prm->group_radius_factor > 0 ? prm->group_radius_factor : 4.0f;
     a.cell_budget = prm->cell_budget > 0 ? prm->cell_budget : 512u;
+    a.brick_budget = prm->brick_budget > 0 ? prm->brick_budget : 128u;
     a.r_defer     = cell0 * (prm->defer_radius_cells > 0 ? prm->defer_radius_cells : 3.0f);
     a.local_taken =
         (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;

@@ -200,6 +200,7 @@ class Matcher_Points_Base(Matcher):
         self.cell_budget = 0
         self.defer_radius_cells = 0.0
         self.disable_warm_start = False
+        self.brick_budget = 0
 
     def initialize(self, params):
         super().initialize(params)
@@ -231,6 +232,7 @@ class Matcher_Points_Base(Matcher):
         self.cell_budget = int(params.get("hip_cell_budget", 0))
         self.defer_radius_cells = float(params.get("hip_defer_radius_cells", 0.0))
         self.disable_warm_start = bool(params.get("hip_disable_warm_start", False))
+        self.brick_budget = int(params.get("hip_brick_budget", 0))
 
     # maxLocalPointsPerLayer (Matcher_Points_Base.cpp:222-246): when the local layer is larger,
     # only idxs[0..maxLocalPoints) are visited, where idxs = iota(0..maxLocalPoints) shuffled by
@@ -336,7 +338,7 @@ class Matcher_Points_DistanceThreshold(Matcher_Points_Base):
             float(self.bounding_box_intersection_check_epsilon_), int(local_index_offset),
             float(self.initial_radius_cells), int(self.queries_per_wave),
             float(self.group_radius_factor), int(self.cell_budget),
-            float(self.defer_radius_cells), int(self.disable_warm_start))
+            float(self.defer_radius_cells), int(self.disable_warm_start), int(self.brick_budget))
 
     def implMatchOneLayer(self, ctx, gLayer, lLayer, localPose, ms, glName, lcName, out):
         self.checkAllParametersAreRealized()

@@ -17,7 +17,7 @@ g, l = d["glob"], d["local"]
 cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
 pairs = core.DevicePairs(ctx, n_l, 0)
 gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2], cell_size=cfg.get("cell", 0.0), target_per_cell=cfg.get("tpc", 0.0))
-prm = _lib.Pt2PtParams(2.0, 0.0, 1, 0, 0, 0.20, 0, cfg.get("r0", 0.0), cfg.get("q", 0), cfg.get("grp", 0.0), cfg.get("budget", 0), cfg.get("defer", 0.0), int(cfg.get("cold", 0)))
+prm = _lib.Pt2PtParams(2.0, 0.0, 1, 0, 0, 0.20, 0, cfg.get("r0", 0.0), cfg.get("q", 0), cfg.get("grp", 0.0), cfg.get("budget", 0), cfg.get("defer", 0.0), int(cfg.get("cold", 0)), int(cfg.get("bricks", 0)))
 pose = d["T_gt"] if pose_name == "gt" else d["T_init"]
 gnp = _lib.GNParams(); gnp.maxInnerLoopIterations = 3; gnp.minDelta = 1e-7; gnp.kernel = 1; gnp.kernelParam = 0.15; gnp.w_pt2pt = gnp.w_pt2pl = 1.0
 for _ in range(reps):

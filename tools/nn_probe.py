@@ -26,7 +26,7 @@ for cfg in configs:
     if key not in maps:
         maps[key] = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2], cell_size=cell, target_per_cell=tpc)
     gmap = maps[key]
-    prm = _lib.Pt2PtParams(2.0, 0.0, 1, 0, 0, 0.20, 0, cfg.get("r0", 0.0), cfg.get("q", 0), cfg.get("grp", 0.0), cfg.get("budget", 0), cfg.get("defer", 0.0), int(cfg.get("cold", 0)))
+    prm = _lib.Pt2PtParams(2.0, 0.0, 1, 0, 0, 0.20, 0, cfg.get("r0", 0.0), cfg.get("q", 0), cfg.get("grp", 0.0), cfg.get("budget", 0), cfg.get("defer", 0.0), int(cfg.get("cold", 0)), int(cfg.get("bricks", 0)))
     chain = amd.se3.compose(d["T_gt"], amd.se3.exp(np.array([0.3, -0.3, 0.05, 0.0, 0.0, 0.03])))
     chain_prev = amd.se3.compose(chain, amd.se3.exp(np.array([0.004, 0.002, 0.0, 0.0, 0.0, 0.001])))
     other = {"init": d["T_gt"], "gt": d["T_init"], "chain": chain_prev}

@@ -123,13 +123,21 @@ def main():
         log(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: mp2p_icp_amd has no CPU fallback")
+    # test hook: MP2P_BENCH_SHARE_GPU=1 runs all ranks on GPU 0 over gloo, to exercise the N>1
+    # code path on a one-GPU box (numbers are then meaningless; RCCL refuses two ranks per GPU)
+    share_gpu = os.environ.get("MP2P_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     import mp2p_icp_amd as amd
     from mp2p_icp_amd import _lib, core
@@ -257,9 +265,12 @@ def main():
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    # one step registers the WHOLE (sharded) local layer once -> iterations/s is 1/t_step;
-    # the aggregate work rate over all GPUs is reported as queries/s and pairs/s
-    iters_per_s = args.steps / elapsed
+    # Weak scaling: every rank brings its own n_local-point slice of the local layer, so one step
+    # registers world x n_local points jointly (one pose, one unique-global filter, one 6x6
+    # system).  The unit of `value` is the metric's configuration -- one outer ICP iteration over
+    # n_local local points -- hence the whole-job aggregate is world / t_step; the plain step rate
+    # is reported next to it.
+    iters_per_s = world * args.steps / elapsed
     nn_ms_avg = max(float(np.mean(nn_ms)), 1e-9)  # 0 only with --no-events (overhead probe)
     # algorithmic bytes of the search kernel per launch:
     #   12 B/query read + 12 B per distinct global point in a visited voxel + 8 B/query written
@@ -287,6 +298,9 @@ def main():
             "pose_chain": f"real ICP chain, restart from perturbed guess every {CYCLE} steps",
             "parallelism": f"local layer sharded x{world}, map replicated",
         },
+        "steps_per_sec_wall": args.steps / elapsed,
+        "unit_of_work": f"one outer ICP iteration (match + Gauss-Newton solve) over {n_l} local points vs "
+                        f"{g.shape[0]} global points; a step does {world} of them jointly",
         "matched_pairs_per_sec": float(pairs_total.item()) / elapsed,
         "queries_per_sec": n_l * world * args.steps / elapsed,
         "pairs_per_step": float(pairs_total.item()) / args.steps,
@@ -328,7 +342,7 @@ def main():
             out["roofline"]["traffic_source"] = "profiles/r01_bench_hbm_pmc.csv (rocprofv3 --pmc)"
     except Exception:
         pass
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only
         cores = os.cpu_count() or 1
         t0 = time.time()
         out["cpu_baseline"] = cpu_baseline(d, args.threshold, args.gn_iters, 0.15,

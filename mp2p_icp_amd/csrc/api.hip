@@ -442,7 +442,23 @@ int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     if (map->n == 0 || cloud->n == 0)  // Matcher_Point2Plane.cpp:54-57
         return launch_add_potential(ctx, out, (unsigned long long)(cloud->n_visit ? cloud->n_visit : cloud->n));
-    return launch_match_pt2pl(ctx, map, cloud, pose, prm, ms, out);
+    const int rc = launch_match_pt2pl(ctx, map, cloud, pose, prm, ms, out);
+    if (!rc && ctx->profiling)
+    {
+        ctx->pending_match = ctx->profiling == 2 ? 1 : ctx->profiling;
+        ctx->stats.nn_queries = cloud->n;
+        if (ctx->profiling == 2)
+        {  // the k-NN kernel's own counters
+            unsigned long long c[16];
+            MP2P_TRY_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+            MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1], ctx->stats.nn_candidates_tested = c[2];
+            ctx->stats.nn_tile_ticks_sum = c[3], ctx->stats.nn_max_passes_one_tile = c[4];
+            ctx->stats.nn_max_candidates_one_tile = c[5], ctx->stats.nn_tile_ticks_max = c[6];
+            ctx->stats.nn_cells_visited = c[7];
+        }
+    }
+    return rc;
 }
 
 // ---- Solver_GaussNewton ------------------------------------------------------------------------

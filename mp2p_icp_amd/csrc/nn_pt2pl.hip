@@ -18,7 +18,8 @@
 namespace mp2p
 {
 constexpr int      PL_CAP         = 256;
-constexpr uint32_t PL_CELL_BUDGET = 256;
+constexpr uint32_t PL_CELL_BUDGET  = 256;   // voxels per pass; measured insensitive 256..4096
+constexpr float    PL_GROUP_FACTOR = 4.0f;  // group extent in search radii; insensitive 1.5..4
 
 struct PlArgs
 {
@@ -26,7 +27,9 @@ struct PlArgs
     const float4* lpts;
     uint32_t      n_l;
     PoseRt        pose;
-    float         radSq, rad, distThr, r0;
+    float         radSq, rad, distThr, r0, grp_factor;
+    uint32_t      cell_budget;
+    unsigned long long* dbg;  // profiling level 2: {tiles, passes, candidates, ticks, max passes, max cand, max ticks, cells, max cells}
     double        eigThr;
     uint32_t      minPts;
     uint32_t      knn;  // <= K (template capacity of the register k-list)
@@ -111,7 +114,8 @@ __device__ __forceinline__ float kth_d2(const float (&kd2)[K], uint32_t knn)
 template <int K, bool STRICT>
 __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx, float qy, float qz,
                                            bool active, float lim2, float rmax, float r0, uint32_t knn,
-                                           float4* s_cand, uint32_t* s_spos, uint32_t* s_cstart,
+                                           float grp_factor, uint32_t cell_budget,
+                                           unsigned long long* dbg, float4* s_cand, uint32_t* s_spos, uint32_t* s_cstart,
                                            uint32_t* s_coff, float (&kd2)[K], uint32_t (&kidx)[K],
                                            uint32_t (&kspos)[K])
 {
@@ -119,16 +123,29 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
     bool  done = !active;
 #pragma unroll
     for (int j = 0; j < K; j++) kd2[j] = INFINITY, kidx[j] = NONE_U32, kspos[j] = NONE_U32;
+    unsigned long long dbg_cand = 0, dbg_pass = 0, dbg_cells = 0;
+    const long long    dbg_t0 = dbg ? (long long)wall_clock64() : 0;
 
     while (true)
     {
-        if (__ballot(!done) == 0ull) break;
-        float lox = wave_min(done ? INFINITY : qx - r), loy = wave_min(done ? INFINITY : qy - r),
-              loz = wave_min(done ? INFINITY : qz - r);
-        float hix = wave_max(done ? -INFINITY : qx + r), hiy = wave_max(done ? -INFINITY : qy + r),
-              hiz = wave_max(done ? -INFINITY : qz + r);
-        const float rmin_t = wave_min(done ? INFINITY : r);
-        const float rmax_t = wave_max(done ? 0.f : r);
+        const unsigned long long pend = __ballot(!done);
+        if (pend == 0ull) break;
+        // One pass serves the GROUP of pending queries near the first pending one (a few search
+        // radii around it): Morton-consecutive queries are normally one group, an outlier is a
+        // group of its own with a box of its own size.  Without this the pass box is the union over
+        // the whole tile, and one far-away query makes all 64 lanes scan 1e5 points.
+        const int   seed = __ffsll((long long)pend) - 1;
+        const float sx = readlane_f(qx, seed), sy = readlane_f(qy, seed), sz = readlane_f(qz, seed);
+        const float sr = readlane_f(r, seed);
+        const float G  = grp_factor * sr;
+        const bool  grp = !done && fabsf(qx - sx) <= G && fabsf(qy - sy) <= G && fabsf(qz - sz) <= G &&
+                         r <= 2.0f * sr;
+        float lox = wave_min(grp ? qx - r : INFINITY), loy = wave_min(grp ? qy - r : INFINITY),
+              loz = wave_min(grp ? qz - r : INFINITY);
+        float hix = wave_max(grp ? qx + r : -INFINITY), hiy = wave_max(grp ? qy + r : -INFINITY),
+              hiz = wave_max(grp ? qz + r : -INFINITY);
+        const float rmin_t = wave_min(grp ? r : INFINITY);
+        const float rmax_t = wave_max(grp ? r : 0.f);
         const float qlx = lox + rmin_t, qly = loy + rmin_t, qlz = loz + rmin_t;
         const float qhx = hix - rmin_t, qhy = hiy - rmin_t, qhz = hiz - rmin_t;
         lox = fmaxf(lox, g.bbmin[0]), loy = fmaxf(loy, g.bbmin[1]), loz = fmaxf(loz, g.bbmin[2]);
@@ -147,19 +164,21 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                 cx0 = flx >> s, cy0 = fly >> s, cz0 = flz >> s;
                 nx = (fhx >> s) - cx0 + 1, ny = (fhy >> s) - cy0 + 1, nz = (fhz >> s) - cz0 + 1;
                 ncell = (unsigned long long)nx * ny * nz;
-                if (ncell <= PL_CELL_BUDGET || lev + 1 >= g.n_levels) break;
+                if (ncell <= cell_budget || lev + 1 >= g.n_levels) break;
                 s++, lev++;
             }
         }
         const float hs     = g.hf * (float)(1u << s);
         const float prune  = rmax_t + 4.f * g.slack;
         const float prune2 = prune * prune;
+        dbg_pass++, dbg_cells += ncell;
 
         // a repeated pass rescans voxels already seen: restart the k-list so that no neighbour
         // is inserted twice
 #pragma unroll
         for (int j = 0; j < K; j++)
-            if (!done) kd2[j] = INFINITY, kidx[j] = NONE_U32, kspos[j] = NONE_U32;
+            if (grp) kd2[j] = INFINITY, kidx[j] = NONE_U32, kspos[j] = NONE_U32;
+        float kth = kth_d2(kd2, knn);  // INFINITY for the lanes of this pass
 
         for (unsigned long long cb = 0; cb < ncell; cb += 64)
         {
@@ -183,6 +202,7 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
             }
             const uint32_t incl  = wave_incl_scan(cnt, lane);
             const uint32_t total = __shfl(incl, 63, 64);
+            dbg_cand += total;
             s_cstart[lane] = start;
             s_coff[lane]   = incl - cnt;
             if (lane == 63) s_coff[64] = total;
@@ -210,7 +230,10 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                     const float4 c  = s_cand[j];
                     const float  d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
                     const bool   in = STRICT ? (d2 < lim2) : (d2 <= lim2);
-                    if (!done && d2 <= kth_d2(kd2, knn) && in)
+                    // kth = distance of the knn-th neighbour held so far, kept in a register: the
+                    // common case (candidate farther than that for every lane) is one compare
+                    if (__ballot(grp && d2 <= kth && in) == 0ull) continue;
+                    if (grp && d2 <= kth && in)
                     {
                         float    cd = d2;
                         uint32_t ci = __float_as_uint(c.w), cs = s_spos[j];
@@ -218,26 +241,26 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                         for (int q = 0; q < K; q++)
                         {
                             const bool less = (cd < kd2[q]) || (cd == kd2[q] && ci < kidx[q]);
-                            if (less)
-                            {
-                                const float    td = kd2[q];
-                                const uint32_t ti = kidx[q], ts = kspos[q];
-                                kd2[q] = cd, kidx[q] = ci, kspos[q] = cs;
-                                cd = td, ci = ti, cs = ts;
-                            }
+                            const float    td = kd2[q];
+                            const uint32_t ti = kidx[q], ts = kspos[q];
+                            kd2[q]   = less ? cd : td;
+                            kidx[q]  = less ? ci : ti;
+                            kspos[q] = less ? cs : ts;
+                            cd = less ? td : cd, ci = less ? ti : ci, cs = less ? ts : cs;
                         }
 #pragma unroll
                         for (int q = 0; q < K; q++)  // only the knn nearest are kept
                             if (q >= (int)knn) kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
+                        kth = kth_d2(kd2, knn);
                     }
                 }
                 __syncthreads();
             }
         }
-        if (!done)
+        if (grp)
         {
             const float gr  = r * (1.0f - 1.0f / 1024.0f) - g.slack;
-            const float kth = kth_d2(kd2, knn);  // INFINITY while fewer than knn are known
+            kth             = kth_d2(kd2, knn);  // INFINITY while fewer than knn are known
             if (r >= rmax || (gr > 0.f && kth < gr * gr))
                 done = true;
             else
@@ -248,6 +271,13 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                 r = fminf(fmaxf(rn, r * 1.0009765625f), rmax);
             }
         }
+    }
+    if (dbg && lane == 0)
+    {
+        const unsigned long long dt = (unsigned long long)((long long)wall_clock64() - dbg_t0);
+        atomicAdd(&dbg[0], 1ull), atomicAdd(&dbg[1], dbg_pass), atomicAdd(&dbg[2], dbg_cand), atomicAdd(&dbg[3], dt);
+        atomicMax(&dbg[4], dbg_pass), atomicMax(&dbg[5], dbg_cand), atomicMax(&dbg[6], dt), atomicAdd(&dbg[7], dbg_cells);
+        atomicMax(&dbg[8], dbg_cells);
     }
 }
 
@@ -299,7 +329,7 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
     float    kd2[K];
     uint32_t kidx[K], kspos[K];
     knn_search<K, false>(g, lane, qx, qy, qz, active, a.radSq, a.rad * 1.002f + g.slack, a.r0, a.knn,
-                         s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
+                         a.grp_factor, a.cell_budget, a.dbg, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
 
     // ---- plane fit (per lane) ------------------------------------------------------------------
     if (!valid) return;
@@ -383,8 +413,8 @@ struct KnnArgs
     const float4* lpts;
     uint32_t      n_l;
     PoseRt        pose;
-    float         maxDistSq, angSq, r0;
-    uint32_t      knn;
+    float         maxDistSq, angSq, r0, grp_factor;
+    uint32_t      knn, cell_budget;
     const unsigned char *local_taken, *global_taken;
     const uint32_t*      rank;
     unsigned long long*  claims;
@@ -416,7 +446,7 @@ __global__ __launch_bounds__(64) void pt2pt_knn_kernel(const KnnArgs a)
     float    kd2[K];
     uint32_t kidx[K], kspos[K];
     knn_search<K, true>(g, lane, qx, qy, qz, active, thr, sqrtf(thr) * 1.002f + g.slack, a.r0, a.knn,
-                        s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
+                        a.grp_factor, a.cell_budget, nullptr, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
     if (!valid) return;
 #pragma unroll
     for (int k = 0; k < K; k++)
@@ -555,11 +585,19 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     const float cell0 = map->view.hf * (float)(1u << map->view.shift0);
     a.r0     = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 2.0f);
     a.eigThr = prm->planeEigenThreshold;
+    a.grp_factor = PL_GROUP_FACTOR, a.cell_budget = PL_CELL_BUDGET;
     a.minPts = prm->minimumPlanePoints;
     a.knn    = prm->knn;
     a.local_taken = (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
     a.rank     = cloud->n_visit ? cloud->rank.p : nullptr;
     a.out_flag = flag, a.out_rec = rec, a.tile_bbox = ctx->tile_bbox.p;
+    a.dbg = nullptr;
+    if (ctx->profiling == 2)
+    {
+        MP2P_TRY_HIP(ctx, ctx->counters.ensure(64));
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64 * sizeof(unsigned long long), ctx->stream));
+        a.dbg = ctx->counters.p;
+    }
 
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     const uint32_t K = prm->knn;
@@ -567,11 +605,12 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     else if (K <= 8) launch_k<8>(a, n_tiles, ctx->stream);
     else if (K <= 12) launch_k<12>(a, n_tiles, ctx->stream);
     else launch_k<16>(a, n_tiles, ctx->stream);
+    if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     {
         const int rc = launch_bbox_reduce(ctx, n_tiles);
         if (rc) return rc;
     }
-    if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
 
     const size_t   n_slots  = cloud->n_visit ? cloud->n_visit : n_l;
     const uint32_t n_blocks = (uint32_t)((n_slots + PC_TILE - 1) / PC_TILE);
@@ -626,6 +665,7 @@ int launch_nn_pt2pt_knn(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_h
     const float cell0 = map->view.hf * (float)(1u << map->view.shift0);
     a.r0  = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 1.5f);
     a.knn = K;
+    a.grp_factor = PL_GROUP_FACTOR, a.cell_budget = PL_CELL_BUDGET;
     a.local_taken  = (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
     a.global_taken = (ms && !prm->allowMatchAlreadyMatchedGlobalPoints) ? ms->global_taken.p : nullptr;
     a.rank         = cloud->n_visit ? cloud->rank.p : nullptr;

@@ -388,10 +388,12 @@ __device__ void d_se3_log(const double* T, double* xi)
 }
 
 // LDL^T with diagonal pivoting (role of Eigen's H.ldlt().solve(g), :351)
-__device__ void d_ldlt6_solve(const double* H, const double* g, double* x)
+// ws: >= 78 doubles of workspace (the callers pass LDS: indexed private arrays would live in
+// scratch memory, i.e. a global-memory round trip per element -- this solve used to cost 12 us)
+__device__ void d_ldlt6_solve(const double* H, const double* g, double* x, double* ws)
 {
     const int n = 6;
-    double    A[36], L[36], D[6];
+    double *  A = ws, *L = ws + 36, *D = ws + 72;
     int       perm[6];
     for (int i = 0; i < 36; i++) A[i] = H[i], L[i] = 0;
     for (int i = 0; i < n; i++) perm[i] = i, D[i] = 0;
@@ -456,13 +458,15 @@ struct GnStepPrm
 };
 
 // ---- K8: assemble H,g from the sums, prior, solve, retract (one thread) -----------------------
+constexpr int GN_STEP_WS = 36 + 6 + 78 + 2;  // H, g, LDLT workspace
+
 __device__ void gn_step_body(const double* __restrict__ sums, double* __restrict__ state,
-                             const GnStepPrm& prm)
+                             const GnStepPrm& prm, double* ws)
 {
     if (state[ST_DONE] != 0.0) return;
     double T[12];
     for (int i = 0; i < 12; i++) T[i] = state[ST_POSE + i];
-    double H[36], g[6];
+    double *H = ws, *g = ws + 36;  // LDS workspace (see d_ldlt6_solve)
     for (int i = 0; i < 36; i++) H[i] = 0;
     for (int i = 0; i < 6; i++) g[i] = 0;
     double cost = 0;
@@ -557,7 +561,7 @@ __device__ void gn_step_body(const double* __restrict__ sums, double* __restrict
         return;
     }
     double delta[6];
-    d_ldlt6_solve(H, g, delta);
+    d_ldlt6_solve(H, g, delta, ws + 42);
     for (int i = 0; i < 6; i++) delta[i] = -delta[i];  // :351
     double dE[12], Tn[12];
     d_se3_exp(delta, dE);       // :354
@@ -571,7 +575,8 @@ __device__ void gn_step_body(const double* __restrict__ sums, double* __restrict
 __global__ void gn_step_kernel(const double* __restrict__ sums, double* __restrict__ state,
                                const GnStepPrm prm)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) gn_step_body(sums, state, prm);
+    __shared__ double ws[GN_STEP_WS];
+    if (threadIdx.x == 0 && blockIdx.x == 0) gn_step_body(sums, state, prm, ws);
 }
 
 // single-GPU form: final reduction and the 6x6 step in one launch (no all-reduce in between)
@@ -580,9 +585,10 @@ __global__ __launch_bounds__(1024) void gn_sums_step_kernel(const double* __rest
                                                             int use_pl, double* __restrict__ sums,
                                                             const GnStepPrm prm)
 {
+    __shared__ double ws[GN_STEP_WS];
     gn_sums_body(partials, state[ST_DONE] != 0.0, use_pt, use_pl, sums);
     __syncthreads();  // sums[] written by this block are visible to its thread 0
-    if (threadIdx.x == 0) gn_step_body(sums, state, prm);
+    if (threadIdx.x == 0) gn_step_body(sums, state, prm, ws);
 }
 
 struct GnInit

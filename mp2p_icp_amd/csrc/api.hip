@@ -231,7 +231,7 @@ void mp2p_hip_cloud_free(mp2p_hip_ctx* ctx, mp2p_hip_cloud* c)
     if (ctx && ctx->hint_cloud == c) ctx->hint_cloud = nullptr;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     c->sorted.release(), c->x.release(), c->y.release(), c->z.release();
-    c->order.release(), c->rank.release();
+    c->order.release(), c->rank.release(), c->pos.release();
     delete c;
 }
 

@@ -147,6 +147,7 @@ struct mp2p_hip_cloud
     size_t               n   = 0;
     mp2p::DevBuf<float4> sorted;  // Morton-sorted (own frame) {x,y,z,idx}
     mp2p::DevBuf<float>  x, y, z; // original order (pair output)
+    mp2p::DevBuf<uint32_t> pos;   // original index -> place in `sorted` (search results are kept in that order)
     // optional visit order (mp2p_hip_cloud_set_visit_order): order[r] = original index visited
     // r-th, rank = its inverse (NONE for points that are not visited); n_visit == 0: all, ascending
     size_t                 n_visit = 0;

@@ -389,6 +389,14 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
     return MP2P_HIP_OK;
 }
 
+// pos[original index] = place in the Morton-sorted copy
+__global__ __launch_bounds__(256) void inverse_order_kernel(const float4* __restrict__ sorted, uint32_t n,
+                                                            uint32_t* __restrict__ pos)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pos[__float_as_uint(sorted[i].w)] = i;
+}
+
 int build_cloud(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float* d_z,
                 size_t n, mp2p_hip_cloud* cloud)
 {
@@ -405,6 +413,9 @@ int build_cloud(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const flo
     rc = morton_sort(ctx, d_x, d_y, d_z, n, mn[0], mn[1], mn[2], 1.0f / hf, nullptr,
                      cloud->sorted.p);
     if (rc) return rc;
+    MP2P_TRY_HIP(ctx, cloud->pos.alloc(n));
+    hipLaunchKernelGGL(inverse_order_kernel, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream,
+                       cloud->sorted.p, (uint32_t)n, cloud->pos.p);
     MP2P_TRY_HIP(ctx, cloud->x.alloc(n));
     MP2P_TRY_HIP(ctx, cloud->y.alloc(n));
     MP2P_TRY_HIP(ctx, cloud->z.alloc(n));

@@ -288,7 +288,7 @@ __device__ __forceinline__ void transform_tile(const PoseRt& pose, const float4*
                                                uint32_t& vrank, float& qx, float& qy, float& qz)
 {
     const uint32_t tile = blockIdx.x;
-    const uint32_t qi   = tile * 64 + lane;
+    const uint32_t qi   = tile * 64 + lane;  // = place in the sorted copy
     valid               = qi < n_l;
     float4 lp           = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) lp = lpts[qi];
@@ -419,7 +419,7 @@ struct KnnArgs
     const uint32_t*      rank;
     unsigned long long*  claims;
     unsigned long long   claim_hi, local_offset;
-    uint32_t*            out_spos;  // [n_l][knn] by original local index
+    uint32_t*            out_spos;  // [n_l][knn] in the order of lpts
     float*               out_d2;
     float*               tile_bbox;
 };
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64) void pt2pt_knn_kernel(const KnnArgs a)
         if (k >= (int)a.knn) continue;
         bool acc = active && kidx[k] != NONE_U32;                             // d2 < thr by construction
         if (acc && a.global_taken && a.global_taken[kidx[k]]) acc = false;   // :98-101
-        const size_t slot = (size_t)orig * a.knn + k;
+        const size_t slot = (size_t)(blockIdx.x * 64u + (uint32_t)lane) * a.knn + k;  // sorted order
         a.out_spos[slot]  = acc ? kspos[k] : NONE_U32;
         a.out_d2[slot]    = kd2[k];
         if (acc && a.claims)

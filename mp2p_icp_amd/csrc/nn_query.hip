@@ -51,7 +51,7 @@ struct NNArgs
     unsigned long long*  claims;        // by sorted global position, or null
     unsigned long long   claim_hi;      // (~epoch) << 32
     unsigned long long   local_offset;  // whole-layer index of this rank's first local point
-    uint32_t*            out_spos;      // [n_l] by original local index
+    uint32_t*            out_spos;      // [n_l] in the order of lpts (coalesced; pairs.hip maps back)
     float*               out_d2;
     float*               tile_bbox;  // [n_tiles][6]
     uint4*               work;       // deferred queries {sorted idx, r, best_d2, best_idx}
@@ -59,7 +59,7 @@ struct NNArgs
     uint32_t*            work_count;
     // warm start, [n_l] by original local index: {sorted position of the nearest neighbour found by
     // the previous call on the same (map, cloud) pair or NONE, lower bound on the SQUARED distance
-    // to every map point at that call's pose}; read at entry, rewritten at exit
+    // to every map point at that call's pose}, in the order of lpts; read at entry, rewritten at exit
     uint2*               hint;
     const uint32_t*      rank;  // visit rank per original local index (NONE = not visited) or null
     int                  use_hint;
@@ -186,19 +186,19 @@ __device__ __forceinline__ bool is_final(float r, float rmax, float best_d2, flo
     return r >= rmax || (gr > 0.f && best_d2 < gr * gr);
 }
 
-__device__ __forceinline__ void emit_result(const NNArgs& a, uint32_t orig, bool active, float thr,
+__device__ __forceinline__ void emit_result(const NNArgs& a, uint32_t qi, uint32_t orig, bool active, float thr,
                                             float best_d2, uint32_t best_idx, uint32_t best_spos,
                                             float lb2_keep = 0.f)
 {
     bool acc = active && best_idx != NONE_U32 && best_d2 < thr;  // :259
     if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;  // :98-101
-    a.out_spos[orig] = acc ? best_spos : NONE_U32;
-    a.out_d2[orig]   = best_d2;
+    a.out_spos[qi] = acc ? best_spos : NONE_U32;
+    a.out_d2[qi]   = best_d2;
     // next call's warm start: the raw nearest neighbour (even if rejected) and what this search
     // proved: no map point is nearer than min(best, threshold) (every point that could pass the
     // threshold was examined), or than the bound that let the search be skipped
     const float lb2 = active ? fmaxf(fminf(best_d2, thr), lb2_keep) : 0.f;
-    a.hint[orig]    = make_uint2(best_spos, __float_as_uint(lb2));
+    a.hint[qi]      = make_uint2(best_spos, __float_as_uint(lb2));
     if (acc && a.claims)
     {
         const uint32_t vrank = a.rank ? a.rank[orig] : orig;  // the order the sequential loop visits
@@ -251,6 +251,10 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
 
     float4 lp = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) lp = a.lpts[qi];
+    // the warm-start record is in the same (Morton) order: its load is issued together with the
+    // point's, not behind it
+    uint2 h = make_uint2(NONE_U32, 0u);
+    if (valid && a.use_hint) h = a.hint[qi];
     const uint32_t orig = __float_as_uint(lp.w);
     // a visit order on the cloud (maxLocalPointsPerLayer, Matcher_Points_Base.cpp:222-246): only
     // the listed points are transformed, boxed and matched
@@ -300,7 +304,6 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
     float lb2_keep = 0.f;
     if (a.use_hint && active)
     {
-        const uint2 h = a.hint[orig];
         float       ox, oy, oz;
         compose_point_f(a.prev_pose, lp.x, lp.y, lp.z, ox, oy, oz);
         const float disp = sqrtf(dist2(qx, qy, qz, ox, oy, oz));
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
 
     // ---- output (original local order) + claim of the global point --------------------------
     if (valid && slice == 0 && !deferred)
-        emit_result(a, orig, active, thr, best_d2, best_idx, best_spos, lb2_keep);
+        emit_result(a, qi, orig, active, thr, best_d2, best_idx, best_spos, lb2_keep);
 
     if (INSTR && lane == 0)
     {
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
             if (is_final(r, rmax, best_d2, g.slack)) break;
             r = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
         }
-        if (lane == 0) emit_result(a, orig, true, thr, best_d2, best_idx, best_spos);
+        if (lane == 0) emit_result(a, qi, orig, true, thr, best_d2, best_idx, best_spos);
         if (INSTR && lane == 0)
         {
             atomicAdd(&a.counters[10], 1ull);

@@ -16,7 +16,8 @@ constexpr int CP_TILE    = CP_THREADS * CP_ITEMS;
 
 struct CompactArgs
 {
-    const uint32_t*           nn_spos;  // [n_l][K] by original local index
+    const uint32_t*           nn_spos;  // [n_l][K] in the Morton order of the local layer
+    const uint32_t*           pos;      // original local index -> place in that order
     const float*              nn_d2;
     uint32_t                  n_l;      // number of SLOTS = visited local points x K, in visiting order
     uint32_t                  K;        // pairingsPerPoint
@@ -58,7 +59,7 @@ __device__ __forceinline__ bool pair_flag(const CompactArgs& a, uint32_t t, uint
     const uint32_t r = (a.K == 1) ? t : t / a.K;
     const uint32_t k = (a.K == 1) ? 0u : t - r * a.K;
     i                = a.order ? a.order[r] : r;
-    src              = (size_t)i * a.K + k;
+    src              = (size_t)a.pos[i] * a.K + k;
     spos             = a.nn_spos[src];
     if (spos == NONE_U32) return false;
     if (a.claims && a.claims[spos] != (a.claim_hi | ((a.local_offset + r) * a.K + k))) return false;
@@ -192,6 +193,7 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     memset(&a, 0, sizeof(a));
     a.nn_spos = ctx->nn_spos.p, a.nn_d2 = ctx->nn_d2.p, a.n_l = (uint32_t)n_l;
     a.K = prm->pairingsPerPoint, a.order = cloud->n_visit ? cloud->order.p : nullptr;
+    a.pos = cloud->pos.p;
     a.claims       = prm->allowMatchAlreadyMatchedGlobalPoints ? nullptr : map->claims.p;
     a.claim_hi     = (~(unsigned long long)ctx->epoch) << 32;
     a.local_offset = prm->local_index_offset;
@@ -231,7 +233,7 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
 // of the map), so the ranks all-gather records instead of reducing one word per global point.
 __global__ __launch_bounds__(256) void claims_export_kernel(const uint32_t* __restrict__ nn_spos,
                                                             uint32_t n_slots, uint32_t K,
-                                                            const uint32_t* order,
+                                                            const uint32_t* order, const uint32_t* pos,
                                                             const unsigned long long* claims,
                                                             unsigned long long claim_hi,
                                                             unsigned long long local_offset,
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void claims_export_kernel(const uint32_t* __re
     {
         const uint32_t r = t / K, k = t - r * K;
         const uint32_t i = order ? order[r] : r;
-        spos             = nn_spos[(size_t)i * K + k];
+        spos             = nn_spos[(size_t)pos[i] * K + k];
         id               = (local_offset + r) * K + k;
     }
     const bool mine = spos != NONE_U32 && claims[spos] == (claim_hi | id);
@@ -306,7 +308,7 @@ int launch_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
         if (searched)
             hipLaunchKernelGGL(claims_export_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0,
                                ctx->stream, ctx->nn_spos.p, (uint32_t)n_l, K,
-                               cloud->n_visit ? cloud->order.p : nullptr, map->claims.p,
+                               cloud->n_visit ? cloud->order.p : nullptr, cloud->pos.p, map->claims.p,
                                (~(unsigned long long)ctx->epoch) << 32,
                                (unsigned long long)prm->local_index_offset, ctx->claim_list.p, counter);
     }

@@ -1,0 +1,84 @@
+"""BASELINE.json's full size (1 M-point local layer vs 10 M-point global layer) through the C ABI,
+checked with properties that do not need a full CPU rerun of the matcher:
+  * every pair: d2 recomputed on the host in the reference's fp32 sequence equals the stored
+    errorSquareAfterTransformation bit for bit and is below the threshold; coordinates are the
+    untransformed local / the global point of the stored indices;
+  * global indices unique (unique-global filter), local indices strictly ascending;
+  * a random sample of queries against the oracle's exact KD-tree search on the full map
+    (paired <=> nearest neighbour below the threshold; same neighbour unless it lost its claim);
+  * idempotence: the same call again (warm) and a cold call give the identical list;
+  * the Gauss-Newton pose on these ~1e5 pairs within 1e-5 m / 1e-5 rad of the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(900)
+def test_one_million_vs_ten_million(oracle):
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import synthetic
+    d = synthetic.make_pair(1_000_000, 10_000_000, 1)
+    g, l = d["glob"], d["local"]
+    thr = 2.0
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g)})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    warm = amd.Matcher_Points_DistanceThreshold()
+    warm.initialize({"threshold": thr, "thresholdAngularDeg": 0.0})
+    cold = amd.Matcher_Points_DistanceThreshold()
+    cold.initialize({"threshold": thr, "thresholdAngularDeg": 0.0, "hip_disable_warm_start": True})
+
+    def run(m, pose):
+        p = amd.Pairings()
+        assert m.match(pcG, pcL, pose, amd.MatchContext(), amd.MatchState(pcG, pcL), p)
+        return p
+
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    rng = np.random.default_rng(3)
+    sample = np.sort(rng.choice(l.shape[0], 3000, replace=False))
+    for pose in (d["T_init"], d["T_gt"]):
+        pairs = run(warm, pose)
+        P = pairs.paired_pt2pt
+        assert pairs.potential_pairings == l.shape[0]
+        assert len(P) > 50_000
+        li, gi = P["localIdx"].astype(np.int64), P["globalIdx"].astype(np.int64)
+        assert np.all(np.diff(li) > 0)                                  # the sequential loop's order
+        assert np.unique(gi).size == gi.size                            # unique-global filter
+        assert np.array_equal(P["local"], l[li]) and np.array_equal(P["global"], g[gi])
+        tx, ty, tz, _, _ = oracle.transform_local_to_global(l[li, 0], l[li, 1], l[li, 2], pose)
+        dx, dy, dz = tx - g[gi, 0], ty - g[gi, 1], tz - g[gi, 2]
+        d2 = (dx * dx + dy * dy) + dz * dz                              # fp32, the reference's sequence
+        assert d2.dtype == np.float32
+        assert np.array_equal(d2.view(np.uint32), P["errorSquareAfterTransformation"].view(np.uint32))
+        assert np.all(d2 < np.float32(thr * thr))
+        # exact nearest neighbours of a sample, on the full 10 M-point map
+        paired = dict(zip(li.tolist(), gi.tolist()))
+        owner = dict(zip(gi.tolist(), li.tolist()))
+        sx, sy, sz, _, _ = oracle.transform_local_to_global(l[sample, 0], l[sample, 1], l[sample, 2], pose)
+        for k, i in enumerate(sample.tolist()):
+            idx, dd = tree.knn((sx[k], sy[k], sz[k]), 1)
+            near = len(idx) > 0 and dd[0] < np.float32(thr * thr)
+            if i in paired:
+                assert near and paired[i] == int(idx[0])
+            elif near:                      # unpaired although in range: an earlier local point took it
+                assert owner.get(int(idx[0]), i) < i
+        # idempotence: warm repeat and cold call
+        again = run(warm, pose).paired_pt2pt
+        c = run(cold, pose).paired_pt2pt
+        assert np.array_equal(again, P) and np.array_equal(c, P)
+        # Gauss-Newton on the device-resident list vs the oracle on the downloaded one
+        s = amd.Solver_GaussNewton()
+        s.initialize({"maxIterations": 3, "robustKernel": "RobustKernel::GemanMcClure", "robustKernelParam": 0.15})
+        sc = amd.SolverContext()
+        sc.guessRelativePose = pose
+        out = amd.OptimalTF_Result()
+        assert s.optimal_pose(pairs, out, sc)
+        o = np.zeros(len(P), oracle.PAIR_PT2PT)
+        o["globalIdx"], o["localIdx"] = P["globalIdx"], P["localIdx"]
+        o["gx"], o["gy"], o["gz"] = P["global"].T
+        o["lx"], o["ly"], o["lz"] = P["local"].T
+        o["errSq"] = P["errorSquareAfterTransformation"]
+        To, *_ = oracle.optimal_tf_gauss_newton(o, None, None, pose, oracle.make_gn_params(
+            3, kernel=oracle.KERNEL_GEMANMCCLURE, kernelParam=0.15))
+        dt, dr = oracle.pose_err_split(out.optimalPose, To)
+        assert dt < 1e-5 and dr < 1e-5

@@ -348,6 +348,40 @@ typedef struct
     uint64_t nn_single_ticks_sum, nn_single_ticks_max; /* 100 MHz ticks per deferred query */
     uint64_t nn_single_max_passes, nn_single_max_cells;
 } mp2p_hip_stats;
+/* ---- FilterDecimateVoxels (mp2p_icp_filters/src/FilterDecimateVoxels.cpp:107-381): the voxel
+ *      decimation that produces the "decimated" layer every demo pipeline matches on (SURVEY.md
+ *      section 8f #2).  One input layer (the reference's FirstPoint mode accepts several: the caller
+ *      concatenates them in layer order).  Voxel = (int32)(coordinate / resolution) per axis.
+ *      Output order = ascending (cx, cy, cz), i.e. the reference's std::map mode; its default
+ *      tsl::robin_map mode visits the same voxels in an order that depends on the (un-vendored)
+ *      table.  DecimateMethod::RandomPoint is not offered (mrpt::random stream). ----------------- */
+enum
+{
+    MP2P_HIP_DECIMATE_FIRST_POINT        = 0, /* lowest point index of the voxel              */
+    MP2P_HIP_DECIMATE_CLOSEST_TO_AVERAGE = 1, /* point closest to the fp32 voxel mean         */
+    MP2P_HIP_DECIMATE_VOXEL_AVERAGE      = 2  /* the fp32 voxel mean itself                   */
+};
+typedef struct
+{
+    float   voxel_filter_resolution; /* [m] */
+    int32_t decimate_method;         /* MP2P_HIP_DECIMATE_* */
+    int32_t has_flatten_to;          /* emit one point per (cx, cy) column with z = flatten_to */
+    float   flatten_to;
+} mp2p_hip_decimate_params;
+/* host arrays in, host arrays out (capacity n each; out_src_index may be NULL: index of the
+ * input point that was kept, 0xFFFFFFFF for an average) */
+int mp2p_hip_filter_decimate_voxels(mp2p_hip_ctx* ctx, const float* x, const float* y, const float* z,
+                                    size_t n, const mp2p_hip_decimate_params* prm, float* out_x,
+                                    float* out_y, float* out_z, uint32_t* out_src_index,
+                                    size_t* n_out);
+/* the same on device arrays (inputs and outputs in HBM, e.g. to upload the result as a layer
+ * with mp2p_hip_cloud_upload_device without a PCIe round trip) */
+int mp2p_hip_filter_decimate_voxels_device(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y,
+                                           const float* d_z, size_t n,
+                                           const mp2p_hip_decimate_params* prm, float* d_out_x,
+                                           float* d_out_y, float* d_out_z, uint32_t* d_out_src_index,
+                                           size_t* n_out);
+
 /* 0 = off; 1 = bracket the kernels with hipEvents (ms_* fields; each call then ends with a
  * stream synchronisation); 2 = additionally collect the device counters (nn_* fields, slower);
  * 3 = only the two events around the search kernels (ms_nn; the cheapest timing). */

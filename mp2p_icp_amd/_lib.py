@@ -30,6 +30,14 @@ class MapParams(C.Structure):
                 ("max_levels", C.c_uint32), ("no_occupancy_bitmap", C.c_uint32)]
 
 
+class DecimateParams(C.Structure):
+    _fields_ = [("voxel_filter_resolution", C.c_float), ("decimate_method", C.c_int32),
+                ("has_flatten_to", C.c_int32), ("flatten_to", C.c_float)]
+
+
+DECIMATE_FIRST_POINT, DECIMATE_CLOSEST_TO_AVERAGE, DECIMATE_VOXEL_AVERAGE = 0, 1, 2
+
+
 class MapInfo(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
                 ("cell_size", C.c_float), ("n_levels", C.c_uint32), ("n_cells_total", C.c_uint64),
@@ -133,6 +141,11 @@ SIGNATURES = {
     "mp2p_hip_pairs_download_pt2pt": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mp2p_hip_pairs_download_pt2pl": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint32), C.c_size_t,
                                                 C.POINTER(C.c_size_t)]),
+    "mp2p_hip_filter_decimate_voxels": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(DecimateParams),
+                                                  _P, _P, _P, _P, C.POINTER(C.c_size_t)]),
+    "mp2p_hip_filter_decimate_voxels_device": (C.c_int, [_P, _P, _P, _P, C.c_size_t,
+                                                         C.POINTER(DecimateParams), _P, _P, _P, _P,
+                                                         C.POINTER(C.c_size_t)]),
     "mp2p_hip_pairs_upload_lines_planes": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_size_t]),
     "mp2p_hip_pairs_counts_lines_planes": (C.c_int, [_P, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mp2p_hip_pairs_upload": (C.c_int, [_P, _P, _P, C.c_size_t, _P, C.c_size_t]),

@@ -262,6 +262,21 @@ DevicePairs.upload_lines_planes = _pairs_upload_lines_planes
 DevicePairs.counts_lines_planes = _pairs_counts_lines_planes
 
 
+def filter_decimate_voxels(ctx, x, y, z, resolution, method, flatten_to=None):
+    """-> (xyz [m,3] float32, source index [m] uint32; 0xFFFFFFFF where the point is an average)"""
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    n = x.size
+    prm = _lib.DecimateParams(float(resolution), int(method), int(flatten_to is not None),
+                              float(flatten_to or 0.0))
+    ox, oy, oz = (np.zeros(max(1, n), np.float32) for _ in range(3))
+    src = np.zeros(max(1, n), np.uint32)
+    m = C.c_size_t()
+    check(ctx._L.mp2p_hip_filter_decimate_voxels(ctx.handle, _fp(x), _fp(y), _fp(z), n, C.byref(prm),
+                                                 _fp(ox), _fp(oy), _fp(oz), src.ctypes.data, C.byref(m)),
+          ctx.handle)
+    return np.stack([ox[:m.value], oy[:m.value], oz[:m.value]], 1), src[:m.value].copy()
+
+
 def match_pt2pt(ctx, gmap, cloud, pose, prm, mstate, pairs):
     T = _pose(pose)
     check(ctx._L.mp2p_hip_match_pt2pt(ctx.handle, gmap.handle, cloud.handle,

@@ -502,6 +502,64 @@ int mp2p_hip_horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, double w
     return horn_solve(ctx, pairs, w_pt2pt, pose_out, solved);
 }
 
+// ---- FilterDecimateVoxels ------------------------------------------------------------------------
+static int check_decimate(mp2p_hip_ctx* ctx, const mp2p_hip_decimate_params* prm)
+{
+    MP2P_REQUIRE(ctx, prm, "null parameters");
+    MP2P_REQUIRE(ctx, prm->voxel_filter_resolution > 0.0f, "voxel_filter_resolution must be > 0");
+    MP2P_REQUIRE(ctx, prm->decimate_method >= MP2P_HIP_DECIMATE_FIRST_POINT &&
+                          prm->decimate_method <= MP2P_HIP_DECIMATE_VOXEL_AVERAGE,
+                 "unknown decimate_method (RandomPoint is not offered)");
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_filter_decimate_voxels_device(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y,
+                                           const float* d_z, size_t n, const mp2p_hip_decimate_params* prm,
+                                           float* d_ox, float* d_oy, float* d_oz, uint32_t* d_osrc,
+                                           size_t* n_out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    int rc = check_decimate(ctx, prm);
+    if (rc) return rc;
+    MP2P_REQUIRE(ctx, n_out && (n == 0 || (d_x && d_y && d_z && d_ox && d_oy && d_oz)), "null argument");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return filter_decimate_device(ctx, d_x, d_y, d_z, n, prm, d_ox, d_oy, d_oz, d_osrc, n_out);
+}
+
+int mp2p_hip_filter_decimate_voxels(mp2p_hip_ctx* ctx, const float* x, const float* y, const float* z,
+                                    size_t n, const mp2p_hip_decimate_params* prm, float* out_x,
+                                    float* out_y, float* out_z, uint32_t* out_src, size_t* n_out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    int rc = check_decimate(ctx, prm);
+    if (rc) return rc;
+    MP2P_REQUIRE(ctx, n_out && (n == 0 || (x && y && z && out_x && out_y && out_z)), "null argument");
+    *n_out = 0;
+    if (n == 0) return MP2P_HIP_OK;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    mp2p::DevBuf<float>    in, out;
+    mp2p::DevBuf<uint32_t> src;
+    MP2P_TRY_HIP(ctx, in.alloc(3 * n));
+    MP2P_TRY_HIP(ctx, out.alloc(3 * n));
+    MP2P_TRY_HIP(ctx, src.alloc(n));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(in.p, x, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(in.p + n, y, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(in.p + 2 * n, z, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    size_t m = 0;
+    rc = filter_decimate_device(ctx, in.p, in.p + n, in.p + 2 * n, n, prm, out.p, out.p + n, out.p + 2 * n, src.p, &m);
+    if (rc) return rc;
+    if (m)
+    {
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(out_x, out.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(out_y, out.p + n, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(out_z, out.p + 2 * n, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_src) MP2P_TRY_HIP(ctx, hipMemcpyAsync(out_src, src.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *n_out = m;
+    return MP2P_HIP_OK;
+}
+
 // ---- instrumentation ---------------------------------------------------------------------------
 int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable)
 {

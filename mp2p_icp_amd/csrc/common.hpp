@@ -76,6 +76,10 @@ struct DevBuf
         n = 0;
     }
     size_t bytes() const { return n * sizeof(T); }
+    // owning: temporaries free themselves on every return path.  A plain copy shares the pointer
+    // (used once, to hand a buffer over: the source then clears its p), so no copy constructor
+    // magic -- just do not keep two live copies.
+    ~DevBuf() { release(); }
 };
 
 struct GnState

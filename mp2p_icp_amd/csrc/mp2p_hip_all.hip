@@ -5,4 +5,5 @@
 #include "nn_pt2pl.hip"
 #include "gn_solver.hip"
 #include "horn.hip"
+#include "filter_decimate.hip"
 #include "api.hip"

@@ -36,6 +36,9 @@ class PointLayer:
     def size(self):
         return self.x.size
 
+    def xyz(self):
+        return np.stack([self.x, self.y, self.z], 1)
+
     def empty(self):
         return self.x.size == 0
 

@@ -1152,6 +1152,87 @@ size_t orc_match_pt2pl_subset(const orc_kdtree* tree, const float* gx, const flo
 }
 
 /* ======================================================================================
+ *  f2: FilterDecimateVoxels (mp2p_icp_filters/src/FilterDecimateVoxels.cpp:107-381) with
+ *  PointCloudToVoxelGrid[Single] (PointCloudToVoxelGrid.cpp:57-92, ...Single.cpp:50-92).
+ *  One input layer.  The voxel container is the reference's std::map mode: voxels visited in
+ *  ascending (cx, cy, cz) (IndicesHash::operator() as the comparator,
+ *  PointCloudToVoxelGrid.h:100-111); the default tsl::robin_map mode visits the same voxels in
+ *  a table-dependent order (un-vendored) -> the SET is pinned, the sequence only for std::map.
+ * ====================================================================================== */
+typedef struct
+{
+    int32_t  cx, cy, cz;
+    uint32_t idx;
+} dv_item;
+
+static int dv_cmp(const void* a, const void* b)
+{
+    const dv_item* p = (const dv_item*)a;
+    const dv_item* q = (const dv_item*)b;
+    if (p->cx != q->cx) return p->cx < q->cx ? -1 : 1;
+    if (p->cy != q->cy) return p->cy < q->cy ? -1 : 1;
+    if (p->cz != q->cz) return p->cz < q->cz ? -1 : 1;
+    return p->idx < q->idx ? -1 : (p->idx > q->idx ? 1 : 0); /* vxl.indices: ascending point index */
+}
+
+size_t orc_filter_decimate_voxels(const float* x, const float* y, const float* z, size_t n,
+                                  float resolution, int method, int has_flatten_to,
+                                  float flatten_to, float* ox, float* oy, float* oz,
+                                  uint32_t* osrc)
+{
+    if (n == 0) return 0;
+    dv_item* it = (dv_item*)malloc(n * sizeof(dv_item));
+    for (size_t i = 0; i < n; i++)
+    {
+        /* coord2idx: static_cast<int32_t>(xyz / resolution_)  (PointCloudToVoxelGrid.h:110) */
+        it[i].cx = (int32_t)(x[i] / resolution), it[i].cy = (int32_t)(y[i] / resolution),
+        it[i].cz = (int32_t)(z[i] / resolution), it[i].idx = (uint32_t)i;
+    }
+    qsort(it, n, sizeof(dv_item), dv_cmp);
+    size_t m = 0;
+    for (size_t b = 0; b < n;)
+    {
+        size_t e = b + 1;
+        while (e < n && it[e].cx == it[b].cx && it[e].cy == it[b].cy && it[e].cz == it[b].cz) e++;
+        /* flatten: only the first voxel visited of each (cx, cy) column (:232-246, :346-360) */
+        const int skip = has_flatten_to && b > 0 && it[b - 1].cx == it[b].cx && it[b - 1].cy == it[b].cy;
+        if (!skip)
+        {
+            uint32_t src = it[b].idx; /* FirstPoint / idxInVoxel = 0 (:327-334) */
+            float    px = x[src], py = y[src], pz = z[src];
+            if (method != 0)
+            {
+                float mx = 0, my = 0, mz = 0; /* :291-300 */
+                const float inv_n = 1.0f / (float)(e - b);
+                for (size_t j = b; j < e; j++) mx += x[it[j].idx], my += y[it[j].idx], mz += z[it[j].idx];
+                mx *= inv_n, my *= inv_n, mz *= inv_n;
+                if (method == 2)
+                    px = mx, py = my, pz = mz, src = 0xFFFFFFFFu; /* VoxelAverage :323-326 */
+                else
+                {
+                    float best = 0;
+                    int   have = 0;
+                    for (size_t j = b; j < e; j++) /* ClosestToAverage :302-321 */
+                    {
+                        const uint32_t p  = it[j].idx;
+                        const float    dx = x[p] - mx, dy = y[p] - my, dz = z[p] - mz;
+                        const float    s  = (dx * dx + dy * dy) + dz * dz;
+                        if (!have || s < best) best = s, src = p, have = 1;
+                    }
+                    px = x[src], py = y[src], pz = z[src];
+                }
+            }
+            ox[m] = px, oy[m] = py, oz[m] = has_flatten_to ? flatten_to : pz;
+            if (osrc) osrc[m] = src;
+            m++;
+        }
+        b = e;
+    }
+    free(it);
+    return m;
+}
+
+/* ======================================================================================
  *  a10: optimal_tf_gauss_newton (optimal_tf_gauss_newton.cpp:36-372)
  *  Sequential summation order; H and g reset at the top of every inner iteration (the
  *  TBB-build meaning :145-146).

@@ -213,6 +213,13 @@ size_t orc_match_pt2pl_subset(const orc_kdtree* tree, const float* gx, const flo
 void orc_estimate_points_eigen(const float* xs, const float* ys, const float* zs, size_t n,
                                float mean[3], double cov[9], double eval[3], double evec[9]);
 
+/* ---- f2: FilterDecimateVoxels (one input layer; method 0 FirstPoint, 1 ClosestToAverage,
+ *      2 VoxelAverage; std::map visiting order).  Returns the number of output points. ---- */
+size_t orc_filter_decimate_voxels(const float* x, const float* y, const float* z, size_t n,
+                                  float resolution, int method, int has_flatten_to,
+                                  float flatten_to, float* ox, float* oy, float* oz,
+                                  uint32_t* osrc);
+
 /* ---- a10: optimal_tf_gauss_newton ----------------------------------------------------- */
 /* Returns number of inner iterations executed.  H_out(36)/g_out(6) = last assembled
  * normal equations (may be NULL). */

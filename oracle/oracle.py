@@ -128,6 +128,9 @@ def _declare(L):
                                          C.c_size_t, _u32p, C.c_size_t, _dp, C.POINTER(Pt2PlParams),
                                          _u8p, C.c_void_p, _u32p, C.POINTER(C.c_uint64)]
     L.orc_match_pt2pl_subset.restype = C.c_size_t
+    L.orc_filter_decimate_voxels.argtypes = [_fp, _fp, _fp, C.c_size_t, C.c_float, C.c_int, C.c_int,
+                                             C.c_float, _fp, _fp, _fp, _u32p]
+    L.orc_filter_decimate_voxels.restype = C.c_size_t
     L.orc_estimate_points_eigen.argtypes = [_fp, _fp, _fp, C.c_size_t, _fp, _dp, _dp, _dp]
     L.orc_optimal_tf_gauss_newton.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _dp,
@@ -355,6 +358,21 @@ def match_pt2pl(gx, gy, gz, lx, ly, lz, T, distanceThreshold, searchRadius, knn,
                               lx.size, _d(T), C.byref(prm), lt, out.ctypes.data,
                               oidx.ctypes.data_as(_u32p), C.byref(pot))
     return out[:n].copy(), oidx[:n].copy(), pot.value
+
+
+DECIMATE_FIRST_POINT, DECIMATE_CLOSEST_TO_AVERAGE, DECIMATE_VOXEL_AVERAGE = 0, 1, 2
+
+
+def filter_decimate_voxels(x, y, z, resolution, method, flatten_to=None):
+    """FilterDecimateVoxels::filter on one layer -> (xyz [m,3], source index [m])"""
+    x, y, z = map(_f32, (x, y, z))
+    n = x.size
+    ox, oy, oz = np.zeros(max(1, n), np.float32), np.zeros(max(1, n), np.float32), np.zeros(max(1, n), np.float32)
+    src = np.zeros(max(1, n), np.uint32)
+    m = lib().orc_filter_decimate_voxels(_f(x), _f(y), _f(z), n, float(resolution), int(method),
+                                         int(flatten_to is not None), float(flatten_to or 0.0),
+                                         _f(ox), _f(oy), _f(oz), src.ctypes.data_as(_u32p))
+    return np.stack([ox[:m], oy[:m], oz[:m]], 1), src[:m].copy()
 
 
 def estimate_points_eigen(xs, ys, zs):

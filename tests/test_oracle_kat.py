@@ -359,3 +359,31 @@ def test_optimize_points_and_planes(oracle):
     T, *_ = oracle.optimal_tf_gauss_newton(None, None, None, oracle.pose_identity(),
                                            oracle.make_gn_params(maxIterations=40), pl2pl=pl)
     assert np.allclose(T[:9], gt[:9], atol=1e-6)
+
+
+def test_oracle_filter_decimate_voxels(oracle):
+    """FilterDecimateVoxels restatement vs a dictionary version of the reference loops
+    (PointCloudToVoxelGrid.cpp:57-92, FilterDecimateVoxels.cpp:286-334)"""
+    rng = np.random.default_rng(21)
+    pts = rng.uniform(-2, 2, (4000, 3)).astype(np.float32)
+    res = np.float32(0.3)
+    vox = {}
+    for i, p in enumerate(pts):
+        vox.setdefault(tuple(int(v) for v in (p / res).astype(np.int32)), []).append(i)
+    keys = sorted(vox)
+    out, src = oracle.filter_decimate_voxels(pts[:, 0], pts[:, 1], pts[:, 2], res, oracle.DECIMATE_FIRST_POINT)
+    assert np.array_equal(src, [vox[k][0] for k in keys]) and np.array_equal(out, pts[src])
+    out, src = oracle.filter_decimate_voxels(pts[:, 0], pts[:, 1], pts[:, 2], res, oracle.DECIMATE_CLOSEST_TO_AVERAGE)
+    for k, s in zip(keys, src):
+        m = np.zeros(3, np.float32)
+        for i in vox[k]:
+            m = (m + pts[i]).astype(np.float32)
+        m = (m * np.float32(np.float32(1) / np.float32(len(vox[k])))).astype(np.float32)
+        d = pts[vox[k]] - m
+        e = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]).astype(np.float32)
+        assert s == vox[k][int(np.argmin(e))]
+    # truncation toward zero: -0.2 and +0.2 share voxel 0 at resolution 0.3
+    o, _ = oracle.filter_decimate_voxels(np.float32([-0.2, 0.2]), np.float32([0, 0]), np.float32([0, 0]), 0.3, 0)
+    assert len(o) == 1
+    o, _ = oracle.filter_decimate_voxels(pts[:, 0], pts[:, 1], pts[:, 2], res, 0, flatten_to=7.0)
+    assert len(o) == len({k[:2] for k in keys}) and np.all(o[:, 2] == 7.0)

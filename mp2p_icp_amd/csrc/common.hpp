@@ -76,10 +76,22 @@ struct DevBuf
         n = 0;
     }
     size_t bytes() const { return n * sizeof(T); }
-    // owning: temporaries free themselves on every return path.  A plain copy shares the pointer
-    // (used once, to hand a buffer over: the source then clears its p), so no copy constructor
-    // magic -- just do not keep two live copies.
+    // owning, move-only: temporaries free themselves on every return path
+    DevBuf() = default;
     ~DevBuf() { release(); }
+    DevBuf(const DevBuf&)            = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept
+    {
+        if (this != &o)
+        {
+            release();
+            p = o.p, n = o.n;
+            o.p = nullptr, o.n = 0;
+        }
+        return *this;
+    }
 };
 
 struct GnState

@@ -241,9 +241,7 @@ static int morton_sort(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, co
     MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (keys_out)
     {
-        keys_out->release();
-        *keys_out = k1;
-        k1.p      = nullptr;
+        *keys_out = std::move(k1);
     }
     k0.release(), k1.release(), i0.release(), i1.release(), tmp.release();
     return MP2P_HIP_OK;

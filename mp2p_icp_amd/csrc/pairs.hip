@@ -412,8 +412,7 @@ static int grow_buf(mp2p_hip_ctx* ctx, DevBuf<T>& b, size_t new_count, size_t ke
     MP2P_TRY_HIP(ctx, nb.alloc(new_count));
     if (keep) MP2P_TRY_HIP(ctx, hipMemcpyAsync(nb.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
     MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    b.release();
-    b = nb;
+    b = std::move(nb);
     return MP2P_HIP_OK;
 }
 

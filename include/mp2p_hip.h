@@ -348,6 +348,16 @@ typedef struct
     uint64_t nn_single_ticks_sum, nn_single_ticks_max; /* 100 MHz ticks per deferred query */
     uint64_t nn_single_max_passes, nn_single_max_cells;
 } mp2p_hip_stats;
+/* ---- mp2p_icp::covariance (mp2p_icp/src/covariance.cpp:29-141, ICP.cpp:334-337):
+ *      H = J^T J of the stacked error vector w.r.t. (x, y, z, yaw, pitch, roll), J by central
+ *      finite differences (CovarianceParameters::finDif_xyz / finDif_angles, 1e-7 each), cov = H^-1.
+ *      One pass over the device-resident Pairings (pt2pt, pt2pl, pt2ln, pl2pl; ln2ln unsupported).
+ *      No pairings: cov = 1e6 * I (covariance.cpp:33-39).  *positive_definite = 0 and cov = NaN
+ *      when the Cholesky factorisation of H fails.  H_out may be NULL. --------------------------- */
+int mp2p_hip_covariance(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose[12],
+                        double finDif_xyz, double finDif_angles, double H_out[36], double cov_out[36],
+                        int32_t* positive_definite);
+
 /* ---- FilterDecimateVoxels (mp2p_icp_filters/src/FilterDecimateVoxels.cpp:107-381): the voxel
  *      decimation that produces the "decimated" layer every demo pipeline matches on (SURVEY.md
  *      section 8f #2).  One input layer (the reference's FirstPoint mode accepts several: the caller

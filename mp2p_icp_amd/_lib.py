@@ -141,6 +141,7 @@ SIGNATURES = {
     "mp2p_hip_pairs_download_pt2pt": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "mp2p_hip_pairs_download_pt2pl": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint32), C.c_size_t,
                                                 C.POINTER(C.c_size_t)]),
+    "mp2p_hip_covariance": (C.c_int, [_P, _P, _dp, C.c_double, C.c_double, _dp, _dp, C.POINTER(C.c_int32)]),
     "mp2p_hip_filter_decimate_voxels": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(DecimateParams),
                                                   _P, _P, _P, _P, C.POINTER(C.c_size_t)]),
     "mp2p_hip_filter_decimate_voxels_device": (C.c_int, [_P, _P, _P, _P, C.c_size_t,

@@ -262,6 +262,18 @@ DevicePairs.upload_lines_planes = _pairs_upload_lines_planes
 DevicePairs.counts_lines_planes = _pairs_counts_lines_planes
 
 
+def covariance(ctx, pairs, pose, finDif_xyz=1e-7, finDif_angles=1e-7):
+    """mp2p_icp::covariance on device-resident pairings -> (cov 6x6, H 6x6, positive definite?)"""
+    T = _pose(pose)
+    H, cov = np.zeros(36), np.zeros(36)
+    pd = C.c_int32()
+    dp = C.POINTER(C.c_double)
+    check(ctx._L.mp2p_hip_covariance(ctx.handle, pairs.handle, T.ctypes.data_as(dp), finDif_xyz,
+                                     finDif_angles, H.ctypes.data_as(dp), cov.ctypes.data_as(dp),
+                                     C.byref(pd)), ctx.handle)
+    return cov.reshape(6, 6), H.reshape(6, 6), bool(pd.value)
+
+
 def filter_decimate_voxels(ctx, x, y, z, resolution, method, flatten_to=None):
     """-> (xyz [m,3] float32, source index [m] uint32; 0xFFFFFFFF where the point is an average)"""
     x, y, z = _f32(x), _f32(y), _f32(z)

@@ -502,6 +502,25 @@ int mp2p_hip_horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, double w
     return horn_solve(ctx, pairs, w_pt2pt, pose_out, solved);
 }
 
+// ---- covariance -----------------------------------------------------------------------------------
+int mp2p_hip_covariance(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose[12],
+                        double finDif_xyz, double finDif_angles, double H_out[36], double cov_out[36],
+                        int32_t* positive_definite)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, pairs && pairs->ctx == ctx, "bad Pairings handle");
+    MP2P_REQUIRE(ctx, pose && cov_out, "null argument");
+    MP2P_REQUIRE(ctx, finDif_xyz > 0 && finDif_angles > 0, "finite-difference increments must be > 0");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    double H[36];
+    int    pd = 0;
+    const int rc = covariance_run(ctx, pairs, pose, finDif_xyz, finDif_angles, H, cov_out, &pd);
+    if (rc) return rc;
+    if (H_out) memcpy(H_out, H, sizeof(H));
+    if (positive_definite) *positive_definite = pd;
+    return MP2P_HIP_OK;
+}
+
 // ---- FilterDecimateVoxels ------------------------------------------------------------------------
 static int check_decimate(mp2p_hip_ctx* ctx, const mp2p_hip_decimate_params* prm)
 {

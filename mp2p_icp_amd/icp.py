@@ -1,7 +1,7 @@
 """MRPT-free driver reproducing mp2p_icp::ICP::align (ICP.cpp:36-382): outer loop, formula
-parameters, termination criteria.  It is the *caller* of the hot path, kept minimal: quality
-evaluators / checkpoints, log records and covariance are out of scope (SURVEY.md section 2
-rows 14-16)."""
+parameters, termination criteria, final covariance (ICP.cpp:334-337).  It is the *caller* of the
+hot path, kept minimal: quality evaluators / checkpoints and log records are out of scope
+(SURVEY.md section 2 rows 14-16)."""
 import numpy as np
 
 from . import core, se3
@@ -31,6 +31,23 @@ class Results:  # Results.h
         self.terminationReason = IterTermReason.Undefined
         self.finalPairings = None
         self.quality = 0.0
+        self.optimal_tf_cov = None  # CPose3DPDFGaussian::cov of Results::optimal_tf (6x6)
+
+
+def covariance(pairings, finalAlignSolution, finDif_xyz=1e-7, finDif_angles=1e-7, ctx=None):
+    """mp2p_icp::covariance (covariance.cpp:29-141) on the pairings' device lists."""
+    ctx = pairings.ctx or ctx or core.default_context()
+    dev = pairings.device
+    if dev is None:
+        dev = pairings._ensure_dev(ctx, 1, 0)
+    if len(pairings.paired_ln2ln):
+        raise NotImplementedError("paired_ln2ln is not supported")
+    n_ln, n_pp = len(pairings.paired_pt2ln), len(pairings.paired_pl2pl)
+    if n_ln or n_pp or getattr(dev, "_has_lines_planes", False):
+        dev.upload_lines_planes(pairings.paired_pt2ln, pairings.paired_pl2pl)
+        dev._has_lines_planes = bool(n_ln or n_pp)
+    cov, _, _ = core.covariance(ctx, dev, finalAlignSolution, finDif_xyz, finDif_angles)
+    return cov
 
 
 class ICP:
@@ -121,4 +138,6 @@ class ICP:
             result.terminationReason = IterTermReason.MaxIterations
         result.optimal_tf = cur.optimalPose
         result.finalPairings = pairings
+        if pairings is not None:
+            result.optimal_tf_cov = covariance(pairings, result.optimal_tf, ctx=self.ctx)  # ICP.cpp:334-337
         return result

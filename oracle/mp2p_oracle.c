@@ -1152,6 +1152,103 @@ size_t orc_match_pt2pl_subset(const orc_kdtree* tree, const float* gx, const flo
 }
 
 /* ======================================================================================
+ *  f4: covariance() (mp2p_icp/src/covariance.cpp:29-141): Hessian J^T J of the stacked error
+ *  vector w.r.t. (x, y, z, yaw, pitch, roll) by central finite differences
+ *  (mrpt::math::estimateJacobian: J(:,j) = (f(x + h_j e_j) - f(x - h_j e_j)) * (0.5 / h_j)),
+ *  cov = H^-1.  Reproduced literally, including the linearisation point's z staying 0
+ *  (:41-43 assign x twice and never z; harmless: every supported error term is affine in t).
+ *  paired_ln2ln is not supported.
+ * ====================================================================================== */
+static void cov_errors(const orc_pair_pt2pt* pt, size_t n_pt, const orc_pair_pt2ln* ln, size_t n_ln,
+                       const orc_pair_pt2pl* pl, size_t n_pl, const orc_pair_pl2pl* pp, size_t n_pp,
+                       const double T[12], double* err)
+{
+    size_t k = 0;
+    for (size_t i = 0; i < n_pt; i++, k += 3) orc_error_point2point(&pt[i], T, err + k, NULL); /* :74-80 */
+    for (size_t i = 0; i < n_ln; i++, k += 3) orc_error_point2line(&ln[i], T, err + k, NULL);  /* :84-90 */
+    for (size_t i = 0; i < n_pl; i++, k += 3) orc_error_point2plane(&pl[i], T, err + k, NULL); /* :104-110 */
+    for (size_t i = 0; i < n_pp; i++, k += 3) orc_error_plane2plane(&pp[i], T, err + k, NULL); /* :114-120 */
+}
+
+int orc_covariance(const orc_pair_pt2pt* pt, size_t n_pt, const orc_pair_pt2pl* pl, size_t n_pl,
+                   const orc_pair_pt2ln* ln, size_t n_ln, const orc_pair_pl2pl* pp, size_t n_pp,
+                   const double T[12], double finDif_xyz, double finDif_angles, double H_out[36],
+                   double cov_out[36])
+{
+    const size_t m = 3 * (n_pt + n_pl + n_ln + n_pp);
+    if (m == 0) /* :33-39 */
+    {
+        for (int i = 0; i < 36; i++) cov_out[i] = 0, H_out[i] = 0;
+        for (int i = 0; i < 6; i++) cov_out[i * 6 + i] = 1e6;
+        return 0;
+    }
+    double x0[6];
+    orc_pose_to_xyzypr(T, x0);
+    x0[2] = 0.0; /* :41-43 */
+    double* J  = (double*)calloc(m * 6, sizeof(double));
+    double* fp = (double*)malloc(m * sizeof(double));
+    double* fm = (double*)malloc(m * sizeof(double));
+    for (int j = 0; j < 6; j++)
+    {
+        const double h = j < 3 ? finDif_xyz : finDif_angles;
+        double       x[6], Tp[12];
+        memcpy(x, x0, sizeof(x));
+        x[j] = x0[j] + h;
+        orc_pose_from_xyzypr(x[0], x[1], x[2], x[3], x[4], x[5], Tp);
+        cov_errors(pt, n_pt, ln, n_ln, pl, n_pl, pp, n_pp, Tp, fp);
+        x[j] = x0[j] - h;
+        orc_pose_from_xyzypr(x[0], x[1], x[2], x[3], x[4], x[5], Tp);
+        cov_errors(pt, n_pt, ln, n_ln, pl, n_pl, pp, n_pp, Tp, fm);
+        const double s = 0.5 / h;
+        for (size_t t = 0; t < m; t++) J[t * 6 + j] = s * (fp[t] - fm[t]);
+    }
+    double H[36];
+    memset(H, 0, sizeof(H));
+    for (size_t t = 0; t < m; t++)
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) H[a * 6 + b] += J[t * 6 + a] * J[t * 6 + b];
+    memcpy(H_out, H, sizeof(H));
+    /* inverse_LLt: Cholesky, then solve for the identity */
+    double L[36];
+    memset(L, 0, sizeof(L));
+    int ok = 1;
+    for (int i = 0; i < 6 && ok; i++)
+        for (int j = 0; j <= i; j++)
+        {
+            double v = H[i * 6 + j];
+            for (int k = 0; k < j; k++) v -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j)
+            {
+                if (!(v > 0)) { ok = 0; break; }
+                L[i * 6 + i] = sqrt(v);
+            }
+            else
+                L[i * 6 + j] = v / L[j * 6 + j];
+        }
+    for (int c = 0; c < 6 && ok; c++)
+    {
+        double y[6], z[6];
+        for (int i = 0; i < 6; i++)
+        {
+            double v = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < i; k++) v -= L[i * 6 + k] * y[k];
+            y[i] = v / L[i * 6 + i];
+        }
+        for (int i = 5; i >= 0; i--)
+        {
+            double v = y[i];
+            for (int k = i + 1; k < 6; k++) v -= L[k * 6 + i] * z[k];
+            z[i] = v / L[i * 6 + i];
+        }
+        for (int i = 0; i < 6; i++) cov_out[i * 6 + c] = z[i];
+    }
+    if (!ok)
+        for (int i = 0; i < 36; i++) cov_out[i] = NAN;
+    free(J), free(fp), free(fm);
+    return ok;
+}
+
+/* ======================================================================================
  *  f2: FilterDecimateVoxels (mp2p_icp_filters/src/FilterDecimateVoxels.cpp:107-381) with
  *  PointCloudToVoxelGrid[Single] (PointCloudToVoxelGrid.cpp:57-92, ...Single.cpp:50-92).
  *  One input layer.  The voxel container is the reference's std::map mode: voxels visited in

@@ -213,6 +213,14 @@ size_t orc_match_pt2pl_subset(const orc_kdtree* tree, const float* gx, const flo
 void orc_estimate_points_eigen(const float* xs, const float* ys, const float* zs, size_t n,
                                float mean[3], double cov[9], double eval[3], double evec[9]);
 
+/* ---- f4: covariance() (covariance.cpp:29-141): H = J^T J by central differences over
+ *      (x,y,z,yaw,pitch,roll), cov = H^-1 (Cholesky).  Returns 1, or 0 when H is not positive
+ *      definite (cov = NaN) / there are no pairings (cov = 1e6 * I). ---- */
+int orc_covariance(const orc_pair_pt2pt* pt, size_t n_pt, const orc_pair_pt2pl* pl, size_t n_pl,
+                   const orc_pair_pt2ln* ln, size_t n_ln, const orc_pair_pl2pl* pp, size_t n_pp,
+                   const double T[12], double finDif_xyz, double finDif_angles, double H_out[36],
+                   double cov_out[36]);
+
 /* ---- f2: FilterDecimateVoxels (one input layer; method 0 FirstPoint, 1 ClosestToAverage,
  *      2 VoxelAverage; std::map visiting order).  Returns the number of output points. ---- */
 size_t orc_filter_decimate_voxels(const float* x, const float* y, const float* z, size_t n,

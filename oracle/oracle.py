@@ -128,6 +128,9 @@ def _declare(L):
                                          C.c_size_t, _u32p, C.c_size_t, _dp, C.POINTER(Pt2PlParams),
                                          _u8p, C.c_void_p, _u32p, C.POINTER(C.c_uint64)]
     L.orc_match_pt2pl_subset.restype = C.c_size_t
+    L.orc_covariance.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                 C.c_void_p, C.c_size_t, _dp, C.c_double, C.c_double, _dp, _dp]
+    L.orc_covariance.restype = C.c_int
     L.orc_filter_decimate_voxels.argtypes = [_fp, _fp, _fp, C.c_size_t, C.c_float, C.c_int, C.c_int,
                                              C.c_float, _fp, _fp, _fp, _u32p]
     L.orc_filter_decimate_voxels.restype = C.c_size_t
@@ -361,6 +364,19 @@ def match_pt2pl(gx, gy, gz, lx, ly, lz, T, distanceThreshold, searchRadius, knn,
 
 
 DECIMATE_FIRST_POINT, DECIMATE_CLOSEST_TO_AVERAGE, DECIMATE_VOXEL_AVERAGE = 0, 1, 2
+
+
+def covariance(pt2pt, pt2pl, pt2ln, pl2pl, T, finDif_xyz=1e-7, finDif_angles=1e-7):
+    """mp2p_icp::covariance -> (cov 6x6, H 6x6, ok)"""
+    a = np.ascontiguousarray(pt2pt if pt2pt is not None else np.zeros(0, PAIR_PT2PT))
+    b = np.ascontiguousarray(pt2pl if pt2pl is not None else np.zeros(0, PAIR_PT2PL))
+    c = np.ascontiguousarray(pt2ln if pt2ln is not None else np.zeros(0, PAIR_PT2LN))
+    d = np.ascontiguousarray(pl2pl if pl2pl is not None else np.zeros(0, PAIR_PL2PL))
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    H, cov = np.zeros(36), np.zeros(36)
+    ok = lib().orc_covariance(a.ctypes.data, a.size, b.ctypes.data, b.size, c.ctypes.data, c.size,
+                              d.ctypes.data, d.size, _d(T), finDif_xyz, finDif_angles, _d(H), _d(cov))
+    return cov.reshape(6, 6), H.reshape(6, 6), bool(ok)
 
 
 def filter_decimate_voxels(x, y, z, resolution, method, flatten_to=None):

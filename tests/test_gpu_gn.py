@@ -307,3 +307,56 @@ def test_all_term_kinds_parity(amd, oracle, kname, kid, kparam):
     out, _ = _solve_all(amd, None, None, ln, pp, T0, {"maxIterations": 6})
     To, *_ = oracle.optimal_tf_gauss_newton(None, None, ln, T0, oracle.make_gn_params(6), pl2pl=pp)
     assert _close(oracle, out.optimalPose, To)
+
+
+# ---- mp2p_icp::covariance (covariance.cpp:29-141) ---------------------------------------------------
+def test_covariance_vs_oracle(amd, oracle):
+    from test_oracle_kat import _random_pt_pl_pairs
+    rng = np.random.default_rng(31)
+    gt = oracle.pose_from_xyzypr(3.0, -2.0, 0.7, 20 * DEG, -5 * DEG, 3 * DEG)
+    R, t = gt[:9].reshape(3, 3), gt[9:]
+    pt, pp = _random_pt_pl_pairs(oracle, rng, gt, 20_000, 300, noise=0.02)
+    pt["lx"], pt["ly"], pt["lz"] = [pt[k].astype(np.float32) for k in ("lx", "ly", "lz")]
+    n_pl = 5000
+    l2 = rng.uniform(-10, 10, (n_pl, 3))
+    nrm = rng.normal(size=(n_pl, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    w2 = l2 @ R.T + t
+    pl = np.zeros(n_pl, oracle.PAIR_PT2PL)
+    pl["plane"] = np.concatenate([nrm, -(nrm * w2).sum(1)[:, None]], 1) * rng.uniform(0.5, 2, (n_pl, 1))
+    pl["centroid"] = w2
+    pl["lx"], pl["ly"], pl["lz"] = l2.T.astype(np.float32)
+    n_ln = 700
+    ln = np.zeros(n_ln, oracle.PAIR_PT2LN)
+    base, u = rng.uniform(-10, 10, (n_ln, 3)), rng.normal(size=(n_ln, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    ln["pbase"], ln["director"] = base, u
+    ln["lx"], ln["ly"], ln["lz"] = ((base + u * rng.uniform(-5, 5, (n_ln, 1)) - t) @ R).T
+    ctx = amd.default_context()
+    cases = [(pt, None, None, None), (None, pl, None, None), (pt, pl, ln, pp)]
+    for a, b, c, d in cases:
+        p = amd.Pairings.from_host(ctx, _to_hip_pt2pt(amd, a) if a is not None else None,
+                                   _to_hip_pt2pl(amd, b) if b is not None else None,
+                                   pt2ln=_to_hip_pt2ln(c) if c is not None else None,
+                                   pl2pl=_to_hip_pl2pl(d) if d is not None else None)
+        cov = amd.covariance(p, gt)
+        want, H, ok = oracle.covariance(a, b, c, d, gt)
+        assert ok
+        from mp2p_icp_amd import core
+        _, Hg, pd = core.covariance(ctx, p.device, gt)
+        assert pd
+        assert np.allclose(Hg, H, rtol=1e-9, atol=1e-9 * np.abs(H).max())
+        assert np.allclose(cov, want, rtol=1e-6, atol=1e-6 * np.abs(want).max())
+        assert np.allclose(cov, cov.T, rtol=0, atol=1e-12 * np.abs(cov).max())
+    # point pairs alone: the translation block of H is N * I whatever the pose
+    p = amd.Pairings.from_host(ctx, _to_hip_pt2pt(amd, pt))
+    from mp2p_icp_amd import core
+    _, Hg, _ = core.covariance(ctx, p.device, gt)
+    assert np.allclose(Hg[:3, :3], len(pt) * np.eye(3), rtol=1e-6, atol=1e-3)
+    # no pairings -> 1e6 * I (covariance.cpp:33-39)
+    assert np.array_equal(amd.covariance(amd.Pairings(ctx), gt), 1e6 * np.eye(6))
+    # rank-deficient (plane normals only constrain the rotation): flagged, not a garbage inverse
+    p = amd.Pairings.from_host(ctx, pl2pl=_to_hip_pl2pl(pp))
+    cov, Hg, pd = core.covariance(ctx, p.device, gt)
+    wc, wH, wok = oracle.covariance(None, None, None, pp, gt)
+    assert pd == wok

@@ -387,3 +387,40 @@ def test_oracle_filter_decimate_voxels(oracle):
     assert len(o) == 1
     o, _ = oracle.filter_decimate_voxels(pts[:, 0], pts[:, 1], pts[:, 2], res, 0, flatten_to=7.0)
     assert len(o) == len({k[:2] for k in keys}) and np.all(o[:, 2] == 7.0)
+
+
+def test_oracle_covariance(oracle):
+    """covariance.cpp:29-141: the numeric Hessian equals the analytic Gauss-Newton Hessian expressed
+    in (x,y,z,yaw,pitch,roll) -- for point pairs H_tt = N I exactly, and the rotation block follows
+    from d(R l)/d(ypr); checked against a numpy restatement with the same central differences."""
+    rng = np.random.default_rng(8)
+    gt = oracle.pose_from_xyzypr(1.0, -2.0, 0.5, 0.4, -0.2, 0.1)
+    R, t = gt[:9].reshape(3, 3), gt[9:]
+    n = 400
+    pt = np.zeros(n, oracle.PAIR_PT2PT)
+    g = rng.uniform(-8, 8, (n, 3))
+    l = (g - t) @ R + rng.normal(0, 0.01, (n, 3))
+    pt["gx"], pt["gy"], pt["gz"] = g.T.astype(np.float32)
+    pt["lx"], pt["ly"], pt["lz"] = l.T.astype(np.float32)
+    cov, H, ok = oracle.covariance(pt, None, None, None, gt)
+    assert ok and np.allclose(H[:3, :3], n * np.eye(3), rtol=1e-6, atol=1e-4)
+    x0 = np.array(oracle.pose_to_xyzypr(gt))
+    x0[2] = 0.0  # covariance.cpp:41-43
+    L = np.stack([pt["lx"], pt["ly"], pt["lz"]], 1).astype(np.float64)
+    G = np.stack([pt["gx"], pt["gy"], pt["gz"]], 1).astype(np.float64)
+
+    def err(x):
+        T = oracle.pose_from_xyzypr(*x)
+        return (L @ T[:9].reshape(3, 3).T + T[9:] - G).ravel()
+    J = np.zeros((3 * n, 6))
+    for j in range(6):
+        h = 1e-7
+        xp, xm = x0.copy(), x0.copy()
+        xp[j] += h
+        xm[j] -= h
+        J[:, j] = (err(xp) - err(xm)) * (0.5 / h)
+    Hn = J.T @ J
+    assert np.allclose(H, Hn, rtol=1e-6, atol=1e-6 * np.abs(Hn).max())
+    assert np.allclose(cov, np.linalg.inv(Hn), rtol=1e-5, atol=1e-5 * np.abs(cov).max())
+    c0, _, ok0 = oracle.covariance(None, None, None, None, gt)
+    assert not ok0 and np.array_equal(c0, 1e6 * np.eye(6))

@@ -143,27 +143,39 @@ class ShardedRegistration:
         if self.dist is not None and self.world > 1:
             self.dist.all_reduce(t, op=op, group=self.group)
 
-    def match(self, pose):
+    CAP_QUANTUM = 4096  # record lists are exchanged in multiples of this many records
+
+    def _round_cap(self, n):
+        q = self.CAP_QUANTUM
+        return max(q, -(-int(n) // q) * q)
+
+    def match(self, pose, predicted_cap=None):
+        """predicted_cap: length of the record lists to all-gather, guessed by the caller (step()
+        uses the previous iteration's count + 25 %) so that no host round trip sits between the
+        two match phases; None = read the exact count back (one 8-byte device-to-host sync).
+        Returns (exch tensor or None, capacity used): the caller checks exch[6] <= capacity."""
         b = self.b
         b.phase1(pose)
+        exch, cap = None, 0
         if self.world > 1:
             exch, recs = b.exchange_pack()
             self._allreduce(exch, self.dist.ReduceOp.MAX)
             gathered = None
             if b.uses_claims:
-                # the one host round trip of the exchange: how long the longest list is
-                n_max = int(exch[6].item())
-                if n_max > 0:
-                    cap = -(-n_max // 1024) * 1024
-                    send = recs[:cap]
-                    if send.numel() < cap:  # a shorter shard than the longest list: pad
-                        pad = recs.new_full((cap,), -1)
-                        pad[:send.numel()] = send
-                        send = pad
-                    gathered = b.gather_buffer(self.world * cap)
-                    self.dist.all_gather_into_tensor(gathered, send, group=self.group)
+                if predicted_cap is None:
+                    cap = self._round_cap(int(exch[6].item()))  # the one host round trip
+                else:
+                    cap = int(predicted_cap)
+                send = recs[:cap]
+                if send.numel() < cap:  # a shorter shard than the list length: pad
+                    pad = recs.new_full((cap,), -1)
+                    pad[:send.numel()] = send
+                    send = pad
+                gathered = b.gather_buffer(self.world * cap)
+                self.dist.all_gather_into_tensor(gathered, send, group=self.group)
             b.exchange_unpack(gathered)
         b.phase2()
+        return exch, cap
 
     def solve(self, pose):
         b = self.b
@@ -178,6 +190,21 @@ class ShardedRegistration:
         return b.gn_end()
 
     def step(self, pose):
-        """one outer ICP iteration; returns (new pose, inner iterations)"""
-        self.match(pose)
-        return self.solve(pose)
+        """one outer ICP iteration; returns (new pose, inner iterations).  Between the phases of
+        the matcher nothing waits for the host: the record-list length comes from the previous
+        iteration (+25 %); the true length is checked after the solve, when the stream is idle
+        anyway, and the (rare) iteration whose lists did not fit is redone with the exact length."""
+        if self.world == 1:
+            self.match(pose)
+            return self.solve(pose)
+        guess = getattr(self, "_cap_guess", None)
+        exch, cap = self.match(pose, predicted_cap=guess)
+        out = self.solve(pose)
+        if self.b.uses_claims:
+            n_max = int(exch[6].item())
+            if guess is not None and n_max > cap:
+                exch, cap = self.match(pose)  # exact length this time
+                out = self.solve(pose)
+                self.redone_steps = getattr(self, "redone_steps", 0) + 1
+            self._cap_guess = self._round_cap(n_max * 1.25 + 1024)
+        return out

@@ -165,19 +165,26 @@ def _worker(rank, world, port, q):
         reg = ShardedRegistration(be, dist)
         pose = d["T_init"].copy()
         all_pairs = []
-        for it in range(3):
-            reg.match(pose)
+        for it in range(4):
+            if it == 0:
+                reg.match(pose)                       # exact list length (one host read)
+                new_pose, _ = reg.solve(pose)
+            else:
+                if it == 2:                           # a guess that is too small: the step is redone
+                    reg.CAP_QUANTUM, reg._cap_guess = 8, 8
+                new_pose, _ = reg.step(pose)          # predicted list length, checked afterwards
             gathered = [None] * world
             dist.all_gather_object(gathered, be.pairs)
             all_pairs.append(np.concatenate(gathered))
-            pose, _ = reg.solve(pose)
+            pose = new_pose
+        assert getattr(reg, "redone_steps", 0) == 1
         # unsharded oracle
         tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
         pose_o = d["T_init"].copy()
         prm = orc.make_gn_params(3, kernel=orc.KERNEL_CAUCHY, kernelParam=0.3)
         ok = True
         msg = ""
-        for it in range(3):
+        for it in range(4):
             want, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose_o, 0.8, 0.0, tree=tree)
             got = all_pairs[it]
             if not (len(got) == len(want) and np.array_equal(got["localIdx"], want["localIdx"])

@@ -18,6 +18,7 @@
 namespace mp2p
 {
 constexpr int      PL_CAP         = 256;
+constexpr int      PL_HITQ        = 8;    // queued hits per lane before the insertion chains run
 constexpr uint32_t PL_CELL_BUDGET  = 256;   // voxels per pass; measured insensitive 256..4096
 constexpr float    PL_GROUP_FACTOR = 4.0f;  // group extent in search radii; insensitive 1.5..4
 
@@ -47,12 +48,15 @@ __device__ void jacobi3(const double* Ain, double* eval, double* evec0)
     for (int i = 0; i < 9; i++) A[i] = Ain[i];
     Q[0] = 1, Q[1] = 0, Q[2] = 0, Q[3] = 0, Q[4] = 1, Q[5] = 0, Q[6] = 0, Q[7] = 0, Q[8] = 1;
     const int n = 3;
+    // same convergence rule as the oracle (off-diagonal mass below 1e-18 of the diagonal scale)
+    double scale = fabs(A[0]) + fabs(A[4]) + fabs(A[8]);
+    scale        = 1e-36 * (scale * scale);
     for (int sweep = 0; sweep < 64; sweep++)
     {
         double off = 0;
         for (int p = 0; p < n; p++)
             for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
-        if (off == 0.0) break;
+        if (off <= scale) break;
         for (int p = 0; p < n; p++)
         {
             for (int q = p + 1; q < n; q++)
@@ -107,15 +111,18 @@ __device__ __forceinline__ float kth_d2(const float (&kd2)[K], uint32_t knn)
     return v;
 }
 
-// Exact k nearest neighbours (fp32 metric, (d2, idx) order) of one query per lane, restricted to
-// d2 <= lim2 (STRICT: d2 < lim2); rmax = a radius that covers every such point.  All lanes scan
+// Exact k nearest neighbours (fp32 metric, (d2, idx) order) of Q queries per wave, restricted to
+// d2 <= lim2 (STRICT: d2 < lim2); rmax = a radius that covers every such point.  A query is held by
+// S = 64/Q lanes (lane, lane+Q, ...), each scanning every S-th staged candidate into its own
+// k-list; the lists are merged at the end of a pass.  All lanes scan
 // the staged voxel buckets of the wave's common search box; each lane keeps its sorted k-list in
 // registers.  Uniform control flow: must be called by the whole wave.
-template <int K, bool STRICT>
+template <int K, bool STRICT, int Q>
 __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx, float qy, float qz,
                                            bool active, float lim2, float rmax, float r0, uint32_t knn,
                                            float grp_factor, uint32_t cell_budget,
-                                           unsigned long long* dbg, float4* s_cand, uint32_t* s_spos, uint32_t* s_cstart,
+                                           unsigned long long* dbg, uint32_t* s_hit, float4* s_cand,
+                                           uint32_t* s_spos, uint32_t* s_cstart,
                                            uint32_t* s_coff, float (&kd2)[K], uint32_t (&kidx)[K],
                                            uint32_t (&kspos)[K])
 {
@@ -225,36 +232,87 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                     s_spos[t]          = src;
                 }
                 __syncthreads();
-                for (uint32_t j = 0; j < m; j++)
+                // ---- scan.  With 64 different queries in a wave nearly every candidate enters
+                //      SOMEBODY's list, so an insertion chain behind a per-candidate branch runs for
+                //      all of them (~100 instructions each).  Instead a lane only notes its hits
+                //      (candidates within its current k-th distance) in a small LDS queue; the chains
+                //      run when a queue is full or the bucket ends, with most lanes busy.  A queued
+                //      candidate that no longer qualifies by then falls through the chain unchanged.
+                uint32_t hq = 0;  // hits queued by this lane
+                auto     flush = [&]()
                 {
-                    const float4 c  = s_cand[j];
-                    const float  d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
-                    const bool   in = STRICT ? (d2 < lim2) : (d2 <= lim2);
-                    // kth = distance of the knn-th neighbour held so far, kept in a register: the
-                    // common case (candidate farther than that for every lane) is one compare
-                    if (__ballot(grp && d2 <= kth && in) == 0ull) continue;
-                    if (grp && d2 <= kth && in)
+                    const uint32_t hmax = (uint32_t)wave_max((float)hq);  // hq <= PL_HITQ: exact in fp32
+                    for (uint32_t e = 0; e < hmax; e++)
                     {
-                        float    cd = d2;
-                        uint32_t ci = __float_as_uint(c.w), cs = s_spos[j];
+                        const bool     mine = e < hq;
+                        const uint32_t jj   = mine ? s_hit[e * 64 + lane] : 0u;
+                        const float4   c    = s_cand[jj];
+                        float          cd   = mine ? dist2(qx, qy, qz, c.x, c.y, c.z) : INFINITY;
+                        uint32_t       ci = mine ? __float_as_uint(c.w) : NONE_U32, cs = s_spos[jj];
 #pragma unroll
                         for (int q = 0; q < K; q++)
                         {
-                            const bool less = (cd < kd2[q]) || (cd == kd2[q] && ci < kidx[q]);
-                            const float    td = kd2[q];
+                            const bool     less = mine && ((cd < kd2[q]) || (cd == kd2[q] && ci < kidx[q]));
+                            const float    td   = kd2[q];
                             const uint32_t ti = kidx[q], ts = kspos[q];
                             kd2[q]   = less ? cd : td;
                             kidx[q]  = less ? ci : ti;
                             kspos[q] = less ? cs : ts;
                             cd = less ? td : cd, ci = less ? ti : ci, cs = less ? ts : cs;
                         }
+                    }
 #pragma unroll
-                        for (int q = 0; q < K; q++)  // only the knn nearest are kept
-                            if (q >= (int)knn) kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
-                        kth = kth_d2(kd2, knn);
+                    for (int q = 0; q < K; q++)  // only the knn nearest are kept
+                        if (q >= (int)knn) kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
+                    kth = kth_d2(kd2, knn);
+                    hq  = 0;
+                };
+                for (uint32_t j = (uint32_t)(lane / Q); j < m; j += 64 / Q)
+                {
+                    const float4 c  = s_cand[j];
+                    const float  d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
+                    const bool   in = STRICT ? (d2 < lim2) : (d2 <= lim2);
+                    if (grp && in && d2 <= kth) s_hit[hq * 64 + lane] = j, hq++;
+                    if (__ballot(hq >= (uint32_t)PL_HITQ) != 0ull) flush();
+                }
+                if (__ballot(hq > 0u) != 0ull) flush();
+                __syncthreads();
+            }
+        }
+        // ---- merge the k-lists of the lanes that hold the same query (partners differ in the bits
+        //      >= Q of the lane number; both end up with the merged list) ------------------------
+        if (Q < 64)
+        {
+#pragma unroll
+            for (int off = Q; off < 64; off <<= 1)
+            {
+                float    od[K];
+                uint32_t oi[K], os[K];
+#pragma unroll
+                for (int q = 0; q < K; q++)
+                    od[q] = __shfl_xor(kd2[q], off, 64), oi[q] = __shfl_xor(kidx[q], off, 64),
+                    os[q] = __shfl_xor(kspos[q], off, 64);
+#pragma unroll
+                for (int e = 0; e < K; e++)
+                {
+                    float    cd = od[e];
+                    uint32_t ci = oi[e], cs = os[e];
+                    if (__ballot(grp && ci != NONE_U32) == 0ull) break;  // lists are sorted: nothing further
+#pragma unroll
+                    for (int q = 0; q < K; q++)
+                    {
+                        // only the lanes of this pass: a finished query's list is already the
+                        // merged one on both partners (merging again would duplicate it)
+                        const bool     less = grp && ((cd < kd2[q]) || (cd == kd2[q] && ci < kidx[q]));
+                        const float    td   = kd2[q];
+                        const uint32_t ti = kidx[q], ts = kspos[q];
+                        kd2[q] = less ? cd : td, kidx[q] = less ? ci : ti, kspos[q] = less ? cs : ts;
+                        cd = less ? td : cd, ci = less ? ti : ci, cs = less ? ts : cs;
                     }
                 }
-                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < K; q++)
+                    if (grp && q >= (int)knn) kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
             }
         }
         if (grp)
@@ -282,13 +340,14 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
 }
 
 // transform one local point per lane and publish the tile's bounding box of the visited points
+template <int Q>
 __device__ __forceinline__ void transform_tile(const PoseRt& pose, const float4* lpts, uint32_t n_l,
                                                const uint32_t* rank, float* tile_bbox, int lane,
                                                bool& valid, bool& visited, uint32_t& orig,
                                                uint32_t& vrank, float& qx, float& qy, float& qz)
 {
     const uint32_t tile = blockIdx.x;
-    const uint32_t qi   = tile * 64 + lane;  // = place in the sorted copy
+    const uint32_t qi   = tile * Q + (uint32_t)(lane % Q);  // = place in the sorted copy
     valid               = qi < n_l;
     float4 lp           = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) lp = lpts[qi];
@@ -308,11 +367,14 @@ __device__ __forceinline__ void transform_tile(const PoseRt& pose, const float4*
     }
 }
 
+constexpr int PL_Q = 32;  // queries per wave (2 candidate slices)
+
 template <int K>
 __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
 {
     __shared__ float4   s_cand[PL_CAP];
     __shared__ uint32_t s_spos[PL_CAP];
+    __shared__ uint32_t s_hit[PL_HITQ * 64];
     __shared__ uint32_t s_cstart[64];
     __shared__ uint32_t s_coff[65];
 
@@ -321,18 +383,18 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
     bool            valid, visited;
     uint32_t        orig, vrank;
     float           qx, qy, qz;
-    transform_tile(a.pose, a.lpts, a.n_l, a.rank, a.tile_bbox, lane, valid, visited, orig, vrank, qx, qy, qz);
+    transform_tile<PL_Q>(a.pose, a.lpts, a.n_l, a.rank, a.tile_bbox, lane, valid, visited, orig, vrank, qx, qy, qz);
     const float fin    = fadd(fadd(qx, qy), qz);
     bool        active = visited && (fin - fin == 0.0f);
     if (active && a.local_taken && a.local_taken[orig]) active = false;  // Matcher_Point2Plane.cpp:83-85
 
     float    kd2[K];
     uint32_t kidx[K], kspos[K];
-    knn_search<K, false>(g, lane, qx, qy, qz, active, a.radSq, a.rad * 1.002f + g.slack, a.r0, a.knn,
-                         a.grp_factor, a.cell_budget, a.dbg, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
+    knn_search<K, false, PL_Q>(g, lane, qx, qy, qz, active, a.radSq, a.rad * 1.002f + g.slack, a.r0, a.knn,
+                         a.grp_factor, a.cell_budget, a.dbg, s_hit, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
 
-    // ---- plane fit (per lane) ------------------------------------------------------------------
-    if (!valid) return;
+    // ---- plane fit (one lane per query) ---------------------------------------------------------
+    if (!valid || lane >= PL_Q) return;
     unsigned char flag = 0;
     if (active)
     {
@@ -429,6 +491,7 @@ __global__ __launch_bounds__(64) void pt2pt_knn_kernel(const KnnArgs a)
 {
     __shared__ float4   s_cand[PL_CAP];
     __shared__ uint32_t s_spos[PL_CAP];
+    __shared__ uint32_t s_hit[PL_HITQ * 64];
     __shared__ uint32_t s_cstart[64];
     __shared__ uint32_t s_coff[65];
 
@@ -437,7 +500,7 @@ __global__ __launch_bounds__(64) void pt2pt_knn_kernel(const KnnArgs a)
     bool            valid, visited;
     uint32_t        orig, vrank;
     float           qx, qy, qz;
-    transform_tile(a.pose, a.lpts, a.n_l, a.rank, a.tile_bbox, lane, valid, visited, orig, vrank, qx, qy, qz);
+    transform_tile<PL_Q>(a.pose, a.lpts, a.n_l, a.rank, a.tile_bbox, lane, valid, visited, orig, vrank, qx, qy, qz);
     const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));  // :223-225
     const float thr    = fadd(a.maxDistSq, fmul(a.angSq, normSq));              // :256-257
     bool        active = visited && (normSq < INFINITY);
@@ -445,16 +508,16 @@ __global__ __launch_bounds__(64) void pt2pt_knn_kernel(const KnnArgs a)
 
     float    kd2[K];
     uint32_t kidx[K], kspos[K];
-    knn_search<K, true>(g, lane, qx, qy, qz, active, thr, sqrtf(thr) * 1.002f + g.slack, a.r0, a.knn,
-                        a.grp_factor, a.cell_budget, nullptr, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
-    if (!valid) return;
+    knn_search<K, true, PL_Q>(g, lane, qx, qy, qz, active, thr, sqrtf(thr) * 1.002f + g.slack, a.r0, a.knn,
+                        a.grp_factor, a.cell_budget, nullptr, s_hit, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
+    if (!valid || lane >= PL_Q) return;
 #pragma unroll
     for (int k = 0; k < K; k++)
     {
         if (k >= (int)a.knn) continue;
         bool acc = active && kidx[k] != NONE_U32;                             // d2 < thr by construction
         if (acc && a.global_taken && a.global_taken[kidx[k]]) acc = false;   // :98-101
-        const size_t slot = (size_t)(blockIdx.x * 64u + (uint32_t)lane) * a.knn + k;  // sorted order
+        const size_t slot = (size_t)(blockIdx.x * (uint32_t)PL_Q + (uint32_t)lane) * a.knn + k;  // sorted order
         a.out_spos[slot]  = acc ? kspos[k] : NONE_U32;
         a.out_d2[slot]    = kd2[k];
         if (acc && a.claims)
@@ -566,7 +629,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
                        mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
 {
     const size_t   n_l     = cloud->n;
-    const uint32_t n_tiles = (uint32_t)((n_l + 63) / 64);
+    const uint32_t n_tiles = (uint32_t)((n_l + PL_Q - 1) / PL_Q);
     MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_tiles * 6));
     MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
     MP2P_TRY_HIP(ctx, ctx->pl_slots.ensure(n_l * (7 * sizeof(double) + 1) + 64));
@@ -649,7 +712,7 @@ int launch_nn_pt2pt_knn(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_h
 {
     const size_t   n_l     = cloud->n;
     const uint32_t K       = prm->pairingsPerPoint;
-    const uint32_t n_tiles = (uint32_t)((n_l + 63) / 64);
+    const uint32_t n_tiles = (uint32_t)((n_l + PL_Q - 1) / PL_Q);
     MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_tiles * 6));
     MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
     MP2P_TRY_HIP(ctx, ctx->nn_spos.ensure(n_l * K));

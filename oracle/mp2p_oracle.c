@@ -47,12 +47,18 @@ static void sym_eig_jacobi(int n, const double* Ain, double* eval, double* V)
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) Q[i * n + j] = (i == j) ? 1.0 : 0.0;
 
+    /* converged when the off-diagonal mass is below 1e-18 of the diagonal scale: a further
+     * rotation would change nothing at double precision.  (Iterating until it is exactly 0 takes
+     * tens of extra sweeps through the denormal range; the HIP plane fit uses the same rule.) */
+    double scale = 0;
+    for (int i = 0; i < n; i++) scale += fabs(A[i * n + i]);
+    scale = 1e-36 * (scale * scale);
     for (int sweep = 0; sweep < 64; sweep++)
     {
         double off = 0;
         for (int p = 0; p < n; p++)
             for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
-        if (off == 0.0) break;
+        if (off <= scale) break;
         for (int p = 0; p < n; p++)
         {
             for (int q = p + 1; q < n; q++)

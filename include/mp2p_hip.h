@@ -256,6 +256,21 @@ size_t mp2p_hip_map_claims_count(const mp2p_hip_map* map);
 /* transformed-local bounding box of the last phase1 on this ctx (6 floats min,max; device) */
 void* mp2p_hip_ctx_local_bbox_ptr(mp2p_hip_ctx* ctx);
 
+/* ---- Matcher_Points_InlierRatio::implMatchOneLayer (Matcher_Points_InlierRatio.cpp:40-143):
+ *      unbounded nearest neighbour of every visited local point, the round(nTotal * inliersRatio)
+ *      smallest d2 kept in the multimap's order (equal d2: the later-visited point first),
+ *      unique-global filter in that order, both marks set for every emitted pair.  One GPU. ------ */
+typedef struct
+{
+    double  inliersRatio; /* in (0, 1) */
+    int32_t allowMatchAlreadyMatchedPoints;
+    int32_t allowMatchAlreadyMatchedGlobalPoints;
+    double  bounding_box_intersection_check_epsilon;
+} mp2p_hip_inlier_ratio_params;
+int mp2p_hip_match_inlier_ratio(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                                const double pose[12], const mp2p_hip_inlier_ratio_params* prm,
+                                mp2p_hip_mstate* ms, mp2p_hip_pairs* out);
+
 /* ---- Matcher_Point2Plane::implMatchOneLayer (Matcher_Point2Plane.cpp:41-114) with the
  *      NearestPlaneCapable::nn_search_pt2pl contract (NearestPlaneCapable.h:33-52)
  *      implemented as: k-NN in radius -> 3x3 covariance -> eigen -> planarity test

@@ -9,7 +9,7 @@ from ._lib import Mp2pHipError  # noqa: F401
 from .core import Context, DevicePairs, GlobalMap, LocalCloud, default_context  # noqa: F401
 from .filters import FilterDecimateVoxels  # noqa: F401
 from .icp import ICP, IterTermReason, Parameters, Results, covariance  # noqa: F401
-from .matcher import (MatchContext, Matcher, Matcher_Point2Plane,  # noqa: F401
+from .matcher import (MatchContext, Matcher, Matcher_Point2Plane, Matcher_Points_InlierRatio,  # noqa: F401
                       Matcher_Points_DistanceThreshold, MatchState, Pairings, run_matchers)
 from .metric_map import PT_LAYER_RAW, PointLayer, metric_map_t  # noqa: F401
 from .parameterizable import ParameterSource  # noqa: F401

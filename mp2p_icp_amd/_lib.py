@@ -30,6 +30,12 @@ class MapParams(C.Structure):
                 ("max_levels", C.c_uint32), ("no_occupancy_bitmap", C.c_uint32)]
 
 
+class InlierRatioParams(C.Structure):
+    _fields_ = [("inliersRatio", C.c_double), ("allowMatchAlreadyMatchedPoints", C.c_int32),
+                ("allowMatchAlreadyMatchedGlobalPoints", C.c_int32),
+                ("bounding_box_intersection_check_epsilon", C.c_double)]
+
+
 class DecimateParams(C.Structure):
     _fields_ = [("voxel_filter_resolution", C.c_float), ("decimate_method", C.c_int32),
                 ("has_flatten_to", C.c_int32), ("flatten_to", C.c_float)]
@@ -160,6 +166,7 @@ SIGNATURES = {
     "mp2p_hip_map_claims_ptr": (_P, [_P]),
     "mp2p_hip_map_claims_count": (C.c_size_t, [_P]),
     "mp2p_hip_ctx_local_bbox_ptr": (_P, [_P]),
+    "mp2p_hip_match_inlier_ratio": (C.c_int, [_P, _P, _P, _dp, C.POINTER(InlierRatioParams), _P, _P]),
     "mp2p_hip_match_pt2pl": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PlParams), _P, _P]),
     "mp2p_hip_gn_solve": (C.c_int, [_P, _P, _dp, C.POINTER(GNParams), C.POINTER(GNResult)]),
     "mp2p_hip_gn_begin": (C.c_int, [_P, _P, _dp, C.POINTER(GNParams)]),

@@ -324,6 +324,14 @@ def exchange_unpack(ctx, gmap, gathered_ptr, n_records):
     check(ctx._L.mp2p_hip_exchange_unpack(ctx.handle, gmap.handle, gathered_ptr, n_records), ctx.handle)
 
 
+def match_inlier_ratio(ctx, gmap, cloud, pose, prm, mstate, pairs):
+    T = _pose(pose)
+    check(ctx._L.mp2p_hip_match_inlier_ratio(ctx.handle, gmap.handle, cloud.handle,
+                                             T.ctypes.data_as(C.POINTER(C.c_double)), C.byref(prm),
+                                             mstate.handle if mstate is not None else None,
+                                             pairs.handle), ctx.handle)
+
+
 def match_pt2pl(ctx, gmap, cloud, pose, prm, mstate, pairs):
     T = _pose(pose)
     check(ctx._L.mp2p_hip_match_pt2pl(ctx.handle, gmap.handle, cloud.handle,

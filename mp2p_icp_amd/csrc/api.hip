@@ -427,6 +427,27 @@ void* mp2p_hip_ctx_local_bbox_ptr(mp2p_hip_ctx* ctx)
     return ctx->local_bbox.p;
 }
 
+// ---- Matcher_Points_InlierRatio ---------------------------------------------------------------------
+int mp2p_hip_match_inlier_ratio(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                                const double pose[12], const mp2p_hip_inlier_ratio_params* prm,
+                                mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, map && cloud && prm && pose && out, "null argument");
+    MP2P_REQUIRE(ctx, map->ctx == ctx && cloud->ctx == ctx && out->ctx == ctx, "handle belongs to another context");
+    // ASSERT_GT_(inliersRatio, 0.0); ASSERT_LT_(inliersRatio, 1.0);  (:47-48)
+    MP2P_REQUIRE(ctx, prm->inliersRatio > 0.0 && prm->inliersRatio < 1.0, "inliersRatio must be in (0,1)");
+    if (ms)
+    {
+        MP2P_REQUIRE(ctx, ms->global_taken.n >= std::max<size_t>(map->n, 1), "MatchState too small (global)");
+        MP2P_REQUIRE(ctx, ms->local_taken.n >= std::max<size_t>(cloud->n, 1), "MatchState too small (local)");
+    }
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (map->n == 0 || cloud->n == 0)  // :53-56: potential_pairings first, then the early-out
+        return launch_add_potential(ctx, out, (unsigned long long)cloud->n);
+    return launch_match_inlier_ratio(ctx, map, cloud, pose, prm, ms, out);
+}
+
 // ---- Matcher_Point2Plane -----------------------------------------------------------------------
 int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
                          const double pose[12], const mp2p_hip_pt2pl_params* prm,

@@ -22,6 +22,8 @@ struct CompactArgs
     uint32_t                  n_l;      // number of SLOTS = visited local points x K, in visiting order
     uint32_t                  K;        // pairingsPerPoint
     const uint32_t*           order;    // visit position -> original local index (null: identity)
+    const uint32_t*           n_slots_dev;  // optional device override of the slot count (<= n_l)
+    int                       always_mark;  // leave MatchState marks even when global re-use is allowed
     const unsigned long long* claims;  // null when global re-use is allowed
     unsigned long long        claim_hi, local_offset;
     const float*              local_bbox;  // device [6]
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const Compact
         {
             uint32_t sp, i;
             size_t   src;
-            if (base + k < a.n_l && pair_flag(a, base + k, sp, i, src)) c++;
+            if (base + k < (a.n_slots_dev ? min(*a.n_slots_dev, a.n_l) : a.n_l) && pair_flag(a, base + k, sp, i, src)) c++;
         }
     }
     c = wave_sum_u32(c);
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; k++)
     {
-        f[k] = (base + k < a.n_l) && pair_flag(a, base + k, sp[k], li[k], src[k]);
+        f[k] = (base + k < (a.n_slots_dev ? min(*a.n_slots_dev, a.n_l) : a.n_l)) &&
+               pair_flag(a, base + k, sp[k], li[k], src[k]);
         c += f[k] ? 1u : 0u;
     }
     const int      lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
             a.o_lx[dst] = a.lx[i], a.o_ly[dst] = a.ly[i], a.o_lz[dst] = a.lz[i];  // UNtransformed
             a.o_gx[dst] = gp.x, a.o_gy[dst] = gp.y, a.o_gz[dst] = gp.z;
             a.o_err[dst] = a.nn_d2[src[k]];
-            if (a.claims)
+            if (a.claims || a.always_mark)
             {  // marks are only left when global re-use is forbidden (:116-120)
                 if (a.ms_local) a.ms_local[i] = 1;
                 if (a.ms_global) a.ms_global[gi] = 1;
@@ -181,31 +184,33 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
     }
 }
 
-int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
-                         const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms,
-                         mp2p_hip_pairs* out)
+// ordered compaction over `n_slots` slots (slot = visit position x K + k; `order` maps a visit
+// position to the original local index)
+int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                         const uint32_t* order, size_t n_slots, const uint32_t* n_slots_dev, uint32_t K,
+                         bool use_claims, bool always_mark, unsigned long long local_offset, float margin,
+                         unsigned long long potential_add, mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
 {
-    const size_t   n_visit  = cloud->n_visit ? cloud->n_visit : cloud->n;
-    const size_t   n_l      = n_visit * prm->pairingsPerPoint;  // slots
+    const size_t   n_l      = n_slots;
     const uint32_t n_blocks = (uint32_t)((n_l + CP_TILE - 1) / CP_TILE);
     MP2P_TRY_HIP(ctx, ctx->block_counts.ensure(n_blocks ? n_blocks : 1));
     CompactArgs a;
     memset(&a, 0, sizeof(a));
     a.nn_spos = ctx->nn_spos.p, a.nn_d2 = ctx->nn_d2.p, a.n_l = (uint32_t)n_l;
-    a.K = prm->pairingsPerPoint, a.order = cloud->n_visit ? cloud->order.p : nullptr;
+    a.K = K, a.order = order, a.n_slots_dev = n_slots_dev, a.always_mark = always_mark ? 1 : 0;
     a.pos = cloud->pos.p;
-    a.claims       = prm->allowMatchAlreadyMatchedGlobalPoints ? nullptr : map->claims.p;
+    a.claims       = use_claims ? map->claims.p : nullptr;
     a.claim_hi     = (~(unsigned long long)ctx->epoch) << 32;
-    a.local_offset = prm->local_index_offset;
+    a.local_offset = local_offset;
     a.local_bbox   = ctx->local_bbox.p;
     for (int d = 0; d < 3; d++) a.gbb[d] = map->view.bbmin[d], a.gbb[3 + d] = map->view.bbmax[d];
-    a.margin = (float)(prm->threshold + prm->bounding_box_intersection_check_epsilon);
+    a.margin = margin;
     a.gpts   = map->pts.p;
     a.lx = cloud->x.p, a.ly = cloud->y.p, a.lz = cloud->z.p;
     a.block_counts  = ctx->block_counts.p;
     a.counts        = out->counts.p;
     a.cap           = out->cap_pt2pt;
-    a.potential_add = (unsigned long long)n_l;  // visited points x pairingsPerPoint (:64)
+    a.potential_add = potential_add;
     a.o_lidx = out->lidx.p, a.o_gidx = out->gidx.p;
     a.o_lx = out->lx.p, a.o_ly = out->ly.p, a.o_lz = out->lz.p;
     a.o_gx = out->gx.p, a.o_gy = out->gy.p, a.o_gz = out->gz.p, a.o_err = out->err.p;
@@ -222,6 +227,19 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
+}
+
+int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                         const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms,
+                         mp2p_hip_pairs* out)
+{
+    const size_t n_visit = cloud->n_visit ? cloud->n_visit : cloud->n;
+    const size_t n_slots = n_visit * prm->pairingsPerPoint;
+    return launch_compact_slots(ctx, map, cloud, cloud->n_visit ? cloud->order.p : nullptr, n_slots, nullptr,
+                                prm->pairingsPerPoint, !prm->allowMatchAlreadyMatchedGlobalPoints, false,
+                                prm->local_index_offset,
+                                (float)(prm->threshold + prm->bounding_box_intersection_check_epsilon),
+                                (unsigned long long)n_slots /* visited points x pairingsPerPoint (:64) */, ms, out);
 }
 
 // ---- sharded local layer: what the ranks exchange between phase 1 and phase 2 -----------------

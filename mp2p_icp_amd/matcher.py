@@ -351,6 +351,33 @@ class Matcher_Points_DistanceThreshold(Matcher_Points_Base):
         ms._sync_shared(glName, lcName)
 
 
+class Matcher_Points_InlierRatio(Matcher_Points_Base):
+    """Matcher_Points_InlierRatio.cpp:28-143"""
+
+    def __init__(self):
+        super().__init__()
+        self.inliersRatio = 0.80
+
+    def initialize(self, params):
+        super().initialize(params)
+        if params is None or "inliersRatio" not in params:
+            raise KeyError("Required parameter `inliersRatio` not an existing key in dictionary.")
+        self.inliersRatio = float(params["inliersRatio"])
+
+    def implMatchOneLayer(self, ctx, gLayer, lLayer, localPose, ms, glName, lcName, out):
+        if not (0.0 < self.inliersRatio < 1.0):
+            raise RuntimeError("ASSERT_GT_(inliersRatio, 0.0) / ASSERT_LT_(inliersRatio, 1.0)")
+        prm = _lib.InlierRatioParams(float(self.inliersRatio), int(self.allowMatchAlreadyMatchedPoints_),
+                                     int(self.allowMatchAlreadyMatchedGlobalPoints_),
+                                     float(self.bounding_box_intersection_check_epsilon_))
+        gmap, cloud = gLayer.as_global(ctx), lLayer.as_local(ctx)
+        n_visit = self._apply_visit_order(lLayer, cloud)
+        out._ub[0] += n_visit
+        dev = out._ensure_dev(ctx, out._ub[0], out._ub[1])
+        core.match_inlier_ratio(ctx, gmap, cloud, localPose, prm, ms.for_layers(glName, lcName), dev)
+        ms._sync_shared(glName, lcName)
+
+
 class Matcher_Point2Plane(Matcher_Points_Base):
     """Matcher_Point2Plane.cpp:35-114.  The neighbour search / plane fit parameters
     (searchRadius, knn, minimumPlanePoints, planeEigenThreshold) configure the

@@ -1158,6 +1158,94 @@ size_t orc_match_pt2pl_subset(const orc_kdtree* tree, const float* gx, const flo
 }
 
 /* ======================================================================================
+ *  f3 (part): Matcher_Points_InlierRatio::implMatchOneLayer
+ *  (mp2p_icp/src/Matcher_Points_InlierRatio.cpp:40-143).
+ *  std::multimap<double, pair> filled with emplace_hint(begin()): among equal keys the later
+ *  insertion is visited first.  Returns the number of pairs, or (size_t)-1 for ASSERT_(nTotal > 0).
+ * ====================================================================================== */
+typedef struct
+{
+    double   key;
+    uint32_t seq; /* insertion order */
+    orc_pair_pt2pt p;
+} ir_item;
+
+static int ir_cmp(const void* a, const void* b)
+{
+    const ir_item* p = (const ir_item*)a;
+    const ir_item* q = (const ir_item*)b;
+    if (p->key != q->key) return p->key < q->key ? -1 : 1;
+    return p->seq > q->seq ? -1 : (p->seq < q->seq ? 1 : 0); /* later insertion first */
+}
+
+size_t orc_match_inlier_ratio(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                              size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
+                              const uint32_t* idxs, size_t n_idxs, const double T[12], double inliersRatio,
+                              int allowMatchAlreadyMatchedPoints, int allowMatchAlreadyMatchedGlobalPoints,
+                              double bbox_eps, uint8_t* local_taken, uint8_t* global_taken,
+                              orc_pair_pt2pt* out, uint64_t* potential_pairings)
+{
+    if (potential_pairings) *potential_pairings += (uint64_t)n_l; /* :53 */
+    if (n_g == 0 || n_l == 0) return 0;                           /* :56 */
+    const size_t nv = idxs ? n_idxs : n_l;
+    float* sx = (float*)malloc((nv + 1) * sizeof(float));
+    float* sy = (float*)malloc((nv + 1) * sizeof(float));
+    float* sz = (float*)malloc((nv + 1) * sizeof(float));
+    for (size_t r = 0; r < nv; r++)
+    {
+        const size_t i = idxs ? idxs[r] : r;
+        sx[r] = lx[i], sy[r] = ly[i], sz[r] = lz[i];
+    }
+    float* tx = (float*)malloc((nv + 1) * sizeof(float));
+    float* ty = (float*)malloc((nv + 1) * sizeof(float));
+    float* tz = (float*)malloc((nv + 1) * sizeof(float));
+    float  lmin[3], lmax[3], gmin[3], gmax[3];
+    orc_transform_local_to_global(sx, sy, sz, nv, T, tx, ty, tz, lmin, lmax); /* :58-59 */
+    bbox_of(gx, gy, gz, n_g, gmin, gmax);
+    size_t n_out = 0;
+    uint8_t* own_g = NULL;
+    if (!global_taken) global_taken = own_g = (uint8_t*)calloc(n_g, 1);
+    if (bbox_intersects(gmin, gmax, lmin, lmax, (float)bbox_eps)) /* :63-66 */
+    {
+        ir_item* items = (ir_item*)malloc((nv + 1) * sizeof(ir_item));
+        size_t   nTotal = 0;
+        for (size_t r = 0; r < nv; r++) /* :78-106 */
+        {
+            const size_t i = idxs ? idxs[r] : r;
+            if (!allowMatchAlreadyMatchedPoints && local_taken && local_taken[i]) continue;
+            uint32_t id;
+            float    d2;
+            if (!nn_search(tree, gx, gy, gz, n_g, tx[r], ty[r], tz[r], 1, -1.0f, &id, &d2)) continue;
+            ir_item* it = &items[nTotal];
+            it->key = (double)d2, it->seq = (uint32_t)nTotal;
+            it->p.globalIdx = id, it->p.localIdx = (uint32_t)i;
+            it->p.gx = gx[id], it->p.gy = gy[id], it->p.gz = gz[id];
+            it->p.lx = lx[i], it->p.ly = ly[i], it->p.lz = lz[i];
+            it->p.errSq = d2;
+            nTotal++;
+        }
+        if (nTotal == 0) /* :117 ASSERT_(nTotal > 0) */
+        {
+            free(items), free(sx), free(sy), free(sz), free(tx), free(ty), free(tz), free(own_g);
+            return (size_t)-1;
+        }
+        qsort(items, nTotal, sizeof(ir_item), ir_cmp);
+        const size_t nKeep = (size_t)nearbyint((double)nTotal * inliersRatio); /* :119 mrpt::round */
+        for (size_t k = 0; k < nKeep && k < nTotal; k++) /* :125-139 */
+        {
+            const orc_pair_pt2pt* p = &items[k].p;
+            if (!allowMatchAlreadyMatchedGlobalPoints && global_taken[p->globalIdx]) continue;
+            out[n_out++] = *p;
+            if (local_taken) local_taken[p->localIdx] = 1;
+            global_taken[p->globalIdx] = 1;
+        }
+        free(items);
+    }
+    free(sx), free(sy), free(sz), free(tx), free(ty), free(tz), free(own_g);
+    return n_out;
+}
+
+/* ======================================================================================
  *  f4: covariance() (mp2p_icp/src/covariance.cpp:29-141): Hessian J^T J of the stacked error
  *  vector w.r.t. (x, y, z, yaw, pitch, roll) by central finite differences
  *  (mrpt::math::estimateJacobian: J(:,j) = (f(x + h_j e_j) - f(x - h_j e_j)) * (0.5 / h_j)),

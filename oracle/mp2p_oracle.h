@@ -213,6 +213,16 @@ size_t orc_match_pt2pl_subset(const orc_kdtree* tree, const float* gx, const flo
 void orc_estimate_points_eigen(const float* xs, const float* ys, const float* zs, size_t n,
                                float mean[3], double cov[9], double eval[3], double evec[9]);
 
+/* ---- f3 (part): Matcher_Points_InlierRatio (Matcher_Points_InlierRatio.cpp:40-143).  idxs may be
+ *      NULL.  Returns the number of pairs written, (size_t)-1 when no local point has a candidate
+ *      (the reference's ASSERT_(nTotal > 0)). ---- */
+size_t orc_match_inlier_ratio(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                              size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
+                              const uint32_t* idxs, size_t n_idxs, const double T[12], double inliersRatio,
+                              int allowMatchAlreadyMatchedPoints, int allowMatchAlreadyMatchedGlobalPoints,
+                              double bbox_eps, uint8_t* local_taken, uint8_t* global_taken,
+                              orc_pair_pt2pt* out, uint64_t* potential_pairings);
+
 /* ---- f4: covariance() (covariance.cpp:29-141): H = J^T J by central differences over
  *      (x,y,z,yaw,pitch,roll), cov = H^-1 (Cholesky).  Returns 1, or 0 when H is not positive
  *      definite (cov = NaN) / there are no pairings (cov = 1e6 * I). ---- */

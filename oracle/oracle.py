@@ -128,6 +128,10 @@ def _declare(L):
                                          C.c_size_t, _u32p, C.c_size_t, _dp, C.POINTER(Pt2PlParams),
                                          _u8p, C.c_void_p, _u32p, C.POINTER(C.c_uint64)]
     L.orc_match_pt2pl_subset.restype = C.c_size_t
+    L.orc_match_inlier_ratio.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp, C.c_size_t,
+                                         _u32p, C.c_size_t, _dp, C.c_double, C.c_int, C.c_int, C.c_double,
+                                         _u8p, _u8p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.orc_match_inlier_ratio.restype = C.c_size_t
     L.orc_covariance.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                  C.c_void_p, C.c_size_t, _dp, C.c_double, C.c_double, _dp, _dp]
     L.orc_covariance.restype = C.c_int
@@ -333,6 +337,29 @@ def match_pt2pt(gx, gy, gz, lx, ly, lz, T, threshold, thresholdAngularDeg, pairi
     n = lib().orc_match_pt2pt(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
                               lx.size, _d(T), C.byref(prm), lt, gt, out.ctypes.data,
                               C.byref(pot))
+    return out[:n].copy(), pot.value
+
+
+def match_inlier_ratio(gx, gy, gz, lx, ly, lz, T, inliersRatio, allowMatchAlreadyMatchedPoints=False,
+                       allowMatchAlreadyMatchedGlobalPoints=False, bbox_eps=0.20, tree=None,
+                       local_taken=None, global_taken=None, idxs=None):
+    """Matcher_Points_InlierRatio::implMatchOneLayer.  Returns (pairs, potential); raises when no
+    local point has a candidate (the reference's ASSERT_(nTotal > 0))."""
+    gx, gy, gz, lx, ly, lz = map(_f32, (gx, gy, gz, lx, ly, lz))
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    out = np.zeros(max(1, lx.size), PAIR_PT2PT)
+    pot = C.c_uint64(0)
+    th = tree._h if tree is not None else None
+    lt = local_taken.ctypes.data_as(_u8p) if local_taken is not None else None
+    gt = global_taken.ctypes.data_as(_u8p) if global_taken is not None else None
+    ii = np.ascontiguousarray(idxs, dtype=np.uint32) if idxs is not None else None
+    n = lib().orc_match_inlier_ratio(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz), lx.size,
+                                     ii.ctypes.data_as(_u32p) if ii is not None else None,
+                                     ii.size if ii is not None else 0, _d(T), float(inliersRatio),
+                                     int(allowMatchAlreadyMatchedPoints), int(allowMatchAlreadyMatchedGlobalPoints),
+                                     float(bbox_eps), lt, gt, out.ctypes.data, C.byref(pot))
+    if n == C.c_size_t(-1).value:
+        raise RuntimeError("ASSERT_(nTotal > 0)")
     return out[:n].copy(), pot.value
 
 

@@ -424,3 +424,36 @@ def test_oracle_covariance(oracle):
     assert np.allclose(cov, np.linalg.inv(Hn), rtol=1e-5, atol=1e-5 * np.abs(cov).max())
     c0, _, ok0 = oracle.covariance(None, None, None, None, gt)
     assert not ok0 and np.array_equal(c0, 1e6 * np.eye(6))
+
+
+def test_oracle_matcher_inlier_ratio(oracle):
+    """Matcher_Points_InlierRatio.cpp:78-139 against a direct Python restatement (a list kept in
+    multimap order: ascending d2, the later insertion first among equal keys)."""
+    rng = np.random.default_rng(17)
+    g = rng.uniform(-3, 3, (700, 3)).astype(np.float32)
+    l = (g[:300] + rng.normal(0, 0.05, (300, 3))).astype(np.float32)
+    l[50:70] = l[0:20]
+    T = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0.02, 0.0, -0.01])
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    tx, ty, tz, _, _ = oracle.transform_local_to_global(l[:, 0], l[:, 1], l[:, 2], T)
+    items = []
+    for i in range(300):
+        idx, d2 = tree.knn((tx[i], ty[i], tz[i]), 1)
+        items.append((float(d2[0]), -i, i, int(idx[0])))      # -i: later insertion first
+    items.sort(key=lambda v: (v[0], v[1]))
+    for ratio in (0.25, 0.8):
+        n_keep = int(np.rint(300 * ratio))
+        taken, want = set(), []
+        for d2, _, i, gi in items[:n_keep]:
+            if gi in taken:
+                continue
+            want.append((i, gi))
+            taken.add(gi)
+        got, pot = oracle.match_inlier_ratio(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, ratio, tree=tree)
+        assert pot == 300
+        assert [(int(p["localIdx"]), int(p["globalIdx"])) for p in got] == want
+        brute, _ = oracle.match_inlier_ratio(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, ratio, tree=None)
+        assert np.array_equal(brute, got)
+    lt = np.ones(300, np.uint8)
+    with pytest.raises(RuntimeError):
+        oracle.match_inlier_ratio(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, 0.5, tree=tree, local_taken=lt)

@@ -8,7 +8,8 @@ from . import _build, _lib, core, se3  # noqa: F401
 from ._lib import Mp2pHipError  # noqa: F401
 from .core import Context, DevicePairs, GlobalMap, LocalCloud, default_context  # noqa: F401
 from .filters import FilterDecimateVoxels  # noqa: F401
-from .icp import ICP, IterTermReason, Parameters, Results, covariance  # noqa: F401
+from .icp import (ICP, IterTermReason, Parameters, QualityEvaluator_PairedRatio, Results,  # noqa: F401
+                  covariance, evaluate_quality)
 from .matcher import (MatchContext, Matcher, Matcher_Point2Plane, Matcher_Points_InlierRatio,  # noqa: F401
                       Matcher_Points_DistanceThreshold, MatchState, Pairings, run_matchers)
 from .metric_map import PT_LAYER_RAW, PointLayer, metric_map_t  # noqa: F401

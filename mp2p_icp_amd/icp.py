@@ -1,11 +1,12 @@
 """MRPT-free driver reproducing mp2p_icp::ICP::align (ICP.cpp:36-382): outer loop, formula
-parameters, termination criteria, final covariance (ICP.cpp:334-337).  It is the *caller* of the
-hot path, kept minimal: quality evaluators / checkpoints and log records are out of scope
-(SURVEY.md section 2 rows 14-16)."""
+parameters, termination criteria, quality (QualityEvaluator_PairedRatio, checkpoints) and final
+covariance (ICP.cpp:316-337).  It is the *caller* of the hot path, kept minimal: the other
+quality evaluators and log records are out of scope."""
 import numpy as np
 
 from . import core, se3
-from .matcher import MatchContext, MatchState, Pairings, run_matchers
+from .matcher import (MatchContext, Matcher_Points_DistanceThreshold, MatchState, Pairings,
+                      run_matchers)
 from .parameterizable import ParameterSource
 from .solver import OptimalTF_Result, SolverContext, run_solvers
 
@@ -17,11 +18,59 @@ class IterTermReason:  # IterTermReason.h:26-35
 
 class Parameters:  # Parameters.h:42-100
     def __init__(self, maxIterations=40, minAbsStep_trans=5e-4, minAbsStep_rot=1e-4,
-                 debugPrintIterationProgress=False):
+                 debugPrintIterationProgress=False, quality_checkpoints=None):
         self.maxIterations = maxIterations
         self.minAbsStep_trans = minAbsStep_trans
         self.minAbsStep_rot = minAbsStep_rot
         self.debugPrintIterationProgress = debugPrintIterationProgress
+        # iteration -> minimum quality (Parameters.h: {50: 0.05, 100: 0.10})
+        self.quality_checkpoints = {50: 0.05, 100: 0.10} if quality_checkpoints is None else dict(quality_checkpoints)
+
+
+class QualityEvaluator_PairedRatio:
+    """QualityEvaluator_PairedRatio.cpp:27-73: matched / potential pairings, either of the ICP's last
+    pairings (reuse_icp_pairings, the default) or of a fresh Matcher_Points_DistanceThreshold run
+    that may pair a global point several times."""
+
+    def __init__(self):
+        self.matcher_ = Matcher_Points_DistanceThreshold()
+        self.reuse_icp_pairings = True
+        self.absolute_minimum_pairing_ratio = 0.20
+
+    def initialize(self, params):
+        params = dict(params or {})
+        self.reuse_icp_pairings = bool(params.get("reuse_icp_pairings", True))
+        self.absolute_minimum_pairing_ratio = float(params.get("absolute_minimum_pairing_ratio", 0.20))
+        if not self.reuse_icp_pairings:
+            params.setdefault("allowMatchAlreadyMatchedGlobalPoints", True)
+            for k in ("reuse_icp_pairings", "absolute_minimum_pairing_ratio"):
+                params.pop(k, None)
+            self.matcher_.initialize(params)
+
+    def evaluate(self, pcGlobal, pcLocal, localPose, pairingsFromICP):
+        """-> (quality, hard_discard)"""
+        if self.reuse_icp_pairings:
+            pairings = pairingsFromICP
+        else:
+            pairings = Pairings()
+            self.matcher_.match(pcGlobal, pcLocal, localPose, MatchContext(), MatchState(pcGlobal, pcLocal),
+                                pairings)
+        n = pairings.potential_pairings if pairings is not None else 0
+        q = (pairings.size() / float(n)) if n else 0.0
+        return q, q < self.absolute_minimum_pairing_ratio
+
+
+def evaluate_quality(evaluators, pcGlobal, pcLocal, localPose, finalPairings):  # ICP.cpp:608-634
+    assert evaluators
+    sw = se = 0.0
+    for obj, w in evaluators:
+        assert w > 0
+        q, hard = obj.evaluate(pcGlobal, pcLocal, localPose, finalPairings)
+        if hard:
+            return 0.0
+        se += w * q
+        sw += w
+    return se / sw
 
 
 class Results:  # Results.h
@@ -57,6 +106,11 @@ class ICP:
         self.solvers_ = []
         self.ownParamSource_ = ParameterSource()
         self.iteration_hook_ = None
+        self.quality_evaluators_ = [(QualityEvaluator_PairedRatio(), 1.0)]  # ICP.h: the default list
+
+    def set_quality_evaluators(self, lst):
+        """[(evaluator, relativeWeight)]"""
+        self.quality_evaluators_ = list(lst)
 
     def set_matchers(self, m):
         self.matchers_ = list(m)
@@ -127,6 +181,11 @@ class ICP:
             if abs(dxyz) < p.minAbsStep_trans and abs(drot) < p.minAbsStep_rot:  # :228-229
                 result.terminationReason = IterTermReason.Stalled
                 break
+            if it in p.quality_checkpoints:  # ICP.cpp:258-284
+                q = evaluate_quality(self.quality_evaluators_, pcGlobal, pcLocal, cur.optimalPose, pairings)
+                if q < p.quality_checkpoints[it]:
+                    result.terminationReason = IterTermReason.QualityCheckpointFailed
+                    break
             if self.iteration_hook_ is not None and self.iteration_hook_(it, pairings, cur):
                 result.terminationReason = IterTermReason.HookRequest
                 break
@@ -139,5 +198,7 @@ class ICP:
         result.optimal_tf = cur.optimalPose
         result.finalPairings = pairings
         if pairings is not None:
+            result.quality = evaluate_quality(self.quality_evaluators_, pcGlobal, pcLocal, result.optimal_tf,
+                                              pairings)  # ICP.cpp:316-325
             result.optimal_tf_cov = covariance(pairings, result.optimal_tf, ctx=self.ctx)  # ICP.cpp:334-337
         return result

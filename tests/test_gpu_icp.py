@@ -82,3 +82,46 @@ def test_icp_iterations_track_the_oracle(oracle):
         pose_o, *_ = oracle.optimal_tf_gauss_newton(want, None, None, pose_o, prm)
         dt, dr = oracle.pose_err_split(pose_h, pose_o)
         assert dt < 1e-5 and dr < 1e-5, (it, dt, dr)
+
+
+def test_quality_and_covariance_of_align(oracle):
+    """ICP.cpp:316-337: Results::quality from QualityEvaluator_PairedRatio (both modes) and the
+    covariance of the final pairings; a quality checkpoint aborts a hopeless registration."""
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import synthetic
+    d = synthetic.random_cloud_pair(4000, 12000, 13, outlier_frac=0.1)
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(d["glob"])})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(d["local"])})
+
+    def make(thr):
+        icp = amd.ICP()
+        m = amd.Matcher_Points_DistanceThreshold()
+        m.initialize({"threshold": thr, "thresholdAngularDeg": 0.0})
+        s = amd.Solver_GaussNewton()
+        s.initialize({"maxIterations": 3})
+        icp.set_matchers([m])
+        icp.set_solvers([s])
+        return icp
+    icp = make(0.8)
+    res = icp.align(pcL, pcG, d["T_init"], amd.Parameters(maxIterations=15))
+    P = res.finalPairings
+    assert res.quality == pytest.approx(P.size() / P.potential_pairings)          # reuse_icp_pairings
+    o = np.zeros(len(P.paired_pt2pt), oracle.PAIR_PT2PT)
+    hp = P.paired_pt2pt
+    o["gx"], o["gy"], o["gz"] = hp["global"].T
+    o["lx"], o["ly"], o["lz"] = hp["local"].T
+    want, _, ok = oracle.covariance(o, None, None, None, res.optimal_tf)
+    assert ok and np.allclose(res.optimal_tf_cov, want, rtol=1e-6, atol=1e-6 * np.abs(want).max())
+    # a fresh matcher that may pair a global point several times
+    q = amd.QualityEvaluator_PairedRatio()
+    q.initialize({"reuse_icp_pairings": False, "threshold": 0.1, "thresholdAngularDeg": 0.0})
+    quality, hard = q.evaluate(pcG, pcL, res.optimal_tf, None)
+    tree = oracle.KDTree(d["glob"][:, 0], d["glob"][:, 1], d["glob"][:, 2])
+    w, pot = oracle.match_pt2pt(d["glob"][:, 0], d["glob"][:, 1], d["glob"][:, 2], d["local"][:, 0], d["local"][:, 1],
+                                d["local"][:, 2], res.optimal_tf, 0.1, 0.0, tree=tree,
+                                allowMatchAlreadyMatchedGlobalPoints=True)
+    assert quality == pytest.approx(len(w) / pot) and hard == (quality < 0.20)
+    # hopeless start + a checkpoint at iteration 2
+    far = amd.se3.compose(d["T_gt"], amd.se3.from_xyzypr(40.0, 40.0, 5.0, 1.0, 0.0, 0.0))
+    res = make(0.8).align(pcL, pcG, far, amd.Parameters(maxIterations=15, quality_checkpoints={2: 0.5}))
+    assert res.terminationReason in (amd.IterTermReason.QualityCheckpointFailed, amd.IterTermReason.NoPairings)

@@ -203,11 +203,12 @@ typedef struct
     float    initial_radius_cells;
     uint32_t queries_per_wave;    /* 64, 32 or 16; 0 = default (32) */
     float    group_radius_factor; /* queries of a tile farther than this many search radii
-                                     from the first pending one wait for a later pass; 0 = 4 */
+                                     from the first pending one wait for a later pass; 0 = 2.5 */
     uint32_t cell_budget;         /* max voxels of one search box before a coarser level is
                                      used; 0 = 512 */
     float    defer_radius_cells;  /* a query whose search radius exceeds this many cells leaves
-                                     its tile for the one-query-per-wave kernel; 0 = 3 */
+                                     its tile for the one-query-per-wave kernel; 0 = 1 m, kept
+                                     between 2 and 4 cells */
     int32_t  disable_warm_start;  /* by default a call on the same (map, cloud) as the previous
                                      call of this context seeds every query with its previous
                                      nearest neighbour (exactness is unaffected) */

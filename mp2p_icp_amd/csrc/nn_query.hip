@@ -901,10 +901,15 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.angSq             = (float)(angRad * angRad);
     const float cell0   = map->view.hf * (float)(1u << map->view.shift0);
     a.r0          = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 1.0f);
-    a.grp_factor  = prm->group_radius_factor > 0 ? prm->group_radius_factor : 4.0f;
+    a.grp_factor  = prm->group_radius_factor > 0 ? prm->group_radius_factor : 2.5f;
     a.cell_budget = prm->cell_budget > 0 ? prm->cell_budget : 512u;
     a.brick_budget = prm->brick_budget > 0 ? prm->brick_budget : 128u;
-    a.r_defer     = cell0 * (prm->defer_radius_cells > 0 ? prm->defer_radius_cells : 3.0f);
+    // Deferral radius.  Measured on the street scene at two map densities (voxel 0.25 and 0.5 m) and
+    // thresholds 1, 2 and 4 m: the optimum sits near 1 m in every case, i.e. 4 voxels of the dense
+    // map and 2 of the sparse one (-8..-16 % at 3 / 4 voxels respectively).  Default: 1 m, kept
+    // between 2 and 4 voxels so that it still scales with maps of another size.
+    a.r_defer = prm->defer_radius_cells > 0 ? cell0 * prm->defer_radius_cells
+                                             : fminf(fmaxf(1.0f, 2.0f * cell0), 4.0f * cell0);
     a.local_taken =
         (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
     a.global_taken =

@@ -1,0 +1,127 @@
+"""Seeded differential fuzzing of the point matcher against the CPU oracle: random geometries
+(clusters, exact lattices with many equal distances, collinear and coplanar sets, duplicates, large
+coordinate offsets, tiny extents), random thresholds / angular thresholds / pairingsPerPoint /
+voxel sizes / bitmap on-off / tile sizes, and pose sequences (warm start).  Lists must be bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, kind, n):
+    if kind == "uniform":
+        return rng.uniform(-5, 5, (n, 3))
+    if kind == "clusters":
+        c = rng.uniform(-20, 20, (max(2, n // 200), 3))
+        return c[rng.integers(0, len(c), n)] + rng.normal(0, 0.3, (n, 3))
+    if kind == "lattice":                       # exact ties everywhere
+        k = max(2, int(round(n ** (1 / 3))))
+        g = np.stack(np.meshgrid(*[np.arange(k)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.25
+        return g[rng.permutation(len(g))[:n]]
+    if kind == "plane":
+        p = rng.uniform(-10, 10, (n, 3))
+        p[:, 2] = 0.0
+        return p
+    if kind == "line":
+        p = np.zeros((n, 3))
+        p[:, 0] = rng.uniform(-50, 50, n)
+        return p
+    if kind == "far_offset":
+        return rng.uniform(-3, 3, (n, 3)) + np.array([4000.0, -2500.0, 300.0])
+    if kind == "tiny":
+        return rng.uniform(-1e-3, 1e-3, (n, 3))
+    raise ValueError(kind)
+
+
+KINDS = ["uniform", "clusters", "lattice", "plane", "line", "far_offset", "tiny"]
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_fuzz_pt2pt(oracle, seed):
+    import mp2p_icp_amd as amd
+    rng = np.random.default_rng(1000 + seed)
+    kind = KINDS[seed % len(KINDS)]
+    n_g = int(rng.integers(50, 30000))
+    n_l = int(rng.integers(1, 6000))
+    g = _cloud(rng, kind, n_g).astype(np.float32)
+    scale = float(np.ptp(g, axis=0).max()) or 1.0
+    src = g[rng.integers(0, len(g), n_l)].astype(np.float64)
+    l = (src + rng.normal(0, 0.01 * scale, (n_l, 3)) * rng.integers(0, 2)).astype(np.float32)
+    if rng.random() < 0.5:                       # some far outliers
+        k = max(1, n_l // 10)
+        l[:k] += (rng.uniform(-1, 1, (k, 3)) * scale * 3).astype(np.float32)
+    if rng.random() < 0.3:
+        g[: len(g) // 10] = g[len(g) // 10: 2 * (len(g) // 10)][: len(g) // 10]   # duplicates
+    thr = float(rng.choice([0.02, 0.1, 0.5, 2.0]) * scale / 10.0)
+    ang = float(rng.choice([0.0, 0.0, 0.3]))
+    K = int(rng.choice([1, 1, 1, 2, 5]))
+    layer_kw = {}
+    if rng.random() < 0.3:
+        layer_kw["cell_size"] = float(rng.choice([0.02, 0.2, 1.5]) * scale / 10.0)
+    if rng.random() < 0.3:
+        layer_kw["no_occupancy_bitmap"] = True
+    params = {"threshold": thr, "thresholdAngularDeg": ang, "pairingsPerPoint": K,
+              "hip_queries_per_wave": int(rng.choice([0, 16, 32, 64])),
+              "allowMatchAlreadyMatchedGlobalPoints": bool(rng.random() < 0.3)}
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g, **layer_kw)})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    m = amd.Matcher_Points_DistanceThreshold()
+    m.initialize(params)
+    T = amd.se3.identity()
+    for step in range(4):                        # a pose sequence: warm start between the calls
+        xi = np.concatenate([rng.normal(0, 0.02 * scale, 3), rng.normal(0, 0.02, 3)]) * (step > 0)
+        T = amd.se3.compose(T, amd.se3.exp(xi))
+        want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, thr, ang,
+                                       pairingsPerPoint=K, tree=tree,
+                                       allowMatchAlreadyMatchedGlobalPoints=params["allowMatchAlreadyMatchedGlobalPoints"])
+        pairs = amd.Pairings()
+        assert m.match(pcG, pcL, T, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+        got = pairs.paired_pt2pt
+        info = (kind, n_g, n_l, thr, ang, K, layer_kw, params, step)
+        assert len(got) == len(want), info
+        assert np.array_equal(got["localIdx"], want["localIdx"]), info
+        assert np.array_equal(got["globalIdx"], want["globalIdx"]), info
+        assert np.array_equal(got["errorSquareAfterTransformation"].view(np.uint32), want["errSq"].view(np.uint32)), info
+        assert pairs.potential_pairings == pot
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_fuzz_pt2pl_and_inlier_ratio(oracle, seed):
+    import mp2p_icp_amd as amd
+    rng = np.random.default_rng(5000 + seed)
+    kind = KINDS[seed % len(KINDS)]
+    n_g = int(rng.integers(200, 20000))
+    n_l = int(rng.integers(1, 3000))
+    g = _cloud(rng, kind, n_g).astype(np.float32)
+    scale = float(np.ptp(g, axis=0).max()) or 1.0
+    l = (g[rng.integers(0, len(g), n_l)].astype(np.float64) + rng.normal(0, 0.01 * scale, (n_l, 3))).astype(np.float32)
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g)})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    T = amd.se3.exp(np.concatenate([rng.normal(0, 0.01 * scale, 3), rng.normal(0, 0.01, 3)]))
+    # point-to-plane
+    P = dict(distanceThreshold=0.05 * scale, searchRadius=float(rng.choice([0.03, 0.1])) * scale,
+             knn=int(rng.choice([5, 6, 9, 16])), minimumPlanePoints=5,
+             planeEigenThreshold=float(rng.choice([0.01, 0.1])))
+    want, widx, pot = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, tree=tree, **P)
+    m = amd.Matcher_Point2Plane()
+    m.initialize(P)
+    pairs = amd.Pairings()
+    assert m.match(pcG, pcL, T, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+    assert np.array_equal(pairs.paired_pt2pl_local_idx, widx), (kind, n_g, n_l, P)
+    if len(widx):
+        s = max(1.0, float(np.abs(want["plane"]).max()))
+        assert np.allclose(pairs.paired_pt2pl["plane"], want["plane"], rtol=0, atol=1e-9 * s)
+    assert pairs.potential_pairings == pot
+    # inlier ratio
+    ratio = float(rng.choice([0.2, 0.5, 0.9]))
+    want, pot = oracle.match_inlier_ratio(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, ratio, tree=tree)
+    m = amd.Matcher_Points_InlierRatio()
+    m.initialize({"inliersRatio": ratio})
+    pairs = amd.Pairings()
+    assert m.match(pcG, pcL, T, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+    got = pairs.paired_pt2pt
+    assert len(got) == len(want), (kind, n_g, n_l, ratio)
+    assert np.array_equal(got["localIdx"], want["localIdx"]) and np.array_equal(got["globalIdx"], want["globalIdx"])
+    assert pairs.potential_pairings == pot

@@ -228,8 +228,10 @@ __device__ __forceinline__ uint32_t defer_lanes(const NNArgs& a, bool mine, unsi
 }
 
 // ================================================================================================
+// 5 waves per SIMD: 96 VGPRs with 4 spilled dwords; measured +3.5 % over the compiler's own 108
+// VGPRs / 4 waves, while 6 waves (80 VGPRs, 22 spilled dwords) give the gain back
 template <int Q, bool INSTR>
-__global__ __launch_bounds__(64) void nn_tile_kernel(const NNArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void nn_tile_kernel(const NNArgs a)
 {
     constexpr int S = 64 / Q;
     __shared__ __attribute__((aligned(16))) float s_x[NN_CAP];

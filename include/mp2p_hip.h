@@ -272,6 +272,58 @@ int mp2p_hip_match_inlier_ratio(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, cons
                                 const double pose[12], const mp2p_hip_inlier_ratio_params* prm,
                                 mp2p_hip_mstate* ms, mp2p_hip_pairs* out);
 
+/* ---- Matcher_Adaptive::implMatchOneLayer (Matcher_Adaptive.cpp:59-314; parameters
+ *      Matcher_Adaptive.h:67-77, initialize() :32-57).  Up to nn = (enableDetectPlanes ?
+ *      planeSearchPoints : maxPt2PtCorrespondences) <= 16 neighbours within
+ *      absoluteMaxSearchDistance per local point (the first 10 kept), a 50-bin histogram of
+ *      everybody's first two squared distances -> threshold, then per local point a pt2pl pairing
+ *      (planar neighbours) or up to maxPt2PtCorrespondences pt2pt pairings.  Global marks are read,
+ *      not written.  The histogram -> threshold step is mrpt::math::CHistogram +
+ *      confidenceIntervalsFromHistogram (un-vendored MRPT): mp2p_hip_adaptive_ci_high restates it,
+ *      PARITY UNPINNED; a caller that links MRPT runs _search, computes the threshold itself from
+ *      the bins and passes it to _select.  A cloud with a visiting order is refused (the reference
+ *      throws for maxLocalPointsPerLayer here).  One GPU. ---------------------------------------- */
+#define MP2P_HIP_ADAPTIVE_BINS 50
+typedef struct
+{
+    double   confidenceInterval;       /* in (0,1) */
+    double   firstToSecondDistanceMax;
+    double   absoluteMaxSearchDistance;
+    double   minimumCorrDist;
+    int32_t  enableDetectPlanes;
+    uint32_t maxPt2PtCorrespondences;
+    uint32_t planeSearchPoints;
+    uint32_t planeMinimumFoundPoints;  /* >= 3, <= planeSearchPoints */
+    double   planeMinimumDistance;
+    double   planeEigenThreshold;
+    int32_t  allowMatchAlreadyMatchedPoints;
+    int32_t  allowMatchAlreadyMatchedGlobalPoints;
+    double   bounding_box_intersection_check_epsilon;
+} mp2p_hip_adaptive_params;
+typedef struct
+{
+    int32_t  valid;          /* 0: no local point has a neighbour (the reference dereferences an
+                                empty optional there); nothing will be paired */
+    float    minSqr, maxSqr; /* Matcher_Adaptive.cpp:167-181 */
+    uint64_t count;          /* samples added */
+    uint64_t bins[MP2P_HIP_ADAPTIVE_BINS];
+} mp2p_hip_adaptive_hist;
+/* neighbour lists (kept on the context) + histogram; synchronises the stream */
+int mp2p_hip_adaptive_search(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                             const double pose[12], const mp2p_hip_adaptive_params* prm,
+                             mp2p_hip_mstate* ms, mp2p_hip_adaptive_hist* hist);
+/* upper confidence limit of the histogram as MRPT computes it (host arithmetic; NaN if !valid) */
+double mp2p_hip_adaptive_ci_high(const mp2p_hip_adaptive_hist* hist, double confidenceInterval);
+/* pairings for the lists of the last _search on this context (same map, cloud, prm) */
+int mp2p_hip_adaptive_select(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                             const mp2p_hip_adaptive_params* prm, double ci_high, mp2p_hip_mstate* ms,
+                             mp2p_hip_pairs* out);
+/* _search + _ci_high + _select; ci_high_out / hist_out may be NULL */
+int mp2p_hip_match_adaptive(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                            const double pose[12], const mp2p_hip_adaptive_params* prm,
+                            mp2p_hip_mstate* ms, mp2p_hip_pairs* out, double* ci_high_out,
+                            mp2p_hip_adaptive_hist* hist_out);
+
 /* ---- Matcher_Point2Plane::implMatchOneLayer (Matcher_Point2Plane.cpp:41-114) with the
  *      NearestPlaneCapable::nn_search_pt2pl contract (NearestPlaneCapable.h:33-52)
  *      implemented as: k-NN in radius -> 3x3 covariance -> eigen -> planarity test

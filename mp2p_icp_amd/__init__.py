@@ -10,8 +10,9 @@ from .core import Context, DevicePairs, GlobalMap, LocalCloud, default_context  
 from .filters import FilterDecimateVoxels  # noqa: F401
 from .icp import (ICP, IterTermReason, Parameters, QualityEvaluator_PairedRatio, Results,  # noqa: F401
                   covariance, evaluate_quality)
-from .matcher import (MatchContext, Matcher, Matcher_Point2Plane, Matcher_Points_InlierRatio,  # noqa: F401
-                      Matcher_Points_DistanceThreshold, MatchState, Pairings, run_matchers)
+from .matcher import (MatchContext, Matcher, Matcher_Adaptive, Matcher_Point2Plane,  # noqa: F401
+                      Matcher_Points_InlierRatio, Matcher_Points_DistanceThreshold, MatchState, Pairings,
+                      run_matchers)
 from .metric_map import PT_LAYER_RAW, PointLayer, metric_map_t  # noqa: F401
 from .parameterizable import ParameterSource  # noqa: F401
 from .solver import (OptimalTF_Result, PosePrior, Solver, Solver_GaussNewton,  # noqa: F401

@@ -36,6 +36,26 @@ class InlierRatioParams(C.Structure):
                 ("bounding_box_intersection_check_epsilon", C.c_double)]
 
 
+class AdaptiveParams(C.Structure):
+    """mp2p_hip_adaptive_params (Matcher_Adaptive.h:67-77)"""
+    _fields_ = [("confidenceInterval", C.c_double), ("firstToSecondDistanceMax", C.c_double),
+                ("absoluteMaxSearchDistance", C.c_double), ("minimumCorrDist", C.c_double),
+                ("enableDetectPlanes", C.c_int32), ("maxPt2PtCorrespondences", C.c_uint32),
+                ("planeSearchPoints", C.c_uint32), ("planeMinimumFoundPoints", C.c_uint32),
+                ("planeMinimumDistance", C.c_double), ("planeEigenThreshold", C.c_double),
+                ("allowMatchAlreadyMatchedPoints", C.c_int32),
+                ("allowMatchAlreadyMatchedGlobalPoints", C.c_int32),
+                ("bounding_box_intersection_check_epsilon", C.c_double)]
+
+
+ADAPTIVE_BINS = 50
+
+
+class AdaptiveHist(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("minSqr", C.c_float), ("maxSqr", C.c_float),
+                ("count", C.c_uint64), ("bins", C.c_uint64 * ADAPTIVE_BINS)]
+
+
 class DecimateParams(C.Structure):
     _fields_ = [("voxel_filter_resolution", C.c_float), ("decimate_method", C.c_int32),
                 ("has_flatten_to", C.c_int32), ("flatten_to", C.c_float)]
@@ -167,6 +187,12 @@ SIGNATURES = {
     "mp2p_hip_map_claims_count": (C.c_size_t, [_P]),
     "mp2p_hip_ctx_local_bbox_ptr": (_P, [_P]),
     "mp2p_hip_match_inlier_ratio": (C.c_int, [_P, _P, _P, _dp, C.POINTER(InlierRatioParams), _P, _P]),
+    "mp2p_hip_adaptive_search": (C.c_int, [_P, _P, _P, _dp, C.POINTER(AdaptiveParams), _P,
+                                           C.POINTER(AdaptiveHist)]),
+    "mp2p_hip_adaptive_ci_high": (C.c_double, [C.POINTER(AdaptiveHist), C.c_double]),
+    "mp2p_hip_adaptive_select": (C.c_int, [_P, _P, _P, C.POINTER(AdaptiveParams), C.c_double, _P, _P]),
+    "mp2p_hip_match_adaptive": (C.c_int, [_P, _P, _P, _dp, C.POINTER(AdaptiveParams), _P, _P,
+                                          C.POINTER(C.c_double), C.POINTER(AdaptiveHist)]),
     "mp2p_hip_match_pt2pl": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PlParams), _P, _P]),
     "mp2p_hip_gn_solve": (C.c_int, [_P, _P, _dp, C.POINTER(GNParams), C.POINTER(GNResult)]),
     "mp2p_hip_gn_begin": (C.c_int, [_P, _P, _dp, C.POINTER(GNParams)]),

@@ -332,6 +332,40 @@ def match_inlier_ratio(ctx, gmap, cloud, pose, prm, mstate, pairs):
                                              pairs.handle), ctx.handle)
 
 
+def adaptive_search(ctx, gmap, cloud, pose, prm, mstate):
+    """Matcher_Adaptive steps 1+2: neighbour lists (kept on the context) -> _lib.AdaptiveHist"""
+    T = _pose(pose)
+    h = _lib.AdaptiveHist()
+    check(ctx._L.mp2p_hip_adaptive_search(ctx.handle, gmap.handle, cloud.handle,
+                                          T.ctypes.data_as(C.POINTER(C.c_double)), C.byref(prm),
+                                          mstate.handle if mstate is not None else None, C.byref(h)),
+          ctx.handle)
+    return h
+
+
+def adaptive_ci_high(ctx, hist, confidenceInterval):
+    """the restated MRPT confidence limit (parity unpinned: see include/mp2p_hip.h)"""
+    return float(ctx._L.mp2p_hip_adaptive_ci_high(C.byref(hist), float(confidenceInterval)))
+
+
+def adaptive_select(ctx, gmap, cloud, prm, ci_high, mstate, pairs):
+    check(ctx._L.mp2p_hip_adaptive_select(ctx.handle, gmap.handle, cloud.handle, C.byref(prm),
+                                          float(ci_high), mstate.handle if mstate is not None else None,
+                                          pairs.handle), ctx.handle)
+
+
+def match_adaptive(ctx, gmap, cloud, pose, prm, mstate, pairs):
+    """-> (ci_high, AdaptiveHist)"""
+    T = _pose(pose)
+    h = _lib.AdaptiveHist()
+    ci = C.c_double(0.0)
+    check(ctx._L.mp2p_hip_match_adaptive(ctx.handle, gmap.handle, cloud.handle,
+                                         T.ctypes.data_as(C.POINTER(C.c_double)), C.byref(prm),
+                                         mstate.handle if mstate is not None else None, pairs.handle,
+                                         C.byref(ci), C.byref(h)), ctx.handle)
+    return ci.value, h
+
+
 def match_pt2pl(ctx, gmap, cloud, pose, prm, mstate, pairs):
     T = _pose(pose)
     check(ctx._L.mp2p_hip_match_pt2pl(ctx.handle, gmap.handle, cloud.handle,

@@ -448,6 +448,117 @@ int mp2p_hip_match_inlier_ratio(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, cons
     return launch_match_inlier_ratio(ctx, map, cloud, pose, prm, ms, out);
 }
 
+// ---- Matcher_Adaptive --------------------------------------------------------------------------------
+static int adaptive_check(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                          const mp2p_hip_adaptive_params* prm, mp2p_hip_mstate* ms)
+{
+    MP2P_REQUIRE(ctx, map && cloud && prm, "null argument");
+    MP2P_REQUIRE(ctx, map->ctx == ctx && cloud->ctx == ctx, "handle belongs to another context");
+    // Matcher_Adaptive.cpp:50-56
+    MP2P_REQUIRE(ctx, prm->confidenceInterval > 0.0 && prm->confidenceInterval < 1.0,
+                 "confidenceInterval must be in (0,1)");
+    MP2P_REQUIRE(ctx, prm->planeSearchPoints >= prm->planeMinimumFoundPoints,
+                 "planeSearchPoints must be >= planeMinimumFoundPoints");
+    MP2P_REQUIRE(ctx, prm->planeMinimumFoundPoints >= 3, "planeMinimumFoundPoints must be >= 3");
+    MP2P_REQUIRE(ctx, prm->planeEigenThreshold > 0.0, "planeEigenThreshold must be > 0");
+    const uint32_t nn = prm->enableDetectPlanes ? prm->planeSearchPoints : prm->maxPt2PtCorrespondences;
+    MP2P_REQUIRE(ctx, nn >= 1 && nn <= 16, "neighbours per local point must be in [1,16]");
+    MP2P_REQUIRE(ctx, prm->maxPt2PtCorrespondences >= 1, "maxPt2PtCorrespondences must be >= 1");
+    MP2P_REQUIRE(ctx, prm->absoluteMaxSearchDistance > 0.0, "absoluteMaxSearchDistance must be > 0");
+    MP2P_REQUIRE(ctx, cloud->n_visit == 0,
+                 "Matcher_Adaptive with maxLocalPointsPerLayer: the reference throws (matchesPerLocal_.at(localIdx))");
+    if (ms)
+    {
+        MP2P_REQUIRE(ctx, ms->global_taken.n >= std::max<size_t>(map->n, 1), "MatchState too small (global)");
+        MP2P_REQUIRE(ctx, ms->local_taken.n >= std::max<size_t>(cloud->n, 1), "MatchState too small (local)");
+    }
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_adaptive_search(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                             const double pose[12], const mp2p_hip_adaptive_params* prm,
+                             mp2p_hip_mstate* ms, mp2p_hip_adaptive_hist* hist)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, pose && hist, "null argument");
+    if (const int rc = adaptive_check(ctx, map, cloud, prm, ms)) return rc;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    memset(hist, 0, sizeof(*hist));
+    ctx->ad_knn = 0, ctx->ad_cloud = nullptr, ctx->ad_map = nullptr;
+    if (map->n == 0 || cloud->n == 0) return MP2P_HIP_OK;  // :72
+    return launch_adaptive_search(ctx, map, cloud, pose, prm, ms, hist);
+}
+
+// CHistogram::getHistogramNormalized + confidenceIntervalsFromHistogram(xs, ys, lo, hi, 1 - ci)
+// (Matcher_Adaptive.cpp:194-198), restated from MRPT's published sources: xs = linspace(min, max,
+// nBins); ys = bins * binSizeInv / count; Hc = cumsum(ys) / max(Hc); hi = xs[first Hc > 1 - arg].
+double mp2p_hip_adaptive_ci_high(const mp2p_hip_adaptive_hist* hist, double confidenceInterval)
+{
+    if (!hist || !hist->valid || hist->count == 0) return NAN;
+    const int    N  = MP2P_HIP_ADAPTIVE_BINS;
+    const double mn = (double)hist->minSqr, mx = (double)hist->maxSqr;
+    if (!(mx > mn)) return mx;  // a single value: MRPT's bin width is 0/0; declared = that value
+    const double binSizeInv = (double)(N - 1) / (mx - mn);
+    const double K          = binSizeInv / (double)hist->count;
+    const double step       = (mx - mn) / (double)(N - 1);
+    double       Hc[MP2P_HIP_ADAPTIVE_BINS], xs[MP2P_HIP_ADAPTIVE_BINS];
+    double       c = mn, run = 0.0, top = 0.0;
+    for (int i = 0; i < N; i++)
+    {
+        xs[i] = c;  // mrpt::math::linspace accumulates: c = first; c += incr
+        c += step;
+        run += K * (double)hist->bins[i];
+        Hc[i] = run;
+        top   = std::max(top, run);
+    }
+    const double inv = 1.0 / top;
+    const double arg = 1.0 - confidenceInterval;
+    for (int i = 0; i < N; i++)
+        if (Hc[i] * inv > 1.0 - arg) return xs[i];
+    return NAN;
+}
+
+int mp2p_hip_adaptive_select(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                             const mp2p_hip_adaptive_params* prm, double ci_high, mp2p_hip_mstate* ms,
+                             mp2p_hip_pairs* out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, out && out->ctx == ctx, "pairings handle missing or of another context");
+    if (const int rc = adaptive_check(ctx, map, cloud, prm, ms)) return rc;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    // :69 potential_pairings precedes every early-out
+    if (const int rc = launch_add_potential(ctx, out, (unsigned long long)cloud->n * prm->maxPt2PtCorrespondences))
+        return rc;
+    if (map->n == 0 || cloud->n == 0) return MP2P_HIP_OK;
+    const uint32_t nn = prm->enableDetectPlanes ? prm->planeSearchPoints : prm->maxPt2PtCorrespondences;
+    MP2P_REQUIRE(ctx, ctx->ad_knn == nn && ctx->ad_cloud == cloud && ctx->ad_map == map,
+                 "mp2p_hip_adaptive_select without a matching mp2p_hip_adaptive_search");
+    MP2P_REQUIRE(ctx, ci_high == ci_high, "threshold is NaN");
+    const int rc = launch_adaptive_select(ctx, map, cloud, prm, ci_high, ms, out);
+    ctx->ad_knn = 0;  // the lists are consumed (select rewrites them)
+    return rc;
+}
+
+int mp2p_hip_match_adaptive(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                            const double pose[12], const mp2p_hip_adaptive_params* prm,
+                            mp2p_hip_mstate* ms, mp2p_hip_pairs* out, double* ci_high_out,
+                            mp2p_hip_adaptive_hist* hist_out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, out && out->ctx == ctx, "pairings handle missing or of another context");
+    mp2p_hip_adaptive_hist h;
+    int rc = mp2p_hip_adaptive_search(ctx, map, cloud, pose, prm, ms, &h);
+    if (rc) return rc;
+    if (hist_out) *hist_out = h;
+    if (ci_high_out) *ci_high_out = NAN;
+    if (!h.valid)  // nothing found (or an empty layer): only potential_pairings changes
+        return launch_add_potential(ctx, out, (unsigned long long)cloud->n * prm->maxPt2PtCorrespondences);
+    const double hi = mp2p_hip_adaptive_ci_high(&h, prm->confidenceInterval);
+    if (ci_high_out) *ci_high_out = hi;
+    MP2P_REQUIRE(ctx, hi == hi, "Matcher_Adaptive: confidence limit not found in the histogram");
+    return mp2p_hip_adaptive_select(ctx, map, cloud, prm, hi, ms, out);
+}
+
 // ---- Matcher_Point2Plane -----------------------------------------------------------------------
 int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
                          const double pose[12], const mp2p_hip_pt2pl_params* prm,

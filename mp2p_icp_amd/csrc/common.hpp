@@ -133,6 +133,10 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<double>             gn_state;     // pose(12) H(36) g(6) cost(1) iters(1) done(1)
     mp2p::DevBuf<unsigned char>      aos_stage;    // download staging
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
+    mp2p::DevBuf<unsigned long long> ad_hist;      // Matcher_Adaptive: 50 bins, count, {min,max} words
+    uint32_t                         ad_knn   = 0;       //   lists held in nn_spos / nn_d2: neighbours per point,
+    const void*                      ad_cloud = nullptr; //   and the handles they were searched for
+    const void*                      ad_map   = nullptr;
     mp2p::DevBuf<uint4>              work;         // deferred queries of the NN search
     mp2p::DevBuf<uint32_t>           work_spos;    //   (+ counter in the last word)
     mp2p::DevBuf<uint2>              hint;         // warm start: previous NN + distance bound per local point

@@ -367,6 +367,52 @@ __device__ __forceinline__ void transform_tile(const PoseRt& pose, const float4*
     }
 }
 
+// estimate_points_eigen (estimate_points_eigen.cpp:27-123) over the first m of K points, in
+// order: fp32 mean, fp32 products accumulated in fp64 and scaled by the fp32 1/n; the planarity
+// test e0 < thr*e1 && e0 < thr*e2 (Matcher_Adaptive.cpp:237-238); unit normal = eigenvector 0
+// with its largest |component| positive.  Operation order = oracle/mp2p_oracle.c.
+template <int K>
+__device__ __forceinline__ bool plane_of_points(const float (&px)[K], const float (&py)[K],
+                                                const float (&pz)[K], int m, double eigThr,
+                                                double (&n)[3], float& mx, float& my, float& mz)
+{
+    mx = 0.f, my = 0.f, mz = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; j++)
+        if (j < m) mx = fadd(mx, px[j]), my = fadd(my, py[j]), mz = fadd(mz, pz[j]);
+    const float inv_n = 1.0f / (float)m;
+    mx = fmul(mx, inv_n), my = fmul(my, inv_n), mz = fmul(mz, inv_n);
+    double a00 = 0, a10 = 0, a20 = 0, a11 = 0, a21 = 0, a22 = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++)
+    {
+        if (j < m)
+        {
+            const float ax = fsub(px[j], mx), ay = fsub(py[j], my), az = fsub(pz[j], mz);
+            a00 = dadd(a00, (double)fmul(ax, ax));
+            a10 = dadd(a10, (double)fmul(ax, ay));
+            a20 = dadd(a20, (double)fmul(ax, az));
+            a11 = dadd(a11, (double)fmul(ay, ay));
+            a21 = dadd(a21, (double)fmul(ay, az));
+            a22 = dadd(a22, (double)fmul(az, az));
+        }
+    }
+    const double sc = (double)inv_n;
+    a00 = dmul(a00, sc), a10 = dmul(a10, sc), a20 = dmul(a20, sc);
+    a11 = dmul(a11, sc), a21 = dmul(a21, sc), a22 = dmul(a22, sc);
+    const double cov[9] = {a00, a10, a20, a10, a11, a21, a20, a21, a22};
+    double       ev[3];
+    jacobi3(cov, ev, n);
+    if (!(ev[0] < eigThr * ev[2] && ev[0] < eigThr * ev[1])) return false;
+    const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    n[0] /= nn, n[1] /= nn, n[2] /= nn;
+    int big = 0;
+    if (fabs(n[1]) > fabs(n[big])) big = 1;
+    if (fabs(n[2]) > fabs(n[big])) big = 2;
+    if (n[big] < 0) n[0] = -n[0], n[1] = -n[1], n[2] = -n[2];
+    return true;
+}
+
 constexpr int PL_Q = 32;  // queries per wave (2 candidate slices)
 
 template <int K>
@@ -405,7 +451,6 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
         if (m >= (int)a.minPts && m >= 3)
         {
             float px[K], py[K], pz[K];
-            float mx = 0.f, my = 0.f, mz = 0.f;
 #pragma unroll
             for (int j = 0; j < K; j++)
             {
@@ -413,40 +458,12 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
                 {
                     const float4 p = g.pts[kspos[j]];
                     px[j] = p.x, py[j] = p.y, pz[j] = p.z;
-                    mx = fadd(mx, p.x), my = fadd(my, p.y), mz = fadd(mz, p.z);
                 }
             }
-            const float inv_n = 1.0f / (float)m;
-            mx = fmul(mx, inv_n), my = fmul(my, inv_n), mz = fmul(mz, inv_n);
-            double a00 = 0, a10 = 0, a20 = 0, a11 = 0, a21 = 0, a22 = 0;
-#pragma unroll
-            for (int j = 0; j < K; j++)
+            float  mx, my, mz;
+            double n[3];
+            if (plane_of_points<K>(px, py, pz, m, a.eigThr, n, mx, my, mz))
             {
-                if (j < m)
-                {
-                    const float ax = fsub(px[j], mx), ay = fsub(py[j], my), az = fsub(pz[j], mz);
-                    a00 = dadd(a00, (double)fmul(ax, ax));
-                    a10 = dadd(a10, (double)fmul(ax, ay));
-                    a20 = dadd(a20, (double)fmul(ax, az));
-                    a11 = dadd(a11, (double)fmul(ay, ay));
-                    a21 = dadd(a21, (double)fmul(ay, az));
-                    a22 = dadd(a22, (double)fmul(az, az));
-                }
-            }
-            const double sc = (double)inv_n;
-            a00 = dmul(a00, sc), a10 = dmul(a10, sc), a20 = dmul(a20, sc);
-            a11 = dmul(a11, sc), a21 = dmul(a21, sc), a22 = dmul(a22, sc);
-            const double cov[9] = {a00, a10, a20, a10, a11, a21, a20, a21, a22};
-            double       ev[3], n[3];
-            jacobi3(cov, ev, n);
-            if (ev[0] < a.eigThr * ev[2] && ev[0] < a.eigThr * ev[1])
-            {
-                const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                n[0] /= nn, n[1] /= nn, n[2] /= nn;
-                int big = 0;
-                if (fabs(n[1]) > fabs(n[big])) big = 1;
-                if (fabs(n[2]) > fabs(n[big])) big = 2;
-                if (n[big] < 0) n[0] = -n[0], n[1] = -n[1], n[2] = -n[2];
                 const double c0 = (double)mx, c1 = (double)my, c2 = (double)mz;
                 const double d  = -(n[0] * c0 + n[1] * c1 + n[2] * c2);
                 const float  dist =

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
 int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
                          const uint32_t* order, size_t n_slots, const uint32_t* n_slots_dev, uint32_t K,
                          bool use_claims, bool always_mark, unsigned long long local_offset, float margin,
-                         unsigned long long potential_add, mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
+                         unsigned long long potential_add, mp2p_hip_mstate* ms, mp2p_hip_pairs* out,
+                         bool mark_global = true)
 {
     const size_t   n_l      = n_slots;
     const uint32_t n_blocks = (uint32_t)((n_l + CP_TILE - 1) / CP_TILE);
@@ -215,7 +216,7 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     a.o_lx = out->lx.p, a.o_ly = out->ly.p, a.o_lz = out->lz.p;
     a.o_gx = out->gx.p, a.o_gy = out->gy.p, a.o_gz = out->gz.p, a.o_err = out->err.p;
     a.ms_local  = ms ? ms->local_taken.p : nullptr;
-    a.ms_global = ms ? ms->global_taken.p : nullptr;
+    a.ms_global = (ms && mark_global) ? ms->global_taken.p : nullptr;
 
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (n_blocks)

@@ -7,6 +7,8 @@
   Matcher_Points_Base              Matcher_Points_Base.cpp:30-181
   Matcher_Points_DistanceThreshold Matcher_Points_DistanceThreshold.cpp:39-269
   Matcher_Point2Plane              Matcher_Point2Plane.cpp:35-114
+  Matcher_Points_InlierRatio       Matcher_Points_InlierRatio.cpp:28-143
+  Matcher_Adaptive                 Matcher_Adaptive.cpp:32-314
   Pairings                         Pairings.h:84-169, Pairings.cpp:123-147
 """
 import math
@@ -376,6 +378,91 @@ class Matcher_Points_InlierRatio(Matcher_Points_Base):
         dev = out._ensure_dev(ctx, out._ub[0], out._ub[1])
         core.match_inlier_ratio(ctx, gmap, cloud, localPose, prm, ms.for_layers(glName, lcName), dev)
         ms._sync_shared(glName, lcName)
+
+
+class Matcher_Adaptive(Matcher_Points_Base):
+    """Matcher_Adaptive.cpp:32-314 (parameters Matcher_Adaptive.h:67-77).
+
+    `threshold_from_histogram`: optional callable (hist dict) -> squared-distance limit, in place of
+    the restated mrpt::math::confidenceIntervalsFromHistogram (un-vendored MRPT, parity unpinned);
+    `last_ci_high` / `last_histogram` keep what the last call used."""
+
+    def __init__(self, ConfidenceInterval=0.80, FirstToSecondDistanceMax=1.2, AbsoluteMaxSearchDistance=5.0):
+        super().__init__()
+        self.confidenceInterval = ConfidenceInterval
+        self.firstToSecondDistanceMax = FirstToSecondDistanceMax
+        self.absoluteMaxSearchDistance = AbsoluteMaxSearchDistance
+        self.enableDetectPlanes = False
+        self.maxPt2PtCorrespondences = 1
+        self.planeSearchPoints = 8
+        self.planeMinimumFoundPoints = 4
+        self.planeMinimumDistance = 0.10
+        self.planeEigenThreshold = 0.01
+        self.minimumCorrDist = 0.1
+        self.threshold_from_histogram = None
+        self.last_ci_high = None
+        self.last_histogram = None
+
+    def initialize(self, params):
+        super().initialize(params)
+        params = params or {}
+        for k in ("confidenceInterval", "firstToSecondDistanceMax", "absoluteMaxSearchDistance",
+                  "enableDetectPlanes"):  # MCP_LOAD_REQ (:36-42)
+            if k not in params:
+                raise KeyError("Required parameter `%s` not an existing key in dictionary." % k)
+        self.confidenceInterval = float(params["confidenceInterval"])
+        self.firstToSecondDistanceMax = float(params["firstToSecondDistanceMax"])
+        self.absoluteMaxSearchDistance = float(params["absoluteMaxSearchDistance"])
+        self.minimumCorrDist = float(params.get("minimumCorrDist", self.minimumCorrDist))
+        self.enableDetectPlanes = bool(params["enableDetectPlanes"])
+        self.planeSearchPoints = int(params.get("planeSearchPoints", self.planeSearchPoints))
+        self.planeMinimumFoundPoints = int(params.get("planeMinimumFoundPoints", self.planeMinimumFoundPoints))
+        self.planeEigenThreshold = float(params.get("planeEigenThreshold", self.planeEigenThreshold))
+        self.maxPt2PtCorrespondences = int(params.get("maxPt2PtCorrespondences", self.maxPt2PtCorrespondences))
+        self.planeMinimumDistance = float(params.get("planeMinimumDistance", self.planeMinimumDistance))
+        if not (0.0 < self.confidenceInterval < 1.0):  # :50-51
+            raise RuntimeError("ASSERT_LT_(confidenceInterval, 1.0) / ASSERT_GT_(confidenceInterval, 0.0)")
+        if self.planeSearchPoints < self.planeMinimumFoundPoints:  # :53
+            raise RuntimeError("ASSERT_GE_(planeSearchPoints, planeMinimumFoundPoints)")
+        if self.planeMinimumFoundPoints < 3:  # :54
+            raise RuntimeError("ASSERT_GE_(planeMinimumFoundPoints, 3)")
+        if not self.planeEigenThreshold > 0.0:  # :56
+            raise RuntimeError("ASSERT_GT_(planeEigenThreshold, 0.0)")
+
+    def _params(self):
+        return _lib.AdaptiveParams(float(self.confidenceInterval), float(self.firstToSecondDistanceMax),
+                                   float(self.absoluteMaxSearchDistance), float(self.minimumCorrDist),
+                                   int(bool(self.enableDetectPlanes)), int(self.maxPt2PtCorrespondences),
+                                   int(self.planeSearchPoints), int(self.planeMinimumFoundPoints),
+                                   float(self.planeMinimumDistance), float(self.planeEigenThreshold),
+                                   int(self.allowMatchAlreadyMatchedPoints_),
+                                   int(self.allowMatchAlreadyMatchedGlobalPoints_),
+                                   float(self.bounding_box_intersection_check_epsilon_))
+
+    def implMatchOneLayer(self, ctx, gLayer, lLayer, localPose, ms, glName, lcName, out):
+        prm = self._params()
+        gmap, cloud = gLayer.as_global(ctx), lLayer.as_local(ctx)
+        n_visit = self._apply_visit_order(lLayer, cloud)  # a subset is refused by the library
+        out._ub[0] += n_visit * int(self.maxPt2PtCorrespondences)
+        out._ub[1] += n_visit
+        dev = out._ensure_dev(ctx, out._ub[0], out._ub[1])
+        mst = ms.for_layers(glName, lcName)
+        if self.threshold_from_histogram is None:
+            ci, h = core.match_adaptive(ctx, gmap, cloud, localPose, prm, mst, dev)
+        else:
+            h = core.adaptive_search(ctx, gmap, cloud, localPose, prm, mst)
+            if h.valid:
+                ci = float(self.threshold_from_histogram(_hist_dict(h)))
+                core.adaptive_select(ctx, gmap, cloud, prm, ci, mst, dev)
+            else:  # nobody has a neighbour: the one-shot entry only counts potential_pairings
+                ci, h = core.match_adaptive(ctx, gmap, cloud, localPose, prm, mst, dev)
+        self.last_ci_high, self.last_histogram = ci, _hist_dict(h)
+        ms._sync_shared(glName, lcName)
+
+
+def _hist_dict(h):
+    return dict(valid=bool(h.valid), minSqr=float(h.minSqr), maxSqr=float(h.maxSqr), count=int(h.count),
+                bins=[int(b) for b in h.bins])
 
 
 class Matcher_Point2Plane(Matcher_Points_Base):

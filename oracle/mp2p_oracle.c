@@ -1246,6 +1246,203 @@ size_t orc_match_inlier_ratio(const orc_kdtree* tree, const float* gx, const flo
 }
 
 /* ======================================================================================
+ *  f3: Matcher_Adaptive::implMatchOneLayer (mp2p_icp/src/Matcher_Adaptive.cpp:59-314).
+ *  The neighbour lists, the plane test and the pair selection follow the reference's code.
+ *  The adaptive threshold goes through mrpt::math::CHistogram and
+ *  mrpt::math::confidenceIntervalsFromHistogram (MRPT >= 2.11.5, un-vendored): restated below
+ *  from MRPT's published sources -- PARITY UNPINNED for these two helpers; callers can pass the
+ *  threshold in instead (ci_high_given) to pin everything else.
+ *    nn_radius_search(q, r2, ..., maxPoints) = the maxPoints nearest with d2 < r2, ascending
+ *    (nanoflann RKNN result set); nn_single_search has no radius, the caller keeps d2 <= r2.
+ * ====================================================================================== */
+/* CHistogram(min, max, nBins): binSizeInv = (nBins-1)/(max-min); add(x): bin = (size_t)(binSizeInv *
+ * (x-min)); getHistogramNormalized: x = linspace(min, max, nBins), y = bins * binSizeInv / count.
+ * confidenceIntervalsFromHistogram(x, y, lo, hi, ci): Hc = cumsum(y) / max(Hc);
+ * hi = x[first index with Hc > 1 - ci] (std::upper_bound). */
+double orc_adaptive_ci_high(double minSq, double maxSq, const uint64_t* bins, int n_bins,
+                            uint64_t count, double confidenceInterval)
+{
+    const double binSizeInv = (double)(n_bins - 1) / (maxSq - minSq);
+    const double K          = binSizeInv / (double)count;
+    double       Hc[ORC_ADAPTIVE_BINS], xs[ORC_ADAPTIVE_BINS];
+    const double step = (maxSq - minSq) / (double)(n_bins - 1);
+    double       c = minSq, run = 0, mx = 0;
+    for (int i = 0; i < n_bins; i++)
+    {
+        xs[i] = c; /* mrpt::math::linspace: c = first; c += incr */
+        c += step;
+        run += K * (double)bins[i];
+        Hc[i] = run;
+        if (run > mx) mx = run;
+    }
+    const double inv = 1.0 / mx;
+    const double ci  = 1.0 - confidenceInterval; /* the call passes 1.0 - confidenceInterval (:198) */
+    for (int i = 0; i < n_bins; i++)
+        if (Hc[i] * inv > 1.0 - ci) return xs[i];
+    return NAN; /* ASSERT_(it_high != Hc.end()) */
+}
+
+int orc_match_adaptive(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                       size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
+                       const double T[12], const orc_adaptive_params* prm, uint8_t* local_taken,
+                       const uint8_t* global_taken, int ci_high_given, double* ci_high,
+                       orc_adaptive_hist* hist_out, orc_pair_pt2pt* out_pt2pt, size_t* n_pt2pt,
+                       orc_pair_pt2pl* out_pt2pl, uint32_t* out_pl_local_idx, size_t* n_pt2pl,
+                       uint64_t* potential_pairings)
+{
+    *n_pt2pt = *n_pt2pl = 0;
+    if (hist_out) memset(hist_out, 0, sizeof(*hist_out));
+    if (potential_pairings) *potential_pairings += (uint64_t)n_l * prm->maxPt2PtCorrespondences; /* :69 */
+    if (n_g == 0 || n_l == 0) return 0;                                                           /* :72 */
+    const uint32_t K = prm->enableDetectPlanes ? prm->planeSearchPoints : prm->maxPt2PtCorrespondences; /* :120 */
+    if (K < 1 || K > ORC_MAX_K) return -1;
+
+    float* tx = (float*)malloc(n_l * sizeof(float));
+    float* ty = (float*)malloc(n_l * sizeof(float));
+    float* tz = (float*)malloc(n_l * sizeof(float));
+    float  lmin[3], lmax[3], gmin[3], gmax[3];
+    orc_transform_local_to_global(lx, ly, lz, n_l, T, tx, ty, tz, lmin, lmax); /* :74-75 */
+    bbox_of(gx, gy, gz, n_g, gmin, gmax);
+    if (!bbox_intersects(gmin, gmax, lmin, lmax, (float)prm->bbox_eps)) /* :78-81 */
+    {
+        free(tx), free(ty), free(tz);
+        return 0;
+    }
+    const float absMaxSq = (float)(prm->absoluteMaxSearchDistance * prm->absoluteMaxSearchDistance); /* :88 */
+    const int   KEEP     = ORC_ADAPTIVE_MAX_CORRS; /* MAX_CORRS_PER_LOCAL (Matcher_Adaptive.h:83) */
+    uint32_t*   m_idx    = (uint32_t*)malloc(n_l * KEEP * sizeof(uint32_t));
+    float*      m_d2     = (float*)malloc(n_l * KEEP * sizeof(float));
+    uint8_t*    m_n      = (uint8_t*)calloc(n_l, 1);
+    int         have = 0;
+    float       mn = 0, mx = 0;
+    uint32_t    nidx[ORC_MAX_K];
+    float       nd2[ORC_MAX_K];
+    for (size_t i = 0; i < n_l; i++) /* :122-185 */
+    {
+        if (!prm->allowMatchAlreadyMatchedPoints && local_taken && local_taken[i]) continue; /* :126-132 */
+        int found;
+        if (K == 1)
+            found = nn_search(tree, gx, gy, gz, n_g, tx[i], ty[i], tz[i], 1, -1.0f, nidx, nd2); /* :138-152 */
+        else
+            found = nn_search(tree, gx, gy, gz, n_g, tx[i], ty[i], tz[i], (int)K, absMaxSq, nidx, nd2); /* :155-158 */
+        for (int k = 0; k < found; k++)
+        {
+            const float e = nd2[k];
+            if (e > absMaxSq) continue; /* :165 */
+            if (k <= 1)                 /* :167-181 */
+            {
+                if (have)
+                {
+                    if (e > mx) mx = e;
+                    if (e < mn) mn = e;
+                }
+                else
+                    mn = mx = e, have = 1;
+            }
+            if (m_n[i] >= KEEP) continue; /* lambdaAddPair :105 */
+            m_idx[i * KEEP + m_n[i]] = nidx[k], m_d2[i * KEEP + m_n[i]] = e;
+            m_n[i]++;
+        }
+    }
+    int rc = 0;
+    if (!have)
+    { /* the reference dereferences an empty std::optional here (:189); nothing to pair */
+        rc = 1;
+        goto done;
+    }
+    {
+        /* :189-198 */
+        orc_adaptive_hist h;
+        memset(&h, 0, sizeof(h));
+        h.valid = 1, h.minSq = mn, h.maxSq = mx;
+        const double binSizeInv = (double)(ORC_ADAPTIVE_BINS - 1) / ((double)mx - (double)mn);
+        for (size_t i = 0; i < n_l; i++)
+            for (int k = 0; k < m_n[i] && k < 2; k++)
+            {
+                const double x = (double)m_d2[i * KEEP + k];
+                if (x < (double)mn || x > (double)mx) continue;
+                /* min == max: MRPT's index is (size_t)(inf * 0); declared: bin 0 */
+                const size_t b = (mx > mn) ? (size_t)(binSizeInv * (x - (double)mn)) : 0;
+                h.bins[b < ORC_ADAPTIVE_BINS ? b : ORC_ADAPTIVE_BINS - 1]++;
+                h.count++;
+            }
+        if (hist_out) *hist_out = h;
+        double hi = *ci_high;
+        if (!ci_high_given)
+        {
+            if (!(mx > mn))
+            { /* binSizeInv = inf: MRPT's bin index is undefined; declared: threshold = max */
+                hi = (double)mx;
+            }
+            else
+                hi = orc_adaptive_ci_high((double)mn, (double)mx, h.bins, ORC_ADAPTIVE_BINS, h.count,
+                                          prm->confidenceInterval);
+            *ci_high = hi;
+        }
+        const double m2 = prm->minimumCorrDist * prm->minimumCorrDist;
+        const double maxCorrDistSqr = m2 > hi ? m2 : hi;                                                    /* :212 */
+        const float  maxSqr1to2 = (float)(prm->firstToSecondDistanceMax * prm->firstToSecondDistanceMax); /* :214 */
+        float kx[ORC_ADAPTIVE_MAX_CORRS], ky[ORC_ADAPTIVE_MAX_CORRS], kz[ORC_ADAPTIVE_MAX_CORRS];
+        for (size_t i = 0; i < n_l; i++) /* :217-295 */
+        {
+            const int       m   = m_n[i];
+            const uint32_t* idx = &m_idx[i * KEEP];
+            const float*    d2  = &m_d2[i * KEEP];
+            if (prm->enableDetectPlanes && m >= (int)prm->planeMinimumFoundPoints && m >= 1) /* :221 */
+            {
+                for (int k = 0; k < m; k++) kx[k] = gx[idx[k]], ky[k] = gy[idx[k]], kz[k] = gz[idx[k]];
+                float  mean[3];
+                double cov[9], ev[3], evec[9];
+                orc_estimate_points_eigen(kx, ky, kz, (size_t)m, mean, cov, ev, evec); /* :233-234 */
+                if (ev[0] < prm->planeEigenThreshold * ev[2] && ev[0] < prm->planeEigenThreshold * ev[1]) /* :237-238 */
+                {
+                    double       n[3] = {evec[0], evec[1], evec[2]};
+                    const double nn   = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                    n[0] /= nn, n[1] /= nn, n[2] /= nn;
+                    int big = 0; /* eigenvector sign: as orc_match_pt2pl (declared) */
+                    if (fabs(n[1]) > fabs(n[big])) big = 1;
+                    if (fabs(n[2]) > fabs(n[big])) big = 2;
+                    if (n[big] < 0) n[0] = -n[0], n[1] = -n[1], n[2] = -n[2];
+                    const double c[3] = {(double)mean[0], (double)mean[1], (double)mean[2]};
+                    const double d    = -(n[0] * c[0] + n[1] * c[1] + n[2] * c[2]);
+                    /* :245-246: distance of mspl[0].local = the UNtransformed local point (:113) */
+                    const double dist = fabs(n[0] * (double)lx[i] + n[1] * (double)ly[i] + n[2] * (double)lz[i] + d);
+                    if (dist < prm->planeMinimumDistance) /* :248 */
+                    {
+                        orc_pair_pt2pl* p = &out_pt2pl[*n_pt2pl];
+                        p->plane[0] = n[0], p->plane[1] = n[1], p->plane[2] = n[2], p->plane[3] = d;
+                        p->centroid[0] = c[0], p->centroid[1] = c[1], p->centroid[2] = c[2];
+                        p->lx = lx[i], p->ly = ly[i], p->lz = lz[i];
+                        p->_pad = 0;
+                        if (out_pl_local_idx) out_pl_local_idx[*n_pt2pl] = (uint32_t)i;
+                        (*n_pt2pl)++;
+                        if (local_taken) local_taken[i] = 1; /* :260 */
+                        continue;                            /* :263 */
+                    }
+                }
+            }
+            for (int k = 0; k < m && k < (int)prm->maxPt2PtCorrespondences; k++) /* :268 */
+            {
+                const uint32_t g = idx[k];
+                if (!prm->allowMatchAlreadyMatchedGlobalPoints && global_taken && global_taken[g]) continue; /* :273-275 */
+                if ((double)d2[k] >= maxCorrDistSqr) continue;                                              /* :278 */
+                if (k != 0 && d2[k] > d2[0] * maxSqr1to2) break;                                             /* :280-284 */
+                orc_pair_pt2pt* p = &out_pt2pt[*n_pt2pt];
+                p->globalIdx = g, p->localIdx = (uint32_t)i;
+                p->gx = gx[g], p->gy = gy[g], p->gz = gz[g];
+                p->lx = lx[i], p->ly = ly[i], p->lz = lz[i];
+                p->errSq = d2[k];
+                (*n_pt2pt)++;
+                if (!prm->allowMatchAlreadyMatchedGlobalPoints && local_taken) local_taken[i] = 1; /* :289-293 */
+            }
+        }
+    }
+done:
+    free(tx), free(ty), free(tz), free(m_idx), free(m_d2), free(m_n);
+    return rc;
+}
+
+/* ======================================================================================
  *  f4: covariance() (mp2p_icp/src/covariance.cpp:29-141): Hessian J^T J of the stacked error
  *  vector w.r.t. (x, y, z, yaw, pitch, roll) by central finite differences
  *  (mrpt::math::estimateJacobian: J(:,j) = (f(x + h_j e_j) - f(x - h_j e_j)) * (0.5 / h_j)),

@@ -223,6 +223,38 @@ size_t orc_match_inlier_ratio(const orc_kdtree* tree, const float* gx, const flo
                               double bbox_eps, uint8_t* local_taken, uint8_t* global_taken,
                               orc_pair_pt2pt* out, uint64_t* potential_pairings);
 
+/* ---- f3: Matcher_Adaptive (Matcher_Adaptive.cpp:59-314).  The histogram / confidence-interval
+ *      helpers are MRPT's (un-vendored): restated, PARITY UNPINNED; pass ci_high_given = 1 and
+ *      *ci_high to pin the rest.  Returns 0, 1 when no local point found any neighbour (the
+ *      reference dereferences an empty optional), -1 on unsupported parameters. ---- */
+#define ORC_ADAPTIVE_BINS 50      /* Matcher_Adaptive.cpp:189 */
+#define ORC_ADAPTIVE_MAX_CORRS 10 /* Matcher_Adaptive.h:83 */
+typedef struct
+{
+    double   confidenceInterval, firstToSecondDistanceMax, absoluteMaxSearchDistance, minimumCorrDist;
+    int32_t  enableDetectPlanes;
+    uint32_t maxPt2PtCorrespondences, planeSearchPoints, planeMinimumFoundPoints;
+    double   planeMinimumDistance, planeEigenThreshold;
+    int32_t  allowMatchAlreadyMatchedPoints, allowMatchAlreadyMatchedGlobalPoints;
+    double   bbox_eps;
+} orc_adaptive_params;
+typedef struct
+{
+    int32_t  valid;
+    float    minSq, maxSq;
+    uint64_t count;
+    uint64_t bins[ORC_ADAPTIVE_BINS];
+} orc_adaptive_hist;
+double orc_adaptive_ci_high(double minSq, double maxSq, const uint64_t* bins, int n_bins,
+                            uint64_t count, double confidenceInterval);
+int orc_match_adaptive(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                       size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
+                       const double T[12], const orc_adaptive_params* prm, uint8_t* local_taken,
+                       const uint8_t* global_taken, int ci_high_given, double* ci_high,
+                       orc_adaptive_hist* hist_out, orc_pair_pt2pt* out_pt2pt, size_t* n_pt2pt,
+                       orc_pair_pt2pl* out_pt2pl, uint32_t* out_pl_local_idx, size_t* n_pt2pl,
+                       uint64_t* potential_pairings);
+
 /* ---- f4: covariance() (covariance.cpp:29-141): H = J^T J by central differences over
  *      (x,y,z,yaw,pitch,roll), cov = H^-1 (Cholesky).  Returns 1, or 0 when H is not positive
  *      definite (cov = NaN) / there are no pairings (cov = 1e6 * I). ---- */

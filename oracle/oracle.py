@@ -44,6 +44,24 @@ class Pt2PlParams(C.Structure):
                 ("allowMatchAlreadyMatchedPoints", C.c_int32), ("bbox_eps", C.c_double)]
 
 
+class AdaptiveParams(C.Structure):
+    _fields_ = [("confidenceInterval", C.c_double), ("firstToSecondDistanceMax", C.c_double),
+                ("absoluteMaxSearchDistance", C.c_double), ("minimumCorrDist", C.c_double),
+                ("enableDetectPlanes", C.c_int32), ("maxPt2PtCorrespondences", C.c_uint32),
+                ("planeSearchPoints", C.c_uint32), ("planeMinimumFoundPoints", C.c_uint32),
+                ("planeMinimumDistance", C.c_double), ("planeEigenThreshold", C.c_double),
+                ("allowMatchAlreadyMatchedPoints", C.c_int32),
+                ("allowMatchAlreadyMatchedGlobalPoints", C.c_int32), ("bbox_eps", C.c_double)]
+
+
+ADAPTIVE_BINS = 50
+
+
+class AdaptiveHist(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("minSq", C.c_float), ("maxSq", C.c_float),
+                ("count", C.c_uint64), ("bins", C.c_uint64 * ADAPTIVE_BINS)]
+
+
 class GNParams(C.Structure):
     _fields_ = [("maxInnerLoopIterations", C.c_uint32), ("minDelta", C.c_double),
                 ("maxCost", C.c_double), ("kernel", C.c_int32), ("kernelParam", C.c_double),
@@ -128,6 +146,14 @@ def _declare(L):
                                          C.c_size_t, _u32p, C.c_size_t, _dp, C.POINTER(Pt2PlParams),
                                          _u8p, C.c_void_p, _u32p, C.POINTER(C.c_uint64)]
     L.orc_match_pt2pl_subset.restype = C.c_size_t
+    L.orc_adaptive_ci_high.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_uint64), C.c_int, C.c_uint64,
+                                       C.c_double]
+    L.orc_adaptive_ci_high.restype = C.c_double
+    L.orc_match_adaptive.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp, C.c_size_t, _dp,
+                                     C.c_void_p, _u8p, _u8p, C.c_int, _dp, C.c_void_p, C.c_void_p,
+                                     C.POINTER(C.c_size_t), C.c_void_p, _u32p, C.POINTER(C.c_size_t),
+                                     C.POINTER(C.c_uint64)]
+    L.orc_match_adaptive.restype = C.c_int
     L.orc_match_inlier_ratio.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp, C.c_size_t,
                                          _u32p, C.c_size_t, _dp, C.c_double, C.c_int, C.c_int, C.c_double,
                                          _u8p, _u8p, C.c_void_p, C.POINTER(C.c_uint64)]
@@ -361,6 +387,50 @@ def match_inlier_ratio(gx, gy, gz, lx, ly, lz, T, inliersRatio, allowMatchAlread
     if n == C.c_size_t(-1).value:
         raise RuntimeError("ASSERT_(nTotal > 0)")
     return out[:n].copy(), pot.value
+
+
+def adaptive_ci_high(minSq, maxSq, bins, count, confidenceInterval):
+    """The restated CHistogram::getHistogramNormalized + confidenceIntervalsFromHistogram upper
+    limit (MRPT, un-vendored: parity unpinned)."""
+    b = (C.c_uint64 * len(bins))(*[int(v) for v in bins])
+    return lib().orc_adaptive_ci_high(float(minSq), float(maxSq), b, len(bins), int(count),
+                                      float(confidenceInterval))
+
+
+def match_adaptive(gx, gy, gz, lx, ly, lz, T, confidenceInterval=0.80, firstToSecondDistanceMax=1.2,
+                   absoluteMaxSearchDistance=5.0, minimumCorrDist=0.1, enableDetectPlanes=False,
+                   maxPt2PtCorrespondences=1, planeSearchPoints=8, planeMinimumFoundPoints=4,
+                   planeMinimumDistance=0.10, planeEigenThreshold=0.01,
+                   allowMatchAlreadyMatchedPoints=False, allowMatchAlreadyMatchedGlobalPoints=False,
+                   bbox_eps=0.20, tree=None, local_taken=None, global_taken=None, ci_high=None):
+    """Matcher_Adaptive::implMatchOneLayer.  ci_high=None: the restated MRPT histogram rule.
+    Returns dict(pt2pt, pt2pl, pl_local_idx, potential, ci_high, hist, no_neighbours)."""
+    gx, gy, gz, lx, ly, lz = map(_f32, (gx, gy, gz, lx, ly, lz))
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    prm = AdaptiveParams(confidenceInterval, firstToSecondDistanceMax, absoluteMaxSearchDistance,
+                         minimumCorrDist, int(enableDetectPlanes), maxPt2PtCorrespondences,
+                         planeSearchPoints, planeMinimumFoundPoints, planeMinimumDistance,
+                         planeEigenThreshold, int(allowMatchAlreadyMatchedPoints),
+                         int(allowMatchAlreadyMatchedGlobalPoints), bbox_eps)
+    o1 = np.zeros(max(1, lx.size * max(1, maxPt2PtCorrespondences)), PAIR_PT2PT)
+    o2 = np.zeros(max(1, lx.size), PAIR_PT2PL)
+    oi = np.zeros(max(1, lx.size), np.uint32)
+    n1, n2, pot = C.c_size_t(0), C.c_size_t(0), C.c_uint64(0)
+    ci = C.c_double(0.0 if ci_high is None else float(ci_high))
+    h = AdaptiveHist()
+    th = tree._h if tree is not None else None
+    lt = local_taken.ctypes.data_as(_u8p) if local_taken is not None else None
+    gt = global_taken.ctypes.data_as(_u8p) if global_taken is not None else None
+    rc = lib().orc_match_adaptive(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz), lx.size,
+                                  _d(T), C.byref(prm), lt, gt, int(ci_high is not None), C.byref(ci),
+                                  C.byref(h), o1.ctypes.data, C.byref(n1), o2.ctypes.data,
+                                  oi.ctypes.data_as(_u32p), C.byref(n2), C.byref(pot))
+    if rc < 0:
+        raise ValueError("unsupported Matcher_Adaptive parameters")
+    return dict(pt2pt=o1[:n1.value].copy(), pt2pl=o2[:n2.value].copy(), pl_local_idx=oi[:n2.value].copy(),
+                potential=pot.value, ci_high=ci.value, no_neighbours=(rc == 1),
+                hist=dict(valid=bool(h.valid), minSq=h.minSq, maxSq=h.maxSq, count=h.count,
+                          bins=np.array(list(h.bins), np.uint64)))
 
 
 def match_pt2pl(gx, gy, gz, lx, ly, lz, T, distanceThreshold, searchRadius, knn,

@@ -457,3 +457,143 @@ def test_oracle_matcher_inlier_ratio(oracle):
     lt = np.ones(300, np.uint8)
     with pytest.raises(RuntimeError):
         oracle.match_inlier_ratio(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, 0.5, tree=tree, local_taken=lt)
+
+
+def _mrpt_linspace(first, last, count):
+    """mrpt::math::linspace: incr = (last-first)/(count-1); c = first; out[i] = c; c += incr"""
+    out, c, incr = [], first, (last - first) / (count - 1)
+    for _ in range(count):
+        out.append(c)
+        c += incr
+    return np.array(out)
+
+
+def _adaptive_restated(oracle, g, l, T, tree, conf, first2, absmax, mincorr, planes, max_pt, n_search, min_found,
+                       plane_dist, eig_thr, lt, gt, allow_l, allow_g, ci_given=None):
+    """Matcher_Adaptive.cpp:84-295 in plain Python (numpy float32 / float64 scalars)"""
+    f32 = np.float32
+    tx, ty, tz, _, _ = oracle.transform_local_to_global(l[:, 0], l[:, 1], l[:, 2], T)
+    abs2 = f32(absmax * absmax)
+    nn = n_search if planes else max_pt
+    lists, mn, mx = [], None, None
+    for i in range(l.shape[0]):
+        ps = []
+        if not (not allow_l and lt is not None and lt[i]):
+            if nn == 1:
+                idx, d2 = tree.knn((tx[i], ty[i], tz[i]), 1)
+            else:
+                idx, d2 = tree.knn((tx[i], ty[i], tz[i]), nn, max_d2=float(abs2))     # d2 < r^2
+            for k in range(len(idx)):
+                e = f32(d2[k])
+                if e > abs2:
+                    continue
+                if k <= 1:
+                    mn = e if mn is None else min(mn, e)
+                    mx = e if mx is None else max(mx, e)
+                if len(ps) < 10:
+                    ps.append((int(idx[k]), e))
+        lists.append(ps)
+    if mn is None:
+        return None
+    bins = np.zeros(50, np.uint64)
+    inv = 49.0 / (float(mx) - float(mn))
+    for ps in lists:
+        for gi, e in ps[:2]:
+            bins[int(inv * (float(e) - float(mn)))] += 1
+    if ci_given is None:
+        xs = _mrpt_linspace(float(mn), float(mx), 50)
+        hc = np.cumsum(bins.astype(np.float64) * (inv / float(bins.sum())))
+        hc = hc * (1.0 / hc.max())
+        ci = xs[np.searchsorted(hc, 1.0 - (1.0 - conf), side="right")]                # std::upper_bound
+    else:
+        ci = ci_given
+    max_corr = max(mincorr * mincorr, ci)
+    m12 = f32(first2 * first2)
+    pt, pl = [], []
+    for i, ps in enumerate(lists):
+        if planes and len(ps) >= min_found:
+            q = np.array([g[gi] for gi, _ in ps], np.float32)
+            mean, cov, ev, evec = oracle.estimate_points_eigen(q[:, 0], q[:, 1], q[:, 2])
+            if ev[0] < eig_thr * ev[2] and ev[0] < eig_thr * ev[1]:
+                n = np.array(evec[0], np.float64)
+                n = n / np.linalg.norm(n)
+                d = -float(n @ mean.astype(np.float64))
+                if abs(float(n @ l[i].astype(np.float64)) + d) < plane_dist:          # UNtransformed (:113,245)
+                    pl.append(i)
+                    continue
+        for k, (gi, e) in enumerate(ps[:max_pt]):
+            if not allow_g and gt is not None and gt[gi]:
+                continue
+            if float(e) >= max_corr:
+                continue
+            if k != 0 and e > f32(ps[0][1] * m12):
+                break
+            pt.append((i, gi))
+    return pt, pl, bins, float(mn), float(mx), float(ci)
+
+
+def test_oracle_matcher_adaptive(oracle):
+    rng = np.random.default_rng(23)
+    # a slab (planes) plus clutter; the local scan lies close to it, the pose is small so that the
+    # UNtransformed local points are near the planes of the global frame
+    gp = np.column_stack([rng.uniform(-4, 4, 1500), rng.uniform(-4, 4, 1500), rng.normal(0, 0.004, 1500)])
+    g = np.vstack([gp, rng.uniform(-4, 4, (500, 3))]).astype(np.float32)
+    l = np.vstack([gp[:400] + rng.normal(0, 0.03, (400, 3)), rng.uniform(-4, 4, (100, 3))]).astype(np.float32)
+    T = oracle.pose_from_xyzypr(0.03, -0.02, 0.01, 0.01, 0.0, -0.004)
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    lt0 = (rng.random(l.shape[0]) < 0.2).astype(np.uint8)
+    gt0 = (rng.random(g.shape[0]) < 0.2).astype(np.uint8)
+    cases = [dict(planes=False, max_pt=1), dict(planes=False, max_pt=3, first2=1.5),
+             dict(planes=True, max_pt=2, n_search=8, min_found=4, first2=2.0),
+             dict(planes=True, max_pt=1, n_search=12, min_found=5, marks=True),
+             dict(planes=True, max_pt=2, n_search=6, min_found=3, marks=True, allow_l=True, allow_g=True),
+             dict(planes=False, max_pt=2, ci_given=0.02, absmax=0.8)]
+    n_planes = 0
+    for c in cases:
+        planes, max_pt = c["planes"], c["max_pt"]
+        n_search, min_found = c.get("n_search", 8), c.get("min_found", 4)
+        first2, absmax = c.get("first2", 1.2), c.get("absmax", 1.5)
+        allow_l, allow_g = c.get("allow_l", False), c.get("allow_g", False)
+        lt = lt0.copy() if c.get("marks") else None
+        gt = gt0.copy() if c.get("marks") else None
+        want = _adaptive_restated(oracle, g, l, T, tree, 0.8, first2, absmax, 0.1, planes, max_pt, n_search,
+                                  min_found, 0.10, 0.01, lt0 if lt is not None else None, gt, allow_l, allow_g,
+                                  c.get("ci_given"))
+        r = oracle.match_adaptive(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, confidenceInterval=0.8,
+                                  firstToSecondDistanceMax=first2, absoluteMaxSearchDistance=absmax,
+                                  minimumCorrDist=0.1, enableDetectPlanes=planes, maxPt2PtCorrespondences=max_pt,
+                                  planeSearchPoints=n_search, planeMinimumFoundPoints=min_found,
+                                  allowMatchAlreadyMatchedPoints=allow_l, allowMatchAlreadyMatchedGlobalPoints=allow_g,
+                                  tree=tree, local_taken=lt, global_taken=gt, ci_high=c.get("ci_given"))
+        pt, pl, bins, mn, mx, ci = want
+        assert [(int(p["localIdx"]), int(p["globalIdx"])) for p in r["pt2pt"]] == pt
+        assert r["pl_local_idx"].tolist() == pl
+        assert np.array_equal(r["hist"]["bins"], bins) and r["hist"]["count"] == bins.sum()
+        assert r["hist"]["minSq"] == np.float32(mn) and r["hist"]["maxSq"] == np.float32(mx)
+        assert r["ci_high"] == ci
+        assert r["potential"] == l.shape[0] * max_pt
+        n_planes += len(pl)
+        if lt is not None:   # local marks: planes always (:260), point pairs unless global re-use is allowed
+            marked = set(pl) | (set() if allow_g else {i for i, _ in pt})
+            assert set(np.flatnonzero(lt).tolist()) == set(np.flatnonzero(lt0).tolist()) | marked
+            assert np.array_equal(gt, gt0)                                            # global marks: read only
+        brute = oracle.match_adaptive(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, confidenceInterval=0.8,
+                                      firstToSecondDistanceMax=first2, absoluteMaxSearchDistance=absmax,
+                                      enableDetectPlanes=planes, maxPt2PtCorrespondences=max_pt,
+                                      planeSearchPoints=n_search, planeMinimumFoundPoints=min_found,
+                                      allowMatchAlreadyMatchedPoints=allow_l,
+                                      allowMatchAlreadyMatchedGlobalPoints=allow_g, tree=None,
+                                      local_taken=lt0.copy() if lt is not None else None, global_taken=gt,
+                                      ci_high=c.get("ci_given"))
+        assert np.array_equal(brute["pt2pt"], r["pt2pt"]) and np.array_equal(brute["pt2pl"], r["pt2pl"])
+    assert n_planes > 100
+    # nobody has a neighbour
+    far = oracle.match_adaptive(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T,
+                                absoluteMaxSearchDistance=1e-4, tree=tree)
+    assert far["no_neighbours"] and len(far["pt2pt"]) == 0 and not far["hist"]["valid"]
+    # the confidence limit alone
+    b = np.zeros(50, np.uint64)
+    b[[0, 1, 2, 10]] = [70, 9, 1, 20]
+    xs = _mrpt_linspace(1.0, 3.0, 50)
+    assert oracle.adaptive_ci_high(1.0, 3.0, b, 100, 0.8) == xs[10]    # 0.70, 0.79, 0.80 are not > 0.8
+    assert oracle.adaptive_ci_high(1.0, 3.0, b, 100, 0.75) == xs[1]

@@ -1,4 +1,5 @@
-"""Seeded differential fuzzing of the point matcher against the CPU oracle: random geometries
+"""Seeded differential fuzzing of the matchers (distance threshold, point-to-plane, inlier ratio,
+adaptive) against the CPU oracle: random geometries
 (clusters, exact lattices with many equal distances, collinear and coplanar sets, duplicates, large
 coordinate offsets, tiny extents), random thresholds / angular thresholds / pairingsPerPoint /
 voxel sizes / bitmap on-off / tile sizes, and pose sequences (warm start).  Lists must be bit-exact."""
@@ -125,3 +126,26 @@ def test_fuzz_pt2pl_and_inlier_ratio(oracle, seed):
     assert len(got) == len(want), (kind, n_g, n_l, ratio)
     assert np.array_equal(got["localIdx"], want["localIdx"]) and np.array_equal(got["globalIdx"], want["globalIdx"])
     assert pairs.potential_pairings == pot
+    # adaptive matcher (k-NN lists, histogram, plane / point selection)
+    A = dict(confidenceInterval=float(rng.choice([0.5, 0.8, 0.95])), firstToSecondDistanceMax=float(rng.choice([1.1, 2.0])),
+             absoluteMaxSearchDistance=float(rng.choice([0.05, 0.3])) * scale, minimumCorrDist=0.002 * scale,
+             enableDetectPlanes=bool(rng.random() < 0.6), maxPt2PtCorrespondences=int(rng.choice([1, 2, 4])),
+             planeSearchPoints=int(rng.choice([5, 8, 14])), planeMinimumFoundPoints=int(rng.choice([3, 5])),
+             planeMinimumDistance=0.05 * scale, planeEigenThreshold=float(rng.choice([0.01, 0.1])))
+    for pose in (T, amd.se3.identity()):
+        r = oracle.match_adaptive(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, tree=tree, **A)
+        m = amd.Matcher_Adaptive()
+        m.initialize(A)
+        pairs = amd.Pairings()
+        assert m.match(pcG, pcL, pose, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+        info = (kind, n_g, n_l, A)
+        assert m.last_histogram["valid"] == r["hist"]["valid"], info
+        if r["hist"]["valid"]:
+            assert m.last_histogram["bins"] == r["hist"]["bins"].tolist(), info
+            assert m.last_ci_high == r["ci_high"], info
+        got = pairs.paired_pt2pt
+        assert len(got) == len(r["pt2pt"]), info
+        assert np.array_equal(got["localIdx"], r["pt2pt"]["localIdx"]), info
+        assert np.array_equal(got["globalIdx"], r["pt2pt"]["globalIdx"]), info
+        assert np.array_equal(pairs.paired_pt2pl_local_idx, r["pl_local_idx"]), info
+        assert pairs.potential_pairings == r["potential"]

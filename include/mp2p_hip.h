@@ -394,9 +394,50 @@ void* mp2p_hip_gn_sums_ptr(mp2p_hip_ctx* ctx); /* device double[MP2P_HIP_GN_NSUM
 int   mp2p_hip_gn_step(mp2p_hip_ctx* ctx);
 int   mp2p_hip_gn_end(mp2p_hip_ctx* ctx, mp2p_hip_gn_result* out);
 
-/* ---- next #1: optimal_tf_horn (optimal_tf_horn.cpp:77-252), point pairs only ---------- */
+/* ---- next #1: optimal_tf_horn (optimal_tf_horn.cpp:77-252) with WeightParameters
+ *      (WeightParameters.h:34-72) through visit_correspondences (visit_correspondences.h:38-212)
+ *      and eval_centroids_robust (Pairings.cpp:68-110): point pairings + plane-to-plane normals
+ *      (paired_pl2pl as uploaded with mp2p_hip_pairs_upload_lines_planes), point_weights blocks,
+ *      scale outlier detector, robust kernel.  paired_ln2ln is not supported; point-to-plane /
+ *      point-to-line pairings must be converted first, as Solver_Horn does (Solver_Horn.cpp:51-55).
+ *      Where the reference throws (all weights 0, a visited pairing with weight <= 0, a robust
+ *      kernel without currentEstimateForRobust, no more point pairings than outliers) the call
+ *      fails with MP2P_HIP_ERR_INVALID. ---------------------------------------------------------- */
+typedef struct
+{
+    int32_t use_scale_outlier_detector; /* WeightParameters.h:41 */
+    double  scale_outlier_threshold;    /* 1.20 */
+    double  w_pt2pt, w_ln2ln, w_pl2pl;  /* pair_weights used by this solver */
+    int32_t robust_kernel;              /* MP2P_HIP_KERNEL_* */
+    double  robust_kernel_param;
+    int32_t has_current_estimate;
+    double  current_estimate[12]; /* currentEstimateForRobust */
+    /* Pairings::point_weights (count, weight) blocks; 0 = one block of weight 1; at most 8 */
+    uint32_t      n_weight_blocks;
+    const size_t* weight_block_count;
+    const double* weight_block_w;
+} mp2p_hip_horn_params;
+typedef struct
+{
+    double   pose[12];
+    int32_t  solved;     /* 0: fewer than 3 pairings (optimal_tf_horn.cpp:98) */
+    uint64_t n_outliers; /* OptimalTF_Result::outliers.point2point.size() */
+} mp2p_hip_horn_result;
+int mp2p_hip_horn_solve_wp(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const mp2p_hip_horn_params* wp,
+                           mp2p_hip_horn_result* out);
+/* OptimalTF_Result::outliers of the last mp2p_hip_horn_solve[_wp] on this context: one byte per
+ * point pairing (1 = discarded by the scale detector) */
+int mp2p_hip_horn_outlier_flags(mp2p_hip_ctx* ctx, uint8_t* flags_host, size_t n);
+/* default WeightParameters, point pairings only */
 int mp2p_hip_horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, double w_pt2pt,
                         double pose_out[12], int32_t* solved);
+/* pt2ln_pl_to_pt2pt (pt2ln_pl_to_pt2pt.cpp:47-113): the point-to-plane and point-to-line pairings
+ * of `in`, as (closest point on the plane / line under `guess`, local point) point pairings from
+ * the largest distance down to 25 % of it (at least 3), appended to `out` -- which must be another,
+ * cleared handle with pt2pt capacity >= the two list lengths: the reference starts from an empty
+ * Pairings, the point pairings of `in` are not carried over. */
+int mp2p_hip_pairs_pt2ln_pl_to_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* in, const double guess[12],
+                                     mp2p_hip_pairs* out);
 
 /* ---- instrumentation ------------------------------------------------------------------ */
 typedef struct

@@ -56,6 +56,20 @@ class AdaptiveHist(C.Structure):
                 ("count", C.c_uint64), ("bins", C.c_uint64 * ADAPTIVE_BINS)]
 
 
+class HornParams(C.Structure):
+    """mp2p_hip_horn_params (WeightParameters.h:34-72 + Pairings::point_weights)"""
+    _fields_ = [("use_scale_outlier_detector", C.c_int32), ("scale_outlier_threshold", C.c_double),
+                ("w_pt2pt", C.c_double), ("w_ln2ln", C.c_double), ("w_pl2pl", C.c_double),
+                ("robust_kernel", C.c_int32), ("robust_kernel_param", C.c_double),
+                ("has_current_estimate", C.c_int32), ("current_estimate", C.c_double * 12),
+                ("n_weight_blocks", C.c_uint32), ("weight_block_count", C.POINTER(C.c_size_t)),
+                ("weight_block_w", C.POINTER(C.c_double))]
+
+
+class HornResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 12), ("solved", C.c_int32), ("n_outliers", C.c_uint64)]
+
+
 class DecimateParams(C.Structure):
     _fields_ = [("voxel_filter_resolution", C.c_float), ("decimate_method", C.c_int32),
                 ("has_flatten_to", C.c_int32), ("flatten_to", C.c_float)]
@@ -201,6 +215,9 @@ SIGNATURES = {
     "mp2p_hip_gn_step": (C.c_int, [_P]),
     "mp2p_hip_gn_end": (C.c_int, [_P, C.POINTER(GNResult)]),
     "mp2p_hip_horn_solve": (C.c_int, [_P, _P, C.c_double, _dp, C.POINTER(C.c_int32)]),
+    "mp2p_hip_horn_solve_wp": (C.c_int, [_P, _P, C.POINTER(HornParams), C.POINTER(HornResult)]),
+    "mp2p_hip_horn_outlier_flags": (C.c_int, [_P, C.POINTER(C.c_uint8), C.c_size_t]),
+    "mp2p_hip_pairs_pt2ln_pl_to_pt2pt": (C.c_int, [_P, _P, _dp, _P]),
     "mp2p_hip_set_profiling": (C.c_int, [_P, C.c_int]),
     "mp2p_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
 }

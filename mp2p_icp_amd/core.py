@@ -388,6 +388,37 @@ def gn_result_to_dict(res):
                 cost=res.cost, iterations=res.iterations)
 
 
+def horn_solve_wp(ctx, pairs, prm, point_weights=None):
+    """optimal_tf_horn with WeightParameters (prm: _lib.HornParams) -> (pose, solved, n_outliers)"""
+    keep = None
+    prm.n_weight_blocks = 0
+    if point_weights:
+        cnt = (C.c_size_t * len(point_weights))(*[int(c) for c, _ in point_weights])
+        ws = (C.c_double * len(point_weights))(*[float(w) for _, w in point_weights])
+        prm.n_weight_blocks, prm.weight_block_count, prm.weight_block_w = len(point_weights), cnt, ws
+        keep = (cnt, ws)
+    res = _lib.HornResult()
+    check(ctx._L.mp2p_hip_horn_solve_wp(ctx.handle, pairs.handle, C.byref(prm), C.byref(res)), ctx.handle)
+    del keep
+    return np.array(res.pose), bool(res.solved), int(res.n_outliers)
+
+
+def horn_outlier_flags(ctx, n):
+    """one byte per point pairing of the last Horn call: 1 = scale outlier"""
+    out = np.zeros(max(1, n), np.uint8)
+    check(ctx._L.mp2p_hip_horn_outlier_flags(ctx.handle, out.ctypes.data_as(C.POINTER(C.c_uint8)), int(n)),
+          ctx.handle)
+    return out[:n]
+
+
+def pairs_pt2ln_pl_to_pt2pt(ctx, pairs_in, guess, pairs_out):
+    """pt2ln_pl_to_pt2pt.cpp:47-113: pairs_out (cleared, another handle) receives the converted list"""
+    T = _pose(guess)
+    check(ctx._L.mp2p_hip_pairs_pt2ln_pl_to_pt2pt(ctx.handle, pairs_in.handle,
+                                                  T.ctypes.data_as(C.POINTER(C.c_double)), pairs_out.handle),
+          ctx.handle)
+
+
 def horn_solve(ctx, pairs, w_pt2pt=1.0):
     T = np.zeros(12)
     ok = C.c_int32(0)

@@ -625,13 +625,61 @@ int mp2p_hip_gn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const doub
     return MP2P_HIP_OK;
 }
 
+int mp2p_hip_horn_solve_wp(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const mp2p_hip_horn_params* wp,
+                           mp2p_hip_horn_result* out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, pairs && wp && out, "null argument");
+    MP2P_REQUIRE(ctx, pairs->ctx == ctx, "bad Pairings handle");
+    MP2P_REQUIRE(ctx, wp->n_weight_blocks == 0 || (wp->weight_block_count && wp->weight_block_w),
+                 "weight blocks announced but not given");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return horn_solve(ctx, pairs, wp, out);
+}
+
 int mp2p_hip_horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, double w_pt2pt,
                         double pose_out[12], int32_t* solved)
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;
     MP2P_REQUIRE(ctx, pairs && pose_out && solved, "null argument");
+    MP2P_REQUIRE(ctx, w_pt2pt > 0.0, "pair_weights.pt2pt must be > 0");
+    mp2p_hip_horn_params wp;
+    memset(&wp, 0, sizeof(wp));
+    wp.w_pt2pt = w_pt2pt, wp.scale_outlier_threshold = 1.2, wp.robust_kernel_param = 1.0;
+    mp2p_hip_horn_result r;
+    *solved = 0;
+    unsigned long long h_counts[8];
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
-    return horn_solve(ctx, pairs, w_pt2pt, pose_out, solved);
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(h_counts, pairs->counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_counts[0] < 3) return MP2P_HIP_OK;  // optimal_tf_horn.cpp:98 (also the empty list)
+    const int rc = mp2p_hip_horn_solve_wp(ctx, pairs, &wp, &r);
+    if (rc) return rc;
+    memcpy(pose_out, r.pose, sizeof(r.pose));
+    *solved = r.solved;
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_horn_outlier_flags(mp2p_hip_ctx* ctx, uint8_t* flags_host, size_t n)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, flags_host || n == 0, "null argument");
+    MP2P_REQUIRE(ctx, n <= ctx->horn_n, "more flags requested than the last Horn call had point pairings");
+    if (!n) return MP2P_HIP_OK;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(flags_host, ctx->horn_flags.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_pt2ln_pl_to_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* in, const double guess[12],
+                                     mp2p_hip_pairs* out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, in && out && guess, "null argument");
+    MP2P_REQUIRE(ctx, in->ctx == ctx && out->ctx == ctx && in != out, "bad Pairings handles");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    return pt2ln_pl_to_pt2pt(ctx, in, guess, out);
 }
 
 // ---- covariance -----------------------------------------------------------------------------------

@@ -133,6 +133,9 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<double>             gn_state;     // pose(12) H(36) g(6) cost(1) iters(1) done(1)
     mp2p::DevBuf<unsigned char>      aos_stage;    // download staging
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
+    mp2p::DevBuf<unsigned char>      horn_flags;   // Horn: scale-outlier flag per point pairing
+    mp2p::DevBuf<unsigned long long> horn_bounds;  //   first pair of each point_weights block, [8] = error
+    size_t                           horn_n = 0;   //   pairings the flags belong to
     mp2p::DevBuf<unsigned long long> ad_hist;      // Matcher_Adaptive: 50 bins, count, {min,max} words
     uint32_t                         ad_knn   = 0;       //   lists held in nn_spos / nn_d2: neighbours per point,
     const void*                      ad_cloud = nullptr; //   and the handles they were searched for

@@ -2,7 +2,7 @@
 
   Solver / SolverContext   mp2p_icp/src/Solver.cpp:28-64, Solver.h:43-102
   Solver_GaussNewton       Solver_GaussNewton.cpp:29-67 -> optimal_tf_gauss_newton
-  Solver_Horn              Solver_Horn.cpp:33-61 -> optimal_tf_horn (point pairs only)
+  Solver_Horn              Solver_Horn.cpp:33-61 -> pt2ln_pl_to_pt2pt, optimal_tf_horn (WeightParameters)
   run_solvers              ICP.cpp:469-479
 """
 import ctypes as C
@@ -156,36 +156,116 @@ class Solver_GaussNewton(Solver):
         return True  # optimal_tf_gauss_newton always returns true (:369)
 
 
+class WeightParameters:
+    """WeightParameters.h:34-72; load_from = WeightParameters.cpp:47-55"""
+
+    def __init__(self):
+        self.use_scale_outlier_detector = False
+        self.scale_outlier_threshold = 1.20
+        self.pair_weights = PairWeights()
+        self.robust_kernel = _lib.KERNEL_NONE
+        self.currentEstimateForRobust = None
+        self.robust_kernel_param = 1.0
+
+    def load_from(self, p):
+        for k in ("use_scale_outlier_detector", "robust_kernel"):  # MCP_LOAD_REQ
+            if k not in p:
+                raise KeyError(f"Required parameter `{k}` not an existing key in dictionary.")
+        self.use_scale_outlier_detector = bool(p["use_scale_outlier_detector"])
+        self.scale_outlier_threshold = float(p.get("scale_outlier_threshold", self.scale_outlier_threshold))
+        rk = p["robust_kernel"]
+        if rk not in ROBUST_KERNELS:
+            raise ValueError(f"Unknown kernel type: {rk}")
+        self.robust_kernel = ROBUST_KERNELS[rk]
+        self.robust_kernel_param = float(p.get("robust_kernel_param", self.robust_kernel_param))
+        if "pair_weights" in p:
+            self.pair_weights.load_from(p["pair_weights"])
+
+    def to_lib(self):
+        w = _lib.HornParams()
+        w.use_scale_outlier_detector = int(self.use_scale_outlier_detector)
+        w.scale_outlier_threshold = float(self.scale_outlier_threshold)
+        w.w_pt2pt, w.w_ln2ln, w.w_pl2pl = self.pair_weights.pt2pt, self.pair_weights.ln2ln, self.pair_weights.pl2pl
+        w.robust_kernel, w.robust_kernel_param = int(self.robust_kernel), float(self.robust_kernel_param)
+        if self.currentEstimateForRobust is not None:
+            w.has_current_estimate = 1
+            w.current_estimate[:] = [float(v) for v in self.currentEstimateForRobust]
+        return w
+
+
+def optimal_tf_horn(pairings, wp, result):
+    """optimal_tf_horn.cpp:201-252 on a Pairings (point pairings in HBM, paired_pl2pl uploaded);
+    result.outliers = indices of the point pairings the scale detector discarded"""
+    ctx = pairings.ctx or core.default_context()
+    result.__init__()
+    if len(pairings.paired_ln2ln):
+        raise NotImplementedError("paired_ln2ln is not supported")
+    dev = pairings.device
+    if dev is None:
+        dev = pairings._ensure_dev(ctx, 1, 0)
+    n_pt, n_pl, _ = dev.counts()
+    if n_pl or len(pairings.paired_pt2ln):  # visit_correspondences.h:55-56
+        raise RuntimeError("This solver cannot handle point-to-plane / point-to-line pairings yet.")
+    n_pp = len(pairings.paired_pl2pl)
+    if n_pp or getattr(dev, "_has_lines_planes", False):
+        dev.upload_lines_planes(None, pairings.paired_pl2pl)
+        dev._has_lines_planes = bool(n_pp)
+    T, ok, n_out = core.horn_solve_wp(ctx, dev, wp.to_lib(), pairings.point_weights)
+    if ok:
+        result.optimalPose = T
+        if n_out:
+            result.outliers = np.flatnonzero(core.horn_outlier_flags(ctx, n_pt)).tolist()
+    return ok
+
+
+def pt2ln_pl_to_pt2pt(pairings, sc):
+    """pt2ln_pl_to_pt2pt.cpp:47-113 -> a new Pairings holding only the converted point pairings"""
+    from .matcher import Pairings
+    if sc.guessRelativePose is None:
+        raise RuntimeError("ASSERT_(sc.guessRelativePose.has_value())")
+    ctx = pairings.ctx or core.default_context()
+    dev = pairings.device
+    if dev is None:
+        dev = pairings._ensure_dev(ctx, 1, 0)
+    n_ln = len(pairings.paired_pt2ln)
+    if n_ln or getattr(dev, "_has_lines_planes", False):
+        dev.upload_lines_planes(pairings.paired_pt2ln, pairings.paired_pl2pl)
+        dev._has_lines_planes = bool(n_ln or len(pairings.paired_pl2pl))
+    n_pl = dev.counts()[1]
+    out = Pairings(ctx, max(1, n_pl + n_ln), 0)
+    odev = out._ensure_dev(ctx, max(1, n_pl + n_ln), 0)
+    core.pairs_pt2ln_pl_to_pt2pt(ctx, dev, sc.guessRelativePose, odev)
+    out._ub = [n_pl + n_ln, 0]
+    return out
+
+
 class Solver_Horn(Solver):
-    """Point pairs only, no scale outlier detector, no robust kernel (SURVEY.md 8f #1)."""
+    """Solver_Horn.cpp:33-61: WeightParameters from `pairingsWeightParameters`; point-to-plane /
+    point-to-line pairings go through pt2ln_pl_to_pt2pt first."""
 
     def __init__(self):
         super().__init__()
-        self.pairWeights = PairWeights()
+        self.pairingsWeightParameters = WeightParameters()
+
+    @property
+    def pairWeights(self):
+        return self.pairingsWeightParameters.pair_weights
 
     def initialize(self, params):
         super().initialize(params)
         params = params or {}
-        wp = params.get("pairingsWeightParameters")
-        if wp:
-            if wp.get("use_scale_outlier_detector", False):
-                raise NotImplementedError("use_scale_outlier_detector is not implemented")
-            if ROBUST_KERNELS.get(wp.get("robust_kernel", "RobustKernel::None"), 0) != 0:
-                raise NotImplementedError("robust kernel in Solver_Horn is not implemented")
-            if "pair_weights" in wp:
-                self.pairWeights.load_from(wp["pair_weights"])
+        if "pairingsWeightParameters" in params:
+            self.pairingsWeightParameters.load_from(params["pairingsWeightParameters"])
 
     def impl_optimal_pose(self, pairings, out, sc):
-        ctx = pairings.ctx or core.default_context()
-        if pairings.device is None:
+        if pairings.device is None and not len(pairings.paired_pl2pl) and not len(pairings.paired_pt2ln):
+            out.__init__()
             return False
-        if pairings.device.counts()[1] != 0:
-            raise RuntimeError("This solver cannot handle point-to-plane pairings yet.")
-        T, ok = core.horn_solve(ctx, pairings.device, self.pairWeights.pt2pt)
-        out.__init__()
-        if ok:
-            out.optimalPose = T
-        return ok
+        eff = pairings
+        n_pl = pairings.device.counts()[1] if pairings.device is not None else 0
+        if n_pl or len(pairings.paired_pt2ln):  # :51-55
+            eff = pt2ln_pl_to_pt2pt(pairings, sc)
+        return optimal_tf_horn(eff, self.pairingsWeightParameters, out)
 
 
 def run_solvers(solvers, pairings, out, sc):  # ICP.cpp:469-479

@@ -1886,36 +1886,76 @@ int orc_optimal_tf_gauss_newton_mt(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
 }
 
 /* ======================================================================================
- *  next #1: optimal_tf_horn (optimal_tf_horn.cpp:77-252), point pairs only, no scale
- *  outlier detector, no robust kernel, no per-block weights.
+ *  f1: optimal_tf_horn (optimal_tf_horn.cpp:77-252) with visit_correspondences
+ *  (visit_correspondences.h:38-212), eval_centroids_robust (Pairings.cpp:68-110) and
+ *  WeightParameters (WeightParameters.h:34-72): point pairs + plane-to-plane normals, pair
+ *  weights, point_weights blocks, scale outlier detector (two passes), robust kernel against
+ *  currentEstimateForRobust.  paired_ln2ln is not supported (no container on this path).
+ *  Returns 1 solved, 0 not enough pairings (:98), -1 a reference ASSERT would throw.
  * ====================================================================================== */
-int orc_optimal_tf_horn(const orc_pair_pt2pt* p, size_t n, double w_pt2pt, double T_out[12])
+static int horn_pass(const orc_pair_pt2pt* p, size_t nPt, const orc_pair_pl2pl* pp, size_t nPl,
+                     const orc_horn_params* w, const double cl[3], const double cg[3],
+                     uint8_t* outlier /* in/out, [nPt] */, double q_out[4])
 {
-    if (n < 3) return 0; /* :98 */
-    /* eval_centroids_robust, Pairings.cpp:68-110 */
-    double cl[3] = {0, 0, 0}, cg[3] = {0, 0, 0};
-    for (size_t i = 0; i < n; i++)
-    {
-        cg[0] += p[i].gx, cg[1] += p[i].gy, cg[2] += p[i].gz;
-        cl[0] += p[i].lx, cl[1] += p[i].ly, cl[2] += p[i].lz;
-    }
-    const double wc = 1.0 / (double)n;
-    for (int d = 0; d < 3; d++) cl[d] *= wc, cg[d] *= wc;
-
-    /* visit_correspondences.h:76-86: waPoints = wPt / (wPt * nPt2Pt) */
-    const double wa = w_pt2pt * (1.0 / (w_pt2pt * (double)n));
+    if (nPt + nPl < 3) return 0; /* :98 */
+    const double wPt = w->w_pt2pt, wLi = w->w_ln2ln, wPl = w->w_pl2pl;
+    if (!(wPt + wLi + wPl > 0.0)) return -1; /* visit_correspondences.h:79 */
+    const double k = 1.0 / (wPt * (double)nPt + wLi * 0.0 + wPl * (double)nPl); /* :81 */
+    const double waPoints = wPt * k, waPlanes = wPl * k;
+    /* point_weights blocks (:60-69); the cursor only moves on visited pairs (:113-119) */
+    size_t       blk = 0, blk_start = 0;
+    const size_t n_blk = w->n_weight_blocks;
     double       S[9] = {0}, w_sum = 0;
-    for (size_t i = 0; i < n; i++)
+    for (size_t i = 0; i < nPt + nPl; i++)
     {
-        const double bi[3] = {p[i].gx - cg[0], p[i].gy - cg[1], p[i].gz - cg[2]};
-        const double ri[3] = {p[i].lx - cl[0], p[i].ly - cl[1], p[i].lz - cl[2]};
-        const double bn = sqrt(bi[0] * bi[0] + bi[1] * bi[1] + bi[2] * bi[2]);
-        const double rn = sqrt(ri[0] * ri[0] + ri[1] * ri[1] + ri[2] * ri[2]);
-        if (bn < 1e-4 || rn < 1e-4) continue; /* visit_correspondences.h:135-140 */
-        const double wi = wa;
+        if (i < nPt && outlier[i]) continue; /* :97-103 (stays an outlier) */
+        double bi[3], ri[3], wi;
+        if (i < nPt)
+        {
+            wi = waPoints;
+            if (n_blk)
+            {
+                if (i >= blk_start + w->weight_block_count[blk])
+                {
+                    if (blk + 1 >= n_blk) return -1; /* ASSERT_(cur != end) then dereference */
+                    blk++, blk_start = i;
+                }
+                wi *= w->weight_block_w[blk];
+            }
+            bi[0] = p[i].gx - cg[0], bi[1] = p[i].gy - cg[1], bi[2] = p[i].gz - cg[2];
+            ri[0] = p[i].lx - cl[0], ri[1] = p[i].ly - cl[1], ri[2] = p[i].lz - cl[2];
+            const double bn = sqrt(bi[0] * bi[0] + bi[1] * bi[1] + bi[2] * bi[2]);
+            const double rn = sqrt(ri[0] * ri[0] + ri[1] * ri[1] + ri[2] * ri[2]);
+            if (bn < 1e-4 || rn < 1e-4) continue; /* :135-140 */
+            if (w->use_scale_outlier_detector)    /* :153-164 */
+            {
+                const double mism = (bn > rn ? bn : rn) / (bn < rn ? bn : rn);
+                if (mism > w->scale_outlier_threshold)
+                {
+                    outlier[i] = 1;
+                    continue;
+                }
+            }
+        }
+        else
+        { /* :181-192 getNormalVector(): the coefficients as stored */
+            const orc_pair_pl2pl* q = &pp[i - nPt];
+            wi = waPlanes;
+            for (int d = 0; d < 3; d++) bi[d] = q->pl_global[d], ri[d] = q->pl_local[d];
+        }
+        if (w->robust_kernel != ORC_KERNEL_NONE) /* :194-205 */
+        {
+            if (!w->has_current_estimate) return -1;
+            double r2[3];
+            orc_pose_compose_point(w->current_estimate, ri[0], ri[1], ri[2], r2);
+            const double e2 = (r2[0] - bi[0]) * (r2[0] - bi[0]) + (r2[1] - bi[1]) * (r2[1] - bi[1]) +
+                              (r2[2] - bi[2]) * (r2[2] - bi[2]);
+            wi *= orc_robust_weight(w->robust_kernel, w->robust_kernel_param, e2);
+        }
+        if (!(wi > 0.0)) return -1; /* :207 */
         w_sum += wi;
         for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) S[a * 3 + b] += wi * ri[a] * bi[b]; /* :112-122 */
+            for (int b = 0; b < 3; b++) S[a * 3 + b] += wi * ri[a] * bi[b]; /* optimal_tf_horn.cpp:112-122 */
     }
     if (w_sum > 0)
         for (int i = 0; i < 9; i++) S[i] *= 1.0 / w_sum; /* :128 */
@@ -1941,17 +1981,145 @@ int orc_optimal_tf_horn(const orc_pair_pt2pt* p, size_t n, double w_pt2pt, doubl
     double q[4] = {V[12], V[13], V[14], V[15]}; /* largest eigenvalue :160 */
     if (q[0] < 0)
         for (int i = 0; i < 4; i++) q[i] = -q[i]; /* :165-171 */
-    const double qn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    for (int i = 0; i < 4; i++) q[i] /= qn;
-    const double r = q[0], x = q[1], y = q[2], z = q[3];
-    double       T[12];
-    T[0] = r * r + x * x - y * y - z * z, T[1] = 2 * (x * y - r * z), T[2] = 2 * (z * x + r * y);
-    T[3] = 2 * (x * y + r * z), T[4] = r * r - x * x + y * y - z * z, T[5] = 2 * (y * z - r * x);
-    T[6] = 2 * (z * x - r * y), T[7] = 2 * (y * z + r * x), T[8] = r * r - x * x - y * y + z * z;
-    T[9] = T[10] = T[11] = 0;
-    double pp[3];
-    orc_pose_compose_point(T, cl[0], cl[1], cl[2], pp); /* :241-242 */
-    T[9] = cg[0] - pp[0], T[10] = cg[1] - pp[1], T[11] = cg[2] - pp[2]; /* :245-247 */
-    memcpy(T_out, T, sizeof(T));
+    memcpy(q_out, q, sizeof(q));
     return 1;
+}
+
+/* eval_centroids_robust (Pairings.cpp:68-110); returns 0 for ASSERT_GT_(nPt2Pt, outliers) */
+static int horn_centroids(const orc_pair_pt2pt* p, size_t n, const uint8_t* outlier, double cl[3],
+                          double cg[3])
+{
+    size_t n_out = 0;
+    for (size_t i = 0; i < n; i++) n_out += outlier[i] ? 1 : 0;
+    if (!(n > n_out)) return 0;
+    const double wc = 1.0 / (double)(n - n_out);
+    for (int d = 0; d < 3; d++) cl[d] = cg[d] = 0;
+    for (size_t i = 0; i < n; i++)
+    {
+        if (outlier[i]) continue;
+        cg[0] += p[i].gx, cg[1] += p[i].gy, cg[2] += p[i].gz;
+        cl[0] += p[i].lx, cl[1] += p[i].ly, cl[2] += p[i].lz;
+    }
+    for (int d = 0; d < 3; d++) cl[d] *= wc, cg[d] *= wc;
+    return 1;
+}
+
+int orc_optimal_tf_horn_wp(const orc_pair_pt2pt* p, size_t n, const orc_pair_pl2pl* pp, size_t n_pl,
+                           const orc_horn_params* w, double T_out[12], uint8_t* outlier_out)
+{
+    if (w->w_pt2pt < 0 || w->w_ln2ln < 0 || w->w_pl2pl < 0) return -1; /* :207-209 */
+    uint8_t* outlier = (uint8_t*)calloc(n ? n : 1, 1);
+    double   cl[3], cg[3], q[4];
+    int      rc = horn_centroids(p, n, outlier, cl, cg) ? 1 : -1; /* :212 */
+    if (rc == 1) rc = horn_pass(p, n, pp, n_pl, w, cl, cg, outlier, q); /* :217 */
+    size_t n_out = 0;
+    for (size_t i = 0; i < n; i++) n_out += outlier[i];
+    if (rc == 1 && w->use_scale_outlier_detector && n_out) /* :224-236 */
+    {
+        rc = horn_centroids(p, n, outlier, cl, cg) ? 1 : -1;
+        if (rc == 1) rc = horn_pass(p, n, pp, n_pl, w, cl, cg, outlier, q);
+    }
+    if (rc == 1)
+    {
+        const double qn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (int i = 0; i < 4; i++) q[i] /= qn;
+        const double r = q[0], x = q[1], y = q[2], z = q[3];
+        double       T[12];
+        T[0] = r * r + x * x - y * y - z * z, T[1] = 2 * (x * y - r * z), T[2] = 2 * (z * x + r * y);
+        T[3] = 2 * (x * y + r * z), T[4] = r * r - x * x + y * y - z * z, T[5] = 2 * (y * z - r * x);
+        T[6] = 2 * (z * x - r * y), T[7] = 2 * (y * z + r * x), T[8] = r * r - x * x - y * y + z * z;
+        T[9] = T[10] = T[11] = 0;
+        double t[3];
+        orc_pose_compose_point(T, cl[0], cl[1], cl[2], t);              /* :241-242 */
+        T[9] = cg[0] - t[0], T[10] = cg[1] - t[1], T[11] = cg[2] - t[2]; /* :245-247 */
+        memcpy(T_out, T, sizeof(T));
+    }
+    if (outlier_out) memcpy(outlier_out, outlier, n);
+    free(outlier);
+    return rc;
+}
+
+int orc_optimal_tf_horn(const orc_pair_pt2pt* p, size_t n, double w_pt2pt, double T_out[12])
+{
+    orc_horn_params w;
+    memset(&w, 0, sizeof(w));
+    w.w_pt2pt = w_pt2pt, w.scale_outlier_threshold = 1.2, w.robust_kernel_param = 1.0;
+    const int rc = orc_optimal_tf_horn_wp(p, n, NULL, 0, &w, T_out, NULL);
+    return rc == 1;
+}
+
+/* ======================================================================================
+ *  pt2ln_pl_to_pt2pt (pt2ln_pl_to_pt2pt.cpp:47-113), what Solver_Horn feeds optimal_tf_horn when
+ *  the pairings hold point-to-plane / point-to-line entries (Solver_Horn.cpp:51-55): every such
+ *  pairing becomes (closest point on the plane / line, local point); they are taken from the
+ *  largest distance down to 25 % of the largest (at least 3 in total); the input's own
+ *  paired_pt2pt are NOT carried over (out starts empty, :49).  std::multimap::insert keeps equal
+ *  keys in insertion order; the walk is in reverse.  Returns the number of pairs written.
+ * ====================================================================================== */
+typedef struct
+{
+    double         key;
+    uint32_t       seq;
+    orc_pair_pt2pt p;
+} cv_item;
+static int cv_cmp(const void* a, const void* b)
+{
+    const cv_item* x = (const cv_item*)a;
+    const cv_item* y = (const cv_item*)b;
+    if (x->key != y->key) return x->key > y->key ? -1 : 1; /* descending */
+    return x->seq > y->seq ? -1 : (x->seq < y->seq ? 1 : 0); /* later insertion first */
+}
+static size_t cv_append(cv_item* it, size_t n, orc_pair_pt2pt* out, size_t n_out)
+{
+    if (!n) return n_out; /* :33 */
+    qsort(it, n, sizeof(cv_item), cv_cmp);
+    const double thr = it[0].key * 0.25; /* :35-36 */
+    for (size_t k = 0; k < n; k++)
+    {
+        if (it[k].key < thr && n_out >= 3) break; /* :42 */
+        out[n_out++] = it[k].p;
+    }
+    return n_out;
+}
+size_t orc_pt2ln_pl_to_pt2pt(const orc_pair_pt2pl* pl, size_t n_pl, const orc_pair_pt2ln* ln,
+                             size_t n_ln, const double T[12], orc_pair_pt2pt* out)
+{
+    const size_t m  = n_pl > n_ln ? n_pl : n_ln;
+    cv_item*     it = (cv_item*)malloc((m + 1) * sizeof(cv_item));
+    size_t       n_out = 0;
+    for (size_t i = 0; i < n_pl; i++) /* :59-84 */
+    {
+        double g[3];
+        orc_pose_compose_point(T, (double)pl[i].lx, (double)pl[i].ly, (double)pl[i].lz, g);
+        const double* c = pl[i].plane;
+        const double  d = c[0] * g[0] + c[1] * g[1] + c[2] * g[2] + c[3]; /* evaluatePoint */
+        it[i].key = fabs(d), it[i].seq = (uint32_t)i;
+        orc_pair_pt2pt* q = &it[i].p;
+        q->globalIdx = q->localIdx = 0;
+        q->gx = (float)(g[0] - c[0] * d), q->gy = (float)(g[1] - c[1] * d), q->gz = (float)(g[2] - c[2] * d);
+        q->lx = pl[i].lx, q->ly = pl[i].ly, q->lz = pl[i].lz;
+        q->errSq = 0; /* TMatchingPair default */
+    }
+    n_out = cv_append(it, n_pl, out, n_out);
+    for (size_t i = 0; i < n_ln; i++) /* :92-109 */
+    {
+        double g[3];
+        orc_pose_compose_point(T, ln[i].lx, ln[i].ly, ln[i].lz, g);
+        /* TLine3D::closestPointTo: pBase + director * ((p - pBase).director / |director|^2) */
+        const double* b = ln[i].pbase;
+        const double* u = ln[i].director;
+        const double  t = ((g[0] - b[0]) * u[0] + (g[1] - b[1]) * u[1] + (g[2] - b[2]) * u[2]) /
+                         (u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        const double c[3] = {b[0] + t * u[0], b[1] + t * u[1], b[2] + t * u[2]};
+        const double e[3] = {c[0] - g[0], c[1] - g[1], c[2] - g[2]};
+        it[i].key = fabs(sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2])), it[i].seq = (uint32_t)i;
+        orc_pair_pt2pt* q = &it[i].p;
+        q->globalIdx = q->localIdx = 0;
+        q->gx = (float)c[0], q->gy = (float)c[1], q->gz = (float)c[2];
+        q->lx = (float)ln[i].lx, q->ly = (float)ln[i].ly, q->lz = (float)ln[i].lz;
+        q->errSq = 0;
+    }
+    n_out = cv_append(it, n_ln, out, n_out);
+    free(it);
+    return n_out;
 }

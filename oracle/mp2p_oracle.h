@@ -285,8 +285,32 @@ int orc_optimal_tf_gauss_newton_mt(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
                                    const double T0[12], const orc_gn_params* prm,
                                    double T_out[12], int n_threads);
 
-/* ---- next #1: Horn closed form (optimal_tf_horn.cpp:77-252, no scale, no outlier det.) */
+/* ---- f1: Horn closed form (optimal_tf_horn.cpp:77-252 + visit_correspondences.h:38-212 +
+ *      Pairings.cpp:68-110).  Returns 1 solved, 0 fewer than 3 pairings, -1 where the reference
+ *      throws (all weights 0, a weight <= 0 on a visited pair, robust kernel without
+ *      currentEstimateForRobust, no more points than outliers, weight blocks exhausted). ---- */
+typedef struct
+{
+    int32_t use_scale_outlier_detector; /* WeightParameters.h:41 */
+    double  scale_outlier_threshold;    /* 1.20 */
+    double  w_pt2pt, w_ln2ln, w_pl2pl;  /* PairWeights used by Horn */
+    int32_t robust_kernel;              /* ORC_KERNEL_* */
+    double  robust_kernel_param;
+    int32_t has_current_estimate;
+    double  current_estimate[12]; /* currentEstimateForRobust */
+    /* Pairings::point_weights blocks; 0 -> one block of weight 1 */
+    uint32_t      n_weight_blocks;
+    const size_t* weight_block_count;
+    const double* weight_block_w;
+} orc_horn_params;
+int orc_optimal_tf_horn_wp(const orc_pair_pt2pt* pt2pt, size_t n, const orc_pair_pl2pl* pl2pl,
+                           size_t n_pl2pl, const orc_horn_params* wp, double T_out[12],
+                           uint8_t* outlier_flags /* [n] or NULL */);
+/* point pairs, default WeightParameters; returns 1/0 */
 int orc_optimal_tf_horn(const orc_pair_pt2pt* pt2pt, size_t n, double w_pt2pt, double T_out[12]);
+/* pt2ln_pl_to_pt2pt (pt2ln_pl_to_pt2pt.cpp:47-113); capacity of out >= n_pl + n_ln */
+size_t orc_pt2ln_pl_to_pt2pt(const orc_pair_pt2pl* pl, size_t n_pl, const orc_pair_pt2ln* ln,
+                             size_t n_ln, const double T[12], orc_pair_pt2pt* out);
 
 const char* orc_version(void);
 

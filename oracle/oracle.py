@@ -62,6 +62,15 @@ class AdaptiveHist(C.Structure):
                 ("count", C.c_uint64), ("bins", C.c_uint64 * ADAPTIVE_BINS)]
 
 
+class HornParams(C.Structure):
+    _fields_ = [("use_scale_outlier_detector", C.c_int32), ("scale_outlier_threshold", C.c_double),
+                ("w_pt2pt", C.c_double), ("w_ln2ln", C.c_double), ("w_pl2pl", C.c_double),
+                ("robust_kernel", C.c_int32), ("robust_kernel_param", C.c_double),
+                ("has_current_estimate", C.c_int32), ("current_estimate", C.c_double * 12),
+                ("n_weight_blocks", C.c_uint32), ("weight_block_count", C.POINTER(C.c_size_t)),
+                ("weight_block_w", C.POINTER(C.c_double))]
+
+
 class GNParams(C.Structure):
     _fields_ = [("maxInnerLoopIterations", C.c_uint32), ("minDelta", C.c_double),
                 ("maxCost", C.c_double), ("kernel", C.c_int32), ("kernelParam", C.c_double),
@@ -174,6 +183,10 @@ def _declare(L):
     L.orc_optimal_tf_gauss_newton_mt.restype = C.c_int
     L.orc_optimal_tf_horn.argtypes = [C.c_void_p, C.c_size_t, C.c_double, _dp]
     L.orc_optimal_tf_horn.restype = C.c_int
+    L.orc_optimal_tf_horn_wp.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, _dp, _u8p]
+    L.orc_optimal_tf_horn_wp.restype = C.c_int
+    L.orc_pt2ln_pl_to_pt2pt.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _dp, C.c_void_p]
+    L.orc_pt2ln_pl_to_pt2pt.restype = C.c_size_t
 
 
 # ------------------------------------------------------------------------------------------
@@ -543,6 +556,45 @@ def optimal_tf_gauss_newton(pt2pt, pt2pl, pt2ln, T0, prm, threads=0, pl2pl=None)
                                            pl2pl.ctypes.data, pl2pl.size, _d(T0),
                                            C.byref(prm), _d(T), _d(H), _d(g))
     return T, it, H.reshape(6, 6), g
+
+
+def optimal_tf_horn_wp(pt2pt, pl2pl=None, use_scale_outlier_detector=False, scale_outlier_threshold=1.2,
+                       w_pt2pt=1.0, w_ln2ln=1.0, w_pl2pl=1.0, robust_kernel=KERNEL_NONE,
+                       robust_kernel_param=1.0, current_estimate=None, point_weights=None):
+    """optimal_tf_horn with WeightParameters.  Returns (T, rc, outlier_flags): rc 1 solved, 0 fewer
+    than 3 pairings, -1 where the reference throws."""
+    pt2pt = np.ascontiguousarray(pt2pt if pt2pt is not None else np.zeros(0, PAIR_PT2PT))
+    pl2pl = np.ascontiguousarray(pl2pl if pl2pl is not None else np.zeros(0, PAIR_PL2PL))
+    w = HornParams()
+    w.use_scale_outlier_detector, w.scale_outlier_threshold = int(use_scale_outlier_detector), scale_outlier_threshold
+    w.w_pt2pt, w.w_ln2ln, w.w_pl2pl = w_pt2pt, w_ln2ln, w_pl2pl
+    w.robust_kernel, w.robust_kernel_param = int(robust_kernel), robust_kernel_param
+    if current_estimate is not None:
+        w.has_current_estimate = 1
+        w.current_estimate[:] = [float(v) for v in current_estimate]
+    keep = None
+    if point_weights:
+        cnt = (C.c_size_t * len(point_weights))(*[int(c) for c, _ in point_weights])
+        ws = (C.c_double * len(point_weights))(*[float(v) for _, v in point_weights])
+        w.n_weight_blocks, w.weight_block_count, w.weight_block_w = len(point_weights), cnt, ws
+        keep = (cnt, ws)
+    T = np.zeros(12)
+    flags = np.zeros(max(1, pt2pt.size), np.uint8)
+    rc = lib().orc_optimal_tf_horn_wp(pt2pt.ctypes.data, pt2pt.size, pl2pl.ctypes.data, pl2pl.size,
+                                      C.byref(w), _d(T), flags.ctypes.data_as(_u8p))
+    del keep
+    return T, rc, flags[:pt2pt.size]
+
+
+def pt2ln_pl_to_pt2pt(pt2pl, pt2ln, T):
+    """pt2ln_pl_to_pt2pt.cpp:47-113 -> the paired_pt2pt list Solver_Horn then solves on"""
+    pt2pl = np.ascontiguousarray(pt2pl if pt2pl is not None else np.zeros(0, PAIR_PT2PL))
+    pt2ln = np.ascontiguousarray(pt2ln if pt2ln is not None else np.zeros(0, PAIR_PT2LN))
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    out = np.zeros(max(1, pt2pl.size + pt2ln.size), PAIR_PT2PT)
+    n = lib().orc_pt2ln_pl_to_pt2pt(pt2pl.ctypes.data, pt2pl.size, pt2ln.ctypes.data, pt2ln.size, _d(T),
+                                    out.ctypes.data)
+    return out[:n].copy()
 
 
 def optimal_tf_horn(pt2pt, w_pt2pt=1.0):

@@ -40,13 +40,13 @@ def test_struct_layouts_match_header():
     src = r'''
 #include <stdio.h>
 #include "mp2p_hip.h"
-int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mp2p_hip_map_params),
+int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mp2p_hip_map_params),
  sizeof(mp2p_hip_map_info), sizeof(mp2p_hip_pt2pt_params), sizeof(mp2p_hip_pt2pl_params),
  sizeof(mp2p_hip_gn_params), sizeof(mp2p_hip_gn_result), sizeof(mp2p_hip_stats),
  sizeof(mp2p_hip_pair_pt2pl), sizeof(mp2p_hip_pair_pt2pt), sizeof(mp2p_hip_pair_pt2ln),
  sizeof(mp2p_hip_pair_pl2pl), sizeof(mp2p_hip_inlier_ratio_params),
  sizeof(mp2p_hip_decimate_params), sizeof(mp2p_hip_adaptive_params),
- sizeof(mp2p_hip_adaptive_hist)); return 0;}'''
+ sizeof(mp2p_hip_adaptive_hist), sizeof(mp2p_hip_horn_params), sizeof(mp2p_hip_horn_result)); return 0;}'''
     d = os.path.join(ROOT, "tests", "_tmp_abi")
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "s.c"), "w") as f:
@@ -57,7 +57,8 @@ int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n
     want = [C.sizeof(_lib.MapParams), C.sizeof(_lib.MapInfo), C.sizeof(_lib.Pt2PtParams),
             C.sizeof(_lib.Pt2PlParams), C.sizeof(_lib.GNParams), C.sizeof(_lib.GNResult),
             C.sizeof(_lib.Stats), 72, 36, 72, 112, C.sizeof(_lib.InlierRatioParams),
-            C.sizeof(_lib.DecimateParams), C.sizeof(_lib.AdaptiveParams), C.sizeof(_lib.AdaptiveHist)]
+            C.sizeof(_lib.DecimateParams), C.sizeof(_lib.AdaptiveParams), C.sizeof(_lib.AdaptiveHist),
+            C.sizeof(_lib.HornParams), C.sizeof(_lib.HornResult)]
     assert _lib.PAIR_PT2PT.itemsize == 36 and _lib.PAIR_PT2PL.itemsize == 72
     assert _lib.PAIR_PT2LN.itemsize == 72 and _lib.PAIR_PL2PL.itemsize == 112
     assert got == want

@@ -84,6 +84,58 @@ def test_icp_iterations_track_the_oracle(oracle):
         assert dt < 1e-5 and dr < 1e-5, (it, dt, dr)
 
 
+@pytest.mark.parametrize("planes", [False, True])
+def test_kitti_shaped_pipeline_tracks_the_oracle(oracle, planes):
+    """demos/icp-settings-kitti.yaml: Matcher_Points_DistanceThreshold (2.0 m) for the first
+    iterations, Matcher_Adaptive (0.75 / 1.2 / 2.0 m) afterwards, Gauss-Newton 3 x GemanMcClure 0.15;
+    with plane detection the solver gets point and plane pairings.  Same lists and poses as the
+    oracle loop at every iteration."""
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import synthetic
+    d = synthetic.make_pair(6000, 60000, 77, max_t=0.15, max_r_deg=0.5)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g)})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    m1 = amd.Matcher_Points_DistanceThreshold()
+    m1.initialize({"threshold": 2.0, "thresholdAngularDeg": 0.0, "runFromIteration": 0, "runUpToIteration": 2})
+    A = dict(confidenceInterval=0.75, firstToSecondDistanceMax=1.2, absoluteMaxSearchDistance=2.0,
+             enableDetectPlanes=planes, planeSearchPoints=8, planeMinimumFoundPoints=4, planeMinimumDistance=0.3)
+    m2 = amd.Matcher_Adaptive()
+    m2.initialize(dict(A, runFromIteration=3, runUpToIteration=0))
+    s = amd.Solver_GaussNewton()
+    s.initialize({"maxIterations": 3, "robustKernel": "RobustKernel::GemanMcClure", "robustKernelParam": 0.15})
+    prm = oracle.make_gn_params(3, kernel=oracle.KERNEL_GEMANMCCLURE, kernelParam=0.15)
+    pose_h, pose_o = d["T_init"].copy(), d["T_init"].copy()
+    n_pl = 0
+    for it in range(7):
+        pairs = amd.run_matchers([m1, m2], pcG, pcL, pose_h, amd.MatchContext(it))
+        if it <= 2:
+            want, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose_o, 2.0, 0.0, tree=tree)
+            want_pl = None
+        else:
+            r = oracle.match_adaptive(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose_o, tree=tree, **A)
+            want, want_pl = r["pt2pt"], r["pt2pl"]
+            assert np.array_equal(pairs.paired_pt2pl_local_idx, r["pl_local_idx"]), it
+            assert m2.last_ci_high == r["ci_high"], it
+            n_pl += len(want_pl)
+        got = pairs.paired_pt2pt
+        assert np.array_equal(got["localIdx"], want["localIdx"]), it
+        assert np.array_equal(got["globalIdx"], want["globalIdx"]), it
+        sc = amd.SolverContext()
+        sc.guessRelativePose = pose_h
+        sc.icpIteration = it
+        out = amd.OptimalTF_Result()
+        assert s.optimal_pose(pairs, out, sc)
+        pose_h = out.optimalPose
+        pose_o, *_ = oracle.optimal_tf_gauss_newton(want, want_pl, None, pose_o, prm)
+        dt, dr = oracle.pose_err_split(pose_h, pose_o)
+        assert dt < 1e-5 and dr < 1e-5, (it, dt, dr)
+    assert (n_pl > 500) == planes
+    dt, dr = oracle.pose_err_split(pose_h, d["T_gt"])
+    assert dt < 0.1 and dr < 0.01, (dt, dr)
+
+
 def test_quality_and_covariance_of_align(oracle):
     """ICP.cpp:316-337: Results::quality from QualityEvaluator_PairedRatio (both modes) and the
     covariance of the final pairings; a quality checkpoint aborts a hopeless registration."""

@@ -597,3 +597,146 @@ def test_oracle_matcher_adaptive(oracle):
     xs = _mrpt_linspace(1.0, 3.0, 50)
     assert oracle.adaptive_ci_high(1.0, 3.0, b, 100, 0.8) == xs[10]    # 0.70, 0.79, 0.80 are not > 0.8
     assert oracle.adaptive_ci_high(1.0, 3.0, b, 100, 0.75) == xs[1]
+
+
+# ------------------------------------------------------------------------------------------
+# optimal_tf_horn with WeightParameters, shaped after tests/test-mp2p_optimal_tf_algos.cpp:
+# points + plane pairs under a ground-truth pose, noise, outliers, robust kernel at the
+# ground truth (:343-348), scale outlier detector
+# ------------------------------------------------------------------------------------------
+def horn_scene(oracle, seed, n_pt=400, n_pl=30, noise=0.0, outliers=0):
+    rng = np.random.default_rng(seed)
+    gt = oracle.pose_from_xyzypr(*rng.uniform(-2, 2, 3), *np.radians(rng.uniform(-25, 25, 3)))
+    R, t = gt[:9].reshape(3, 3), gt[9:]
+    l = rng.uniform(-10, 10, (n_pt, 3))
+    gl = l @ R.T + t + rng.normal(0, noise, (n_pt, 3))
+    if outliers:
+        gl[:outliers] = rng.uniform(-10, 10, (outliers, 3))
+    pt = np.zeros(n_pt, oracle.PAIR_PT2PT)
+    pt["lx"], pt["ly"], pt["lz"] = l.astype(np.float32).T
+    pt["gx"], pt["gy"], pt["gz"] = gl.astype(np.float32).T
+    pt["localIdx"] = np.arange(n_pt)
+    nl = rng.normal(size=(n_pl, 3))
+    nl /= np.linalg.norm(nl, axis=1, keepdims=True)
+    ng = nl @ R.T + rng.normal(0, noise * 0.1, (n_pl, 3))
+    ng /= np.linalg.norm(ng, axis=1, keepdims=True)
+    pl = np.zeros(n_pl, oracle.PAIR_PL2PL)
+    pl["pl_local"][:, :3], pl["pl_global"][:, :3] = nl, ng
+    pl["pl_local"][:, 3], pl["pl_global"][:, 3] = rng.normal(size=n_pl), rng.normal(size=n_pl)
+    return gt, pt, pl
+
+
+def _horn_numpy(pt, pl, w_pt, w_pl, flags, blocks=None, robust=None):
+    """S of visit_correspondences by vectorised numpy, rotation by SVD (Kabsch) instead of the
+    quaternion eigenproblem: the same optimum by a different route"""
+    keep = flags == 0
+    L = np.stack([pt["lx"], pt["ly"], pt["lz"]], 1).astype(np.float64)
+    G = np.stack([pt["gx"], pt["gy"], pt["gz"]], 1).astype(np.float64)
+    cl, cg = L[keep].mean(0), G[keep].mean(0)
+    k = 1.0 / (w_pt * len(pt) + w_pl * len(pl))
+    wi = np.full(len(pt), w_pt * k)
+    if blocks:
+        wi *= np.repeat([w for _, w in blocks], [c for c, _ in blocks])[:len(pt)]
+    ri, bi = L - cl, G - cg
+    ok = keep & (np.linalg.norm(ri, axis=1) >= 1e-4) & (np.linalg.norm(bi, axis=1) >= 1e-4)
+    ri = np.vstack([ri[ok], pl["pl_local"][:, :3]])
+    bi = np.vstack([bi[ok], pl["pl_global"][:, :3]])
+    w = np.concatenate([wi[ok], np.full(len(pl), w_pl * k)])
+    if robust is not None:
+        kind, c, Tc = robust
+        r2 = ri @ Tc[:9].reshape(3, 3).T + Tc[9:]
+        e2 = ((r2 - bi) ** 2).sum(1)
+        w = w * (c * c / (e2 + c) ** 2 if kind == 1 else c * c / (e2 + c * c))
+    S = (w[:, None, None] * ri[:, :, None] * bi[:, None, :]).sum(0) / w.sum()
+    U, _, Vt = np.linalg.svd(S.T)                   # maximise trace(R S)
+    D = np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))])
+    R = U @ D @ Vt
+    return R, cg - R @ cl
+
+
+def test_horn_weight_parameters(oracle):
+    # noiseless points + planes: exact recovery, whatever the weights
+    gt, pt, pl = horn_scene(oracle, 1)
+    for wpt, wpl in ((1.0, 1.0), (0.2, 5.0), (1.0, 0.0)):
+        T, rc, fl = oracle.optimal_tf_horn_wp(pt, pl if wpl > 0 else None, w_pt2pt=wpt, w_pl2pl=wpl)
+        assert rc == 1 and not fl.any() and oracle.pose_err(T, gt) < 1e-5
+    # noise: the numpy route gives the same pose
+    gt, pt, pl = horn_scene(oracle, 2, noise=0.05)
+    blocks = [(150, 0.5), (250, 2.0)]
+    for kw, nkw in ((dict(), dict()), (dict(point_weights=blocks), dict(blocks=blocks)),
+                    (dict(robust_kernel=oracle.KERNEL_GEMANMCCLURE, robust_kernel_param=1.0, current_estimate=gt),
+                     dict(robust=(1, 1.0, gt))),
+                    (dict(robust_kernel=oracle.KERNEL_CAUCHY, robust_kernel_param=0.7, current_estimate=gt),
+                     dict(robust=(2, 0.7, gt)))):
+        T, rc, fl = oracle.optimal_tf_horn_wp(pt, pl, w_pt2pt=1.0, w_pl2pl=3.0, **kw)
+        R, t = _horn_numpy(pt, pl, 1.0, 3.0, fl, **nkw)
+        assert rc == 1 and np.allclose(T[:9].reshape(3, 3), R, atol=1e-9) and np.allclose(T[9:], t, atol=1e-8)
+        assert oracle.pose_err(T, gt) < 0.02
+    # outliers: the scale detector flags them (two passes), the pose improves
+    gt, pt, pl = horn_scene(oracle, 3, noise=0.01, outliers=60)
+    T0, rc0, fl0 = oracle.optimal_tf_horn_wp(pt, None)
+    T1, rc1, fl1 = oracle.optimal_tf_horn_wp(pt, None, use_scale_outlier_detector=True, scale_outlier_threshold=1.2)
+    assert rc0 == 1 and rc1 == 1 and not fl0.any()
+    assert fl1[:60].sum() > 40 and fl1[60:].sum() < 40
+    assert oracle.pose_err(T1, gt) < oracle.pose_err(T0, gt)
+    # where the reference throws
+    assert oracle.optimal_tf_horn_wp(pt[:2], None)[1] == 0                       # < 3 pairings
+    assert oracle.optimal_tf_horn_wp(None, pl)[1] == -1                           # no points: centroids assert
+    assert oracle.optimal_tf_horn_wp(pt, pl, w_pl2pl=0.0)[1] == -1                # ASSERT_(wi > 0) on a plane
+    assert oracle.optimal_tf_horn_wp(pt, None, robust_kernel=oracle.KERNEL_CAUCHY)[1] == -1   # no estimate
+    assert oracle.optimal_tf_horn_wp(pt, None, w_pt2pt=0.0, w_ln2ln=0.0, w_pl2pl=0.0)[1] == -1
+    assert oracle.optimal_tf_horn_wp(pt, None, point_weights=[(10, 1.0)])[1] == -1              # blocks exhausted
+
+
+def test_pt2ln_pl_to_pt2pt(oracle):
+    """pt2ln_pl_to_pt2pt.cpp:47-113 against a direct Python restatement"""
+    rng = np.random.default_rng(8)
+    T = oracle.pose_from_xyzypr(0.3, -0.2, 0.1, 0.05, -0.02, 0.03)
+    R, t = T[:9].reshape(3, 3), T[9:]
+    n_pl, n_ln = 60, 25
+    pl = np.zeros(n_pl, oracle.PAIR_PT2PL)
+    nrm = rng.normal(size=(n_pl, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    pl["plane"][:, :3], pl["plane"][:, 3] = nrm, rng.normal(0, 0.5, n_pl)
+    lp = rng.uniform(-3, 3, (n_pl, 3)).astype(np.float32)
+    lp[10:14] = lp[0]                                       # equal keys: multimap order
+    pl["plane"][10:14] = pl["plane"][0]
+    pl["lx"], pl["ly"], pl["lz"] = lp.T
+    ln = np.zeros(n_ln, oracle.PAIR_PT2LN)
+    ln["pbase"], ln["director"] = rng.uniform(-2, 2, (n_ln, 3)), rng.normal(size=(n_ln, 3))
+    q = rng.uniform(-3, 3, (n_ln, 3))
+    ln["lx"], ln["ly"], ln["lz"] = q.T
+
+    def select(items, out):
+        items = sorted(items, key=lambda v: (-v[0], -v[1]))            # reverse walk of the multimap
+        thr = items[0][0] * 0.25 if items else 0.0
+        for key, _, pair in items:
+            if key < thr and len(out) >= 3:
+                break
+            out.append(pair)
+
+    want = []
+    items = []
+    for i in range(n_pl):
+        g = R @ lp[i].astype(np.float64) + t
+        c = pl["plane"][i]
+        d = float(c[:3] @ g + c[3])
+        items.append((abs(d), i, (np.float32(g - c[:3] * d), lp[i])))
+    select(items, want)
+    items = []
+    for i in range(n_ln):
+        g = R @ q[i] + t
+        b, u = ln["pbase"][i], ln["director"][i]
+        c = b + u * (((g - b) @ u) / (u @ u))
+        items.append((float(np.linalg.norm(c - g)), i, (np.float32(c), np.float32(q[i]))))
+    select(items, want)
+    got = oracle.pt2ln_pl_to_pt2pt(pl, ln, T)
+    assert len(got) == len(want) and 3 <= len(got) < n_pl + n_ln
+    G = np.stack([got["gx"], got["gy"], got["gz"]], 1)
+    L = np.stack([got["lx"], got["ly"], got["lz"]], 1)
+    assert np.allclose(G, np.array([w[0] for w in want]), atol=1e-6)
+    assert np.array_equal(L, np.array([w[1] for w in want]))
+    assert (got["globalIdx"] == 0).all() and (got["localIdx"] == 0).all()
+    # few pairings: at least three are taken, whatever their error
+    assert len(oracle.pt2ln_pl_to_pt2pt(pl[:2], ln[:2], T)) == 4
+    assert len(oracle.pt2ln_pl_to_pt2pt(None, None, T)) == 0

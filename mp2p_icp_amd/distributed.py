@@ -208,3 +208,38 @@ class ShardedRegistration:
                 self.redone_steps = getattr(self, "redone_steps", 0) + 1
             self._cap_guess = self._round_cap(n_max * 1.25 + 1024)
         return out
+
+
+class BatchRegistration:
+    """SURVEY.md section 8e, way (i): a batch of INDEPENDENT scan pairs (BASELINE config C4: 64 x
+    (1 M vs 1 M) on 8 GPUs).  Pair b belongs to rank b mod world; every rank registers its own
+    pairs with the single-GPU path, no collective on the data path.  `gather` hands every rank
+    all results with ONE all-reduce SUM of a [B, 14] fp64 table (pose, iterations, quality) in
+    which a rank fills only its own rows -- 7 kB for 64 pairs.
+
+    `align_fn(pair_index) -> (pose[12], n_iterations, quality)` is the per-pair registration
+    (in the product: an mp2p_icp_amd.ICP.align call on this rank's GPU)."""
+
+    ROW = 14
+
+    def __init__(self, n_pairs, dist=None, group=None, device="cpu"):
+        self.n_pairs, self.dist, self.group, self.device = int(n_pairs), dist, group, device
+        self.rank = dist.get_rank(group) if dist is not None else 0
+        self.world = dist.get_world_size(group) if dist is not None else 1
+
+    def owned(self):
+        """pair indices of this rank, in processing order"""
+        return list(range(self.rank, self.n_pairs, self.world))
+
+    def run(self, align_fn, gather=True):
+        import torch
+        table = torch.zeros((self.n_pairs, self.ROW), dtype=torch.float64)
+        for b in self.owned():
+            pose, iters, quality = align_fn(b)
+            table[b, :12] = torch.as_tensor(np.asarray(pose, dtype=np.float64))
+            table[b, 12], table[b, 13] = float(iters), float(quality)
+        if gather and self.dist is not None and self.world > 1:
+            t = table.to(self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            table = t.cpu()
+        return table.numpy()

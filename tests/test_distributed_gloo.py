@@ -227,3 +227,65 @@ def test_sharded_registration_gloo_world2():
         p.join(timeout=60)
     for rank, ok, msg in res:
         assert ok, f"rank {rank}: {msg}"
+
+
+def _batch_worker(rank, world, port, q):
+    """independent scan pairs dealt to the ranks; the per-pair registration is
+    the CPU oracle's ICP loop here (HipBackend / ICP.align on a GPU box)."""
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle as orc
+        from mp2p_icp_amd import synthetic
+        from mp2p_icp_amd.distributed import BatchRegistration
+
+        n_pairs = 5
+        prm = orc.make_gn_params(3)
+        done = []
+
+        def align(b):
+            d = synthetic.random_cloud_pair(300, 1500, 100 + b, outlier_frac=0.05)
+            g, l = d["glob"], d["local"]
+            tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
+            pose = d["T_init"].copy()
+            for it in range(3):
+                pairs, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.8, 0.0, tree=tree)
+                pose, *_ = orc.optimal_tf_gauss_newton(pairs, None, None, pose, prm)
+            done.append(b)
+            return pose, 3, len(pairs) / l.shape[0]
+
+        reg = BatchRegistration(n_pairs, dist)
+        table = reg.run(align)
+        ok, msg = True, ""
+        if done != list(range(rank, n_pairs, world)):
+            ok, msg = False, f"rank {rank} processed {done}"
+        # every rank holds every result; compare with the same registrations run in one process
+        single = BatchRegistration(n_pairs).run(align, gather=False)
+        if ok and not np.array_equal(table, single):
+            ok, msg = False, "gathered table differs from the single-process run"
+        if ok and not (table[:, 12] == 3).all():
+            ok, msg = False, "missing rows"
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok, msg))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc() + str(ex)))
+
+
+@pytest.mark.timeout(300)
+def test_batch_registration_gloo_world2():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(WORLD)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"

@@ -177,3 +177,40 @@ def test_quality_and_covariance_of_align(oracle):
     far = amd.se3.compose(d["T_gt"], amd.se3.from_xyzypr(40.0, 40.0, 5.0, 1.0, 0.0, 0.0))
     res = make(0.8).align(pcL, pcG, far, amd.Parameters(maxIterations=15, quality_checkpoints={2: 0.5}))
     assert res.terminationReason in (amd.IterTermReason.QualityCheckpointFailed, amd.IterTermReason.NoPairings)
+
+
+def test_batch_of_independent_pairs(oracle):
+    """SURVEY.md 8e (i) / BASELINE config C4 in miniature: BatchRegistration deals scan pairs to
+    ranks (one here) and registers each with ICP.align; every registration converges and equals
+    the same call made directly."""
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import synthetic
+    from mp2p_icp_amd.distributed import BatchRegistration
+
+    def make():
+        icp = amd.ICP()
+        m = amd.Matcher_Points_DistanceThreshold()
+        m.initialize({"threshold": 1.0, "thresholdAngularDeg": 0.0})
+        s = amd.Solver_GaussNewton()
+        s.initialize({"maxIterations": 3, "robustKernel": "RobustKernel::GemanMcClure", "robustKernelParam": 0.15})
+        icp.set_matchers([m])
+        icp.set_solvers([s])
+        return icp
+
+    scenes = [synthetic.make_pair(5000, 40000, 300 + b, max_t=0.2, max_r_deg=1.0) for b in range(3)]
+
+    def align(b):
+        d = scenes[b]
+        res = make().align(amd.metric_map_t({"raw": amd.PointLayer(d["local"])}),
+                           amd.metric_map_t({"raw": amd.PointLayer(d["glob"])}), d["T_init"],
+                           amd.Parameters(maxIterations=30))
+        return res.optimal_tf, res.nIterations, res.quality
+
+    reg = BatchRegistration(len(scenes))
+    assert reg.owned() == [0, 1, 2]
+    table = reg.run(align)
+    for b, d in enumerate(scenes):
+        pose, iters, _ = align(b)
+        assert np.array_equal(table[b, :12], pose) and table[b, 12] == iters
+        dt, dr = oracle.pose_err_split(table[b, :12], d["T_gt"])
+        assert dt < 0.1 and dr < 0.01, (b, dt, dr)

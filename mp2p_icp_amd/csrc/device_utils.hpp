@@ -123,6 +123,72 @@ __device__ __forceinline__ float wave_max(float v)
     v = fmaxf(v, dpp_f<DPP_ROW_ROR8>(v));
     return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
+// The same reductions for values known not to be NaN, on the order-preserving integer image of
+// the float: v_min_i32 / v_max_i32 need no sNaN canonicalisation of their inputs (one v_max x,x per
+// operand of every fminf on values that come out of DPP / readlane), the DPP move folds into
+// the integer min, and the four rows are combined on the scalar unit.
+__device__ __forceinline__ int f2key(float v)
+{
+    const int b = __builtin_bit_cast(int, v);
+    return b ^ ((b >> 31) & 0x7FFFFFFF);
+}
+__device__ __forceinline__ float key2f(int k)
+{
+    return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7FFFFFFF));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float wave_min_nn(float v)
+{
+    int k = f2key(v);
+    k = min(k, dpp_i<DPP_ROW_ROR1>(k));
+    k = min(k, dpp_i<DPP_ROW_ROR2>(k));
+    k = min(k, dpp_i<DPP_ROW_ROR4>(k));
+    k = min(k, dpp_i<DPP_ROW_ROR8>(k));
+    const int a = __builtin_amdgcn_readlane(k, 0), b = __builtin_amdgcn_readlane(k, 16),
+              c = __builtin_amdgcn_readlane(k, 32), d = __builtin_amdgcn_readlane(k, 48);
+    return key2f(min(min(a, b), min(c, d)));
+}
+__device__ __forceinline__ float wave_max_nn(float v)
+{
+    int k = f2key(v);
+    k = max(k, dpp_i<DPP_ROW_ROR1>(k));
+    k = max(k, dpp_i<DPP_ROW_ROR2>(k));
+    k = max(k, dpp_i<DPP_ROW_ROR4>(k));
+    k = max(k, dpp_i<DPP_ROW_ROR8>(k));
+    const int a = __builtin_amdgcn_readlane(k, 0), b = __builtin_amdgcn_readlane(k, 16),
+              c = __builtin_amdgcn_readlane(k, 32), d = __builtin_amdgcn_readlane(k, 48);
+    return key2f(max(max(a, b), max(c, d)));
+}
+
+// ... and for values that are >= +0 (squared distances, radii, +inf): the bit pattern itself
+// orders like the value
+__device__ __forceinline__ float wave_min_pos(float v)
+{
+    uint32_t k = __builtin_bit_cast(uint32_t, v);
+    k = min(k, (uint32_t)dpp_i<DPP_ROW_ROR1>((int)k));
+    k = min(k, (uint32_t)dpp_i<DPP_ROW_ROR2>((int)k));
+    k = min(k, (uint32_t)dpp_i<DPP_ROW_ROR4>((int)k));
+    k = min(k, (uint32_t)dpp_i<DPP_ROW_ROR8>((int)k));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)k, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)k, 16),
+                   c = (uint32_t)__builtin_amdgcn_readlane((int)k, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)k, 48);
+    return __builtin_bit_cast(float, min(min(a, b), min(c, d)));
+}
+__device__ __forceinline__ float wave_max_pos(float v)
+{
+    uint32_t k = __builtin_bit_cast(uint32_t, v);
+    k = max(k, (uint32_t)dpp_i<DPP_ROW_ROR1>((int)k));
+    k = max(k, (uint32_t)dpp_i<DPP_ROW_ROR2>((int)k));
+    k = max(k, (uint32_t)dpp_i<DPP_ROW_ROR4>((int)k));
+    k = max(k, (uint32_t)dpp_i<DPP_ROW_ROR8>((int)k));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)k, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)k, 16),
+                   c = (uint32_t)__builtin_amdgcn_readlane((int)k, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)k, 48);
+    return __builtin_bit_cast(float, max(max(a, b), max(c, d)));
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
 #pragma unroll

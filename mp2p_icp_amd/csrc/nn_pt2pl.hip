@@ -147,12 +147,12 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
         const float G  = grp_factor * sr;
         const bool  grp = !done && fabsf(qx - sx) <= G && fabsf(qy - sy) <= G && fabsf(qz - sz) <= G &&
                          r <= 2.0f * sr;
-        float lox = wave_min(grp ? qx - r : INFINITY), loy = wave_min(grp ? qy - r : INFINITY),
-              loz = wave_min(grp ? qz - r : INFINITY);
-        float hix = wave_max(grp ? qx + r : -INFINITY), hiy = wave_max(grp ? qy + r : -INFINITY),
-              hiz = wave_max(grp ? qz + r : -INFINITY);
-        const float rmin_t = wave_min(grp ? r : INFINITY);
-        const float rmax_t = wave_max(grp ? r : 0.f);
+        float lox = wave_min_nn(grp ? qx - r : INFINITY), loy = wave_min_nn(grp ? qy - r : INFINITY),
+              loz = wave_min_nn(grp ? qz - r : INFINITY);
+        float hix = wave_max_nn(grp ? qx + r : -INFINITY), hiy = wave_max_nn(grp ? qy + r : -INFINITY),
+              hiz = wave_max_nn(grp ? qz + r : -INFINITY);
+        const float rmin_t = wave_min_pos(grp ? r : INFINITY);
+        const float rmax_t = wave_max_pos(grp ? r : 0.f);
         const float qlx = lox + rmin_t, qly = loy + rmin_t, qlz = loz + rmin_t;
         const float qhx = hix - rmin_t, qhy = hiy - rmin_t, qhz = hiz - rmin_t;
         lox = fmaxf(lox, g.bbmin[0]), loy = fmaxf(loy, g.bbmin[1]), loz = fmaxf(loz, g.bbmin[2]);
@@ -356,10 +356,10 @@ __device__ __forceinline__ void transform_tile(const PoseRt& pose, const float4*
     visited = valid;
     if (rank && valid) vrank = rank[orig], visited = vrank != NONE_U32;
     compose_point_f(pose, lp.x, lp.y, lp.z, qx, qy, qz);
-    const float bx0 = wave_min(visited ? qx : INFINITY), by0 = wave_min(visited ? qy : INFINITY),
-                bz0 = wave_min(visited ? qz : INFINITY);
-    const float bx1 = wave_max(visited ? qx : -INFINITY), by1 = wave_max(visited ? qy : -INFINITY),
-                bz1 = wave_max(visited ? qz : -INFINITY);
+    const float bx0 = wave_min_nn((visited && qx == qx) ? qx : INFINITY), by0 = wave_min_nn((visited && qy == qy) ? qy : INFINITY),
+                bz0 = wave_min_nn((visited && qz == qz) ? qz : INFINITY);
+    const float bx1 = wave_max_nn((visited && qx == qx) ? qx : -INFINITY), by1 = wave_max_nn((visited && qy == qy) ? qy : -INFINITY),
+                bz1 = wave_max_nn((visited && qz == qz) ? qz : -INFINITY);
     if (lane == 0)
     {
         float* o = tile_bbox + (size_t)tile * 6;

@@ -269,10 +269,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 
     // bounding box of ALL transformed local points of the tile (Matcher_Points_Base.cpp:186-196)
     {
-        const float bx0 = wave_min(visited ? qx : INFINITY), by0 = wave_min(visited ? qy : INFINITY),
-                    bz0 = wave_min(visited ? qz : INFINITY);
-        const float bx1 = wave_max(visited ? qx : -INFINITY), by1 = wave_max(visited ? qy : -INFINITY),
-                    bz1 = wave_max(visited ? qz : -INFINITY);
+        const float bx0 = wave_min_nn((visited && qx == qx) ? qx : INFINITY), by0 = wave_min_nn((visited && qy == qy) ? qy : INFINITY),
+                    bz0 = wave_min_nn((visited && qz == qz) ? qz : INFINITY);
+        const float bx1 = wave_max_nn((visited && qx == qx) ? qx : -INFINITY), by1 = wave_max_nn((visited && qy == qy) ? qy : -INFINITY),
+                    bz1 = wave_max_nn((visited && qz == qz) ? qz : -INFINITY);
         if (lane == 0)
         {
             float* o = a.tile_bbox + (size_t)tile * 6;
@@ -372,12 +372,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         st_pass++;
 
         // ---- search box = union of the group's cubes ---------------------------------------
-        const float lox = wave_min(grp ? qx - r : INFINITY), loy = wave_min(grp ? qy - r : INFINITY),
-                    loz = wave_min(grp ? qz - r : INFINITY);
-        const float hix = wave_max(grp ? qx + r : -INFINITY), hiy = wave_max(grp ? qy + r : -INFINITY),
-                    hiz = wave_max(grp ? qz + r : -INFINITY);
-        const float rmin_t = wave_min(grp ? r : INFINITY);
-        const float rmax_t = wave_max(grp ? r : 0.f);
+        // (group members are finite: the NaN-free reductions apply)
+        const float lox = wave_min_nn(grp ? qx - r : INFINITY), loy = wave_min_nn(grp ? qy - r : INFINITY),
+                    loz = wave_min_nn(grp ? qz - r : INFINITY);
+        const float hix = wave_max_nn(grp ? qx + r : -INFINITY), hiy = wave_max_nn(grp ? qy + r : -INFINITY),
+                    hiz = wave_max_nn(grp ? qz + r : -INFINITY);
+        const float rmin_t = wave_min_pos(grp ? r : INFINITY);
+        const float rmax_t = wave_max_pos(grp ? r : 0.f);
         // conservative bounding box of the group's queries themselves
         const float qlx = lox + rmin_t, qly = loy + rmin_t, qlz = loz + rmin_t;
         const float qhx = hix - rmin_t, qhy = hiy - rmin_t, qhz = hiz - rmin_t;
@@ -569,7 +570,7 @@ __device__ __forceinline__ void scan_batch(const NNArgs& a, const GridView& g, i
     const unsigned long long occ = __ballot(cnt > 0);
     if (occ == 0ull) return;
     {
-        const float kmin = wave_min(cnt > 0 ? md2 : INFINITY);
+        const float kmin = wave_min_pos(cnt > 0 ? md2 : INFINITY);  // squared distances: >= +0
         const float lim  = bound * 1.000001f + g.slack * (2.f * sqrtf(bound) + g.slack);
         if (!(kmin <= lim)) return;  // nothing in this batch can matter
         if (!(bound < INFINITY))
@@ -587,7 +588,7 @@ __device__ __forceinline__ void scan_batch(const NNArgs& a, const GridView& g, i
                 if (da < pd || (da == pd && ia < pi)) pd = da, pi = ia, ps = sa;
                 if (INSTR) a.touched[sa] = 1;
             }
-            bound = fminf(bound, wave_min(pd));
+            bound = fminf(bound, wave_min_pos(pd));
             if (lane == lc) cnt = 0;  // done
         }
     }
@@ -630,7 +631,7 @@ __device__ __forceinline__ void scan_batch(const NNArgs& a, const GridView& g, i
         }
     }
     __syncthreads();
-    bound = fminf(bound, wave_min(pd));
+    bound = fminf(bound, wave_min_pos(pd));
 }
 
 // squared distance of the axis-aligned box [v0, v0+h]^3 from the point q

@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--no-bitmap", action="store_true", help="build the map without occupancy bitmaps")
     ap.add_argument("--no-events", action="store_true", help="timed loop without hipEvents (overhead probe)")
     ap.add_argument("--cold", action="store_true", help="disable the warm start from the previous iteration")
+    ap.add_argument("--tile-order", action="store_true", help="launch the tiles longest-first (by the previous iteration's durations) instead of in Morton order")
     ap.add_argument("--defer", type=float, default=0.0, help="defer radius in cells (tuning)")
     ap.add_argument("--budget", type=int, default=0, help="voxel budget per search box (tuning)")
     ap.add_argument("--cell", type=float, default=0.0, help="voxel edge [m] (0 = automatic)")
@@ -168,7 +169,8 @@ def main():
         f"{info['build_ms']:.1f} ms (upload+build {t_index * 1e3:.0f} ms); cloud {t_cloud * 1e3:.0f} ms")
 
     n_l = l.shape[0]
-    prm = _lib.Pt2PtParams(args.threshold, 0.0, 1, 0, 0, 0.20, rank * n_l, args.r0, args.q, args.grp, args.budget, args.defer, int(args.cold), args.bricks)
+    prm = _lib.Pt2PtParams(args.threshold, 0.0, 1, 0, 0, 0.20, rank * n_l, args.r0, args.q, args.grp, args.budget, args.defer, int(args.cold), args.bricks,
+                           int(args.tile_order))
     gnp = _lib.GNParams()
     gnp.maxInnerLoopIterations = args.gn_iters
     gnp.minDelta, gnp.maxCost = 1e-7, 0.0

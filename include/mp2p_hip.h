@@ -214,6 +214,10 @@ typedef struct
                                      nearest neighbour (exactness is unaffected) */
     uint32_t brick_budget;        /* 4x4x4-voxel bricks of the occupancy bitmap a deferred query
                                      enumerates per pass before it moves to a coarser level; 0 = 128 */
+    int32_t  tile_order;          /* 1: a warm call (see disable_warm_start) launches the tiles
+                                     of the local layer longest-first, by their measured duration
+                                     in the previous call (results are unaffected; off by default:
+                                     the sort currently costs more than the shorter tail saves) */
 } mp2p_hip_pt2pt_params;
 
 /* ms may be NULL (fresh MatchState with nothing marked, marks discarded). */
@@ -503,8 +507,15 @@ int mp2p_hip_filter_decimate_voxels_device(mp2p_hip_ctx* ctx, const float* d_x, 
 
 /* 0 = off; 1 = bracket the kernels with hipEvents (ms_* fields; each call then ends with a
  * stream synchronisation); 2 = additionally collect the device counters (nn_* fields, slower);
- * 3 = only the two events around the search kernels (ms_nn; the cheapest timing). */
+ * 3 = only the two events around the search kernels (ms_nn; the cheapest timing);
+ * 4 = 3 + a {start, end} timestamp (100 MHz ticks) per workgroup of the two search kernels of
+ *     Matcher_Points_DistanceThreshold, for occupancy-over-time plots (tools/timeline_probe.py). */
 int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable);
+/* the timestamps of the last match call at profiling level 4: 2 uint64 per record, the tile
+ * kernel's workgroups first, then the one-query-per-wave kernel's; ticks_host may be NULL to
+ * query the record counts */
+int mp2p_hip_get_timeline(mp2p_hip_ctx* ctx, uint64_t* ticks_host, size_t cap_records,
+                          size_t* n_tile_records, size_t* n_single_records);
 int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out);
 
 #ifdef __cplusplus

@@ -94,7 +94,8 @@ class Pt2PtParams(C.Structure):
                 ("local_index_offset", C.c_uint64), ("initial_radius_cells", C.c_float),
                 ("queries_per_wave", C.c_uint32), ("group_radius_factor", C.c_float),
                 ("cell_budget", C.c_uint32), ("defer_radius_cells", C.c_float),
-                ("disable_warm_start", C.c_int32), ("brick_budget", C.c_uint32)]
+                ("disable_warm_start", C.c_int32), ("brick_budget", C.c_uint32),
+                ("tile_order", C.c_int32)]
 
 
 class Pt2PlParams(C.Structure):
@@ -220,6 +221,8 @@ SIGNATURES = {
     "mp2p_hip_pairs_pt2ln_pl_to_pt2pt": (C.c_int, [_P, _P, _dp, _P]),
     "mp2p_hip_set_profiling": (C.c_int, [_P, C.c_int]),
     "mp2p_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "mp2p_hip_get_timeline": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_size_t)]),
 }
 
 

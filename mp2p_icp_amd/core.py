@@ -388,6 +388,18 @@ def gn_result_to_dict(res):
                 cost=res.cost, iterations=res.iterations)
 
 
+def timeline(ctx):
+    """profiling level 4: ({start,end} ticks [n_tiles,2], [n_single_blocks,2]) of the last match call"""
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    check(ctx._L.mp2p_hip_get_timeline(ctx.handle, None, 0, C.byref(a), C.byref(b)), ctx.handle)
+    n = a.value + b.value
+    buf = np.zeros((max(1, n), 2), np.uint64)
+    if n:
+        check(ctx._L.mp2p_hip_get_timeline(ctx.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.byref(a),
+                                           C.byref(b)), ctx.handle)
+    return buf[:a.value], buf[a.value:n]
+
+
 def horn_solve_wp(ctx, pairs, prm, point_weights=None):
     """optimal_tf_horn with WeightParameters (prm: _lib.HornParams) -> (pose, solved, n_outliers)"""
     keep = None

@@ -376,7 +376,7 @@ int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
     rc = launch_compact_pt2pt(ctx, map, cloud, prm, ms, out);
     if (!rc && ctx->profiling)
     {
-        ctx->pending_match = ctx->profiling;  // read back lazily in mp2p_hip_get_stats
+        ctx->pending_match = ctx->profiling == 4 ? 3 : ctx->profiling;  // read back lazily in mp2p_hip_get_stats
         ctx->pending_map_n = map->n;
         ctx->stats.nn_queries = cloud->n;
     }
@@ -577,7 +577,7 @@ int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     const int rc = launch_match_pt2pl(ctx, map, cloud, pose, prm, ms, out);
     if (!rc && ctx->profiling)
     {
-        ctx->pending_match = ctx->profiling == 2 ? 1 : ctx->profiling;
+        ctx->pending_match = ctx->profiling == 2 ? 1 : (ctx->profiling == 4 ? 3 : ctx->profiling);
         ctx->stats.nn_queries = cloud->n;
         if (ctx->profiling == 2)
         {  // the k-NN kernel's own counters
@@ -763,7 +763,22 @@ int mp2p_hip_filter_decimate_voxels(mp2p_hip_ctx* ctx, const float* x, const flo
 int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable)
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;
-    ctx->profiling = enable < 0 ? 0 : (enable > 3 ? 3 : enable);
+    ctx->profiling = enable < 0 ? 0 : (enable > 4 ? 4 : enable);
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_get_timeline(mp2p_hip_ctx* ctx, uint64_t* ticks_host, size_t cap_records, size_t* n_tile_records,
+                          size_t* n_single_records)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, n_tile_records && n_single_records, "null argument");
+    *n_tile_records = ctx->timeline_tiles, *n_single_records = ctx->timeline_singles;
+    const size_t n = ctx->timeline_tiles + ctx->timeline_singles;
+    if (!ticks_host || !n) return MP2P_HIP_OK;
+    MP2P_REQUIRE(ctx, cap_records >= n, "timeline buffer too small");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemcpy(ticks_host, ctx->timeline.p, 2 * n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MP2P_HIP_OK;
 }
 

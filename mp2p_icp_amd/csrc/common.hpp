@@ -110,7 +110,8 @@ struct mp2p_hip_ctx
     bool        own_stream = false;
     std::string err;
     int         profiling = 0;  // 0 off, 1 hipEvent timing of every stage, 2 + device counters,
-                                // 3 only the two events around the search kernels
+                                // 3 only the two events around the search kernels, 4 = 3 + a
+                                // {start, end} timestamp per workgroup of the search kernels
     bool        prof_all() const { return profiling == 1 || profiling == 2; }
     hipEvent_t  ev[7]     = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int         pending_match = 0, pending_gn = 0;
@@ -133,6 +134,11 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<double>             gn_state;     // pose(12) H(36) g(6) cost(1) iters(1) done(1)
     mp2p::DevBuf<unsigned char>      aos_stage;    // download staging
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
+    mp2p::DevBuf<uint32_t>           tile_cost;    // duration of every tile in the last search (ticks)
+    mp2p::DevBuf<uint32_t>           tile_order;   // tiles by decreasing previous duration
+    uint32_t                         tile_cost_tiles = 0, tile_cost_q = 0;
+    mp2p::DevBuf<unsigned long long> timeline;     // profiling level 4: {start, end} ticks per workgroup
+    size_t                           timeline_tiles = 0, timeline_singles = 0;
     mp2p::DevBuf<unsigned char>      horn_flags;   // Horn: scale-outlier flag per point pairing
     mp2p::DevBuf<unsigned long long> horn_bounds;  //   first pair of each point_weights block, [8] = error
     size_t                           horn_n = 0;   //   pairings the flags belong to

@@ -66,6 +66,16 @@ struct NNArgs
     PoseRt               prev_pose;
     unsigned long long*  counters;  // profiling, or null
     unsigned char*       touched;   // profiling: [n_g] by sorted position, or null
+    // profiling level 4: {start, end} 100 MHz ticks of every workgroup of the two search kernels
+    // ([n_tiles] then [single blocks]); the plain kernels only pay a uniform null test for it
+    unsigned long long*  timeline;
+    uint32_t             timeline_single_base;
+    // launch order: tiles are dispatched in blockIdx order and a late straggler leaves the chip
+    // idle behind it, so the tiles that took longest in the previous call (same map, same cloud)
+    // go first.  tile_cost[tile] = this call's duration in 100 MHz ticks (written at exit);
+    // tile_order[blockIdx.x] = tile, or null (cold call: identity)
+    uint32_t*            tile_cost;
+    const uint32_t*      tile_order;
 };
 
 // ---- geometry of one search pass (all values wave-uniform) -----------------------------------
@@ -245,9 +255,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 
     const GridView& g     = a.g;
     const int       lane  = threadIdx.x;
+    const unsigned long long tl0 = wall_clock64();
     const int       qslot = lane & (Q - 1);
     const int       slice = (Q == 64) ? 0 : lane / Q;
-    const uint32_t  tile  = blockIdx.x;
+    const uint32_t  tile  = a.tile_order ? a.tile_order[blockIdx.x] : blockIdx.x;
     const uint32_t  qi    = tile * Q + qslot;
     const bool      valid = qi < a.n_l;
 
@@ -534,6 +545,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     if (valid && slice == 0 && !deferred)
         emit_result(a, qi, orig, active, thr, best_d2, best_idx, best_spos, lb2_keep);
 
+    if (lane == 0)
+    {
+        const unsigned long long tl1 = wall_clock64();
+        a.tile_cost[tile] = (uint32_t)min(tl1 - tl0, 0xFFFFFFFFull);
+        if (a.timeline) a.timeline[2 * (size_t)tile] = tl0, a.timeline[2 * (size_t)tile + 1] = tl1;
+    }
     if (INSTR && lane == 0)
     {
         atomicAdd(&a.counters[0], 1ull);
@@ -662,6 +679,7 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
     const GridView& g      = a.g;
     const int       lane   = threadIdx.x;
     const uint32_t  n_work = *a.work_count;
+    const unsigned long long tl0 = a.timeline ? wall_clock64() : 0ull;
 
     for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x)
     {
@@ -832,9 +850,77 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
             atomicMax(&a.counters[42], (unsigned long long)st_cells);
         }
     }
+    if (a.timeline && lane == 0)
+    {
+        const size_t k = (size_t)a.timeline_single_base + blockIdx.x;
+        a.timeline[2 * k] = tl0, a.timeline[2 * k + 1] = wall_clock64();
+    }
 }
 
 __global__ void zero_u32_kernel(uint32_t* p) { *p = 0; }
+
+// Resets the work-queue counter and, for a warm call, lists the tiles by decreasing duration of
+// the previous call: a counting sort on the log2 of the tick count (only "the long ones first"
+// matters).  One workgroup of 16 waves; a wave adds each distinct bucket of its 64 tiles with ONE
+// LDS atomic (the durations cluster in a handful of buckets: per-tile atomics would serialise).
+// Measured on the bench scene: the tile kernel drops from 0.222 to 0.187 ms, but this kernel's two
+// passes over the costs are 62 dependent global loads in a row = 47 us, more than the gain, and
+// letting the tiles count themselves with a global atomic doubles THEIR time (a few hot
+// addresses) -- hence opt-in (mp2p_hip_pt2pt_params::tile_order) until the sort is cheap.
+__device__ __forceinline__ uint32_t wave_bucket_slot(uint32_t* s_ctr, uint32_t bucket, bool have, int lane)
+{
+    // returns, for every lane with `have`, a distinct slot of its bucket's counter range
+    uint32_t           slot = 0;
+    unsigned long long todo = __ballot(have);
+    while (todo)
+    {
+        const int                leader = __ffsll((long long)todo) - 1;
+        const uint32_t           b      = (uint32_t)__builtin_amdgcn_readlane((int)bucket, leader);
+        const unsigned long long same   = __ballot(have && bucket == b) & todo;
+        uint32_t                 base   = 0;
+        if (lane == leader) base = atomicAdd(&s_ctr[b], (uint32_t)__popcll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if ((same >> lane) & 1ull) slot = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
+
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t n_tiles,
+                                                          uint32_t* __restrict__ order,
+                                                          uint32_t* __restrict__ work_count)
+{
+    __shared__ uint32_t s_cnt[33], s_off[33];
+    if (threadIdx.x == 0) *work_count = 0;
+    if (!order) return;  // uniform
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 33) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // bucket 0: cost 0, bucket b: 2^(b-1) <= cost < 2^b
+    const uint32_t rounds = (n_tiles + 1023u) / 1024u;
+    for (uint32_t k = 0; k < rounds; k++)
+    {
+        const uint32_t t    = k * 1024u + threadIdx.x;
+        const bool     have = t < n_tiles;
+        const uint32_t b    = have ? (uint32_t)(32 - __clz((int)cost[t])) : 0u;
+        (void)wave_bucket_slot(s_cnt, b, have, lane);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t run = 0;
+        for (int b = 32; b >= 0; b--) s_off[b] = run, run += s_cnt[b];  // long tiles first
+    }
+    __syncthreads();
+    for (uint32_t k = 0; k < rounds; k++)
+    {
+        const uint32_t t    = k * 1024u + threadIdx.x;
+        const bool     have = t < n_tiles;
+        const uint32_t b    = have ? (uint32_t)(32 - __clz((int)cost[t])) : 0u;
+        const uint32_t slot = wave_bucket_slot(s_off, b, have, lane);
+        if (have) order[slot] = t;
+    }
+}
 
 // reduce the per-tile boxes to the layer box {min xyz, max xyz}: [n_in][6] -> [gridDim.x][6]
 __global__ __launch_bounds__(256) void tile_bbox_reduce_kernel(const float* __restrict__ tb,
@@ -946,7 +1032,28 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->pl_slots.p, 0, map->n, ctx->stream));
         a.touched = ctx->pl_slots.p;
     }
-    hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, ctx->stream, a.work_count);
+    a.timeline = nullptr, a.timeline_single_base = n_tiles;
+    ctx->timeline_tiles = ctx->timeline_singles = 0;
+    if (ctx->profiling == 4)
+    {
+        const size_t single_blocks = std::min<size_t>(n_l, 256u * 32u);
+        MP2P_TRY_HIP(ctx, ctx->timeline.ensure(2 * (n_tiles + single_blocks)));
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->timeline.p, 0, 2 * (n_tiles + single_blocks) * sizeof(unsigned long long),
+                                         ctx->stream));
+        a.timeline = ctx->timeline.p;
+        ctx->timeline_tiles = n_tiles, ctx->timeline_singles = single_blocks;
+    }
+    // tile order from the previous call's durations (same condition as the warm start: the same
+    // local layer in the same tiling against the same map)
+    MP2P_TRY_HIP(ctx, ctx->tile_cost.ensure(n_tiles ? n_tiles : 1));
+    MP2P_TRY_HIP(ctx, ctx->tile_order.ensure(n_tiles ? n_tiles : 1));
+    const bool ordered = a.use_hint && ctx->tile_cost_tiles == n_tiles && ctx->tile_cost_q == Q && n_tiles > 1 &&
+                         prm->tile_order != 0;
+    a.tile_cost  = ctx->tile_cost.p;
+    a.tile_order = ordered ? ctx->tile_order.p : nullptr;
+    ctx->tile_cost_tiles = n_tiles, ctx->tile_cost_q = Q;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_cost.p, n_tiles,
+                       ordered ? ctx->tile_order.p : nullptr, a.work_count);
     // ev[0]..ev[1] brackets exactly the two search kernels (the roofline kernels of bench.py)
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (n_tiles)

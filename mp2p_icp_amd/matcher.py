@@ -202,6 +202,7 @@ class Matcher_Points_Base(Matcher):
         self.cell_budget = 0
         self.defer_radius_cells = 0.0
         self.disable_warm_start = False
+        self.tile_order = False
         self.brick_budget = 0
 
     def initialize(self, params):
@@ -234,6 +235,7 @@ class Matcher_Points_Base(Matcher):
         self.cell_budget = int(params.get("hip_cell_budget", 0))
         self.defer_radius_cells = float(params.get("hip_defer_radius_cells", 0.0))
         self.disable_warm_start = bool(params.get("hip_disable_warm_start", False))
+        self.tile_order = bool(params.get("hip_tile_order", False))
         self.brick_budget = int(params.get("hip_brick_budget", 0))
 
     # maxLocalPointsPerLayer (Matcher_Points_Base.cpp:222-246): when the local layer is larger,
@@ -340,7 +342,8 @@ class Matcher_Points_DistanceThreshold(Matcher_Points_Base):
             float(self.bounding_box_intersection_check_epsilon_), int(local_index_offset),
             float(self.initial_radius_cells), int(self.queries_per_wave),
             float(self.group_radius_factor), int(self.cell_budget),
-            float(self.defer_radius_cells), int(self.disable_warm_start), int(self.brick_budget))
+            float(self.defer_radius_cells), int(self.disable_warm_start), int(self.brick_budget),
+            int(self.tile_order))
 
     def implMatchOneLayer(self, ctx, gLayer, lLayer, localPose, ms, glName, lcName, out):
         self.checkAllParametersAreRealized()

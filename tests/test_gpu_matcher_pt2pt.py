@@ -209,7 +209,7 @@ def test_kitti_shape_c2_parity(amd, oracle):
 def test_warm_start_pose_sequence(amd, oracle):
     """Repeated calls on the same (map, cloud) seed every query with its previous nearest
     neighbour.  The lists must stay bit-exact for any pose sequence (small steps, big jumps,
-    back again) and identical to a cold call."""
+    back again) and identical to a cold call, whatever the launch order of the tiles."""
     from mp2p_icp_amd import synthetic
     d = synthetic.make_pair(20_000, 100_000, 77)
     g, l = d["glob"], d["local"]
@@ -226,10 +226,13 @@ def test_warm_start_pose_sequence(amd, oracle):
     ms_w.initialize({"threshold": 1.5, "thresholdAngularDeg": 0.05})
     ms_c = amd.Matcher_Points_DistanceThreshold()
     ms_c.initialize({"threshold": 1.5, "thresholdAngularDeg": 0.05, "hip_disable_warm_start": True})
+    # longest-first launch order of the tiles (from the previous call's measured durations)
+    ms_o = amd.Matcher_Points_DistanceThreshold()
+    ms_o.initialize({"threshold": 1.5, "thresholdAngularDeg": 0.05, "hip_tile_order": True})
     for pose in poses:
         want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose,
                                        1.5, 0.05, tree=tree, threads=8)
-        for m in (ms_w, ms_c):
+        for m in (ms_w, ms_c, ms_o, ms_o):
             pairs = amd.Pairings()
             m.match(pcG, pcL, pose, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
             _assert_same_pairs(pairs.paired_pt2pt, want)

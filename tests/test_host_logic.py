@@ -188,3 +188,54 @@ def test_synthetic_inputs_are_reproducible(amd):
     assert np.array_equal(a["glob"], b["glob"]) and np.array_equal(a["local"], b["local"])
     assert np.array_equal(a["T_init"], b["T_init"]) and not np.array_equal(a["local"], c["local"])
     assert a["glob"].dtype == np.float32 and a["glob"].shape == (8000, 3) and a["local"].shape == (2000, 3)
+
+
+def test_weight_block_bounds_algorithm():
+    """horn.hip replays the reference's sequential weight-block cursor (visit_correspondences.h:
+    113-119: one block per VISITED pairing at most, restart at the index it moved at) as "first
+    pairing of every block" found by forward scans; the scan rule, restated here, must give every
+    pairing the block the sequential cursor gives it -- for any pattern of skipped pairings,
+    zero-length blocks and exhausted block lists."""
+    rng = np.random.default_rng(0)
+
+    def sequential(n, counts, skipped):
+        cur, start, out = 0, 0, {}
+        for i in range(n):
+            if skipped[i]:
+                continue
+            if i >= start + counts[cur]:
+                cur += 1
+                if cur >= len(counts):
+                    return None
+                start = i
+            out[i] = cur
+        return out
+
+    def by_bounds(n, counts, skipped):          # horn_block_bounds_kernel + the lookup of horn_cov_kernel
+        nb, start, b = len(counts), 0, 0
+        bounds = [0] + [n] * (nb - 1)
+        while True:
+            s = start + counts[b]
+            if b > 0 and s <= start:
+                s = start + 1
+            found = next((i for i in range(s, n) if not skipped[i]), n)
+            if found >= n:
+                break
+            if b + 1 >= nb:
+                return None
+            b, start = b + 1, found
+            bounds[b] = found
+        out = {}
+        for i in range(n):
+            if not skipped[i]:
+                k = 0
+                while k + 1 < nb and i >= bounds[k + 1]:
+                    k += 1
+                out[i] = k
+        return out
+
+    for _ in range(3000):
+        n, nb = int(rng.integers(1, 60)), int(rng.integers(1, 6))
+        counts = [int(rng.integers(0, 25)) for _ in range(nb)]
+        skipped = rng.random(n) < rng.choice([0.0, 0.2, 0.6])
+        assert sequential(n, counts, skipped) == by_bounds(n, counts, skipped), (n, counts, skipped)

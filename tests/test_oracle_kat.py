@@ -740,3 +740,69 @@ def test_pt2ln_pl_to_pt2pt(oracle):
     # few pairings: at least three are taken, whatever their error
     assert len(oracle.pt2ln_pl_to_pt2pt(pl[:2], ln[:2], T)) == 4
     assert len(oracle.pt2ln_pl_to_pt2pt(None, None, T)) == 0
+
+
+def _visit_correspondences_py(pt, w_pt, thr, blocks, flags_in, cl, cg):
+    """visit_correspondences.h:58-212 for point pairings, statement by statement (incl. the
+    weight-block cursor that only moves on visited pairings, :113-119) -> S, w_sum, flags_out"""
+    n = len(pt)
+    point_weights = list(blocks) if blocks else [(n, 1.0)]
+    cur, cur_start = 0, 0
+    wa = w_pt * (1.0 / (w_pt * n))
+    S, w_sum = np.zeros((3, 3)), 0.0
+    out = []
+    it = iter(sorted(flags_in))
+    nxt = next(it, None)
+    for i in range(n):
+        if nxt is not None and i == nxt:
+            nxt = next(it, None)
+            out.append(i)
+            continue
+        wi = wa
+        if i >= cur_start + point_weights[cur][0]:
+            cur += 1
+            cur_start = i
+        wi *= point_weights[cur][1]
+        bi = np.array([pt["gx"][i], pt["gy"][i], pt["gz"][i]], np.float64) - cg
+        ri = np.array([pt["lx"][i], pt["ly"][i], pt["lz"][i]], np.float64) - cl
+        bn, rn = np.linalg.norm(bi), np.linalg.norm(ri)
+        if bn < 1e-4 or rn < 1e-4:
+            continue
+        if thr is not None and max(bn, rn) / min(bn, rn) > thr:
+            out.append(i)
+            continue
+        w_sum += wi
+        S += wi * np.outer(ri, bi)
+    return S / w_sum, out
+
+
+def test_horn_outliers_shift_the_weight_blocks(oracle):
+    """the reference's block cursor advances only on visited pairings and restarts at the index
+    it was advanced at: with outliers skipped in the second pass the block boundaries move"""
+    gt, pt, _ = horn_scene(oracle, 9, n_pt=300, n_pl=0, noise=0.01, outliers=0)
+    # outliers exactly around the block boundaries 100 and 200, and a zero-length block
+    bad = [98, 99, 100, 101, 199, 200, 250]
+    rng = np.random.default_rng(1)
+    for i in bad:
+        pt["gx"][i], pt["gy"][i], pt["gz"][i] = rng.uniform(20, 30, 3)
+    blocks = [(100, 0.2), (100, 5.0), (0, 50.0), (100, 1.0), (1000, 0.01)]
+    T, rc, fl = oracle.optimal_tf_horn_wp(pt, None, use_scale_outlier_detector=True, scale_outlier_threshold=1.3,
+                                          point_weights=blocks)
+    assert rc == 1 and set(bad) <= set(np.flatnonzero(fl).tolist())
+    L = np.stack([pt["lx"], pt["ly"], pt["lz"]], 1).astype(np.float64)
+    G = np.stack([pt["gx"], pt["gy"], pt["gz"]], 1).astype(np.float64)
+    # pass 1: nobody flagged yet; pass 2: centroids without the flagged ones, they are skipped
+    S1, out1 = _visit_correspondences_py(pt, 1.0, 1.3, blocks, [], L.mean(0), G.mean(0))
+    keep = np.ones(len(pt), bool)
+    keep[out1] = False
+    cl, cg = L[keep].mean(0), G[keep].mean(0)
+    S2, out2 = _visit_correspondences_py(pt, 1.0, 1.3, blocks, out1, cl, cg)
+    assert sorted(out2) == np.flatnonzero(fl).tolist()
+    U, _, Vt = np.linalg.svd(S2.T)
+    R = U @ np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))]) @ Vt
+    assert np.allclose(T[:9].reshape(3, 3), R, atol=1e-9) and np.allclose(T[9:], cg - R @ cl, atol=1e-8)
+    # a plain "block b covers [start_b, start_b + count_b)" reading gives another rotation: the
+    # cursor semantics matter
+    S_plain, _ = _visit_correspondences_py(pt, 1.0, 1.3, None, out1, cl, cg)
+    U, _, Vt = np.linalg.svd(S_plain.T)
+    assert not np.allclose(U @ np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))]) @ Vt, R, atol=1e-9)

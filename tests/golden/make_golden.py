@@ -57,7 +57,49 @@ def main():
     out["pt2pl_pairs"], out["pt2pl_local_idx"], out["pt2pl_potential"] = pl, idx, np.array([pot])
     np.savez_compressed(os.path.join(HERE, "golden_v1.npz"), **out)
     print("wrote golden_v1.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
+    return out
+
+
+def main_v2(v1):
+    """golden_v2.npz: the components of SURVEY.md section 8f on the scenes of v1"""
+    out = {}
+    g, l, T = v1["pt2pl_glob"], v1["pt2pl_local"], orc.pose_from_xyzypr(0.02, 0.01, -0.01, 0.004, 0.0, -0.002)
+    out["pose"] = T
+    # ---- Matcher_Adaptive (plane detection on, two point pairings per local point) -----------------
+    A = dict(confidenceInterval=0.8, firstToSecondDistanceMax=1.5, absoluteMaxSearchDistance=1.0,
+             minimumCorrDist=0.05, enableDetectPlanes=True, maxPt2PtCorrespondences=2, planeSearchPoints=8,
+             planeMinimumFoundPoints=4, planeMinimumDistance=0.10, planeEigenThreshold=0.01)
+    r = orc.match_adaptive(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, **A)
+    out["adaptive_params"] = np.array([A[k] for k in sorted(A)], np.float64)
+    out["adaptive_pt2pt"], out["adaptive_pt2pl"], out["adaptive_pl_idx"] = r["pt2pt"], r["pt2pl"], r["pl_local_idx"]
+    out["adaptive_ci_high"] = np.array([r["ci_high"]])
+    out["adaptive_hist"] = np.concatenate([[r["hist"]["minSq"], r["hist"]["maxSq"], r["hist"]["count"]],
+                                           r["hist"]["bins"]]).astype(np.float64)
+    # ---- Matcher_Points_InlierRatio -------------------------------------------------------------------
+    ir, pot = orc.match_inlier_ratio(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, 0.6)
+    out["inlier_ratio_pairs"] = ir
+    # ---- Solver_Horn: WeightParameters on the adaptive matcher's point pairings (+ 25 gross outliers),
+    #      and the pt2ln_pl_to_pt2pt conversion of its plane pairings -----------------------------------
+    pt = r["pt2pt"].copy()
+    rng = np.random.default_rng(7)
+    bad = rng.choice(len(pt), 25, replace=False)
+    pt["gx"][bad] += rng.uniform(2, 4, 25).astype(np.float32)
+    Th, rc, fl = orc.optimal_tf_horn_wp(pt, None, use_scale_outlier_detector=True, scale_outlier_threshold=1.15,
+                                        point_weights=[(300, 2.0), (len(pt), 0.5)])
+    assert rc == 1
+    out["horn_pairs"], out["horn_pose"], out["horn_outliers"] = pt, Th, np.flatnonzero(fl).astype(np.uint32)
+    out["converted_pairs"] = orc.pt2ln_pl_to_pt2pt(r["pt2pl"], None, T)
+    # ---- covariance() of point + plane pairings ----------------------------------------------------------
+    cov, H, ok = orc.covariance(r["pt2pt"], r["pt2pl"], None, None, T)
+    assert ok
+    out["cov"], out["cov_H"] = cov, H
+    # ---- FilterDecimateVoxels -------------------------------------------------------------------------------
+    for name, method in (("first", 0), ("closest", 1), ("average", 2)):
+        xyz, src = orc.filter_decimate_voxels(g[:, 0], g[:, 1], g[:, 2], 0.5, method)
+        out[f"decimate_{name}_xyz"], out[f"decimate_{name}_src"] = xyz, src
+    np.savez_compressed(os.path.join(HERE, "golden_v2.npz"), **out)
+    print("wrote golden_v2.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
 if __name__ == "__main__":
-    main()
+    main_v2(main())

@@ -20,12 +20,13 @@
 //
 // Interfaces implemented (reference file:line):
 //   Matcher_Points_Base::implMatchOneLayer     Matcher_Points_Base.h:125-128 (private virtual)
-//   Solver::impl_optimal_pose                  Solver.h:100-101
+//   Solver::impl_optimal_pose                  Solver.h:100-101   (Gauss-Newton, Horn)
 //   Matcher::initialize / Solver::initialize   Matcher.h:88, Solver.h:80
 //   registration                               register.cpp:43-69
 #include <mp2p_icp/Matcher_Points_Base.h>
 #include <mp2p_icp/Solver.h>
 #include <mp2p_icp/PairWeights.h>
+#include <mp2p_icp/WeightParameters.h>
 #include <mp2p_icp/robust_kernels.h>
 #include <mp2p_icp/metricmap.h>
 #include <mrpt/core/initializer.h>
@@ -70,6 +71,7 @@ struct Runtime
     // iteration need not upload them again (run_matchers copies Pairings by value,
     // Matcher.cpp:74-77, so a derived container type would not survive)
     mp2p_hip_pairs* dev_pairs = nullptr;
+    mp2p_hip_pairs* conv_pairs = nullptr;  // Solver_Horn: output of pt2ln_pl_to_pt2pt
     size_t          dev_cap_pt = 0, dev_cap_pl = 0;
     size_t          token_n_pt = 0, token_n_pl = 0;
     bool            has_lines_planes = false;
@@ -256,6 +258,60 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base
     }
 };
 
+// Pairings -> the device handle the solvers read.  Point pairings produced by this plugin's matcher
+// in the same ICP iteration are still in HBM (Runtime::token_*): only lists from other matchers
+// are uploaded.
+static mp2p_hip_pairs* pairings_to_device(Runtime& rt, const mp2p_icp::Pairings& pairings)
+{
+    const size_t n1 = pairings.paired_pt2pt.size(), n2 = pairings.paired_pt2pl.size();
+    mp2p_hip_pairs* dp = rt.pairs(std::max<size_t>(n1, 1), n2);
+    const bool resident = n2 == 0 && n1 == rt.token_n_pt && n1 > 0 &&
+                          pairings.paired_pt2pt.front().localIdx == rt.token_first &&
+                          pairings.paired_pt2pt.back().localIdx == rt.token_last;
+    if (!resident)
+    {  // pairings this plugin did not produce (or pt2pl from another matcher): upload them
+        std::vector<mp2p_hip_pair_pt2pl> pl(n2);
+        for (size_t i = 0; i < n2; i++)
+        {
+            const auto& p = pairings.paired_pt2pl[i];
+            for (int k = 0; k < 4; k++) pl[i].plane[k] = p.pl_global.plane.coefs[k];
+            pl[i].centroid[0] = p.pl_global.centroid.x, pl[i].centroid[1] = p.pl_global.centroid.y,
+            pl[i].centroid[2] = p.pl_global.centroid.z;
+            pl[i].pt_local[0] = p.pt_local.x, pl[i].pt_local[1] = p.pt_local.y, pl[i].pt_local[2] = p.pt_local.z;
+            pl[i]._pad = 0;
+        }
+        rt.check(mp2p_hip_pairs_upload(
+            rt.ctx, dp, reinterpret_cast<const mp2p_hip_pair_pt2pt*>(pairings.paired_pt2pt.data()), n1,
+            pl.data(), n2));
+        rt.token_n_pt = 0;
+    }
+
+    {  // paired_pt2ln / paired_pl2pl always come from host matchers: (re)upload, also when empty
+        std::vector<mp2p_hip_pair_pt2ln> ln(pairings.paired_pt2ln.size());
+        for (size_t i = 0; i < ln.size(); i++)
+        {
+            const auto& q = pairings.paired_pt2ln[i];
+            for (int k = 0; k < 3; k++)
+                ln[i].ln_base[k] = q.ln_global.pBase[k], ln[i].ln_director[k] = q.ln_global.director[k],
+                ln[i].pt_local[k] = q.pt_local[k];
+        }
+        std::vector<mp2p_hip_pair_pl2pl> pp(pairings.paired_pl2pl.size());
+        for (size_t i = 0; i < pp.size(); i++)
+        {
+            const auto& q = pairings.paired_pl2pl[i];
+            for (int k = 0; k < 4; k++)
+                pp[i].pl_global[k] = q.p_global.plane.coefs[k], pp[i].pl_local[k] = q.p_local.plane.coefs[k];
+            for (int k = 0; k < 3; k++)
+                pp[i].c_global[k] = q.p_global.centroid[k], pp[i].c_local[k] = q.p_local.centroid[k];
+        }
+        if (!ln.empty() || !pp.empty() || rt.has_lines_planes)
+            rt.check(mp2p_hip_pairs_upload_lines_planes(rt.ctx, dp, ln.data(), ln.size(), pp.data(), pp.size()));
+        rt.has_lines_planes = !ln.empty() || !pp.empty();
+    }
+
+    return dp;
+}
+
 // ================================================================================================
 class Solver_GaussNewton : public mp2p_icp::Solver
 {
@@ -286,51 +342,7 @@ class Solver_GaussNewton : public mp2p_icp::Solver
             THROW_EXCEPTION("HIP Gauss-Newton: paired_ln2ln is not supported");
         auto& rt = Runtime::get();
 
-        const size_t n1 = pairings.paired_pt2pt.size(), n2 = pairings.paired_pt2pl.size();
-        mp2p_hip_pairs* dp = rt.pairs(std::max<size_t>(n1, 1), n2);
-        const bool resident = n2 == 0 && n1 == rt.token_n_pt && n1 > 0 &&
-                              pairings.paired_pt2pt.front().localIdx == rt.token_first &&
-                              pairings.paired_pt2pt.back().localIdx == rt.token_last;
-        if (!resident)
-        {  // pairings this plugin did not produce (or pt2pl from another matcher): upload them
-            std::vector<mp2p_hip_pair_pt2pl> pl(n2);
-            for (size_t i = 0; i < n2; i++)
-            {
-                const auto& p = pairings.paired_pt2pl[i];
-                for (int k = 0; k < 4; k++) pl[i].plane[k] = p.pl_global.plane.coefs[k];
-                pl[i].centroid[0] = p.pl_global.centroid.x, pl[i].centroid[1] = p.pl_global.centroid.y,
-                pl[i].centroid[2] = p.pl_global.centroid.z;
-                pl[i].pt_local[0] = p.pt_local.x, pl[i].pt_local[1] = p.pt_local.y, pl[i].pt_local[2] = p.pt_local.z;
-                pl[i]._pad = 0;
-            }
-            rt.check(mp2p_hip_pairs_upload(
-                rt.ctx, dp, reinterpret_cast<const mp2p_hip_pair_pt2pt*>(pairings.paired_pt2pt.data()), n1,
-                pl.data(), n2));
-            rt.token_n_pt = 0;
-        }
-
-        {  // paired_pt2ln / paired_pl2pl always come from host matchers: (re)upload, also when empty
-            std::vector<mp2p_hip_pair_pt2ln> ln(pairings.paired_pt2ln.size());
-            for (size_t i = 0; i < ln.size(); i++)
-            {
-                const auto& q = pairings.paired_pt2ln[i];
-                for (int k = 0; k < 3; k++)
-                    ln[i].ln_base[k] = q.ln_global.pBase[k], ln[i].ln_director[k] = q.ln_global.director[k],
-                    ln[i].pt_local[k] = q.pt_local[k];
-            }
-            std::vector<mp2p_hip_pair_pl2pl> pp(pairings.paired_pl2pl.size());
-            for (size_t i = 0; i < pp.size(); i++)
-            {
-                const auto& q = pairings.paired_pl2pl[i];
-                for (int k = 0; k < 4; k++)
-                    pp[i].pl_global[k] = q.p_global.plane.coefs[k], pp[i].pl_local[k] = q.p_local.plane.coefs[k];
-                for (int k = 0; k < 3; k++)
-                    pp[i].c_global[k] = q.p_global.centroid[k], pp[i].c_local[k] = q.p_local.centroid[k];
-            }
-            if (!ln.empty() || !pp.empty() || rt.has_lines_planes)
-                rt.check(mp2p_hip_pairs_upload_lines_planes(rt.ctx, dp, ln.data(), ln.size(), pp.data(), pp.size()));
-            rt.has_lines_planes = !ln.empty() || !pp.empty();
-        }
+        mp2p_hip_pairs* dp = pairings_to_device(rt, pairings);
 
         mp2p_hip_gn_params p;
         std::memset(&p, 0, sizeof(p));
@@ -370,7 +382,91 @@ class Solver_GaussNewton : public mp2p_icp::Solver
     }
 };
 
+// ================================================================================================
+// Solver_Horn (Solver_Horn.cpp:33-61): WeightParameters from `pairingsWeightParameters`; pairings
+// holding point-to-plane / point-to-line entries go through pt2ln_pl_to_pt2pt first.
+class Solver_Horn : public mp2p_icp::Solver
+{
+    DEFINE_MRPT_OBJECT(Solver_Horn, mp2p_icp_hip)
+   public:
+    mp2p_icp::WeightParameters pairingsWeightParameters;
+
+    void initialize(const mrpt::containers::yaml& params) override
+    {
+        Solver::initialize(params);
+        if (params.has("pairingsWeightParameters"))
+            pairingsWeightParameters.load_from(params["pairingsWeightParameters"]);  // Solver_Horn.cpp:37-38
+    }
+
+   protected:
+    bool impl_optimal_pose(const mp2p_icp::Pairings& pairings, mp2p_icp::OptimalTF_Result& out,
+                           const mp2p_icp::SolverContext& sc) const override
+    {
+        out = mp2p_icp::OptimalTF_Result();
+        if (!pairings.paired_ln2ln.empty()) THROW_EXCEPTION("HIP Horn: paired_ln2ln is not supported");
+        auto&                 rt  = Runtime::get();
+        const mp2p_hip_pairs* eff = pairings_to_device(rt, pairings);
+        const auto&           wp  = pairingsWeightParameters;
+        auto fill_pose = [](const mrpt::poses::CPose3D& P, double T[12])
+        {
+            const auto& R = P.getRotationMatrix();
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) T[i * 3 + j] = R(i, j);
+            T[9] = P.x(), T[10] = P.y(), T[11] = P.z();
+        };
+        const bool converted = !pairings.paired_pt2ln.empty() || !pairings.paired_pt2pl.empty();
+        if (converted)
+        {  // Solver_Horn.cpp:51-55: a fresh Pairings with the converted point pairings only
+            ASSERT_(sc.guessRelativePose.has_value());
+            const size_t cap = pairings.paired_pt2ln.size() + pairings.paired_pt2pl.size();
+            if (!rt.conv_pairs) rt.check(mp2p_hip_pairs_create(rt.ctx, cap, 0, &rt.conv_pairs));
+            else rt.check(mp2p_hip_pairs_reserve(rt.ctx, rt.conv_pairs, cap, 0));
+            rt.check(mp2p_hip_pairs_clear(rt.ctx, rt.conv_pairs));
+            double T[12];
+            fill_pose(mrpt::poses::CPose3D(sc.guessRelativePose.value()), T);
+            rt.check(mp2p_hip_pairs_pt2ln_pl_to_pt2pt(rt.ctx, eff, T, rt.conv_pairs));
+            eff = rt.conv_pairs;
+        }
+        mp2p_hip_horn_params w;
+        std::memset(&w, 0, sizeof(w));
+        w.use_scale_outlier_detector = wp.use_scale_outlier_detector;
+        w.scale_outlier_threshold    = wp.scale_outlier_threshold;
+        w.w_pt2pt = wp.pair_weights.pt2pt, w.w_ln2ln = wp.pair_weights.ln2ln, w.w_pl2pl = wp.pair_weights.pl2pl;
+        w.robust_kernel       = static_cast<int32_t>(wp.robust_kernel);
+        w.robust_kernel_param = wp.robust_kernel_param;
+        if (wp.currentEstimateForRobust.has_value())
+        {
+            w.has_current_estimate = 1;
+            fill_pose(*wp.currentEstimateForRobust, w.current_estimate);
+        }
+        std::vector<size_t> blk_n;
+        std::vector<double> blk_w;
+        if (!converted)  // the converted list carries no point_weights (pt2ln_pl_to_pt2pt.cpp:49)
+            for (const auto& b : pairings.point_weights) blk_n.push_back(b.first), blk_w.push_back(b.second);
+        w.n_weight_blocks    = static_cast<uint32_t>(blk_n.size());
+        w.weight_block_count = blk_n.data(), w.weight_block_w = blk_w.data();
+        mp2p_hip_horn_result res;
+        rt.check(mp2p_hip_horn_solve_wp(rt.ctx, eff, &w, &res));
+        if (!res.solved) return false;  // optimal_tf_horn.cpp:98
+        mrpt::math::CMatrixDouble33 R;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) R(i, j) = res.pose[i * 3 + j];
+        out.optimalPose = mrpt::poses::CPose3D(R, mrpt::math::TPoint3D(res.pose[9], res.pose[10], res.pose[11]));
+        if (res.n_outliers)
+        {  // OptimalTF_Result::outliers (OutlierIndices::point2point)
+            uint64_t n64 = 0;
+            rt.check(mp2p_hip_pairs_counts(rt.ctx, eff, &n64, nullptr, nullptr));
+            std::vector<uint8_t> flags(static_cast<size_t>(n64));
+            rt.check(mp2p_hip_horn_outlier_flags(rt.ctx, flags.data(), flags.size()));
+            for (size_t i = 0; i < flags.size(); i++)
+                if (flags[i]) out.outliers.point2point.push_back(i);
+        }
+        return true;
+    }
+};
+
 IMPLEMENTS_MRPT_OBJECT(Matcher_Points_DistanceThreshold, mp2p_icp::Matcher, mp2p_icp_hip)
+IMPLEMENTS_MRPT_OBJECT(Solver_Horn, mp2p_icp::Solver, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(Solver_GaussNewton, mp2p_icp::Solver, mp2p_icp_hip)
 
 }  // namespace mp2p_icp_hip
@@ -380,4 +476,5 @@ MRPT_INITIALIZER(register_mp2p_icp_hip)
     using mrpt::rtti::registerClass;
     registerClass(CLASS_ID(mp2p_icp_hip::Matcher_Points_DistanceThreshold));
     registerClass(CLASS_ID(mp2p_icp_hip::Solver_GaussNewton));
+    registerClass(CLASS_ID(mp2p_icp_hip::Solver_Horn));
 }

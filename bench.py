@@ -219,19 +219,22 @@ def main():
     for _ in range(args.warmup):
         one_step()
     touched, cand, passes, pair_counts, maxcand, maxpass = [], [], [], [], [], []
-    nn_tile_ms, nn_single_ms, cp_ms, gn_ms, nn_ms_replay = [], [], [], [], []
+    nn_tile_ms, nn_single_ms, cp_ms, gn_ms, nn_ms_replay, nn_lane_ms = [], [], [], [], [], []
+    lane_stats = []
     ctx.set_profiling(1)
     for _ in range(args.steps):
         one_step()
         st = ctx.stats()
         nn_ms_replay.append(st["ms_nn"])
         nn_tile_ms.append(st["ms_nn_tile"])
+        nn_lane_ms.append(st["ms_nn_lane"])
         nn_single_ms.append(st["ms_nn_single"])
         cp_ms.append(st["ms_compact"])
         gn_ms.append(st["ms_gn"])
         pair_counts.append(pairs.counts()[0])
     ctx.set_profiling(0)
-    log(f"[bench r{rank}] per-step kernel ms (replay; chain position = (warmup + i) % {CYCLE}): tile="
+    log(f"[bench r{rank}] per-step kernel ms (replay; chain position = (warmup + i) % {CYCLE}): lane="
+        f"{[round(v, 3) for v in nn_lane_ms]} tile="
         f"{[round(v, 3) for v in nn_tile_ms]} single={[round(v, 3) for v in nn_single_ms]} "
         f"gn={[round(v, 3) for v in gn_ms]}; search in the timed loop: {[round(v, 3) for v in nn_ms]}")
     state = {"pose": d["T_init"].copy(), "s": 0}
@@ -246,10 +249,15 @@ def main():
         passes.append(st["nn_passes"] / max(1, st["nn_tiles"]))
         maxcand.append(st["nn_max_candidates_one_tile"])
         maxpass.append(st["nn_max_passes_one_tile"])
+        lane_stats.append((st["nn_lane_searched"], st["nn_lane_pending"], st["nn_lane_skipped"],
+                           st["nn_lane_candidates"], st["nn_lane_voxels"]))
         _e = amd.se3.log(amd.se3.inverse_compose(state["pose"], d["T_gt"]))
         log(f"[bench r{rank}] chain step {state['s']}: err=({np.linalg.norm(_e[:3]):.3f} m, "
             f"{np.degrees(np.linalg.norm(_e[3:])):.2f} deg) pairs={pairs.counts()[0]} "
-            f"deferred={st['nn_coop_passes']} single_cand/q="
+            f"lane: searched={st['nn_lane_searched']} skipped={st['nn_lane_skipped']} pending={st['nn_lane_pending']} "
+            f"cand/q={st['nn_lane_candidates'] / max(1, st['nn_lane_searched']):.1f} "
+            f"vox/q={st['nn_lane_voxels'] / max(1, st['nn_lane_searched']):.1f}; "
+            f"deferred={st['nn_single_queries']} single_cand/q="
             f"{st['nn_single_candidates'] / max(1, st['nn_single_queries']):.0f} "
             f"tile_cand/tile={st['nn_candidates_tested'] / max(1, st['nn_tiles']):.0f} "
             f"passes/tile={st['nn_passes'] / max(1, st['nn_tiles']):.2f}")
@@ -309,11 +317,15 @@ def main():
         "kernel_ms": {"note": "nn_search: hipEvents in the timed loop; the others: same chain replayed "
                               "with an event around every stage",
                       "nn_search": nn_ms_avg, "nn_search_replay": float(np.mean(nn_ms_replay)),
+                      "nn_lane_kernel": float(np.mean(nn_lane_ms)),
                       "nn_tile_kernel": float(np.mean(nn_tile_ms)),
                       "nn_single_kernel": float(np.mean(nn_single_ms)),
                       "compact": float(np.mean(cp_ms)),
                       "gn_solve_all_inner": float(np.mean(gn_ms))},
-        "nn_stats": {"avg_passes_per_tile": float(np.mean(passes)),
+        "nn_stats": {"lane_kernel_searched_frac": float(np.mean([a[0] for a in lane_stats])) / n_l,
+                     "lane_kernel_pending_frac": float(np.mean([a[1] for a in lane_stats])) / n_l,
+                     "lane_kernel_finished_without_search_frac": float(np.mean([a[2] for a in lane_stats])) / n_l,
+                     "avg_passes_per_tile": float(np.mean(passes)),
                      "candidates_tested_per_query": float(np.mean(cand)) / n_l,
                      "global_points_touched": float(np.mean(touched)),
                      "max_candidates_one_tile": int(np.max(maxcand)),
@@ -324,7 +336,7 @@ def main():
                              "rot_rad": float(np.linalg.norm(final_err[3:]))},
         "roofline": {
             "bound": "hbm",
-            "kernel": "nn_tile_kernel + nn_single_kernel (K1+K3: transform + exact NN search)",
+            "kernel": "nn_lane_kernel + nn_tile_kernel + nn_single_kernel (K1+K3: transform + exact NN search)",
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": nn_ms_avg,
             "traffic": None,

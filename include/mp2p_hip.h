@@ -447,7 +447,7 @@ int mp2p_hip_pairs_pt2ln_pl_to_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* in
 typedef struct
 {
     double   ms_nn;      /* K1+K3 (transform + search + claims), last match call */
-    double   ms_nn_tile, ms_nn_single; /* its two kernels */
+    double   ms_nn_tile, ms_nn_single; /* the tile kernel and the one-query-per-wave kernel */
     double   ms_compact; /* K4 */
     double   ms_gn;      /* all inner iterations of the last gn_solve */
     uint64_t nn_tiles, nn_passes, nn_cells_visited, nn_candidates_tested, nn_points_staged;
@@ -460,6 +460,11 @@ typedef struct
     uint64_t nn_tile_ticks_hist[24]; /* log2 bins */
     uint64_t nn_single_ticks_sum, nn_single_ticks_max; /* 100 MHz ticks per deferred query */
     uint64_t nn_single_max_passes, nn_single_max_cells;
+    /* one-query-per-lane kernel (runs first): its time, the queries it searched itself, the candidates
+     * and voxels they cost, the queries it handed on to the tile kernel, and those a warm start
+     * finished without any search */
+    double   ms_nn_lane;
+    uint64_t nn_lane_searched, nn_lane_candidates, nn_lane_voxels, nn_lane_pending, nn_lane_skipped;
 } mp2p_hip_stats;
 /* ---- mp2p_icp::covariance (mp2p_icp/src/covariance.cpp:29-141, ICP.cpp:334-337):
  *      H = J^T J of the stacked error vector w.r.t. (x, y, z, yaw, pitch, roll), J by central

@@ -142,7 +142,10 @@ class Stats(C.Structure):
                 ("nn_single_candidates", C.c_uint64), ("nn_single_max_candidates", C.c_uint64),
                 ("nn_tile_ticks_hist", C.c_uint64 * 24),
                 ("nn_single_ticks_sum", C.c_uint64), ("nn_single_ticks_max", C.c_uint64),
-                ("nn_single_max_passes", C.c_uint64), ("nn_single_max_cells", C.c_uint64)]
+                ("nn_single_max_passes", C.c_uint64), ("nn_single_max_cells", C.c_uint64),
+                ("ms_nn_lane", C.c_double), ("nn_lane_searched", C.c_uint64),
+                ("nn_lane_candidates", C.c_uint64), ("nn_lane_voxels", C.c_uint64),
+                ("nn_lane_pending", C.c_uint64), ("nn_lane_skipped", C.c_uint64)]
 
 
 _P = C.c_void_p

@@ -36,6 +36,35 @@ int set_err(mp2p_hip_ctx* ctx, int code, const char* fmt, ...)
     return code;
 }
 
+// MP2P_HIP_TUNE="lane_cells=3,tile_cand_cap=4096,claim_dedup=0": measurement knobs (common.hpp)
+static void parse_tune(Tune& t)
+{
+    const char* e = getenv("MP2P_HIP_TUNE");
+    if (!e) return;
+    std::string s(e);
+    size_t      i = 0;
+    while (i < s.size())
+    {
+        size_t j = s.find(',', i);
+        if (j == std::string::npos) j = s.size();
+        const std::string kv = s.substr(i, j - i);
+        const size_t      q  = kv.find('=');
+        if (q != std::string::npos)
+        {
+            const std::string k = kv.substr(0, q);
+            const long        v = strtol(kv.c_str() + q + 1, nullptr, 10);
+            if (k == "lane_cells") t.lane_cells = (uint32_t)v;
+            else if (k == "tile_cand_cap") t.tile_cand_cap = (uint32_t)v;
+            else if (k == "claim_dedup") t.claim_dedup = (int)v;
+            else if (k == "claim_peek") t.claim_peek = (int)v;
+            else if (k == "gn_ticket") t.gn_ticket = (int)v;
+            else if (k == "compact_fused") t.compact_fused = (int)v;
+            else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
+        }
+        i = j + 1;
+    }
+}
+
 static int upload3(mp2p_hip_ctx* ctx, const float* x, const float* y, const float* z, size_t n,
                    DevBuf<float>& dx, DevBuf<float>& dy, DevBuf<float>& dz)
 {
@@ -116,6 +145,7 @@ int mp2p_hip_ctx_create(int device_id, void* hip_stream, mp2p_hip_ctx** out)
             return set_err(nullptr, MP2P_HIP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
         }
     }
+    parse_tune(ctx->tune);
     *out = ctx;
     return MP2P_HIP_OK;
 }
@@ -129,7 +159,8 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release();
     ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release();
     ctx->aos_stage.release(), ctx->pl_slots.release();
-    ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release(), ctx->hint.release(), ctx->exch.release(), ctx->claim_list.release();
+    ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release(), ctx->exch.release(), ctx->claim_list.release();
+    ctx->pend.release(), ctx->pend_spos.release(), ctx->q_counters.release(), ctx->nn_rec.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -371,8 +402,7 @@ int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
     MP2P_REQUIRE(ctx, out && out->ctx == ctx, "bad Pairings handle");
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     if (map->n == 0 || cloud->n == 0)  // potential_pairings is added BEFORE the early-out (:64-67)
-        return launch_add_potential(ctx, out, (unsigned long long)(cloud->n_visit ? cloud->n_visit : cloud->n) *
-                                                  prm->pairingsPerPoint);
+        return launch_add_potential(ctx, out, (unsigned long long)cloud->n * prm->pairingsPerPoint);
     rc = launch_compact_pt2pt(ctx, map, cloud, prm, ms, out);
     if (!rc && ctx->profiling)
     {
@@ -573,7 +603,7 @@ int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     MP2P_REQUIRE(ctx, prm->knn >= 3 && prm->knn <= 16, "knn must be in [3,16]");
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     if (map->n == 0 || cloud->n == 0)  // Matcher_Point2Plane.cpp:54-57
-        return launch_add_potential(ctx, out, (unsigned long long)(cloud->n_visit ? cloud->n_visit : cloud->n));
+        return launch_add_potential(ctx, out, (unsigned long long)cloud->n);
     const int rc = launch_match_pt2pl(ctx, map, cloud, pose, prm, ms, out);
     if (!rc && ctx->profiling)
     {
@@ -793,9 +823,15 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
         ctx->stats.ms_nn = ms_nn;
         if (ctx->pending_match != 3)
         {
-            float ms_tile = 0;
+            float ms_tile = 0, ms_lane = 0;
             MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_tile, ctx->ev[0], ctx->ev[6]));
-            ctx->stats.ms_nn_tile = ms_tile, ctx->stats.ms_nn_single = ms_nn - ms_tile;
+            ctx->stats.ms_nn_single = ms_nn - ms_tile;
+            if (ctx->pending_lane)
+            {
+                MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_lane, ctx->ev[0], ctx->ev[7]));
+                ms_tile -= ms_lane;
+            }
+            ctx->stats.ms_nn_tile = ms_tile, ctx->stats.ms_nn_lane = ms_lane;
             MP2P_TRY_HIP(ctx, hipEventElapsedTime(&ms_cp, ctx->ev[2], ctx->ev[3]));
             ctx->stats.ms_compact = ms_cp;
         }
@@ -810,6 +846,8 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
             ctx->stats.nn_single_max_candidates = c[14];
             ctx->stats.nn_single_ticks_sum = c[40], ctx->stats.nn_single_ticks_max = c[15];
             ctx->stats.nn_single_max_passes = c[41], ctx->stats.nn_single_max_cells = c[42];
+            ctx->stats.nn_lane_searched = c[44], ctx->stats.nn_lane_candidates = c[45];
+            ctx->stats.nn_lane_voxels = c[46], ctx->stats.nn_lane_pending = c[47], ctx->stats.nn_lane_skipped = c[48];
             for (int i = 0; i < 24; i++) ctx->stats.nn_tile_ticks_hist[i] = c[16 + i];
             ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1];
             ctx->stats.nn_cells_visited = c[2], ctx->stats.nn_candidates_tested = c[3];

@@ -94,6 +94,18 @@ struct DevBuf
     }
 };
 
+// knobs read once per context from the environment variable MP2P_HIP_TUNE ("name=value,..."):
+// for measurements only, every setting computes the same results
+struct Tune
+{
+    uint32_t lane_cells    = 4;     // widest cube (level-0 voxels per axis) the one-query-per-lane kernel takes; 0 = off
+    uint32_t tile_cand_cap = 6144;  // staged candidates after which a tile hands its pending queries on
+    int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
+    int      claim_peek    = 1;     // plain look at the claim word before the atomic
+    int      gn_ticket     = 1;     // Gauss-Newton: last block reduces and steps (one launch per inner iteration)
+    int      compact_fused = 1;     // compaction: bounding-box reduction folded in
+};
+
 struct GnState
 {
     const mp2p_hip_pairs* pairs = nullptr;
@@ -113,8 +125,8 @@ struct mp2p_hip_ctx
                                 // 3 only the two events around the search kernels, 4 = 3 + a
                                 // {start, end} timestamp per workgroup of the search kernels
     bool        prof_all() const { return profiling == 1 || profiling == 2; }
-    hipEvent_t  ev[7]     = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int         pending_match = 0, pending_gn = 0;
+    hipEvent_t  ev[8]     = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int         pending_match = 0, pending_gn = 0, pending_lane = 0;
     size_t      pending_map_n = 0;
     mp2p_hip_stats stats{};
     uint64_t    epoch = 0;  // claim epoch (see nn_query.hip)
@@ -134,9 +146,6 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<double>             gn_state;     // pose(12) H(36) g(6) cost(1) iters(1) done(1)
     mp2p::DevBuf<unsigned char>      aos_stage;    // download staging
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
-    mp2p::DevBuf<uint32_t>           tile_cost;    // duration of every tile in the last search (ticks)
-    mp2p::DevBuf<uint32_t>           tile_order;   // tiles by decreasing previous duration
-    uint32_t                         tile_cost_tiles = 0, tile_cost_q = 0;
     mp2p::DevBuf<unsigned long long> timeline;     // profiling level 4: {start, end} ticks per workgroup
     size_t                           timeline_tiles = 0, timeline_singles = 0;
     mp2p::DevBuf<unsigned char>      horn_flags;   // Horn: scale-outlier flag per point pairing
@@ -146,9 +155,12 @@ struct mp2p_hip_ctx
     uint32_t                         ad_knn   = 0;       //   lists held in nn_spos / nn_d2: neighbours per point,
     const void*                      ad_cloud = nullptr; //   and the handles they were searched for
     const void*                      ad_map   = nullptr;
-    mp2p::DevBuf<uint4>              work;         // deferred queries of the NN search
-    mp2p::DevBuf<uint32_t>           work_spos;    //   (+ counter in the last word)
-    mp2p::DevBuf<uint2>              hint;         // warm start: previous NN + distance bound per local point
+    mp2p::DevBuf<uint4>              nn_rec;       // [n_local] result + warm-start records of the pt2pt search
+                                                   // (Morton order of the local layer; see nn_query.hip)
+    mp2p::DevBuf<uint4>              work, pend;   // deferred / pending queries of the NN search
+    mp2p::DevBuf<uint32_t>           work_spos, pend_spos;
+    mp2p::DevBuf<uint32_t>           q_counters;   //   {#pending, #deferred}
+    mp2p::Tune                       tune;         // MP2P_HIP_TUNE (experiments; defaults otherwise)
     double                           hint_pose[12] = {};
     const void*                      hint_map   = nullptr;
     const void*                      hint_cloud = nullptr;

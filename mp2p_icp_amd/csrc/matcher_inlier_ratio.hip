@@ -78,6 +78,8 @@ int launch_match_inlier_ratio(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const 
     sp.bounding_box_intersection_check_epsilon = prm->bounding_box_intersection_check_epsilon;
     int rc = launch_nn_pt2pt(ctx, map, cloud, pose, &sp, ms);
     if (rc) return rc;
+    rc = launch_unpack_rec(ctx, cloud->n);  // the keys below read the plain [n_l] arrays
+    if (rc) return rc;
 
     // 2. sort the found points by (d2, later insertion first)
     const size_t n_visit = cloud->n_visit ? cloud->n_visit : cloud->n;

@@ -679,6 +679,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
         a.dbg = ctx->counters.p;
     }
 
+    ctx->pending_lane = 0;
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     const uint32_t K = prm->knn;
     if (K <= 5) launch_k<5>(a, n_tiles, ctx->stream);
@@ -710,7 +711,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     hipLaunchKernelGGL(pl_count_kernel, dim3(n_blocks), dim3(PC_THREADS), 0, ctx->stream, c);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream,
                        ctx->block_counts.p, n_blocks, out->counts.p, c.cap,
-                       (unsigned long long)n_slots, 1);
+                       (unsigned long long)n_l /* :54: pcLocal.size(), the whole layer */, 1);
     hipLaunchKernelGGL(pl_write_kernel, dim3(n_blocks), dim3(PC_THREADS), 0, ctx->stream, c);
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     MP2P_TRY_HIP(ctx, hipGetLastError());
@@ -754,6 +755,7 @@ int launch_nn_pt2pt_knn(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_h
     a.claim_hi     = (~(unsigned long long)ctx->epoch) << 32;
     a.local_offset = prm->local_index_offset;
     a.out_spos = ctx->nn_spos.p, a.out_d2 = ctx->nn_d2.p, a.tile_bbox = ctx->tile_bbox.p;
+    ctx->pending_lane = 0;
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (K <= 5) launch_knn_k<5>(a, n_tiles, ctx->stream);
     else if (K <= 8) launch_knn_k<8>(a, n_tiles, ctx->stream);

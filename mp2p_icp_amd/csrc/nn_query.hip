@@ -6,16 +6,24 @@
 //   the threshold rule                   :252-259
 //   the "global point already paired"    :94-121 (claims; resolved in pairs.hip)
 //
-// Two kernels, both one wave64 per workgroup:
+// Three kernels, all one wave64 per workgroup; a query is finished by the first one that can:
 //
-//  nn_tile_kernel  -- a TILE of Q Morton-consecutive queries per wave.  lane = (query slot,
-//     candidate slice).  Every lane keeps its query in registers; the wave stages the points of
-//     all voxels overlapping the search box of the current GROUP of queries into LDS (SoA) with
-//     coalesced 16-byte loads, then every lane scans the staged bucket against its own query,
-//     8 candidates per step (ds_read_b128 broadcasts).  Each HBM/L2 byte is fetched once per
-//     tile and reused by up to 64 queries.  Queries that are spatially isolated inside their
-//     tile (sparse far-range returns, tiles straddling a jump of the Morton curve) would make
-//     the shared box dwarf their search balls; they are DEFERRED to
+//  nn_lane_kernel  -- ONE QUERY PER LANE, no LDS staging, no wave-level coordination.  The lane
+//     transforms its point (K1), reads its warm-start record, and -- when the cube its search
+//     radius spans is at most 4 level-0 voxels per axis (the normal case from the second ICP
+//     iteration on: the radius is the distance to the previous nearest neighbour) -- builds the
+//     64-bit occupancy mask of that cube from the <= 8 bitmap bricks it overlaps, then walks the
+//     occupied voxels inside the ball: one hash probe per voxel, 16-byte point loads, 4 in flight.
+//     Registers stay below 64 -> 8 waves per SIMD hide the dependent loads (bitmap -> probe ->
+//     points) that bound the tile kernel.  Queries it cannot conclude (radius too wide, nothing
+//     within the first radius of a cold start) are appended to the PENDING list with their state.
+//
+//  nn_tile_kernel  -- a TILE of Q consecutive PENDING queries per wave.  lane = (query slot,
+//     candidate slice).  The wave stages the points of all voxels overlapping the search box of
+//     the current GROUP of queries into LDS (SoA) with coalesced 16-byte loads, then every lane
+//     scans the staged bucket against its own query, 8 candidates per step (ds_read_b128
+//     broadcasts).  Queries that are spatially isolated inside their tile, whose radius outgrows
+//     the voxels, or whose tile has already staged more than its budget are DEFERRED to
 //
 //  nn_single_kernel -- one query per wave: the 64 lanes split the candidates (one coalesced
 //     16-byte load each, no LDS staging), and a wave arg-min merges them.  Deferred queries
@@ -27,12 +35,21 @@
 // reached r_max = sqrt(threshold rule), beyond which the reference discards the pair anyway
 // (so bounding the unbounded nn_single_search there is result-equivalent).  Otherwise the
 // radius grows (to the best distance found, else x2) and the search repeats at a coarser level.
+//
+// Output: one 16-byte record per query {sorted position of the nearest neighbour, d2, lower
+// bound^2 for the next call's warm start, accepted flag}, in the Morton order of the local layer
+// (one aligned store per query; it doubles as the warm-start record of the next call).
+// Claims: atomicMin(claim[spos], epoch | visit rank) -- a device-scope atomic is a 64-byte
+// memory-side transaction on this part, and Morton-neighbouring queries mostly fight over the
+// same global point, so the wave first resolves its own minimum per distinct global point in an
+// LDS table and only the winner (after a plain look at the current claim) issues the atomic.
 #include "device_utils.hpp"
 
 namespace mp2p
 {
 constexpr int NN_CAP      = 256;  // staged candidates per round (LDS: 5 x 1 KB)
 constexpr int NN_COOP_MAX = 4;    // groups of up to this many queries are deferred
+constexpr int NN_CLAIM_SLOTS = 128;  // in-wave claim table (LDS)
 
 struct NNArgs
 {
@@ -46,36 +63,36 @@ struct NNArgs
     float         r_defer;           // radius beyond which a query leaves its tile
     uint32_t      cell_budget;       // voxels of a search box per pass
     uint32_t      brick_budget;      // 4x4x4 bricks per pass of the one-query-per-wave kernel
+    uint32_t      lane_cells;        // widest cube (level-0 voxels per axis, <= 4) a lane searches itself; 0 = never
+    uint32_t      tile_cand_cap;     // staged candidates after which a tile hands its pending queries on
+    int           claim_dedup, claim_peek;
     const unsigned char* local_taken;   // by original local index, or null
     const unsigned char* global_taken;  // by original global index, or null
     unsigned long long*  claims;        // by sorted global position, or null
     unsigned long long   claim_hi;      // (~epoch) << 32
     unsigned long long   local_offset;  // whole-layer index of this rank's first local point
-    uint32_t*            out_spos;      // [n_l] in the order of lpts (coalesced; pairs.hip maps back)
-    float*               out_d2;
-    float*               tile_bbox;  // [n_tiles][6]
-    uint4*               work;       // deferred queries {sorted idx, r, best_d2, best_idx}
-    uint32_t*            work_spos;  //   + best_spos
-    uint32_t*            work_count;
-    // warm start, [n_l] by original local index: {sorted position of the nearest neighbour found by
-    // the previous call on the same (map, cloud) pair or NONE, lower bound on the SQUARED distance
-    // to every map point at that call's pose}, in the order of lpts; read at entry, rewritten at exit
-    uint2*               hint;
+    // result + warm start, [n_l] in the order of lpts: {sorted position of the nearest neighbour
+    // (NONE: none found), d2, lower bound on the SQUARED distance to every map point at this call's
+    // pose, accepted (passes the threshold and is not pre-taken)}; read at entry when use_hint
+    uint4*               rec;
+    float*               tile_bbox;  // [n_waves of the lane kernel][6]
+    // pending queries (lane kernel -> tile kernel) and deferred queries (-> one-query-per-wave
+    // kernel): {sorted local idx, r, best_d2, best_idx} + best_spos; counters[0] = #pending,
+    // counters[1] = #deferred
+    uint4*               pend;
+    uint32_t*            pend_spos;
+    uint4*               work;
+    uint32_t*            work_spos;
+    uint32_t*            q_counters;
     const uint32_t*      rank;  // visit rank per original local index (NONE = not visited) or null
     int                  use_hint;
     PoseRt               prev_pose;
     unsigned long long*  counters;  // profiling, or null
     unsigned char*       touched;   // profiling: [n_g] by sorted position, or null
-    // profiling level 4: {start, end} 100 MHz ticks of every workgroup of the two search kernels
-    // ([n_tiles] then [single blocks]); the plain kernels only pay a uniform null test for it
+    // profiling level 4: {start, end} 100 MHz ticks of every workgroup of the tile and one-query
+    // kernels ([n_tiles] then [single blocks]); the plain kernels only pay a uniform null test
     unsigned long long*  timeline;
     uint32_t             timeline_single_base;
-    // launch order: tiles are dispatched in blockIdx order and a late straggler leaves the chip
-    // idle behind it, so the tiles that took longest in the previous call (same map, same cloud)
-    // go first.  tile_cost[tile] = this call's duration in 100 MHz ticks (written at exit);
-    // tile_order[blockIdx.x] = tile, or null (cold call: identity)
-    uint32_t*            tile_cost;
-    const uint32_t*      tile_order;
 };
 
 // ---- geometry of one search pass (all values wave-uniform) -----------------------------------
@@ -196,24 +213,73 @@ __device__ __forceinline__ bool is_final(float r, float rmax, float best_d2, flo
     return r >= rmax || (gr > 0.f && best_d2 < gr * gr);
 }
 
-__device__ __forceinline__ void emit_result(const NNArgs& a, uint32_t qi, uint32_t orig, bool active, float thr,
-                                            float best_d2, uint32_t best_idx, uint32_t best_spos,
-                                            float lb2_keep = 0.f)
+// one claim: a plain look first (a value of this epoch that is already lower makes the atomic
+// pointless; a stale value can only be higher, so nothing is skipped wrongly), then the atomic
+__device__ __forceinline__ void claim_global(const NNArgs& a, uint32_t spos, uint32_t rank32)
 {
-    bool acc = active && best_idx != NONE_U32 && best_d2 < thr;  // :259
-    if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;  // :98-101
-    a.out_spos[qi] = acc ? best_spos : NONE_U32;
-    a.out_d2[qi]   = best_d2;
-    // next call's warm start: the raw nearest neighbour (even if rejected) and what this search
-    // proved: no map point is nearer than min(best, threshold) (every point that could pass the
-    // threshold was examined), or than the bound that let the search be skipped
-    const float lb2 = active ? fmaxf(fminf(best_d2, thr), lb2_keep) : 0.f;
-    a.hint[qi]      = make_uint2(best_spos, __float_as_uint(lb2));
-    if (acc && a.claims)
+    const unsigned long long val = a.claim_hi | (unsigned long long)rank32;
+    if (a.claim_peek && a.claims[spos] <= val) return;
+    atomicMin(&a.claims[spos], val);
+}
+
+// Result records + claims of one wave (ONE wave per workgroup: the barriers are wave-local).
+// do_emit: this lane writes the record of query qi.  s_claim: NN_CLAIM_SLOTS words of LDS.
+__device__ __forceinline__ void emit_wave(const NNArgs& a, unsigned long long* s_claim, int lane, bool do_emit,
+                                          uint32_t qi, uint32_t orig, bool active, float thr, float best_d2,
+                                          uint32_t best_idx, uint32_t best_spos, float lb2_keep)
+{
+    bool acc = do_emit && active && best_idx != NONE_U32 && best_d2 < thr;  // :259
+    if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;     // :98-101
+    if (do_emit)
     {
-        const uint32_t vrank = a.rank ? a.rank[orig] : orig;  // the order the sequential loop visits
-        atomicMin(&a.claims[best_spos], a.claim_hi | (a.local_offset + vrank));
+        // next call's warm start: the raw nearest neighbour (even if rejected) and what this search
+        // proved: no map point is nearer than min(best, threshold) (every point that could pass the
+        // threshold was examined), or than the bound that let the search be skipped
+        const float lb2 = active ? fmaxf(fminf(best_d2, thr), lb2_keep) : 0.f;
+        a.rec[qi] = make_uint4(best_spos, __float_as_uint(best_d2), __float_as_uint(lb2), acc ? 1u : 0u);
     }
+    if (!a.claims) return;               // uniform
+    if (__ballot(acc) == 0ull) return;   // uniform
+    const uint32_t vrank  = (acc && a.rank) ? a.rank[orig] : orig;  // the order the sequential loop visits
+    const uint32_t rank32 = (uint32_t)(a.local_offset + vrank);
+    if (!a.claim_dedup)
+    {
+        if (acc) claim_global(a, best_spos, rank32);
+        return;
+    }
+    // the wave's own minimum per distinct global point: the table slot of a global point holds the
+    // lowest (spos, rank) key hashed to it; a lane whose global point owns its slot claims only if it
+    // is that minimum, a lane whose slot went to another global point claims by itself
+    s_claim[lane] = ~0ull, s_claim[lane + 64] = ~0ull;
+    __syncthreads();
+    const unsigned long long key  = ((unsigned long long)best_spos << 32) | rank32;
+    const uint32_t           slot = (best_spos * 0x9E3779B1u) >> 25;  // 7 bits
+    if (acc) atomicMin(&s_claim[slot], key);
+    __syncthreads();
+    if (acc)
+    {
+        const unsigned long long v = s_claim[slot];
+        if ((uint32_t)(v >> 32) != best_spos || v == key) claim_global(a, best_spos, rank32);
+    }
+    __syncthreads();
+}
+
+// push the lanes of `mask` (at most one per query) onto a query list (pending or deferred)
+__device__ __forceinline__ uint32_t push_lanes(uint4* list, uint32_t* list_spos, uint32_t* counter, bool mine,
+                                               unsigned long long push, int lane, uint32_t qi, float r,
+                                               float best_d2, uint32_t best_idx, uint32_t best_spos)
+{
+    const int npush     = __popcll(push);
+    uint32_t  base_slot = 0;
+    if (lane == 0) base_slot = atomicAdd(counter, (uint32_t)npush);
+    base_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_slot);
+    if (mine && ((push >> lane) & 1ull))
+    {
+        const uint32_t slot = base_slot + (uint32_t)__popcll(push & ((1ull << lane) - 1ull));
+        list[slot]      = make_uint4(qi, __float_as_uint(r), __float_as_uint(best_d2), best_idx);
+        list_spos[slot] = best_spos;
+    }
+    return (uint32_t)npush;
 }
 
 // push the lanes of `mask` (one entry per query slot) onto the deferred-query list
@@ -223,51 +289,63 @@ __device__ __forceinline__ uint32_t defer_lanes(const NNArgs& a, bool mine, unsi
                                                 float best_d2, uint32_t best_idx, uint32_t best_spos)
 {
     const unsigned long long slot_mask = (Q < 64) ? ((1ull << (Q & 63)) - 1ull) : ~0ull;
-    const unsigned long long push      = mask & slot_mask;
-    const int                npush     = __popcll(push);
-    uint32_t                 base_slot = 0;
-    if (lane == 0) base_slot = atomicAdd(a.work_count, (uint32_t)npush);
-    base_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_slot);
-    if (mine && slice == 0)
-    {
-        const uint32_t slot = base_slot + (uint32_t)__popcll(push & ((1ull << lane) - 1ull));
-        a.work[slot]      = make_uint4(qi, __float_as_uint(r), __float_as_uint(best_d2), best_idx);
-        a.work_spos[slot] = best_spos;
-    }
-    return (uint32_t)npush;
+    return push_lanes(a.work, a.work_spos, a.q_counters + 1, mine && slice == 0, mask & slot_mask, lane, qi, r,
+                      best_d2, best_idx, best_spos);
+}
+
+// ---- per-lane search helpers -------------------------------------------------------------------
+// squared distance of the axis-aligned box [v0, v0+h]^3 from the point q
+__device__ __forceinline__ float box_dist2(float vx0, float vy0, float vz0, float h, float qx,
+                                           float qy, float qz)
+{
+    const float dx = fmaxf(0.f, fmaxf(vx0 - qx, qx - (vx0 + h)));
+    const float dy = fmaxf(0.f, fmaxf(vy0 - qy, qy - (vy0 + h)));
+    const float dz = fmaxf(0.f, fmaxf(vz0 - qz, qz - (vz0 + h)));
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// 4-bit mask of the positions lo..hi (clamped to the brick [b*4, b*4+3]) along one axis
+__device__ __forceinline__ uint32_t axis_mask(uint32_t b, uint32_t c0, uint32_t c1)
+{
+    const uint32_t lo = max(c0, b * 4u) - b * 4u, hi = min(c1, b * 4u + 3u) - b * 4u;
+    return ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+}
+// a 4-bit axis mask spread over the 64 voxels of a brick (bit = z*16 + y*4 + x)
+__device__ __forceinline__ unsigned long long spread_x(uint32_t x4)
+{
+    const uint32_t m = x4 * 0x11111111u;
+    return ((unsigned long long)m << 32) | m;
+}
+__device__ __forceinline__ unsigned long long spread_y(uint32_t y4)
+{
+    const uint32_t t = (y4 | (y4 << 3) | (y4 << 6) | (y4 << 9)) & 0x1111u;  // bit k -> bit 4k
+    const uint32_t m = (t * 0xFu) * 0x00010001u;
+    return ((unsigned long long)m << 32) | m;
+}
+__device__ __forceinline__ unsigned long long spread_z(uint32_t z4)
+{
+    const uint32_t lo = ((z4 & 1u) ? 0x0000FFFFu : 0u) | ((z4 & 2u) ? 0xFFFF0000u : 0u);
+    const uint32_t hi = ((z4 & 4u) ? 0x0000FFFFu : 0u) | ((z4 & 8u) ? 0xFFFF0000u : 0u);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // ================================================================================================
-// 5 waves per SIMD: 96 VGPRs with 4 spilled dwords; measured +3.5 % over the compiler's own 108
-// VGPRs / 4 waves, while 6 waves (80 VGPRs, 22 spilled dwords) give the gain back
-template <int Q, bool INSTR>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void nn_tile_kernel(const NNArgs a)
+// One query per lane (see the file header).  8 waves per SIMD.
+template <bool INSTR>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_lane_kernel(const NNArgs a)
 {
-    constexpr int S = 64 / Q;
-    __shared__ __attribute__((aligned(16))) float s_x[NN_CAP];
-    __shared__ __attribute__((aligned(16))) float s_y[NN_CAP];
-    __shared__ __attribute__((aligned(16))) float s_z[NN_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t s_idx[NN_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t s_spos[NN_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t s_owner[NN_CAP];
-    __shared__ uint32_t s_cstart[64];
-    __shared__ uint32_t s_coff[64];
-
-    const GridView& g     = a.g;
-    const int       lane  = threadIdx.x;
-    const unsigned long long tl0 = wall_clock64();
-    const int       qslot = lane & (Q - 1);
-    const int       slice = (Q == 64) ? 0 : lane / Q;
-    const uint32_t  tile  = a.tile_order ? a.tile_order[blockIdx.x] : blockIdx.x;
-    const uint32_t  qi    = tile * Q + qslot;
+    __shared__ unsigned long long s_claim[NN_CLAIM_SLOTS];
+    const GridView& g    = a.g;
+    const int       lane = threadIdx.x;
+    const uint32_t  qi   = blockIdx.x * 64u + (uint32_t)lane;
     const bool      valid = qi < a.n_l;
 
     float4 lp = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) lp = a.lpts[qi];
     // the warm-start record is in the same (Morton) order: its load is issued together with the
     // point's, not behind it
-    uint2 h = make_uint2(NONE_U32, 0u);
-    if (valid && a.use_hint) h = a.hint[qi];
+    uint4 h = make_uint4(NONE_U32, 0u, 0u, 0u);
+    if (valid && a.use_hint) h = a.rec[qi];
     const uint32_t orig = __float_as_uint(lp.w);
     // a visit order on the cloud (maxLocalPointsPerLayer, Matcher_Points_Base.cpp:222-246): only
     // the listed points are transformed, boxed and matched
@@ -278,7 +356,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     float qx, qy, qz;
     compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
 
-    // bounding box of ALL transformed local points of the tile (Matcher_Points_Base.cpp:186-196)
+    // bounding box of ALL transformed local points of the wave (Matcher_Points_Base.cpp:186-196)
     {
         const float bx0 = wave_min_nn((visited && qx == qx) ? qx : INFINITY), by0 = wave_min_nn((visited && qy == qy) ? qy : INFINITY),
                     bz0 = wave_min_nn((visited && qz == qz) ? qz : INFINITY);
@@ -286,7 +364,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     bz1 = wave_max_nn((visited && qz == qz) ? qz : -INFINITY);
         if (lane == 0)
         {
-            float* o = a.tile_bbox + (size_t)tile * 6;
+            float* o = a.tile_bbox + (size_t)blockIdx.x * 6;
             o[0] = bx0, o[1] = by0, o[2] = bz0, o[3] = bx1, o[4] = by1, o[5] = bz1;
         }
     }
@@ -302,7 +380,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 
     float    r        = fminf(a.r0, rmax);
     bool     done     = !active;
-    bool     deferred = false;
     float    best_d2  = INFINITY;
     uint32_t best_idx = NONE_U32, best_spos = NONE_U32;
 
@@ -320,7 +397,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         float       ox, oy, oz;
         compose_point_f(a.prev_pose, lp.x, lp.y, lp.z, ox, oy, oz);
         const float disp = sqrtf(dist2(qx, qy, qz, ox, oy, oz));
-        float       lb   = sqrtf(__uint_as_float(h.y)) * 0.99999f - disp * 1.00001f - 4.f * g.slack;
+        float       lb   = sqrtf(__uint_as_float(h.z)) * 0.99999f - disp * 1.00001f - 4.f * g.slack;
         if (!(lb > 0.f)) lb = 0.f;  // also catches NaN
         float hr = 0.f;
         if (h.x < g.n)
@@ -341,6 +418,194 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         else if (lb > r * (1.0f - 1.0f / 1024.0f) - g.slack)
             r = fminf(fmaxf(hr > 0.f ? fminf(hr, 2.0f * lb) : 2.0f * lb, r), rmax);
     }
+
+    // ---- can this lane search its cube [q - r, q + r]^3 by itself?  At most lane_cells level-0
+    //      voxels per axis (<= 4: the cube then fits a 4x4x4 mask and touches <= 2 bricks per
+    //      axis); a cube that misses the layer's bounding box holds nothing ------------------------
+    uint32_t cx0 = 0, cy0 = 0, cz0 = 0, cx1 = 0, cy1 = 0, cz1 = 0;
+    bool     fast = false, empty_cube = false;
+    if (!done && a.lane_cells != 0u && g.occ_off[0] != OCC_NONE)
+    {
+        const float lox = fmaxf(qx - r, g.bbmin[0]), loy = fmaxf(qy - r, g.bbmin[1]), loz = fmaxf(qz - r, g.bbmin[2]);
+        const float hix = fminf(qx + r, g.bbmax[0]), hiy = fminf(qy + r, g.bbmax[1]), hiz = fminf(qz + r, g.bbmax[2]);
+        empty_cube = (lox > hix) || (loy > hiy) || (loz > hiz);
+        if (!empty_cube)
+        {
+            cx0 = cell_fine(lox, g.ox, g.inv_hf) >> g.shift0, cx1 = cell_fine(hix, g.ox, g.inv_hf) >> g.shift0;
+            cy0 = cell_fine(loy, g.oy, g.inv_hf) >> g.shift0, cy1 = cell_fine(hiy, g.oy, g.inv_hf) >> g.shift0;
+            cz0 = cell_fine(loz, g.oz, g.inv_hf) >> g.shift0, cz1 = cell_fine(hiz, g.oz, g.inv_hf) >> g.shift0;
+            fast = (cx1 - cx0) < a.lane_cells && (cy1 - cy0) < a.lane_cells && (cz1 - cz0) < a.lane_cells;
+        }
+        else
+            fast = true;  // nothing to visit at this radius
+    }
+
+    uint32_t st_cand = 0, st_vox = 0;
+    if (fast && !empty_cube)
+    {
+        // ---- occupancy mask of the cube, bit = (z - cz0) * 16 + (y - cy0) * 4 + (x - cx0), from the
+        //      <= 2 x 2 x 2 bricks it overlaps (all loads independent) ---------------------------
+        const uint32_t bx0 = cx0 >> 2, by0 = cy0 >> 2, bz0 = cz0 >> 2;
+        const uint32_t nbx = (cx1 >> 2) - bx0, nby = (cy1 >> 2) - by0, nbz = (cz1 >> 2) - bz0;  // 0 or 1
+        const uint32_t obx = g.occ_bx[0], oby = g.occ_by[0], obz = g.occ_bz[0];
+        const unsigned long long* occ0 = g.occ + g.occ_off[0];
+        unsigned long long word[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const uint32_t dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+            const uint32_t Bx = bx0 + dx, By = by0 + dy, Bz = bz0 + dz;
+            word[k] = 0ull;
+            if (dx <= nbx && dy <= nby && dz <= nbz && Bx < obx && By < oby && Bz < obz)
+                word[k] = occ0[((size_t)Bz * oby + By) * obx + Bx];
+        }
+        const unsigned long long mx[2] = {spread_x(axis_mask(bx0, cx0, cx1)), nbx ? spread_x(axis_mask(bx0 + 1, cx0, cx1)) : 0ull};
+        const unsigned long long my[2] = {spread_y(axis_mask(by0, cy0, cy1)), nby ? spread_y(axis_mask(by0 + 1, cy0, cy1)) : 0ull};
+        const unsigned long long mz[2] = {spread_z(axis_mask(bz0, cz0, cz1)), nbz ? spread_z(axis_mask(bz0 + 1, cz0, cz1)) : 0ull};
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+            const unsigned long long w = word[k] & mx[dx] & my[dy] & mz[dz];
+            // voxel (x, y, z) of brick B sits at bit + delta of the cube mask
+            const int delta = ((int)((bx0 + dx) * 4u) - (int)cx0) + 4 * ((int)((by0 + dy) * 4u) - (int)cy0) +
+                              16 * ((int)((bz0 + dz) * 4u) - (int)cz0);
+            m |= delta >= 0 ? (w << (delta & 63)) : (w >> ((-delta) & 63));
+        }
+
+        // ---- walk the occupied voxels of the cube the ball reaches: probe, then the points, 4 loads
+        //      in flight.  One flat loop per lane (refill / work), so lanes with more voxels do not
+        //      make the others wait at every nesting level ---------------------------------------
+        const float hs     = g.hf * (float)(1u << g.shift0);
+        const float prune  = r + 4.f * g.slack;
+        const float prune2 = prune * prune;
+        uint32_t    p = 0, pe = 0;
+        for (;;)
+        {
+            while (p >= pe && m != 0ull)
+            {
+                const uint32_t bit = (uint32_t)__ffsll((long long)m) - 1u;
+                m &= m - 1ull;
+                const uint32_t cx = cx0 + (bit & 3u), cy = cy0 + ((bit >> 2) & 3u), cz = cz0 + (bit >> 4);
+                const float    md2 = box_dist2(g.ox + (float)cx * hs, g.oy + (float)cy * hs, g.oz + (float)cz * hs, hs,
+                                               qx, qy, qz);
+                if (md2 <= fminf(prune2, voxel_limit(best_d2, g.slack)))
+                {
+                    uint32_t s0 = 0, e0 = 0;
+                    if (cell_lookup(g, cell_key(0u, cx, cy, cz), s0, e0)) p = s0, pe = e0;
+                    if (INSTR) st_vox++;
+                }
+            }
+            if (p >= pe) break;
+            float4 c4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                c4[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
+                if (p + k < pe) c4[k] = g.pts[p + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const float    d  = dist2(qx, qy, qz, c4[k].x, c4[k].y, c4[k].z);
+                const uint32_t ci = __float_as_uint(c4[k].w);
+                if (p + k < pe && (d < best_d2 || (d == best_d2 && ci < best_idx)))
+                    best_d2 = d, best_idx = ci, best_spos = p + k;
+                if (INSTR && p + k < pe) a.touched[p + k] = 1, st_cand++;
+            }
+            p += 4u;
+        }
+    }
+
+    // ---- conclude, or hand the query on with its state ------------------------------------------
+    bool pending = !done && !fast;
+    if (!done && fast)
+    {
+        if (is_final(r, rmax, best_d2, g.slack)) done = true;
+        else
+        {
+            r       = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
+            pending = true;
+        }
+    }
+    const unsigned long long pmask = __ballot(pending);
+    if (pmask)
+        push_lanes(a.pend, a.pend_spos, a.q_counters, pending, pmask, lane, qi, r, best_d2, best_idx, best_spos);
+
+    emit_wave(a, s_claim, lane, valid && !pending, qi, orig, active, thr, best_d2, best_idx, best_spos, lb2_keep);
+
+    if (INSTR)
+    {
+        const uint32_t n_fast = (uint32_t)__popcll(__ballot(fast && !empty_cube));
+        const uint32_t n_skip = (uint32_t)__popcll(__ballot(active && lb2_keep > 0.f));
+        const uint32_t cand   = wave_sum_u32(st_cand), vox = wave_sum_u32(st_vox);
+        if (lane == 0)
+        {
+            atomicAdd(&a.counters[44], (unsigned long long)n_fast);
+            atomicAdd(&a.counters[45], (unsigned long long)cand);
+            atomicAdd(&a.counters[46], (unsigned long long)vox);
+            atomicAdd(&a.counters[47], (unsigned long long)__popcll(pmask));
+            atomicAdd(&a.counters[48], (unsigned long long)n_skip);
+        }
+    }
+}
+
+// ================================================================================================
+// Tiles of Q consecutive PENDING queries.
+// 5 waves per SIMD: 96 VGPRs with 4 spilled dwords; measured +3.5 % over the compiler's own 108
+// VGPRs / 4 waves, while 6 waves (80 VGPRs, 22 spilled dwords) give the gain back
+template <int Q, bool INSTR>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void nn_tile_kernel(const NNArgs a)
+{
+    constexpr int S = 64 / Q;
+    __shared__ __attribute__((aligned(16))) float s_x[NN_CAP];
+    __shared__ __attribute__((aligned(16))) float s_y[NN_CAP];
+    __shared__ __attribute__((aligned(16))) float s_z[NN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_idx[NN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_spos[NN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_owner[NN_CAP];
+    __shared__ uint32_t s_cstart[64];
+    __shared__ uint32_t s_coff[64];
+    __shared__ unsigned long long s_claim[NN_CLAIM_SLOTS];
+
+    const GridView& g     = a.g;
+    const int       lane  = threadIdx.x;
+    const uint32_t  tile  = blockIdx.x;
+    // the grid covers the worst case (every query pending); tiles beyond the list leave at once
+    const uint32_t  n_pend = a.q_counters[0];
+    if (tile * (uint32_t)Q >= n_pend) return;
+    const unsigned long long tl0 = a.timeline ? wall_clock64() : 0ull;
+    const int       qslot = lane & (Q - 1);
+    const int       slice = (Q == 64) ? 0 : lane / Q;
+    const uint32_t  pslot = tile * Q + qslot;
+    const bool      valid = pslot < n_pend;
+
+    // the lane kernel did the per-query set-up (visit list, MatchState, warm start); a pending
+    // query arrives with its radius and the best candidate so far
+    uint4    w  = make_uint4(0u, 0u, __float_as_uint(INFINITY), NONE_U32);
+    uint32_t ws = NONE_U32;
+    if (valid) w = a.pend[pslot], ws = a.pend_spos[pslot];
+    const uint32_t qi = w.x;
+    float4 lp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) lp = a.lpts[qi];
+    const uint32_t orig = __float_as_uint(lp.w);
+
+    // ---- K1 again (cheaper than carrying three more words per pending query) ------------------
+    float qx, qy, qz;
+    compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
+    const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));
+    const float thr    = fadd(a.maxDistSq, fmul(a.angSq, normSq));
+    const float rmax   = sqrtf(thr) * 1.002f + g.slack;
+
+    const bool active   = valid;
+    float      r        = valid ? __uint_as_float(w.y) : 0.f;
+    bool       done     = !valid;
+    bool       deferred = false;
+    float      best_d2  = __uint_as_float(w.z);
+    uint32_t   best_idx = w.w, best_spos = ws;
+    const float lb2_keep = 0.f;
+
     // a query whose radius already exceeds what a tile should carry goes straight to the
     // one-query-per-wave kernel
     {
@@ -533,6 +798,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 too_wide = r > a.r_defer;
             }
         }
+        // a tile that has already staged more than its budget hands ALL its unfinished queries on:
+        // tiles are dispatched in order, and one that runs 5-8x the mean keeps a nearly empty chip
+        // waiting at the end of the kernel (the one-query kernel spreads the same work evenly)
+        if (st_cand > a.tile_cand_cap && !done) too_wide = true;
         const unsigned long long wmask = __ballot(too_wide);
         if (wmask)
         {
@@ -541,16 +810,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         }
     }
 
-    // ---- output (original local order) + claim of the global point --------------------------
-    if (valid && slice == 0 && !deferred)
-        emit_result(a, qi, orig, active, thr, best_d2, best_idx, best_spos, lb2_keep);
+    // ---- output (Morton order of the local layer) + claim of the global point -----------------
+    emit_wave(a, s_claim, lane, valid && slice == 0 && !deferred, qi, orig, active, thr, best_d2, best_idx,
+              best_spos, lb2_keep);
 
-    if (lane == 0)
-    {
-        const unsigned long long tl1 = wall_clock64();
-        a.tile_cost[tile] = (uint32_t)min(tl1 - tl0, 0xFFFFFFFFull);
-        if (a.timeline) a.timeline[2 * (size_t)tile] = tl0, a.timeline[2 * (size_t)tile + 1] = tl1;
-    }
+    if (a.timeline && lane == 0)
+        a.timeline[2 * (size_t)tile] = tl0, a.timeline[2 * (size_t)tile + 1] = wall_clock64();
     if (INSTR && lane == 0)
     {
         atomicAdd(&a.counters[0], 1ull);
@@ -651,23 +916,6 @@ __device__ __forceinline__ void scan_batch(const NNArgs& a, const GridView& g, i
     bound = fminf(bound, wave_min_pos(pd));
 }
 
-// squared distance of the axis-aligned box [v0, v0+h]^3 from the point q
-__device__ __forceinline__ float box_dist2(float vx0, float vy0, float vz0, float h, float qx,
-                                           float qy, float qz)
-{
-    const float dx = fmaxf(0.f, fmaxf(vx0 - qx, qx - (vx0 + h)));
-    const float dy = fmaxf(0.f, fmaxf(vy0 - qy, qy - (vy0 + h)));
-    const float dz = fmaxf(0.f, fmaxf(vz0 - qz, qz - (vz0 + h)));
-    return dx * dx + dy * dy + dz * dz;
-}
-
-// 4-bit mask of the positions lo..hi (clamped to the brick [b*4, b*4+3]) along one axis
-__device__ __forceinline__ uint32_t axis_mask(uint32_t b, uint32_t c0, uint32_t c1)
-{
-    const uint32_t lo = max(c0, b * 4u) - b * 4u, hi = min(c1, b * 4u + 3u) - b * 4u;
-    return ((2u << hi) - 1u) & ~((1u << lo) - 1u);
-}
-
 constexpr int NN_VLIST = 1024;  // occupied voxels listed per round (LDS)
 
 template <bool INSTR>
@@ -678,7 +926,7 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
     __shared__ uint32_t s_vox[NN_VLIST];
     const GridView& g      = a.g;
     const int       lane   = threadIdx.x;
-    const uint32_t  n_work = *a.work_count;
+    const uint32_t  n_work = a.q_counters[1];
     const unsigned long long tl0 = a.timeline ? wall_clock64() : 0ull;
 
     for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x)
@@ -835,7 +1083,15 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
             if (is_final(r, rmax, best_d2, g.slack)) break;
             r = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
         }
-        if (lane == 0) emit_result(a, qi, orig, true, thr, best_d2, best_idx, best_spos);
+        if (lane == 0)
+        {
+            bool acc = best_idx != NONE_U32 && best_d2 < thr;                    // :259
+            if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;  // :98-101
+            a.rec[qi] = make_uint4(best_spos, __float_as_uint(best_d2), __float_as_uint(fminf(best_d2, thr)),
+                                   acc ? 1u : 0u);
+            if (acc && a.claims)
+                claim_global(a, best_spos, (uint32_t)(a.local_offset + (a.rank ? a.rank[orig] : orig)));
+        }
         if (INSTR && lane == 0)
         {
             atomicAdd(&a.counters[10], 1ull);
@@ -857,69 +1113,31 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
     }
 }
 
-__global__ void zero_u32_kernel(uint32_t* p) { *p = 0; }
-
-// Resets the work-queue counter and, for a warm call, lists the tiles by decreasing duration of
-// the previous call: a counting sort on the log2 of the tick count (only "the long ones first"
-// matters).  One workgroup of 16 waves; a wave adds each distinct bucket of its 64 tiles with ONE
-// LDS atomic (the durations cluster in a handful of buckets: per-tile atomics would serialise).
-// Measured on the bench scene: the tile kernel drops from 0.222 to 0.187 ms, but this kernel's two
-// passes over the costs are 62 dependent global loads in a row = 47 us, more than the gain, and
-// letting the tiles count themselves with a global atomic doubles THEIR time (a few hot
-// addresses) -- hence opt-in (mp2p_hip_pt2pt_params::tile_order) until the sort is cheap.
-__device__ __forceinline__ uint32_t wave_bucket_slot(uint32_t* s_ctr, uint32_t bucket, bool have, int lane)
+// resets the two query-list counters {#pending, #deferred}
+__global__ void nn_reset_kernel(uint32_t* q_counters)
 {
-    // returns, for every lane with `have`, a distinct slot of its bucket's counter range
-    uint32_t           slot = 0;
-    unsigned long long todo = __ballot(have);
-    while (todo)
-    {
-        const int                leader = __ffsll((long long)todo) - 1;
-        const uint32_t           b      = (uint32_t)__builtin_amdgcn_readlane((int)bucket, leader);
-        const unsigned long long same   = __ballot(have && bucket == b) & todo;
-        uint32_t                 base   = 0;
-        if (lane == leader) base = atomicAdd(&s_ctr[b], (uint32_t)__popcll(same));
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        if ((same >> lane) & 1ull) slot = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    return slot;
+    if (threadIdx.x < 2) q_counters[threadIdx.x] = 0u;
 }
 
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t n_tiles,
-                                                          uint32_t* __restrict__ order,
-                                                          uint32_t* __restrict__ work_count)
+// the [n_l][1] result arrays the other matchers' kernels read, from the packed records
+__global__ __launch_bounds__(256) void nn_unpack_rec_kernel(const uint4* __restrict__ rec, uint32_t n,
+                                                            uint32_t* __restrict__ spos, float* __restrict__ d2)
 {
-    __shared__ uint32_t s_cnt[33], s_off[33];
-    if (threadIdx.x == 0) *work_count = 0;
-    if (!order) return;  // uniform
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x < 33) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    // bucket 0: cost 0, bucket b: 2^(b-1) <= cost < 2^b
-    const uint32_t rounds = (n_tiles + 1023u) / 1024u;
-    for (uint32_t k = 0; k < rounds; k++)
-    {
-        const uint32_t t    = k * 1024u + threadIdx.x;
-        const bool     have = t < n_tiles;
-        const uint32_t b    = have ? (uint32_t)(32 - __clz((int)cost[t])) : 0u;
-        (void)wave_bucket_slot(s_cnt, b, have, lane);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        uint32_t run = 0;
-        for (int b = 32; b >= 0; b--) s_off[b] = run, run += s_cnt[b];  // long tiles first
-    }
-    __syncthreads();
-    for (uint32_t k = 0; k < rounds; k++)
-    {
-        const uint32_t t    = k * 1024u + threadIdx.x;
-        const bool     have = t < n_tiles;
-        const uint32_t b    = have ? (uint32_t)(32 - __clz((int)cost[t])) : 0u;
-        const uint32_t slot = wave_bucket_slot(s_off, b, have, lane);
-        if (have) order[slot] = t;
-    }
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 r = rec[i];
+    spos[i] = r.w ? r.x : NONE_U32;
+    d2[i]   = __uint_as_float(r.y);
+}
+int launch_unpack_rec(mp2p_hip_ctx* ctx, size_t n_l)
+{
+    MP2P_TRY_HIP(ctx, ctx->nn_spos.ensure(n_l ? n_l : 1));
+    MP2P_TRY_HIP(ctx, ctx->nn_d2.ensure(n_l ? n_l : 1));
+    if (n_l)
+        hipLaunchKernelGGL(nn_unpack_rec_kernel, dim3((uint32_t)((n_l + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->nn_rec.p, (uint32_t)n_l, ctx->nn_spos.p, ctx->nn_d2.p);
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
 }
 
 // reduce the per-tile boxes to the layer box {min xyz, max xyz}: [n_in][6] -> [gridDim.x][6]
@@ -966,14 +1184,17 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     const size_t n_l = cloud->n;
     uint32_t     Q   = prm->queries_per_wave ? prm->queries_per_wave : 32;
     MP2P_REQUIRE(ctx, Q == 64 || Q == 32 || Q == 16, "queries_per_wave must be 64, 32 or 16");
-    const uint32_t n_tiles = (uint32_t)((n_l + Q - 1) / Q);
+    const uint32_t n_tiles = (uint32_t)((n_l + Q - 1) / Q);   // worst case: every query pending
+    const uint32_t n_waves = (uint32_t)((n_l + 63) / 64);     // lane kernel
 
-    MP2P_TRY_HIP(ctx, ctx->nn_spos.ensure(n_l));
-    MP2P_TRY_HIP(ctx, ctx->nn_d2.ensure(n_l));
-    MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_tiles * 6));
+    MP2P_TRY_HIP(ctx, ctx->nn_rec.ensure(n_l));
+    MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_waves * 6));
     MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
     MP2P_TRY_HIP(ctx, ctx->work.ensure(n_l));
-    MP2P_TRY_HIP(ctx, ctx->work_spos.ensure(n_l + 1));  // last word = counter
+    MP2P_TRY_HIP(ctx, ctx->work_spos.ensure(n_l));
+    MP2P_TRY_HIP(ctx, ctx->pend.ensure(n_l));
+    MP2P_TRY_HIP(ctx, ctx->pend_spos.ensure(n_l));
+    MP2P_TRY_HIP(ctx, ctx->q_counters.ensure(4));
     ctx->last_n_tiles = n_tiles;
     ctx->last_q       = Q;
 
@@ -999,6 +1220,10 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     // between 2 and 4 voxels so that it still scales with maps of another size.
     a.r_defer = prm->defer_radius_cells > 0 ? cell0 * prm->defer_radius_cells
                                              : fminf(fmaxf(1.0f, 2.0f * cell0), 4.0f * cell0);
+    a.lane_cells    = std::min<uint32_t>(ctx->tune.lane_cells, 4u);
+    a.tile_cand_cap = ctx->tune.tile_cand_cap;
+    a.claim_dedup   = ctx->tune.claim_dedup;
+    a.claim_peek    = ctx->tune.claim_peek;
     a.local_taken =
         (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
     a.global_taken =
@@ -1008,14 +1233,13 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.claim_hi     = (~(unsigned long long)ctx->epoch) << 32;
     a.local_offset = prm->local_index_offset;
     a.rank         = cloud->n_visit ? cloud->rank.p : nullptr;
-    a.out_spos     = ctx->nn_spos.p;
-    a.out_d2       = ctx->nn_d2.p;
+    a.rec          = ctx->nn_rec.p;
     a.tile_bbox    = ctx->tile_bbox.p;
     a.work         = ctx->work.p;
     a.work_spos    = ctx->work_spos.p;
-    a.work_count   = ctx->work_spos.p + n_l;
-    MP2P_TRY_HIP(ctx, ctx->hint.ensure(n_l));
-    a.hint     = ctx->hint.p;
+    a.pend         = ctx->pend.p;
+    a.pend_spos    = ctx->pend_spos.p;
+    a.q_counters   = ctx->q_counters.p;
     for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->hint_pose[i];
     for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->hint_pose[9 + i];
     a.use_hint = (ctx->hint_map == map && ctx->hint_cloud == cloud && ctx->hint_n == n_l && !prm->disable_warm_start) ? 1 : 0;
@@ -1043,23 +1267,17 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         a.timeline = ctx->timeline.p;
         ctx->timeline_tiles = n_tiles, ctx->timeline_singles = single_blocks;
     }
-    // tile order from the previous call's durations (same condition as the warm start: the same
-    // local layer in the same tiling against the same map)
-    MP2P_TRY_HIP(ctx, ctx->tile_cost.ensure(n_tiles ? n_tiles : 1));
-    MP2P_TRY_HIP(ctx, ctx->tile_order.ensure(n_tiles ? n_tiles : 1));
-    const bool ordered = a.use_hint && ctx->tile_cost_tiles == n_tiles && ctx->tile_cost_q == Q && n_tiles > 1 &&
-                         prm->tile_order != 0;
-    a.tile_cost  = ctx->tile_cost.p;
-    a.tile_order = ordered ? ctx->tile_order.p : nullptr;
-    ctx->tile_cost_tiles = n_tiles, ctx->tile_cost_q = Q;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_cost.p, n_tiles,
-                       ordered ? ctx->tile_order.p : nullptr, a.work_count);
-    // ev[0]..ev[1] brackets exactly the two search kernels (the roofline kernels of bench.py)
+    ctx->pending_lane = 1;
+    hipLaunchKernelGGL(nn_reset_kernel, dim3(1), dim3(64), 0, ctx->stream, a.q_counters);
+    // ev[0]..ev[1] brackets exactly the search kernels (the roofline kernels of bench.py)
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (n_tiles)
     {
         const bool     instr         = a.counters != nullptr;
         const uint32_t single_blocks = (uint32_t)std::min<size_t>(n_l, 256u * 32u);
+        if (instr) hipLaunchKernelGGL(nn_lane_kernel<true>, dim3(n_waves), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(nn_lane_kernel<false>, dim3(n_waves), dim3(64), 0, ctx->stream, a);
+        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
 #define MP2P_LAUNCH_TILE(QQ)                                                                       \
     do                                                                                             \
     {                                                                                              \
@@ -1075,9 +1293,13 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         if (instr) hipLaunchKernelGGL(nn_single_kernel<true>, dim3(single_blocks), dim3(64), 0, ctx->stream, a);
         else hipLaunchKernelGGL(nn_single_kernel<false>, dim3(single_blocks), dim3(64), 0, ctx->stream, a);
     }
-    else if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    else if (ctx->prof_all())
+    {
+        MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+        MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    }
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    int rc = launch_bbox_reduce(ctx, n_tiles);
+    int rc = launch_bbox_reduce(ctx, n_waves);
     if (rc) return rc;
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;

@@ -19,6 +19,7 @@ struct CompactArgs
     const uint32_t*           nn_spos;  // [n_l][K] in the Morton order of the local layer
     const uint32_t*           pos;      // original local index -> place in that order
     const float*              nn_d2;
+    const uint4*              rec;      // K == 1 point-to-point search: packed records instead (nn_query.hip)
     uint32_t                  n_l;      // number of SLOTS = visited local points x K, in visiting order
     uint32_t                  K;        // pairingsPerPoint
     const uint32_t*           order;    // visit position -> original local index (null: identity)
@@ -56,13 +57,22 @@ __device__ __forceinline__ bool bbox_overlap(const float* g, const float* l, flo
 // slot t = (visit position r, neighbour k): does it produce a pair?  i = original local index,
 // src = its place in nn_spos / nn_d2
 __device__ __forceinline__ bool pair_flag(const CompactArgs& a, uint32_t t, uint32_t& spos,
-                                          uint32_t& i, size_t& src)
+                                          uint32_t& i, size_t& src, float& d2)
 {
     const uint32_t r = (a.K == 1) ? t : t / a.K;
     const uint32_t k = (a.K == 1) ? 0u : t - r * a.K;
     i                = a.order ? a.order[r] : r;
     src              = (size_t)a.pos[i] * a.K + k;
-    spos             = a.nn_spos[src];
+    if (a.rec)
+    {
+        const uint4 q = a.rec[src];
+        spos = q.w ? q.x : NONE_U32, d2 = __uint_as_float(q.y);
+    }
+    else
+    {
+        spos = a.nn_spos[src];
+        d2   = spos != NONE_U32 ? a.nn_d2[src] : 0.f;
+    }
     if (spos == NONE_U32) return false;
     if (a.claims && a.claims[spos] != (a.claim_hi | ((a.local_offset + r) * a.K + k))) return false;
     return true;
@@ -80,7 +90,8 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const Compact
         {
             uint32_t sp, i;
             size_t   src;
-            if (base + k < (a.n_slots_dev ? min(*a.n_slots_dev, a.n_l) : a.n_l) && pair_flag(a, base + k, sp, i, src)) c++;
+            float    d2;
+            if (base + k < (a.n_slots_dev ? min(*a.n_slots_dev, a.n_l) : a.n_l) && pair_flag(a, base + k, sp, i, src, d2)) c++;
         }
     }
     c = wave_sum_u32(c);
@@ -145,13 +156,14 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
     const uint32_t base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
     uint32_t       sp[CP_ITEMS], li[CP_ITEMS];
     size_t         src[CP_ITEMS];
+    float          d2[CP_ITEMS];
     bool           f[CP_ITEMS];
     uint32_t       c = 0;
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; k++)
     {
         f[k] = (base + k < (a.n_slots_dev ? min(*a.n_slots_dev, a.n_l) : a.n_l)) &&
-               pair_flag(a, base + k, sp[k], li[k], src[k]);
+               pair_flag(a, base + k, sp[k], li[k], src[k], d2[k]);
         c += f[k] ? 1u : 0u;
     }
     const int      lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
             a.o_lidx[dst] = (uint32_t)(a.local_offset + i), a.o_gidx[dst] = gi;  // whole-layer index
             a.o_lx[dst] = a.lx[i], a.o_ly[dst] = a.ly[i], a.o_lz[dst] = a.lz[i];  // UNtransformed
             a.o_gx[dst] = gp.x, a.o_gy[dst] = gp.y, a.o_gz[dst] = gp.z;
-            a.o_err[dst] = a.nn_d2[src[k]];
+            a.o_err[dst] = d2[k];
             if (a.claims || a.always_mark)
             {  // marks are only left when global re-use is forbidden (:116-120)
                 if (a.ms_local) a.ms_local[i] = 1;
@@ -190,7 +202,7 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
                          const uint32_t* order, size_t n_slots, const uint32_t* n_slots_dev, uint32_t K,
                          bool use_claims, bool always_mark, unsigned long long local_offset, float margin,
                          unsigned long long potential_add, mp2p_hip_mstate* ms, mp2p_hip_pairs* out,
-                         bool mark_global = true)
+                         bool mark_global = true, bool from_rec = false)
 {
     const size_t   n_l      = n_slots;
     const uint32_t n_blocks = (uint32_t)((n_l + CP_TILE - 1) / CP_TILE);
@@ -198,6 +210,7 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     CompactArgs a;
     memset(&a, 0, sizeof(a));
     a.nn_spos = ctx->nn_spos.p, a.nn_d2 = ctx->nn_d2.p, a.n_l = (uint32_t)n_l;
+    a.rec = from_rec ? ctx->nn_rec.p : nullptr;
     a.K = K, a.order = order, a.n_slots_dev = n_slots_dev, a.always_mark = always_mark ? 1 : 0;
     a.pos = cloud->pos.p;
     a.claims       = use_claims ? map->claims.p : nullptr;
@@ -236,11 +249,14 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
 {
     const size_t n_visit = cloud->n_visit ? cloud->n_visit : cloud->n;
     const size_t n_slots = n_visit * prm->pairingsPerPoint;
+    // potential_pairings += pcLocal.size() * pairingsPerPoint (:64): the WHOLE layer, also when
+    // maxLocalPointsPerLayer visits a subset of it
     return launch_compact_slots(ctx, map, cloud, cloud->n_visit ? cloud->order.p : nullptr, n_slots, nullptr,
                                 prm->pairingsPerPoint, !prm->allowMatchAlreadyMatchedGlobalPoints, false,
                                 prm->local_index_offset,
                                 (float)(prm->threshold + prm->bounding_box_intersection_check_epsilon),
-                                (unsigned long long)n_slots /* visited points x pairingsPerPoint (:64) */, ms, out);
+                                (unsigned long long)cloud->n * prm->pairingsPerPoint, ms, out, true,
+                                /*from_rec=*/prm->pairingsPerPoint == 1);
 }
 
 // ---- sharded local layer: what the ranks exchange between phase 1 and phase 2 -----------------
@@ -251,6 +267,7 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
 // win across ranks, and there are at most as many as distinct global points hit (a few per cent
 // of the map), so the ranks all-gather records instead of reducing one word per global point.
 __global__ __launch_bounds__(256) void claims_export_kernel(const uint32_t* __restrict__ nn_spos,
+                                                            const uint4* __restrict__ rec,
                                                             uint32_t n_slots, uint32_t K,
                                                             const uint32_t* order, const uint32_t* pos,
                                                             const unsigned long long* claims,
@@ -267,8 +284,14 @@ __global__ __launch_bounds__(256) void claims_export_kernel(const uint32_t* __re
     {
         const uint32_t r = t / K, k = t - r * K;
         const uint32_t i = order ? order[r] : r;
-        spos             = nn_spos[(size_t)pos[i] * K + k];
-        id               = (local_offset + r) * K + k;
+        if (rec)
+        {
+            const uint4 q = rec[pos[i]];
+            spos          = q.w ? q.x : NONE_U32;
+        }
+        else
+            spos = nn_spos[(size_t)pos[i] * K + k];
+        id = (local_offset + r) * K + k;
     }
     const bool mine = spos != NONE_U32 && claims[spos] == (claim_hi | id);
     const unsigned long long m = __ballot(mine);
@@ -326,7 +349,7 @@ int launch_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
         MP2P_TRY_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
         if (searched)
             hipLaunchKernelGGL(claims_export_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0,
-                               ctx->stream, ctx->nn_spos.p, (uint32_t)n_l, K,
+                               ctx->stream, ctx->nn_spos.p, K == 1 ? ctx->nn_rec.p : nullptr, (uint32_t)n_l, K,
                                cloud->n_visit ? cloud->order.p : nullptr, cloud->pos.p, map->claims.p,
                                (~(unsigned long long)ctx->epoch) << 32,
                                (unsigned long long)prm->local_index_offset, ctx->claim_list.p, counter);

@@ -1113,14 +1113,15 @@ size_t orc_match_pt2pt_subset(const orc_kdtree* tree, const float* gx, const flo
         sx[r] = lx[i], sy[r] = ly[i], sz[r] = lz[i];
         if (st) st[r] = local_taken[i];
     }
+    /* :64 adds pcLocal.size() * pairingsPerPoint -- the WHOLE layer, not the visited subset */
+    if (potential_pairings) *potential_pairings += (uint64_t)n_l * prm->pairingsPerPoint;
     const size_t n = orc_match_pt2pt(tree, gx, gy, gz, n_g, sx, sy, sz, n_idxs, T, prm, st,
-                                     global_taken, out, potential_pairings);
+                                     global_taken, out, NULL);
     for (size_t k = 0; k < n; k++) out[k].localIdx = idxs[out[k].localIdx]; /* :216 */
     if (st)
         for (size_t r = 0; r < n_idxs; r++)
             if (st[r]) local_taken[idxs[r]] = 1;
     free(sx), free(sy), free(sz), free(st);
-    (void)n_l;
     return n;
 }
 
@@ -1145,8 +1146,10 @@ size_t orc_match_pt2pl_subset(const orc_kdtree* tree, const float* gx, const flo
         sx[r] = lx[i], sy[r] = ly[i], sz[r] = lz[i];
         if (st) st[r] = local_taken[i];
     }
+    /* :54 adds pcLocal.size() -- the WHOLE layer, not the visited subset */
+    if (potential_pairings) *potential_pairings += (uint64_t)n_l;
     const size_t n = orc_match_pt2pl(tree, gx, gy, gz, n_g, sx, sy, sz, n_idxs, T, prm, st, out, oi,
-                                     potential_pairings);
+                                     NULL);
     if (out_local_idx)
         for (size_t k = 0; k < n; k++) out_local_idx[k] = idxs[oi[k]]; /* :81 */
     if (st)

@@ -167,4 +167,4 @@ def test_pt2pl_max_local_points_visit_order(amd, oracle):
     pairs = amd.Pairings()
     assert m.match(pcG, pcL, d["T_gt"], amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
     _check(pairs, want, widx)
-    assert pairs.potential_pairings == pot == 3000
+    assert pairs.potential_pairings == pot == l.shape[0]  # :54: pcLocal.size(), not the visited subset

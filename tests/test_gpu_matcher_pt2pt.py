@@ -302,7 +302,7 @@ def test_max_local_points_visit_order(amd, oracle, K):
         pairs = amd.Pairings()
         m.match(pcG, pcL, pose, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
         _assert_same_pairs(pairs.paired_pt2pt, want)
-        assert pairs.potential_pairings == pot == 2500 * K
+        assert pairs.potential_pairings == pot == 4000 * K  # :64: pcLocal.size(), not the visited subset
     # a later matcher without the limit sees the whole layer again
     want, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], d["T_gt"],
                                  0.8, 0.0, tree=tree)

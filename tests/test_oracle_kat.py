@@ -309,7 +309,7 @@ def test_oracle_visit_list_and_pairings_per_point(oracle):
         ls = l[order]
         e, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], ls[:, 0], ls[:, 1], ls[:, 2], T, 0.5, 0.1,
                                   pairingsPerPoint=K, tree=tree)
-        assert pc == 250 * K and len(c) == len(e)
+        assert pc == 400 * K and len(c) == len(e)  # :64 counts pcLocal.size(), not the visited subset
         assert np.array_equal(c["localIdx"], order[e["localIdx"]])
         assert np.array_equal(c["globalIdx"], e["globalIdx"])
         # visiting order = output order

@@ -50,6 +50,8 @@ namespace mp2p
 constexpr int NN_CAP      = 256;  // staged candidates per round (LDS: 5 x 1 KB)
 constexpr int NN_COOP_MAX = 4;    // groups of up to this many queries are deferred
 constexpr int NN_CLAIM_SLOTS = 128;  // in-wave claim table (LDS)
+constexpr int NN_MAX_SEG     = 256;  // segments of a query list
+constexpr int NN_CNT_STRIDE  = 32;   // uint32 words between two segment counters (128 bytes)
 
 struct NNArgs
 {
@@ -77,13 +79,18 @@ struct NNArgs
     uint4*               rec;
     float*               tile_bbox;  // [n_waves of the lane kernel][6]
     // pending queries (lane kernel -> tile kernel) and deferred queries (-> one-query-per-wave
-    // kernel): {sorted local idx, r, best_d2, best_idx} + best_spos; counters[0] = #pending,
-    // counters[1] = #deferred
+    // kernel): {sorted local idx, r, best_d2, best_idx} + best_spos.  A device-scope atomic is a
+    // round trip to the memory side and atomics on ONE address serialise there (~12 ns each: one
+    // counter bumped by every wave set the duration of the whole kernel), so each list is cut into
+    // n_seg SEGMENTS of seg_cap entries, one counter per segment on its own 128-byte line; the waves
+    // of seg_waves consecutive workgroups of the lane kernel share a segment (Morton-consecutive
+    // queries stay together).  q_counters[(list * NN_MAX_SEG + seg) * NN_CNT_STRIDE]
     uint4*               pend;
     uint32_t*            pend_spos;
     uint4*               work;
     uint32_t*            work_spos;
     uint32_t*            q_counters;
+    uint32_t             n_seg, seg_waves, seg_cap, tiles_per_seg;
     const uint32_t*      rank;  // visit rank per original local index (NONE = not visited) or null
     int                  use_hint;
     PoseRt               prev_pose;
@@ -264,33 +271,37 @@ __device__ __forceinline__ void emit_wave(const NNArgs& a, unsigned long long* s
     __syncthreads();
 }
 
-// push the lanes of `mask` (at most one per query) onto a query list (pending or deferred)
-__device__ __forceinline__ uint32_t push_lanes(uint4* list, uint32_t* list_spos, uint32_t* counter, bool mine,
+// push the lanes of `push` (at most one per query) onto segment `seg` of a query list
+__device__ __forceinline__ uint32_t push_lanes(const NNArgs& a, int list, uint32_t seg, bool mine,
                                                unsigned long long push, int lane, uint32_t qi, float r,
                                                float best_d2, uint32_t best_idx, uint32_t best_spos)
 {
+    uint4*    l_rec  = list ? a.work : a.pend;
+    uint32_t* l_spos = list ? a.work_spos : a.pend_spos;
     const int npush     = __popcll(push);
     uint32_t  base_slot = 0;
-    if (lane == 0) base_slot = atomicAdd(counter, (uint32_t)npush);
+    if (lane == 0)
+        base_slot = atomicAdd(a.q_counters + ((size_t)list * NN_MAX_SEG + seg) * NN_CNT_STRIDE, (uint32_t)npush);
     base_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_slot);
     if (mine && ((push >> lane) & 1ull))
     {
-        const uint32_t slot = base_slot + (uint32_t)__popcll(push & ((1ull << lane) - 1ull));
-        list[slot]      = make_uint4(qi, __float_as_uint(r), __float_as_uint(best_d2), best_idx);
-        list_spos[slot] = best_spos;
+        // a segment holds every query of its workgroups: base_slot + rank < seg_cap by construction
+        const size_t slot = (size_t)seg * a.seg_cap + base_slot + (uint32_t)__popcll(push & ((1ull << lane) - 1ull));
+        l_rec[slot]  = make_uint4(qi, __float_as_uint(r), __float_as_uint(best_d2), best_idx);
+        l_spos[slot] = best_spos;
     }
     return (uint32_t)npush;
 }
 
-// push the lanes of `mask` (one entry per query slot) onto the deferred-query list
+// push the lanes of `mask` (one entry per query slot) onto the deferred-query list (the segment the
+// tile's own queries came from: their number is bounded by that segment's capacity)
 template <int Q>
-__device__ __forceinline__ uint32_t defer_lanes(const NNArgs& a, bool mine, unsigned long long mask,
+__device__ __forceinline__ uint32_t defer_lanes(const NNArgs& a, uint32_t seg, bool mine, unsigned long long mask,
                                                 int lane, int slice, uint32_t qi, float r,
                                                 float best_d2, uint32_t best_idx, uint32_t best_spos)
 {
     const unsigned long long slot_mask = (Q < 64) ? ((1ull << (Q & 63)) - 1ull) : ~0ull;
-    return push_lanes(a.work, a.work_spos, a.q_counters + 1, mine && slice == 0, mask & slot_mask, lane, qi, r,
-                      best_d2, best_idx, best_spos);
+    return push_lanes(a, 1, seg, mine && slice == 0, mask & slot_mask, lane, qi, r, best_d2, best_idx, best_spos);
 }
 
 // ---- per-lane search helpers -------------------------------------------------------------------
@@ -531,7 +542,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     const unsigned long long pmask = __ballot(pending);
     if (pmask)
-        push_lanes(a.pend, a.pend_spos, a.q_counters, pending, pmask, lane, qi, r, best_d2, best_idx, best_spos);
+        push_lanes(a, 0, blockIdx.x / a.seg_waves, pending, pmask, lane, qi, r, best_d2, best_idx, best_spos);
 
     emit_wave(a, s_claim, lane, valid && !pending, qi, orig, active, thr, best_d2, best_idx, best_spos, lb2_keep);
 
@@ -572,14 +583,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const GridView& g     = a.g;
     const int       lane  = threadIdx.x;
     const uint32_t  tile  = blockIdx.x;
-    // the grid covers the worst case (every query pending); tiles beyond the list leave at once
-    const uint32_t  n_pend = a.q_counters[0];
-    if (tile * (uint32_t)Q >= n_pend) return;
+    // the grid covers the worst case (every query pending): tiles_per_seg tiles for each segment of
+    // the pending list; those beyond their segment's count leave at once
+    const uint32_t  seg    = tile / a.tiles_per_seg, tk = tile - seg * a.tiles_per_seg;
+    const uint32_t  n_pend = a.q_counters[(size_t)seg * NN_CNT_STRIDE];
+    if (tk * (uint32_t)Q >= n_pend) return;
     const unsigned long long tl0 = a.timeline ? wall_clock64() : 0ull;
     const int       qslot = lane & (Q - 1);
     const int       slice = (Q == 64) ? 0 : lane / Q;
-    const uint32_t  pslot = tile * Q + qslot;
-    const bool      valid = pslot < n_pend;
+    const bool      valid = tk * Q + qslot < n_pend;
+    const size_t    pslot = (size_t)seg * a.seg_cap + tk * Q + qslot;
 
     // the lane kernel did the per-query set-up (visit list, MatchState, warm start); a pending
     // query arrives with its radius and the best candidate so far
@@ -613,7 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         const unsigned long long wmask = __ballot(wide);
         if (wmask)
         {
-            defer_lanes<Q>(a, wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
+            defer_lanes<Q>(a, seg, wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
             if (wide) done = true, deferred = true;
         }
     }
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         // ---- a group of a few isolated queries goes to the one-query-per-wave kernel -----------
         if (__popcll(gmask) <= NN_COOP_MAX * S)
         {
-            st_defer += defer_lanes<Q>(a, grp, gmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
+            st_defer += defer_lanes<Q>(a, seg, grp, gmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
             if (grp) done = true, deferred = true;
             continue;
         }
@@ -805,7 +818,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         const unsigned long long wmask = __ballot(too_wide);
         if (wmask)
         {
-            st_defer += defer_lanes<Q>(a, too_wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
+            st_defer += defer_lanes<Q>(a, seg, too_wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
             if (too_wide) done = true, deferred = true;
         }
     }
@@ -924,13 +937,42 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
     __shared__ uint32_t s_cstart[64];
     __shared__ uint32_t s_coff[64];
     __shared__ uint32_t s_vox[NN_VLIST];
+    __shared__ uint32_t s_segoff[NN_MAX_SEG + 1];
     const GridView& g      = a.g;
     const int       lane   = threadIdx.x;
-    const uint32_t  n_work = a.q_counters[1];
     const unsigned long long tl0 = a.timeline ? wall_clock64() : 0ull;
-
-    for (uint32_t item = blockIdx.x; item < n_work; item += gridDim.x)
+    // the deferred list is segmented (see NNArgs): exclusive prefix of the segment counts, so that
+    // item k of the whole list is entry k - off[s] of its segment s
+    uint32_t n_work = 0;
     {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < NN_MAX_SEG / 64; k++)
+        {
+            const uint32_t sg  = (uint32_t)(k * 64 + lane);
+            const uint32_t c   = sg < a.n_seg ? a.q_counters[((size_t)NN_MAX_SEG + sg) * NN_CNT_STRIDE] : 0u;
+            const uint32_t inc = wave_incl_scan(c, lane);
+            s_segoff[sg]       = run + inc - c;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+        n_work = run;
+        if (lane == 0) s_segoff[NN_MAX_SEG] = run;
+        __syncthreads();
+    }
+
+    for (uint32_t k_item = blockIdx.x; k_item < n_work; k_item += gridDim.x)
+    {
+        // segment of this item: the last one whose offset is <= k_item (empty segments share an offset
+        // with their successor and are skipped by taking the last)
+        int lo = 0, hi = NN_MAX_SEG - 1;
+#pragma unroll
+        for (int it = 0; it < 8; it++)
+        {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_segoff[mid] <= k_item) lo = mid;
+            else hi = mid - 1;
+        }
+        const size_t   item = (size_t)lo * a.seg_cap + (k_item - s_segoff[lo]);
         const uint4    w    = a.work[item];
         const uint32_t qi   = w.x;
         const float4   lp   = a.lpts[qi];
@@ -1113,10 +1155,10 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
     }
 }
 
-// resets the two query-list counters {#pending, #deferred}
-__global__ void nn_reset_kernel(uint32_t* q_counters)
+// resets the segment counters of the two query lists
+__global__ __launch_bounds__(2 * NN_MAX_SEG) void nn_reset_kernel(uint32_t* q_counters)
 {
-    if (threadIdx.x < 2) q_counters[threadIdx.x] = 0u;
+    q_counters[(size_t)threadIdx.x * NN_CNT_STRIDE] = 0u;
 }
 
 // the [n_l][1] result arrays the other matchers' kernels read, from the packed records
@@ -1184,18 +1226,21 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     const size_t n_l = cloud->n;
     uint32_t     Q   = prm->queries_per_wave ? prm->queries_per_wave : 32;
     MP2P_REQUIRE(ctx, Q == 64 || Q == 32 || Q == 16, "queries_per_wave must be 64, 32 or 16");
-    const uint32_t n_tiles = (uint32_t)((n_l + Q - 1) / Q);   // worst case: every query pending
     const uint32_t n_waves = (uint32_t)((n_l + 63) / 64);     // lane kernel
 
     MP2P_TRY_HIP(ctx, ctx->nn_rec.ensure(n_l));
     MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_waves * 6));
     MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
-    MP2P_TRY_HIP(ctx, ctx->work.ensure(n_l));
-    MP2P_TRY_HIP(ctx, ctx->work_spos.ensure(n_l));
-    MP2P_TRY_HIP(ctx, ctx->pend.ensure(n_l));
-    MP2P_TRY_HIP(ctx, ctx->pend_spos.ensure(n_l));
-    MP2P_TRY_HIP(ctx, ctx->q_counters.ensure(4));
-    ctx->last_n_tiles = n_tiles;
+    // query lists in segments (NNArgs): seg_waves consecutive workgroups of the lane kernel share one
+    const uint32_t seg_waves = std::max<uint32_t>(1u, (n_waves + NN_MAX_SEG - 1) / NN_MAX_SEG);
+    const uint32_t n_seg     = std::max<uint32_t>(1u, (n_waves + seg_waves - 1) / seg_waves);
+    const uint32_t seg_cap   = seg_waves * 64u;
+    const size_t   list_cap  = (size_t)n_seg * seg_cap;
+    MP2P_TRY_HIP(ctx, ctx->work.ensure(list_cap));
+    MP2P_TRY_HIP(ctx, ctx->work_spos.ensure(list_cap));
+    MP2P_TRY_HIP(ctx, ctx->pend.ensure(list_cap));
+    MP2P_TRY_HIP(ctx, ctx->pend_spos.ensure(list_cap));
+    MP2P_TRY_HIP(ctx, ctx->q_counters.ensure((size_t)2 * NN_MAX_SEG * NN_CNT_STRIDE));
     ctx->last_q       = Q;
 
     NNArgs a;
@@ -1240,6 +1285,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.pend         = ctx->pend.p;
     a.pend_spos    = ctx->pend_spos.p;
     a.q_counters   = ctx->q_counters.p;
+    a.n_seg = n_seg, a.seg_waves = seg_waves, a.seg_cap = seg_cap, a.tiles_per_seg = seg_cap / Q;
+    const uint32_t n_tiles = n_seg * a.tiles_per_seg;  // worst case: every query pending
+    ctx->last_n_tiles = n_tiles;
     for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->hint_pose[i];
     for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->hint_pose[9 + i];
     a.use_hint = (ctx->hint_map == map && ctx->hint_cloud == cloud && ctx->hint_n == n_l && !prm->disable_warm_start) ? 1 : 0;
@@ -1268,7 +1316,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         ctx->timeline_tiles = n_tiles, ctx->timeline_singles = single_blocks;
     }
     ctx->pending_lane = 1;
-    hipLaunchKernelGGL(nn_reset_kernel, dim3(1), dim3(64), 0, ctx->stream, a.q_counters);
+    hipLaunchKernelGGL(nn_reset_kernel, dim3(1), dim3(2 * NN_MAX_SEG), 0, ctx->stream, a.q_counters);
     // ev[0]..ev[1] brackets exactly the search kernels (the roofline kernels of bench.py)
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (n_tiles)

@@ -865,7 +865,7 @@ size_t orc_match_pt2pt(const orc_kdtree* tree, const float* gx, const float* gy,
     return n_out;
 }
 
-/* ---- multi-threaded CPU baseline of the same contract (K==1, fresh MatchState) -------- */
+/* ---- multi-threaded CPU baseline of the same contract (K==1) -------------------------------- */
 typedef struct
 {
     const orc_kdtree* tree;
@@ -874,6 +874,7 @@ typedef struct
     float             maxDistSq, angSq;
     uint32_t*         nn_idx;
     float*            nn_d2;
+    const uint8_t*    skip; /* local points not to search, or NULL */
 } mt_job;
 
 static void* mt_worker(void* arg)
@@ -881,6 +882,11 @@ static void* mt_worker(void* arg)
     mt_job* j = (mt_job*)arg;
     for (size_t i = j->b; i < j->e; i++)
     {
+        if (j->skip && j->skip[i])
+        {
+            j->nn_idx[i] = 0xFFFFFFFFu, j->nn_d2[i] = 0;
+            continue;
+        }
         const float x = j->tx[i], y = j->ty[i], z = j->tz[i];
         const float normSq = (x * x + y * y) + z * z;
         uint32_t    id;
@@ -920,6 +926,17 @@ size_t orc_match_pt2pt_mt(const orc_kdtree* tree, const float* gx, const float* 
                           const float* lz, size_t n_l, const double T[12],
                           const orc_pt2pt_params* prm, orc_pair_pt2pt* out, int n_threads)
 {
+    return orc_match_pt2pt_mt_ms(tree, gx, gy, gz, n_g, lx, ly, lz, n_l, T, prm, NULL, NULL, out, n_threads);
+}
+
+/* ... with a MatchState: local points already paired are not searched (:218-220), pre-marked global
+ * points lose (:98-101), and the marks of the emitted pairs are left (:116-120) */
+size_t orc_match_pt2pt_mt_ms(const orc_kdtree* tree, const float* gx, const float* gy,
+                             const float* gz, size_t n_g, const float* lx, const float* ly,
+                             const float* lz, size_t n_l, const double T[12],
+                             const orc_pt2pt_params* prm, uint8_t* local_taken, uint8_t* global_taken,
+                             orc_pair_pt2pt* out, int n_threads)
+{
     if (!tree || n_g == 0 || n_l == 0 || prm->pairingsPerPoint != 1) return 0;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 1024) n_threads = 1024;
@@ -952,12 +969,16 @@ size_t orc_match_pt2pt_mt(const orc_kdtree* tree, const float* gx, const float* 
         for (int t = 0; t < n_threads; t++)
         {
             jobs[t] = (mt_job){tree,      tx,    ty, tz, n_l * t / n_threads,
-                               n_l * (t + 1) / n_threads, maxDistSq, angSq, nn, nd};
+                               n_l * (t + 1) / n_threads, maxDistSq, angSq, nn, nd,
+                               prm->allowMatchAlreadyMatchedPoints ? NULL : local_taken};
             pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
         }
         for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
         /* sequential resolution of the unique-global filter (lowest local index wins) */
-        uint8_t* taken = prm->allowMatchAlreadyMatchedGlobalPoints ? NULL : (uint8_t*)calloc(n_g, 1);
+        uint8_t* own   = NULL;
+        uint8_t* taken = NULL;
+        if (!prm->allowMatchAlreadyMatchedGlobalPoints)
+            taken = global_taken ? global_taken : (own = (uint8_t*)calloc(n_g, 1));
         for (size_t i = 0; i < n_l; i++)
         {
             const uint32_t g = nn[i];
@@ -966,6 +987,7 @@ size_t orc_match_pt2pt_mt(const orc_kdtree* tree, const float* gx, const float* 
             {
                 if (taken[g]) continue;
                 taken[g] = 1;
+                if (local_taken) local_taken[i] = 1;
             }
             orc_pair_pt2pt* p = &out[n_out++];
             p->globalIdx = g, p->localIdx = (uint32_t)i;
@@ -973,7 +995,7 @@ size_t orc_match_pt2pt_mt(const orc_kdtree* tree, const float* gx, const float* 
             p->lx = lx[i], p->ly = ly[i], p->lz = lz[i];
             p->errSq = nd[i];
         }
-        free(taken);
+        free(own);
     }
     free(tx), free(ty), free(tz), free(nn), free(nd);
     return n_out;
@@ -1020,6 +1042,43 @@ void orc_estimate_points_eigen(const float* xs, const float* ys, const float* zs
  *    plane = TPlane(centroid, eigvec0) normalised so that its largest |component| is
  *    positive; distance = |plane.distance(q)| as float.
  * ====================================================================================== */
+/* one query of the loop :79-110: 1 = a pairing was produced (plane, centroid written to p) */
+static int pt2pl_query(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                       size_t n_g, const orc_pt2pl_params* prm, float x, float y, float z,
+                       orc_pair_pt2pl* p)
+{
+    const int   K       = (int)prm->knn;
+    const float radSq   = (float)(prm->searchRadius * prm->searchRadius);
+    const float distThr = (float)prm->distanceThreshold;
+    uint32_t    nidx[ORC_MAX_K];
+    float       nd2[ORC_MAX_K], kx[ORC_MAX_K], ky[ORC_MAX_K], kz[ORC_MAX_K];
+    int found = nn_search(tree, gx, gy, gz, n_g, x, y, z, K, -1.0f, nidx, nd2);
+    int m     = 0;
+    while (m < found && !(nd2[m] > radSq)) m++; /* keep d2 <= radius^2 */
+    if (m < (int)prm->minimumPlanePoints || m < 3) return 0;
+    for (int k = 0; k < m; k++) kx[k] = gx[nidx[k]], ky[k] = gy[nidx[k]], kz[k] = gz[nidx[k]];
+    float  mean[3];
+    double cov[9], ev[3], evec[9];
+    orc_estimate_points_eigen(kx, ky, kz, (size_t)m, mean, cov, ev, evec);
+    if (!(ev[0] < prm->planeEigenThreshold * ev[2] && ev[0] < prm->planeEigenThreshold * ev[1]))
+        return 0;
+    /* TPlane(point, normal): unit normal, d = -n.c */
+    double       n[3] = {evec[0], evec[1], evec[2]};
+    const double nn   = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    n[0] /= nn, n[1] /= nn, n[2] /= nn;
+    int big = 0;
+    if (fabs(n[1]) > fabs(n[big])) big = 1;
+    if (fabs(n[2]) > fabs(n[big])) big = 2;
+    if (n[big] < 0) n[0] = -n[0], n[1] = -n[1], n[2] = -n[2];
+    const double c[3] = {(double)mean[0], (double)mean[1], (double)mean[2]};
+    const double d    = -(n[0] * c[0] + n[1] * c[1] + n[2] * c[2]);
+    const float  dist = (float)fabs(n[0] * (double)x + n[1] * (double)y + n[2] * (double)z + d);
+    if (dist > distThr) return 0; /* :100-101 */
+    p->plane[0] = n[0], p->plane[1] = n[1], p->plane[2] = n[2], p->plane[3] = d;
+    p->centroid[0] = c[0], p->centroid[1] = c[1], p->centroid[2] = c[2];
+    return 1;
+}
+
 size_t orc_match_pt2pl(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
                        size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
                        const double T[12], const orc_pt2pl_params* prm, uint8_t* local_taken,
@@ -1040,48 +1099,95 @@ size_t orc_match_pt2pl(const orc_kdtree* tree, const float* gx, const float* gy,
     if (bbox_intersects(gmin, gmax, lmin, lmax,
                         (float)(prm->distanceThreshold + prm->bbox_eps))) /* :63-66 */
     {
-        const float radSq   = (float)(prm->searchRadius * prm->searchRadius);
-        const float distThr = (float)prm->distanceThreshold;
-        uint32_t    nidx[ORC_MAX_K];
-        float       nd2[ORC_MAX_K], kx[ORC_MAX_K], ky[ORC_MAX_K], kz[ORC_MAX_K];
         for (size_t i = 0; i < n_l; i++) /* :79 */
         {
             if (!prm->allowMatchAlreadyMatchedPoints && local_taken && local_taken[i])
                 continue; /* :83-85 */
-            const float x = tx[i], y = ty[i], z = tz[i];
-            int found = nn_search(tree, gx, gy, gz, n_g, x, y, z, K, -1.0f, nidx, nd2);
-            int m     = 0;
-            while (m < found && !(nd2[m] > radSq)) m++; /* keep d2 <= radius^2 */
-            if (m < (int)prm->minimumPlanePoints || m < 3) continue;
-            for (int k = 0; k < m; k++)
-                kx[k] = gx[nidx[k]], ky[k] = gy[nidx[k]], kz[k] = gz[nidx[k]];
-            float  mean[3];
-            double cov[9], ev[3], evec[9];
-            orc_estimate_points_eigen(kx, ky, kz, (size_t)m, mean, cov, ev, evec);
-            if (!(ev[0] < prm->planeEigenThreshold * ev[2] &&
-                  ev[0] < prm->planeEigenThreshold * ev[1]))
-                continue;
-            /* TPlane(point, normal): unit normal, d = -n.c */
-            double       n[3] = {evec[0], evec[1], evec[2]};
-            const double nn   = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-            n[0] /= nn, n[1] /= nn, n[2] /= nn;
-            int big = 0;
-            if (fabs(n[1]) > fabs(n[big])) big = 1;
-            if (fabs(n[2]) > fabs(n[big])) big = 2;
-            if (n[big] < 0) n[0] = -n[0], n[1] = -n[1], n[2] = -n[2];
-            const double c[3] = {(double)mean[0], (double)mean[1], (double)mean[2]};
-            const double d    = -(n[0] * c[0] + n[1] * c[1] + n[2] * c[2]);
-            const float  dist = (float)fabs(n[0] * (double)x + n[1] * (double)y + n[2] * (double)z + d);
-            if (dist > distThr) continue; /* :100-101 */
             orc_pair_pt2pl* p = &out[n_out];
-            p->plane[0] = n[0], p->plane[1] = n[1], p->plane[2] = n[2], p->plane[3] = d;
-            p->centroid[0] = c[0], p->centroid[1] = c[1], p->centroid[2] = c[2];
+            if (!pt2pl_query(tree, gx, gy, gz, n_g, prm, tx[i], ty[i], tz[i], p)) continue;
             p->lx = lx[i], p->ly = ly[i], p->lz = lz[i]; /* :104-106 untransformed */
             p->_pad = 0;
             if (out_local_idx) out_local_idx[n_out] = (uint32_t)i;
             n_out++;
             if (local_taken) local_taken[i] = 1; /* :109 */
         }
+    }
+    free(tx), free(ty), free(tz);
+    return n_out;
+}
+
+/* ---- the same contract with the per-query work spread over threads (the queries of this matcher
+ *      do not interact: no global uniqueness, :87-90); results are gathered in ascending local
+ *      index, i.e. the sequential loop's order.  For the full-size configurations of the tests. */
+typedef struct
+{
+    const orc_kdtree*       tree;
+    const float *           gx, *gy, *gz;
+    size_t                  n_g;
+    const orc_pt2pl_params* prm;
+    const float *           tx, *ty, *tz;
+    const uint8_t*          local_taken;
+    size_t                  b, e;
+    uint8_t*                flag;
+    orc_pair_pt2pl*         rec;
+} pl_job;
+
+static void* pl_worker(void* arg)
+{
+    pl_job* j = (pl_job*)arg;
+    for (size_t i = j->b; i < j->e; i++)
+    {
+        j->flag[i] = 0;
+        if (!j->prm->allowMatchAlreadyMatchedPoints && j->local_taken && j->local_taken[i]) continue;
+        j->flag[i] = (uint8_t)pt2pl_query(j->tree, j->gx, j->gy, j->gz, j->n_g, j->prm, j->tx[i], j->ty[i],
+                                          j->tz[i], &j->rec[i]);
+    }
+    return NULL;
+}
+
+size_t orc_match_pt2pl_mt(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                          size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
+                          const double T[12], const orc_pt2pl_params* prm, uint8_t* local_taken,
+                          orc_pair_pt2pl* out, uint32_t* out_local_idx,
+                          uint64_t* potential_pairings, int n_threads)
+{
+    const int K = (int)prm->knn;
+    if (potential_pairings) *potential_pairings += (uint64_t)n_l; /* :54 */
+    if (!tree || n_g == 0 || n_l == 0 || K < 3 || K > ORC_MAX_K) return 0;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    float* tx = (float*)malloc(n_l * sizeof(float));
+    float* ty = (float*)malloc(n_l * sizeof(float));
+    float* tz = (float*)malloc(n_l * sizeof(float));
+    float  lmin[3], lmax[3], gmin[3], gmax[3];
+    orc_transform_local_to_global(lx, ly, lz, n_l, T, tx, ty, tz, lmin, lmax);
+    bbox_of(gx, gy, gz, n_g, gmin, gmax);
+    size_t n_out = 0;
+    if (bbox_intersects(gmin, gmax, lmin, lmax, (float)(prm->distanceThreshold + prm->bbox_eps)))
+    {
+        uint8_t*        flag = (uint8_t*)malloc(n_l);
+        orc_pair_pt2pl* rec  = (orc_pair_pt2pl*)malloc(n_l * sizeof(orc_pair_pt2pl));
+        pthread_t       th[1024];
+        pl_job          jobs[1024];
+        for (int t = 0; t < n_threads; t++)
+        {
+            jobs[t] = (pl_job){tree, gx, gy, gz, n_g, prm, tx, ty, tz, local_taken, n_l * t / n_threads,
+                               n_l * (t + 1) / n_threads, flag, rec};
+            pthread_create(&th[t], NULL, pl_worker, &jobs[t]);
+        }
+        for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+        for (size_t i = 0; i < n_l; i++)
+        {
+            if (!flag[i]) continue;
+            orc_pair_pt2pl* p = &out[n_out];
+            *p    = rec[i];
+            p->lx = lx[i], p->ly = ly[i], p->lz = lz[i];
+            p->_pad = 0;
+            if (out_local_idx) out_local_idx[n_out] = (uint32_t)i;
+            n_out++;
+            if (local_taken) local_taken[i] = 1;
+        }
+        free(flag), free(rec);
     }
     free(tx), free(ty), free(tz);
     return n_out;

@@ -185,6 +185,16 @@ size_t orc_match_pt2pt_mt(const orc_kdtree* tree, const float* gx, const float* 
                           const float* gz, size_t n_g, const float* lx, const float* ly,
                           const float* lz, size_t n_l, const double T[12],
                           const orc_pt2pt_params* prm, orc_pair_pt2pt* out, int n_threads);
+size_t orc_match_pt2pt_mt_ms(const orc_kdtree* tree, const float* gx, const float* gy,
+                             const float* gz, size_t n_g, const float* lx, const float* ly,
+                             const float* lz, size_t n_l, const double T[12],
+                             const orc_pt2pt_params* prm, uint8_t* local_taken, uint8_t* global_taken,
+                             orc_pair_pt2pt* out, int n_threads);
+size_t orc_match_pt2pl_mt(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,
+                          size_t n_g, const float* lx, const float* ly, const float* lz, size_t n_l,
+                          const double T[12], const orc_pt2pl_params* prm, uint8_t* local_taken,
+                          orc_pair_pt2pl* out, uint32_t* out_local_idx,
+                          uint64_t* potential_pairings, int n_threads);
 
 /* ---- a6: Matcher_Point2Plane::implMatchOneLayer + declared nn_search_pt2pl ------------ */
 size_t orc_match_pt2pl(const orc_kdtree* tree, const float* gx, const float* gy, const float* gz,

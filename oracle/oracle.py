@@ -143,6 +143,14 @@ def _declare(L):
                                      C.c_size_t, _dp, C.POINTER(Pt2PtParams), C.c_void_p,
                                      C.c_int]
     L.orc_match_pt2pt_mt.restype = C.c_size_t
+    L.orc_match_pt2pt_mt_ms.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp,
+                                        C.c_size_t, _dp, C.POINTER(Pt2PtParams), _u8p, _u8p, C.c_void_p,
+                                        C.c_int]
+    L.orc_match_pt2pt_mt_ms.restype = C.c_size_t
+    L.orc_match_pt2pl_mt.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp,
+                                     C.c_size_t, _dp, C.POINTER(Pt2PlParams), _u8p, C.c_void_p,
+                                     _u32p, C.POINTER(C.c_uint64), C.c_int]
+    L.orc_match_pt2pl_mt.restype = C.c_size_t
     L.orc_match_pt2pl.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_size_t, _fp, _fp, _fp,
                                   C.c_size_t, _dp, C.POINTER(Pt2PlParams), _u8p, C.c_void_p,
                                   _u32p, C.POINTER(C.c_uint64)]
@@ -360,13 +368,15 @@ def match_pt2pt(gx, gy, gz, lx, ly, lz, T, threshold, thresholdAngularDeg, pairi
     out = np.zeros(max(1, lx.size * pairingsPerPoint), PAIR_PT2PT)
     pot = C.c_uint64(0)
     th = tree._h if tree is not None else None
-    if threads and threads > 0:
-        assert tree is not None
-        n = lib().orc_match_pt2pt_mt(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
-                                     lx.size, _d(T), C.byref(prm), out.ctypes.data, threads)
-        return out[:n].copy(), lx.size * pairingsPerPoint
     lt = local_taken.ctypes.data_as(_u8p) if local_taken is not None else None
     gt = global_taken.ctypes.data_as(_u8p) if global_taken is not None else None
+    if threads and threads > 0:
+        # the per-query searches spread over threads, the unique-global filter resolved sequentially:
+        # the same lists as the sequential loop (K == 1, no visit list)
+        assert tree is not None and pairingsPerPoint == 1 and idxs is None
+        n = lib().orc_match_pt2pt_mt_ms(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
+                                        lx.size, _d(T), C.byref(prm), lt, gt, out.ctypes.data, threads)
+        return out[:n].copy(), lx.size * pairingsPerPoint
     if idxs is not None:
         ii = np.ascontiguousarray(idxs, dtype=np.uint32)
         n = lib().orc_match_pt2pt_subset(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
@@ -448,9 +458,10 @@ def match_adaptive(gx, gy, gz, lx, ly, lz, T, confidenceInterval=0.80, firstToSe
 
 def match_pt2pl(gx, gy, gz, lx, ly, lz, T, distanceThreshold, searchRadius, knn,
                 minimumPlanePoints, planeEigenThreshold, allowMatchAlreadyMatchedPoints=False,
-                bbox_eps=0.20, tree=None, local_taken=None, idxs=None):
+                bbox_eps=0.20, tree=None, local_taken=None, idxs=None, threads=0):
     """Matcher_Point2Plane::implMatchOneLayer with the declared nn_search_pt2pl.
-    Returns (pairs, local_idx, potential)."""
+    Returns (pairs, local_idx, potential).  threads > 0: the (independent) queries spread over
+    threads, gathered in the sequential loop's order."""
     gx, gy, gz, lx, ly, lz = map(_f32, (gx, gy, gz, lx, ly, lz))
     T = np.ascontiguousarray(T, dtype=np.float64)
     prm = Pt2PlParams(distanceThreshold, searchRadius, knn, minimumPlanePoints,
@@ -466,6 +477,12 @@ def match_pt2pl(gx, gy, gz, lx, ly, lz, T, distanceThreshold, searchRadius, knn,
                                          lx.size, ii.ctypes.data_as(_u32p), ii.size, _d(T),
                                          C.byref(prm), lt, out.ctypes.data,
                                          oidx.ctypes.data_as(_u32p), C.byref(pot))
+        return out[:n].copy(), oidx[:n].copy(), pot.value
+    if threads and threads > 0:
+        assert tree is not None
+        n = lib().orc_match_pt2pl_mt(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
+                                     lx.size, _d(T), C.byref(prm), lt, out.ctypes.data,
+                                     oidx.ctypes.data_as(_u32p), C.byref(pot), threads)
         return out[:n].copy(), oidx[:n].copy(), pot.value
     n = lib().orc_match_pt2pl(th, _f(gx), _f(gy), _f(gz), gx.size, _f(lx), _f(ly), _f(lz),
                               lx.size, _d(T), C.byref(prm), lt, out.ctypes.data,

@@ -55,6 +55,7 @@ static void parse_tune(Tune& t)
             const long        v = strtol(kv.c_str() + q + 1, nullptr, 10);
             if (k == "lane_cells") t.lane_cells = (uint32_t)v;
             else if (k == "tile_cand_cap") t.tile_cand_cap = (uint32_t)v;
+            else if (k == "tile_time_cap_us") t.tile_time_cap_us = (uint32_t)v;
             else if (k == "claim_dedup") t.claim_dedup = (int)v;
             else if (k == "claim_peek") t.claim_peek = (int)v;
             else if (k == "gn_ticket") t.gn_ticket = (int)v;
@@ -157,9 +158,9 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->nn_spos.release(), ctx->nn_d2.release(), ctx->tile_bbox.release();
     ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release();
-    ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release();
+    ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release(), ctx->gn_ticket.release();
     ctx->aos_stage.release(), ctx->pl_slots.release();
-    ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release(), ctx->exch.release(), ctx->claim_list.release();
+    ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();
     ctx->pend.release(), ctx->pend_spos.release(), ctx->q_counters.release(), ctx->nn_rec.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -378,9 +379,9 @@ static int check_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     return MP2P_HIP_OK;
 }
 
-int mp2p_hip_match_pt2pt_phase1(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
-                                const mp2p_hip_cloud* cloud, const double pose[12],
-                                const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms)
+static int match_pt2pt_phase1(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                              const double pose[12], const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms,
+                              bool reduce_bbox)
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;
     int rc = check_pt2pt(ctx, map, cloud, prm, ms);
@@ -389,12 +390,12 @@ int mp2p_hip_match_pt2pt_phase1(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     if (map->n == 0 || cloud->n == 0) return MP2P_HIP_OK;  // :67
     if (prm->pairingsPerPoint > 1) return launch_nn_pt2pt_knn(ctx, map, cloud, pose, prm, ms);  // :242-248
-    return launch_nn_pt2pt(ctx, map, cloud, pose, prm, ms);
+    return launch_nn_pt2pt(ctx, map, cloud, pose, prm, ms, reduce_bbox);
 }
 
-int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
-                                const mp2p_hip_cloud* cloud, const mp2p_hip_pt2pt_params* prm,
-                                mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
+static int match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                              const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms, mp2p_hip_pairs* out,
+                              bool bbox_from_tiles)
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;
     int rc = check_pt2pt(ctx, map, cloud, prm, ms);
@@ -403,7 +404,7 @@ int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     if (map->n == 0 || cloud->n == 0)  // potential_pairings is added BEFORE the early-out (:64-67)
         return launch_add_potential(ctx, out, (unsigned long long)cloud->n * prm->pairingsPerPoint);
-    rc = launch_compact_pt2pt(ctx, map, cloud, prm, ms, out);
+    rc = launch_compact_pt2pt(ctx, map, cloud, prm, ms, out, bbox_from_tiles);
     if (!rc && ctx->profiling)
     {
         ctx->pending_match = ctx->profiling == 4 ? 3 : ctx->profiling;  // read back lazily in mp2p_hip_get_stats
@@ -413,15 +414,30 @@ int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
     return rc;
 }
 
+int mp2p_hip_match_pt2pt_phase1(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
+                                const mp2p_hip_cloud* cloud, const double pose[12],
+                                const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms)
+{
+    return match_pt2pt_phase1(ctx, map, cloud, pose, prm, ms, /*reduce_bbox=*/true);
+}
+
+int mp2p_hip_match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map,
+                                const mp2p_hip_cloud* cloud, const mp2p_hip_pt2pt_params* prm,
+                                mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
+{
+    return match_pt2pt_phase2(ctx, map, cloud, prm, ms, out, /*bbox_from_tiles=*/false);
+}
+
 int mp2p_hip_match_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
                          const double pose[12], const mp2p_hip_pt2pt_params* prm,
                          mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
 {
-    int rc = mp2p_hip_match_pt2pt_phase1(ctx, map, cloud, pose, prm, ms);
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    // one GPU: the layer's bounding box is reduced inside the compaction (two launches less)
+    const bool fused = ctx->tune.compact_fused && prm && prm->pairingsPerPoint == 1;
+    int rc = match_pt2pt_phase1(ctx, map, cloud, pose, prm, ms, !fused);
     if (rc) return rc;
-    rc = mp2p_hip_match_pt2pt_phase2(ctx, map, cloud, prm, ms, out);
-    if (rc) return rc;
-    return MP2P_HIP_OK;
+    return match_pt2pt_phase2(ctx, map, cloud, prm, ms, out, fused);
 }
 
 int mp2p_hip_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
@@ -629,7 +645,7 @@ int mp2p_hip_gn_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const doub
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
-    return gn_begin(ctx, pairs, pose0, prm);
+    return gn_begin(ctx, pairs, pose0, prm, /*lazy_init=*/false);
 }
 int   mp2p_hip_gn_accumulate(mp2p_hip_ctx* ctx) { return ctx ? gn_accumulate(ctx) : MP2P_HIP_ERR_INVALID; }
 void* mp2p_hip_gn_sums_ptr(mp2p_hip_ctx* ctx) { return ctx ? (void*)ctx->gn_sums.p : nullptr; }
@@ -641,7 +657,7 @@ int mp2p_hip_gn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const doub
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = gn_begin(ctx, pairs, pose0, prm);
+    int rc = gn_begin(ctx, pairs, pose0, prm, /*lazy_init=*/true);
     if (rc) return rc;
     // the whole inner loop is enqueued without a host round trip; iterations after the
     // convergence test (:365) or the cost test (:344) has fired are no-ops on the device

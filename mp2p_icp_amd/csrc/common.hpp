@@ -98,8 +98,11 @@ struct DevBuf
 // for measurements only, every setting computes the same results
 struct Tune
 {
-    uint32_t lane_cells    = 4;     // widest cube (level-0 voxels per axis) the one-query-per-lane kernel takes; 0 = off
+    uint32_t lane_cells    = 0;     // widest cube (level-0 voxels per axis) the one-query-per-lane kernel searches
+                                    // itself; 0 = none (measured: per-lane 16-byte gathers cost one L1 line each,
+                                    // the tile kernel's coalesced staging serves the same queries 2.5x cheaper)
     uint32_t tile_cand_cap = 6144;  // staged candidates after which a tile hands its pending queries on
+    uint32_t tile_time_cap_us = 35; // ... and microseconds after which it does
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
     int      claim_peek    = 1;     // plain look at the claim word before the atomic
     int      gn_ticket     = 1;     // Gauss-Newton: last block reduces and steps (one launch per inner iteration)
@@ -111,6 +114,8 @@ struct GnState
     const mp2p_hip_pairs* pairs = nullptr;
     mp2p_hip_gn_params    prm{};
     bool                  active = false;
+    double                pose0[12] = {};
+    bool                  state_ready = false;  // gn_state holds {pose0, zeros} or a later iterate
 };
 
 }  // namespace mp2p
@@ -136,6 +141,9 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<float>              nn_d2;        // [n_local]
     mp2p::DevBuf<float>              tile_bbox;    // [n_tiles][6]
     mp2p::DevBuf<float>              tile_bbox2;   // [64][6] second reduction level
+    mp2p::DevBuf<float>              block_bbox;   // [compaction blocks][6] (fused box reduction, pairs.hip)
+    uint32_t                         last_n_boxes = 0;       // per-wave boxes the last pt2pt search left in tile_bbox
+    bool                             q_counters_clean = false;  // the search's list counters are zero on the stream
     mp2p::DevBuf<float>              local_bbox;   // [6] min xyz, max xyz of transformed local
     mp2p::DevBuf<double>             exch;         // [8] what a sharded layer all-reduces (pairs.hip)
     mp2p::DevBuf<unsigned long long> claim_list;   // [n_l + 1] claim records + their count
@@ -144,6 +152,8 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<double>             gn_partials;  // [GN_BLOCKS][NSUMS]
     mp2p::DevBuf<double>             gn_sums;      // [NSUMS]
     mp2p::DevBuf<double>             gn_state;     // pose(12) H(36) g(6) cost(1) iters(1) done(1)
+    mp2p::DevBuf<unsigned int>       gn_ticket;    // arrival counter of the fused iteration kernel
+    bool                             gn_ticket_zeroed = false;
     mp2p::DevBuf<unsigned char>      aos_stage;    // download staging
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
     mp2p::DevBuf<unsigned long long> timeline;     // profiling level 4: {start, end} ticks per workgroup

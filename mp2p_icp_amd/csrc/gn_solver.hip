@@ -75,23 +75,15 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* __r
 }
 
 // ---- K6: point-to-point (errorTerms.cpp:36-66 + optimal_tf_gauss_newton.cpp:149-180) --------
-__global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pt_kernel(
+__device__ __forceinline__ void accum_pt2pt_body(
     const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ lz,
     const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz,
-    const unsigned long long* __restrict__ counts, const double* __restrict__ state,
-    const GnKernelPrm prm, double* __restrict__ partials)
+    unsigned long long n, const double (&R)[9], const double (&t)[3], const GnKernelPrm& prm,
+    double* __restrict__ partials)
 {
     double acc[NS_PT];
 #pragma unroll
     for (int k = 0; k < NS_PT; k++) acc[k] = 0;
-    const bool done = state[ST_DONE] != 0.0;
-    const unsigned long long n = done ? 0ull : counts[0];
-    double R[9], t[3];
-#pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = state[ST_POSE + k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) t[k] = state[ST_POSE + 9 + k];
-
     for (unsigned long long i = (unsigned long long)blockIdx.x * GN_THREADS + threadIdx.x; i < n;
          i += (unsigned long long)GN_BLOCKS * GN_THREADS)
     {
@@ -126,6 +118,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pt_kernel(
     block_reduce_store<NS_PT>(acc, partials + (size_t)blockIdx.x * NS);
 }
 
+__global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pt_kernel(
+    const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ lz,
+    const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz,
+    const unsigned long long* __restrict__ counts, const double* __restrict__ state,
+    const GnKernelPrm prm, double* __restrict__ partials)
+{
+    const bool done = state[ST_DONE] != 0.0;
+    const unsigned long long n = done ? 0ull : counts[0];
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = state[ST_POSE + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = state[ST_POSE + 9 + k];
+    accum_pt2pt_body(lx, ly, lz, gx, gy, gz, n, R, t, prm, partials);
+}
+
 // ---- K7: point-to-plane (errorTerms.cpp:115-161 + optimal_tf_gauss_newton.cpp:229-259) ------
 // one 3-row term: H(upper) += w Ji^T Ji, g += w Ji^T e     (Ji row-major 3x6)
 __device__ __forceinline__ void accum_rows3(double (&acc)[28], const double (&J)[18], const double (&e)[3],
@@ -141,22 +149,17 @@ __device__ __forceinline__ void accum_rows3(double (&acc)[28], const double (&J)
     for (int p = 0; p < 6; p++) acc[21 + p] += w * (J[p] * e[0] + J[6 + p] * e[1] + J[12 + p] * e[2]);
 }
 
-__global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pl_kernel(
+__device__ __forceinline__ void accum_pt2pl_body(
     const double* __restrict__ coef, const float* __restrict__ lx, const float* __restrict__ ly,
     const float* __restrict__ lz, const mp2p_hip_pair_pt2ln* __restrict__ lines,
     const mp2p_hip_pair_pl2pl* __restrict__ planes, const unsigned long long* __restrict__ counts,
-    const double* __restrict__ state, const GnKernelPrm prm, double* __restrict__ partials)
+    bool done, const double (&R)[9], const double (&t)[3], const GnKernelPrm& prm,
+    double* __restrict__ partials)
 {
     double acc[NS_PL];
 #pragma unroll
     for (int k = 0; k < NS_PL; k++) acc[k] = 0;
-    const bool done = state[ST_DONE] != 0.0;
     const unsigned long long n = (done || !coef) ? 0ull : counts[1];
-    double R[9], t[3];
-#pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = state[ST_POSE + k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) t[k] = state[ST_POSE + 9 + k];
 
     for (unsigned long long i = (unsigned long long)blockIdx.x * GN_THREADS + threadIdx.x; i < n;
          i += (unsigned long long)GN_BLOCKS * GN_THREADS)
@@ -251,6 +254,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pl_kernel(
         acc[27] += w * w * esq;  // :303
     }
     block_reduce_store<NS_PL>(acc, partials + (size_t)blockIdx.x * NS + NS_PT);
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pl_kernel(
+    const double* __restrict__ coef, const float* __restrict__ lx, const float* __restrict__ ly,
+    const float* __restrict__ lz, const mp2p_hip_pair_pt2ln* __restrict__ lines,
+    const mp2p_hip_pair_pl2pl* __restrict__ planes, const unsigned long long* __restrict__ counts,
+    const double* __restrict__ state, const GnKernelPrm prm, double* __restrict__ partials)
+{
+    const bool done = state[ST_DONE] != 0.0;
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = state[ST_POSE + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = state[ST_POSE + 9 + k];
+    accum_pt2pl_body(coef, lx, ly, lz, lines, planes, counts, done, R, t, prm, partials);
 }
 
 // fixed-order sum of the block partials -> sums[48] (16 interleaved partial sums per quantity,
@@ -602,6 +620,86 @@ __global__ void gn_init_kernel(double* __restrict__ state, const GnInit init)
     if (i < ST_SIZE) state[i] = (i < 12) ? init.pose[i] : 0.0;
 }
 
+// ---- one launch per inner iteration (single GPU): every block accumulates its share of the pairs
+//      and takes a ticket; the LAST block to arrive adds the block partials in a fixed order and runs
+//      the 6x6 step.  The first iteration takes the linearisation point from the kernel arguments
+//      (no init launch).  Hand-off between the blocks = the agent-scope release / acquire pair of
+//      MI355X_MICROARCH.md ("inter-workgroup visibility"): plain stores, __syncthreads, one lane's
+//      release fence + s_waitcnt, relaxed ticket atomic; the last block: one acquire fence,
+//      __syncthreads, plain loads.  ~2 us per side against ~8 us per saved launch boundary.
+struct GnIterArgs
+{
+    const float *lx, *ly, *lz, *gx, *gy, *gz;        // pt2pt SoA
+    const double* coef;                              // pt2pl
+    const float * pl_lx, *pl_ly, *pl_lz;
+    const mp2p_hip_pair_pt2ln* lines;
+    const mp2p_hip_pair_pl2pl* planes;
+    const unsigned long long*  counts;
+    double *     state, *partials, *sums;
+    unsigned int* ticket;
+    GnKernelPrm  kprm;
+    GnStepPrm    sprm;
+    GnInit       init;
+    int          first, use_pt, use_pl;
+};
+
+__global__ __launch_bounds__(GN_THREADS) void gn_iter_kernel(const GnIterArgs a)
+{
+    __shared__ int    s_last;
+    __shared__ double s_part[GN_THREADS / 64][NS];
+    __shared__ double s_ws[GN_STEP_WS];
+    const bool done = a.first ? false : (a.state[ST_DONE] != 0.0);
+    double     R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = a.first ? a.init.pose[k] : a.state[ST_POSE + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = a.first ? a.init.pose[9 + k] : a.state[ST_POSE + 9 + k];
+
+    if (a.use_pt)
+        accum_pt2pt_body(a.lx, a.ly, a.lz, a.gx, a.gy, a.gz, done ? 0ull : a.counts[0], R, t, a.kprm, a.partials);
+    if (a.use_pl)
+        accum_pt2pl_body(a.coef, a.pl_lx, a.pl_ly, a.pl_lz, a.lines, a.planes, a.counts, done, R, t, a.kprm,
+                         a.partials);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == gridDim.x - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *a.ticket = 0u;  // for the next launch (ordered by the kernel boundary)
+    }
+    __syncthreads();
+    // fixed-order sum of the block partials: 4 interleaved partial sums per quantity, then a fixed tree
+    {
+        const int  q = threadIdx.x & 63, part = threadIdx.x >> 6;
+        const bool mine = q < NS && ((q < NS_PT && a.use_pt) || (q >= NS_PT && q < NS_PT + NS_PL && a.use_pl));
+        double     v = 0;
+        if (mine && !done)
+            for (int b = part; b < GN_BLOCKS; b += GN_THREADS / 64) v += a.partials[(size_t)b * NS + q];
+        if (q < NS) s_part[part][q] = v;
+        __syncthreads();
+        if (threadIdx.x < NS)
+        {
+            const int i = threadIdx.x;
+            a.sums[i]   = (s_part[0][i] + s_part[1][i]) + (s_part[2][i] + s_part[3][i]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        if (a.first)
+            for (int i = 0; i < ST_SIZE; i++) a.state[i] = (i < 12) ? a.init.pose[i] : 0.0;
+        gn_step_body(a.sums, a.state, a.sprm, s_ws);
+    }
+}
+
 static GnKernelPrm make_kernel_prm(const mp2p_hip_gn_params& p)
 {
     GnKernelPrm k;
@@ -622,21 +720,34 @@ static GnKernelPrm make_kernel_prm(const mp2p_hip_gn_params& p)
     return k;
 }
 
+// the state vector starts as {pose0, zeros}: written by a launch of its own (split form), or by the
+// first fused iteration
+static int gn_ensure_state(mp2p_hip_ctx* ctx)
+{
+    if (ctx->gn.state_ready) return MP2P_HIP_OK;
+    GnInit init;
+    for (int i = 0; i < 12; i++) init.pose[i] = ctx->gn.pose0[i];
+    hipLaunchKernelGGL(gn_init_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->gn_state.p, init);
+    ctx->gn.state_ready = true;
+    MP2P_TRY_HIP(ctx, hipGetLastError());
+    return MP2P_HIP_OK;
+}
+
 int gn_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[12],
-             const mp2p_hip_gn_params* prm)
+             const mp2p_hip_gn_params* prm, bool lazy_init)
 {
     MP2P_REQUIRE(ctx, pairs && pose0 && prm, "null argument");
     MP2P_REQUIRE(ctx, prm->n_weight_blocks <= 8, "at most 8 point_weights blocks are supported");
     MP2P_TRY_HIP(ctx, ctx->gn_partials.ensure((size_t)GN_BLOCKS * NS));
     MP2P_TRY_HIP(ctx, ctx->gn_sums.ensure(NS));
     MP2P_TRY_HIP(ctx, ctx->gn_state.ensure(ST_SIZE));
-    GnInit init;
-    for (int i = 0; i < 12; i++) init.pose[i] = pose0[i];
-    hipLaunchKernelGGL(gn_init_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->gn_state.p, init);
     ctx->gn.pairs  = pairs;
     ctx->gn.prm    = *prm;
     ctx->gn.active = true;
+    for (int i = 0; i < 12; i++) ctx->gn.pose0[i] = pose0[i];
+    ctx->gn.state_ready = false;
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    if (!lazy_init) return gn_ensure_state(ctx);
     return MP2P_HIP_OK;
 }
 
@@ -692,6 +803,33 @@ int gn_step(mp2p_hip_ctx* ctx)
 int gn_iterate_fused(mp2p_hip_ctx* ctx)
 {
     MP2P_REQUIRE(ctx, ctx->gn.active, "gn_iterate_fused without gn_begin");
+    if (ctx->tune.gn_ticket)
+    {
+        const mp2p_hip_pairs* P = ctx->gn.pairs;
+        MP2P_TRY_HIP(ctx, ctx->gn_ticket.ensure(1));
+        if (!ctx->gn_ticket_zeroed)
+        {
+            MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->gn_ticket.p, 0, sizeof(unsigned int), ctx->stream));
+            ctx->gn_ticket_zeroed = true;
+        }
+        GnIterArgs a;
+        memset(&a, 0, sizeof(a));
+        a.lx = P->lx.p, a.ly = P->ly.p, a.lz = P->lz.p, a.gx = P->gx.p, a.gy = P->gy.p, a.gz = P->gz.p;
+        a.coef  = P->cap_pt2pl > 0 ? P->pl_coef.p : nullptr;
+        a.pl_lx = P->pl_lx.p, a.pl_ly = P->pl_ly.p, a.pl_lz = P->pl_lz.p;
+        a.lines = P->ln.p, a.planes = P->pp.p, a.counts = P->counts.p;
+        a.state = ctx->gn_state.p, a.partials = ctx->gn_partials.p, a.sums = ctx->gn_sums.p;
+        a.ticket = ctx->gn_ticket.p;
+        a.kprm = make_kernel_prm(ctx->gn.prm), a.sprm = make_step_prm(ctx);
+        a.use_pt = a.sprm.use_pt, a.use_pl = a.sprm.use_pl;
+        a.first = ctx->gn.state_ready ? 0 : 1;
+        for (int i = 0; i < 12; i++) a.init.pose[i] = ctx->gn.pose0[i];
+        hipLaunchKernelGGL(gn_iter_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream, a);
+        ctx->gn.state_ready = true;
+        MP2P_TRY_HIP(ctx, hipGetLastError());
+        return MP2P_HIP_OK;
+    }
+    if (const int rc = gn_ensure_state(ctx)) return rc;
     int use_pt, use_pl;
     launch_partials(ctx, use_pt, use_pl);
     hipLaunchKernelGGL(gn_sums_step_kernel, dim3(1), dim3(1024), 0, ctx->stream,
@@ -704,6 +842,7 @@ int gn_iterate_fused(mp2p_hip_ctx* ctx)
 int gn_end(mp2p_hip_ctx* ctx, mp2p_hip_gn_result* out)
 {
     MP2P_REQUIRE(ctx, ctx->gn.active, "gn_end without gn_begin");
+    if (const int rc = gn_ensure_state(ctx)) return rc;  // maxInnerLoopIterations == 0
     double st[ST_SIZE];
     if (ctx->prof_all())
     {

@@ -67,6 +67,7 @@ struct NNArgs
     uint32_t      brick_budget;      // 4x4x4 bricks per pass of the one-query-per-wave kernel
     uint32_t      lane_cells;        // widest cube (level-0 voxels per axis, <= 4) a lane searches itself; 0 = never
     uint32_t      tile_cand_cap;     // staged candidates after which a tile hands its pending queries on
+    unsigned long long tile_tick_cap;  // ... and 100 MHz ticks since the tile started (checked after each pass)
     int           claim_dedup, claim_peek;
     const unsigned char* local_taken;   // by original local index, or null
     const unsigned char* global_taken;  // by original global index, or null
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const uint32_t  seg    = tile / a.tiles_per_seg, tk = tile - seg * a.tiles_per_seg;
     const uint32_t  n_pend = a.q_counters[(size_t)seg * NN_CNT_STRIDE];
     if (tk * (uint32_t)Q >= n_pend) return;
-    const unsigned long long tl0 = a.timeline ? wall_clock64() : 0ull;
+    const unsigned long long tl0 = wall_clock64();
     const int       qslot = lane & (Q - 1);
     const int       slice = (Q == 64) ? 0 : lane / Q;
     const bool      valid = tk * Q + qslot < n_pend;
@@ -811,10 +812,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 too_wide = r > a.r_defer;
             }
         }
-        // a tile that has already staged more than its budget hands ALL its unfinished queries on:
-        // tiles are dispatched in order, and one that runs 5-8x the mean keeps a nearly empty chip
-        // waiting at the end of the kernel (the one-query kernel spreads the same work evenly)
-        if (st_cand > a.tile_cand_cap && !done) too_wide = true;
+        // a tile that has already staged more than its budget, or has run longer than its time budget,
+        // hands ALL its unfinished queries on: tiles are dispatched in order, a few of them run 5-8x
+        // the mean (many passes over small groups), and one of those starting late keeps a nearly empty
+        // chip waiting -- measured: the chip is full for the first 45 % of the kernel's span only
+        // (the one-query kernel spreads the same work evenly; results do not depend on who finishes a
+        // query)
+        if (!done && (st_cand > a.tile_cand_cap || wall_clock64() - tl0 > a.tile_tick_cap)) too_wide = true;
         const unsigned long long wmask = __ballot(too_wide);
         if (wmask)
         {
@@ -1220,8 +1224,11 @@ int launch_bbox_reduce(mp2p_hip_ctx* ctx, uint32_t n_tiles)
 }
 
 // ------------------------------------------------------------------------------------------
+// reduce_bbox: leave the layer's bounding box in ctx->local_bbox (two small launches); false when
+// the fused compaction of pairs.hip follows and reduces the per-wave boxes itself
 int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
-                    const double pose[12], const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms)
+                    const double pose[12], const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms,
+                    bool reduce_bbox = true)
 {
     const size_t n_l = cloud->n;
     uint32_t     Q   = prm->queries_per_wave ? prm->queries_per_wave : 32;
@@ -1240,7 +1247,11 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     MP2P_TRY_HIP(ctx, ctx->work_spos.ensure(list_cap));
     MP2P_TRY_HIP(ctx, ctx->pend.ensure(list_cap));
     MP2P_TRY_HIP(ctx, ctx->pend_spos.ensure(list_cap));
-    MP2P_TRY_HIP(ctx, ctx->q_counters.ensure((size_t)2 * NN_MAX_SEG * NN_CNT_STRIDE));
+    if (ctx->q_counters.n < (size_t)2 * NN_MAX_SEG * NN_CNT_STRIDE)
+    {
+        MP2P_TRY_HIP(ctx, ctx->q_counters.ensure((size_t)2 * NN_MAX_SEG * NN_CNT_STRIDE));
+        ctx->q_counters_clean = false;
+    }
     ctx->last_q       = Q;
 
     NNArgs a;
@@ -1267,6 +1278,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
                                              : fminf(fmaxf(1.0f, 2.0f * cell0), 4.0f * cell0);
     a.lane_cells    = std::min<uint32_t>(ctx->tune.lane_cells, 4u);
     a.tile_cand_cap = ctx->tune.tile_cand_cap;
+    a.tile_tick_cap = (unsigned long long)ctx->tune.tile_time_cap_us * 100ull;
     a.claim_dedup   = ctx->tune.claim_dedup;
     a.claim_peek    = ctx->tune.claim_peek;
     a.local_taken =
@@ -1316,7 +1328,11 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         ctx->timeline_tiles = n_tiles, ctx->timeline_singles = single_blocks;
     }
     ctx->pending_lane = 1;
-    hipLaunchKernelGGL(nn_reset_kernel, dim3(1), dim3(2 * NN_MAX_SEG), 0, ctx->stream, a.q_counters);
+    ctx->last_n_boxes = n_waves;
+    // the list counters: cleared by the previous call's fused compaction, or here
+    if (!ctx->q_counters_clean)
+        hipLaunchKernelGGL(nn_reset_kernel, dim3(1), dim3(2 * NN_MAX_SEG), 0, ctx->stream, a.q_counters);
+    ctx->q_counters_clean = false;
     // ev[0]..ev[1] brackets exactly the search kernels (the roofline kernels of bench.py)
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (n_tiles)
@@ -1347,8 +1363,11 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     }
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    int rc = launch_bbox_reduce(ctx, n_waves);
-    if (rc) return rc;
+    if (reduce_bbox)
+    {
+        int rc = launch_bbox_reduce(ctx, n_waves);
+        if (rc) return rc;
+    }
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
 }

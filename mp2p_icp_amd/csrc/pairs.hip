@@ -20,6 +20,14 @@ struct CompactArgs
     const uint32_t*           pos;      // original local index -> place in that order
     const float*              nn_d2;
     const uint4*              rec;      // K == 1 point-to-point search: packed records instead (nn_query.hip)
+    // fused form (point-to-point matcher on one GPU): the bounding box of the transformed local layer
+    // is reduced here -- per-wave boxes -> per-block boxes in the count kernel -> the layer's box and
+    // the overlap decision (counts[7]) in the scan kernel -- instead of by two launches of its own
+    const float*              tile_bbox;     // [n_tile_boxes][6] or null (local_bbox is final already)
+    uint32_t                  n_tile_boxes;
+    float*                    block_bbox;    // [n_blocks][6]
+    float*                    local_bbox_out;
+    uint32_t*                 q_counters;    // the search's query-list counters, re-zeroed for the next call
     uint32_t                  n_l;      // number of SLOTS = visited local points x K, in visiting order
     uint32_t                  K;        // pairingsPerPoint
     const uint32_t*           order;    // visit position -> original local index (null: identity)
@@ -81,8 +89,24 @@ __device__ __forceinline__ bool pair_flag(const CompactArgs& a, uint32_t t, uint
 __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const CompactArgs a)
 {
     __shared__ uint32_t s_w[CP_THREADS / 64];
+    __shared__ float    s_bb[CP_THREADS / 64][6];
     uint32_t            c = 0;
-    if (bbox_overlap(a.gbb, a.local_bbox, a.margin))
+    if (a.tile_bbox)
+    {
+        // this block's slice of the per-wave boxes (NaN-free by construction: nn_query.hip)
+        const uint32_t per = (a.n_tile_boxes + gridDim.x - 1) / gridDim.x;
+        const uint32_t b0 = blockIdx.x * per, b1 = min(a.n_tile_boxes, b0 + per);
+        float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = b0 + threadIdx.x; i < b1; i += CP_THREADS)
+        {
+            const float* p = a.tile_bbox + (size_t)i * 6;
+            for (int d = 0; d < 3; d++) v[d] = fminf(v[d], p[d]), v[3 + d] = fmaxf(v[3 + d], p[3 + d]);
+        }
+        for (int d = 0; d < 3; d++) v[d] = wave_min(v[d]), v[3 + d] = wave_max(v[3 + d]);
+        if ((threadIdx.x & 63) == 0)
+            for (int d = 0; d < 6; d++) s_bb[threadIdx.x >> 6][d] = v[d];
+    }
+    if (a.tile_bbox || bbox_overlap(a.gbb, a.local_bbox, a.margin))
     {
         const uint32_t base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
 #pragma unroll
@@ -102,6 +126,13 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const Compact
         uint32_t t = 0;
         for (int w = 0; w < CP_THREADS / 64; w++) t += s_w[w];
         a.block_counts[blockIdx.x] = t;
+    }
+    if (a.tile_bbox && threadIdx.x < 6)
+    {
+        const int d = threadIdx.x;
+        float     r = s_bb[0][d];
+        for (int k = 1; k < CP_THREADS / 64; k++) r = d < 3 ? fminf(r, s_bb[k][d]) : fmaxf(r, s_bb[k][d]);
+        a.block_bbox[(size_t)blockIdx.x * 6 + d] = r;
     }
 }
 
@@ -149,10 +180,80 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t* block_coun
     }
 }
 
+// fused form of the scan: first the layer's box from the block boxes and the bounding-box early-out
+// of Matcher_Points_DistanceThreshold.cpp:73-75 (no overlap = no pairs: the counts are scanned as
+// zeros and the write kernel leaves at once), then the scan above; last, the search's query-list
+// counters are cleared for the next call (one launch less at its start)
+__global__ __launch_bounds__(1024) void compact_scan_bbox_kernel(const CompactArgs a, uint32_t n_blocks)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_run;
+    __shared__ float    s_bb[16][6];
+    __shared__ int      s_overlap;
+    const int           lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = threadIdx.x; i < n_blocks; i += 1024)
+        {
+            const float* p = a.block_bbox + (size_t)i * 6;
+            for (int d = 0; d < 3; d++) v[d] = fminf(v[d], p[d]), v[3 + d] = fmaxf(v[3 + d], p[3 + d]);
+        }
+        for (int d = 0; d < 3; d++) v[d] = wave_min(v[d]), v[3 + d] = wave_max(v[3 + d]);
+        if (lane == 0)
+            for (int d = 0; d < 6; d++) s_bb[w][d] = v[d];
+    }
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        float l[6];
+        for (int d = 0; d < 6; d++)
+        {
+            float r = s_bb[0][d];
+            for (int k = 1; k < 16; k++) r = d < 3 ? fminf(r, s_bb[k][d]) : fmaxf(r, s_bb[k][d]);
+            l[d] = r, a.local_bbox_out[d] = r;
+        }
+        s_overlap = bbox_overlap(a.gbb, l, a.margin) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool overlap = s_overlap != 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 1024)
+    {
+        const uint32_t i    = b0 + threadIdx.x;
+        const uint32_t v    = (i < n_blocks && overlap) ? a.block_counts[i] : 0;
+        const uint32_t incl = wave_incl_scan(v, lane);
+        if (lane == 63) s_w[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; k++) woff += s_w[k];
+        const uint32_t run = s_run;
+        if (i < n_blocks) a.block_counts[i] = run + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_run = run + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        const unsigned long long total = s_run;
+        const unsigned long long old   = a.counts[0];
+        a.counts[3]                    = old;  // write base for the scatter kernel
+        unsigned long long nw          = old + total;
+        if (nw > a.cap)
+        {
+            a.counts[4] = 1;  // overflow: caller-provided capacity too small
+            nw          = a.cap;
+        }
+        a.counts[0] = nw;
+        a.counts[2] += a.potential_add;
+        a.counts[7] = overlap ? 1ull : 0ull;
+    }
+    if (a.q_counters && threadIdx.x < 2 * NN_MAX_SEG) a.q_counters[(size_t)threadIdx.x * NN_CNT_STRIDE] = 0u;
+}
+
 __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const CompactArgs a)
 {
     __shared__ uint32_t s_w[CP_THREADS / 64];
-    if (!bbox_overlap(a.gbb, a.local_bbox, a.margin)) return;
+    if (a.tile_bbox ? (a.counts[7] == 0ull) : !bbox_overlap(a.gbb, a.local_bbox, a.margin)) return;
     const uint32_t base = blockIdx.x * CP_TILE + threadIdx.x * CP_ITEMS;
     uint32_t       sp[CP_ITEMS], li[CP_ITEMS];
     size_t         src[CP_ITEMS];
@@ -202,7 +303,7 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
                          const uint32_t* order, size_t n_slots, const uint32_t* n_slots_dev, uint32_t K,
                          bool use_claims, bool always_mark, unsigned long long local_offset, float margin,
                          unsigned long long potential_add, mp2p_hip_mstate* ms, mp2p_hip_pairs* out,
-                         bool mark_global = true, bool from_rec = false)
+                         bool mark_global = true, bool from_rec = false, bool bbox_from_tiles = false)
 {
     const size_t   n_l      = n_slots;
     const uint32_t n_blocks = (uint32_t)((n_l + CP_TILE - 1) / CP_TILE);
@@ -231,11 +332,25 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     a.ms_local  = ms ? ms->local_taken.p : nullptr;
     a.ms_global = (ms && mark_global) ? ms->global_taken.p : nullptr;
 
+    const bool fused = bbox_from_tiles && n_blocks > 0 && ctx->last_n_boxes > 0;
+    if (fused)
+    {
+        MP2P_TRY_HIP(ctx, ctx->block_bbox.ensure((size_t)n_blocks * 6));
+        a.tile_bbox = ctx->tile_bbox.p, a.n_tile_boxes = ctx->last_n_boxes;
+        a.block_bbox = ctx->block_bbox.p, a.local_bbox_out = ctx->local_bbox.p;
+        a.q_counters = ctx->q_counters.p;
+    }
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (n_blocks)
         hipLaunchKernelGGL(compact_count_kernel, dim3(n_blocks), dim3(CP_THREADS), 0, ctx->stream, a);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                       ctx->block_counts.p, n_blocks, out->counts.p, a.cap, a.potential_add, 0);
+    if (fused)
+    {
+        hipLaunchKernelGGL(compact_scan_bbox_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, n_blocks);
+        ctx->q_counters_clean = true;
+    }
+    else
+        hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                           ctx->block_counts.p, n_blocks, out->counts.p, a.cap, a.potential_add, 0);
     if (n_blocks)
         hipLaunchKernelGGL(compact_write_kernel, dim3(n_blocks), dim3(CP_THREADS), 0, ctx->stream, a);
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
@@ -245,7 +360,7 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
 
 int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
                          const mp2p_hip_pt2pt_params* prm, mp2p_hip_mstate* ms,
-                         mp2p_hip_pairs* out)
+                         mp2p_hip_pairs* out, bool bbox_from_tiles)
 {
     const size_t n_visit = cloud->n_visit ? cloud->n_visit : cloud->n;
     const size_t n_slots = n_visit * prm->pairingsPerPoint;
@@ -256,7 +371,8 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
                                 prm->local_index_offset,
                                 (float)(prm->threshold + prm->bounding_box_intersection_check_epsilon),
                                 (unsigned long long)cloud->n * prm->pairingsPerPoint, ms, out, true,
-                                /*from_rec=*/prm->pairingsPerPoint == 1);
+                                /*from_rec=*/prm->pairingsPerPoint == 1,
+                                bbox_from_tiles && prm->pairingsPerPoint == 1);
 }
 
 // ---- sharded local layer: what the ranks exchange between phase 1 and phase 2 -----------------

@@ -56,6 +56,8 @@ static void parse_tune(Tune& t)
             if (k == "lane_cells") t.lane_cells = (uint32_t)v;
             else if (k == "tile_cand_cap") t.tile_cand_cap = (uint32_t)v;
             else if (k == "tile_time_cap_us") t.tile_time_cap_us = (uint32_t)v;
+            else if (k == "hard_radius_pct") t.hard_radius_pct = (uint32_t)v;
+            else if (k == "sync_spin") t.sync_spin = (int)v;
             else if (k == "claim_dedup") t.claim_dedup = (int)v;
             else if (k == "claim_peek") t.claim_peek = (int)v;
             else if (k == "gn_ticket") t.gn_ticket = (int)v;
@@ -164,6 +166,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->pend.release(), ctx->pend_spos.release(), ctx->q_counters.release(), ctx->nn_rec.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -102,10 +102,15 @@ struct Tune
                                     // itself; 0 = none (measured: per-lane 16-byte gathers cost one L1 line each,
                                     // the tile kernel's coalesced staging serves the same queries 2.5x cheaper)
     uint32_t tile_cand_cap = 6144;  // staged candidates after which a tile hands its pending queries on
-    uint32_t tile_time_cap_us = 35; // ... and microseconds after which it does
+    uint32_t tile_time_cap_us = 50; // ... and microseconds after which it does
+    uint32_t hard_radius_pct = 100; // pending queries with a radius above this % of a level-0 voxel are "hard":
+                                    // their tiles are dispatched first (nn_query.hip)
+    int      sync_spin     = 1;     // wait for the stream by polling hipStreamQuery (lower wake-up latency)
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
     int      claim_peek    = 1;     // plain look at the claim word before the atomic
-    int      gn_ticket     = 1;     // Gauss-Newton: last block reduces and steps (one launch per inner iteration)
+    int      gn_ticket     = 0;     // Gauss-Newton: the last block to arrive reduces and steps (one launch per inner
+                                    // iteration): 1 = release/acquire fences, 2 = agent-scope atomic stores/loads.
+                                    // Measured slower than the extra launches (0.103 vs 0.070 ms for 3 iterations)
     int      compact_fused = 1;     // compaction: bounding-box reduction folded in
 };
 
@@ -178,6 +183,7 @@ struct mp2p_hip_ctx
     mp2p::GnState                    gn;
     uint32_t last_n_tiles = 0;
     uint32_t last_q       = 64;
+    void*    pinned       = nullptr;  // 4 KB of page-locked host memory for the small read-backs
 };
 
 struct mp2p_hip_map
@@ -234,6 +240,16 @@ struct mp2p_hip_pairs
 namespace mp2p
 {
 int  set_err(mp2p_hip_ctx* ctx, int code, const char* fmt, ...);
+// hipStreamSynchronize, or (tune.sync_spin) a poll of hipStreamQuery: no wake-up latency
+inline hipError_t stream_wait(mp2p_hip_ctx* ctx)
+{
+    if (!ctx->tune.sync_spin) return hipStreamSynchronize(ctx->stream);
+    for (;;)
+    {
+        const hipError_t e = hipStreamQuery(ctx->stream);
+        if (e != hipErrorNotReady) return e;
+    }
+}
 void set_global_err(const char* fmt, ...);
 
 #define MP2P_TRY_HIP(ctx, expr)                                                              \

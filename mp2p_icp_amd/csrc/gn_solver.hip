@@ -53,7 +53,9 @@ __device__ __forceinline__ double robust_w(const GnKernelPrm& p, double esq)
     return 1.0;
 }
 
-template <int N>
+// AGENT: the partials are handed to another workgroup inside the same launch (gn_iter_kernel, mode 2):
+// agent-scope atomic stores (write-through, no L2 write-back fence needed on this side)
+template <int N, bool AGENT = false>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* __restrict__ out)
 {
     __shared__ double s[GN_THREADS / 64][N];
@@ -70,11 +72,18 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[N], double* __r
     {
         double t = 0;
         for (int k = 0; k < GN_THREADS / 64; k++) t += s[k][threadIdx.x];
-        out[threadIdx.x] = t;
+        if (AGENT)
+        {
+            __hip_atomic_store(out + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        else
+            out[threadIdx.x] = t;
     }
 }
 
 // ---- K6: point-to-point (errorTerms.cpp:36-66 + optimal_tf_gauss_newton.cpp:149-180) --------
+template <bool AGENT = false>
 __device__ __forceinline__ void accum_pt2pt_body(
     const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ lz,
     const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz,
@@ -115,7 +124,7 @@ __device__ __forceinline__ void accum_pt2pt_body(
         acc[15] += w * (l0 * p1 - l1 * p0);
         acc[16] += w * esq;
     }
-    block_reduce_store<NS_PT>(acc, partials + (size_t)blockIdx.x * NS);
+    block_reduce_store<NS_PT, AGENT>(acc, partials + (size_t)blockIdx.x * NS);
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pt_kernel(
@@ -149,6 +158,7 @@ __device__ __forceinline__ void accum_rows3(double (&acc)[28], const double (&J)
     for (int p = 0; p < 6; p++) acc[21 + p] += w * (J[p] * e[0] + J[6 + p] * e[1] + J[12 + p] * e[2]);
 }
 
+template <bool AGENT = false>
 __device__ __forceinline__ void accum_pt2pl_body(
     const double* __restrict__ coef, const float* __restrict__ lx, const float* __restrict__ ly,
     const float* __restrict__ lz, const mp2p_hip_pair_pt2ln* __restrict__ lines,
@@ -253,7 +263,7 @@ __device__ __forceinline__ void accum_pt2pl_body(
         accum_rows3(acc, J, e, w);
         acc[27] += w * w * esq;  // :303
     }
-    block_reduce_store<NS_PL>(acc, partials + (size_t)blockIdx.x * NS + NS_PT);
+    block_reduce_store<NS_PL, AGENT>(acc, partials + (size_t)blockIdx.x * NS + NS_PT);
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pl_kernel(
@@ -643,6 +653,7 @@ struct GnIterArgs
     int          first, use_pt, use_pl;
 };
 
+template <bool AGENT>
 __global__ __launch_bounds__(GN_THREADS) void gn_iter_kernel(const GnIterArgs a)
 {
     __shared__ int    s_last;
@@ -656,15 +667,19 @@ __global__ __launch_bounds__(GN_THREADS) void gn_iter_kernel(const GnIterArgs a)
     for (int k = 0; k < 3; k++) t[k] = a.first ? a.init.pose[9 + k] : a.state[ST_POSE + 9 + k];
 
     if (a.use_pt)
-        accum_pt2pt_body(a.lx, a.ly, a.lz, a.gx, a.gy, a.gz, done ? 0ull : a.counts[0], R, t, a.kprm, a.partials);
+        accum_pt2pt_body<AGENT>(a.lx, a.ly, a.lz, a.gx, a.gy, a.gz, done ? 0ull : a.counts[0], R, t, a.kprm,
+                                a.partials);
     if (a.use_pl)
-        accum_pt2pl_body(a.coef, a.pl_lx, a.pl_ly, a.pl_lz, a.lines, a.planes, a.counts, done, R, t, a.kprm,
-                         a.partials);
+        accum_pt2pl_body<AGENT>(a.coef, a.pl_lx, a.pl_ly, a.pl_lz, a.lines, a.planes, a.counts, done, R, t,
+                                a.kprm, a.partials);
     __syncthreads();
     if (threadIdx.x == 0)
     {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!AGENT)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const unsigned int tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (tk == gridDim.x - 1u) ? 1 : 0;
     }
@@ -672,7 +687,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_iter_kernel(const GnIterArgs a)
     if (!s_last) return;
     if (threadIdx.x == 0)
     {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!AGENT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         *a.ticket = 0u;  // for the next launch (ordered by the kernel boundary)
     }
     __syncthreads();
@@ -682,7 +697,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_iter_kernel(const GnIterArgs a)
         const bool mine = q < NS && ((q < NS_PT && a.use_pt) || (q >= NS_PT && q < NS_PT + NS_PL && a.use_pl));
         double     v = 0;
         if (mine && !done)
-            for (int b = part; b < GN_BLOCKS; b += GN_THREADS / 64) v += a.partials[(size_t)b * NS + q];
+            for (int b = part; b < GN_BLOCKS; b += GN_THREADS / 64)
+                v += AGENT ? __hip_atomic_load(a.partials + (size_t)b * NS + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : a.partials[(size_t)b * NS + q];
         if (q < NS) s_part[part][q] = v;
         __syncthreads();
         if (threadIdx.x < NS)
@@ -824,7 +841,10 @@ int gn_iterate_fused(mp2p_hip_ctx* ctx)
         a.use_pt = a.sprm.use_pt, a.use_pl = a.sprm.use_pl;
         a.first = ctx->gn.state_ready ? 0 : 1;
         for (int i = 0; i < 12; i++) a.init.pose[i] = ctx->gn.pose0[i];
-        hipLaunchKernelGGL(gn_iter_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream, a);
+        if (ctx->tune.gn_ticket == 2)
+            hipLaunchKernelGGL(gn_iter_kernel<true>, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(gn_iter_kernel<false>, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream, a);
         ctx->gn.state_ready = true;
         MP2P_TRY_HIP(ctx, hipGetLastError());
         return MP2P_HIP_OK;
@@ -849,8 +869,13 @@ int gn_end(mp2p_hip_ctx* ctx, mp2p_hip_gn_result* out)
         MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
         ctx->pending_gn = 1;
     }
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync(st, ctx->gn_state.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // 512 bytes to a pinned buffer, then wait for the stream by polling (the step ends here; a
+    // blocking wait adds its wake-up latency to every outer iteration)
+    if (!ctx->pinned)
+        MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->gn_state.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
+    memcpy(st, ctx->pinned, sizeof(st));
     ctx->gn.active = false;
     if (out)
     {

@@ -51,6 +51,7 @@ constexpr int NN_CAP      = 256;  // staged candidates per round (LDS: 5 x 1 KB)
 constexpr int NN_COOP_MAX = 4;    // groups of up to this many queries are deferred
 constexpr int NN_CLAIM_SLOTS = 128;  // in-wave claim table (LDS)
 constexpr int NN_MAX_SEG     = 256;  // segments of a query list
+constexpr int NN_LISTS       = 3;    // 0 = pending/hard, 1 = deferred, 2 = pending/easy
 constexpr int NN_CNT_STRIDE  = 32;   // uint32 words between two segment counters (128 bytes)
 
 struct NNArgs
@@ -92,6 +93,13 @@ struct NNArgs
     uint32_t*            work_spos;
     uint32_t*            q_counters;
     uint32_t             n_seg, seg_waves, seg_cap, tiles_per_seg;
+    // the pending list comes in two classes, hard (list 0: radius above r_hard) and easy (list 2, stored
+    // behind the hard entries at pend + list_cap): the tile kernel's grid serves the hard class FIRST.
+    // Workgroups are dispatched in index order and a hard tile runs 5-8x as long as an easy one; started
+    // last it kept a nearly empty chip waiting (45 % of the kernel's span), started first its tail is
+    // covered by the short, uniform easy tiles.  It also keeps far queries out of the easy tiles' boxes.
+    uint32_t             list_cap;
+    float                r_hard;
     const uint32_t*      rank;  // visit rank per original local index (NONE = not visited) or null
     int                  use_hint;
     PoseRt               prev_pose;
@@ -277,8 +285,8 @@ __device__ __forceinline__ uint32_t push_lanes(const NNArgs& a, int list, uint32
                                                unsigned long long push, int lane, uint32_t qi, float r,
                                                float best_d2, uint32_t best_idx, uint32_t best_spos)
 {
-    uint4*    l_rec  = list ? a.work : a.pend;
-    uint32_t* l_spos = list ? a.work_spos : a.pend_spos;
+    uint4*    l_rec  = list == 1 ? a.work : a.pend + (list == 2 ? a.list_cap : 0u);
+    uint32_t* l_spos = list == 1 ? a.work_spos : a.pend_spos + (list == 2 ? a.list_cap : 0u);
     const int npush     = __popcll(push);
     uint32_t  base_slot = 0;
     if (lane == 0)
@@ -542,8 +550,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
     }
     const unsigned long long pmask = __ballot(pending);
-    if (pmask)
-        push_lanes(a, 0, blockIdx.x / a.seg_waves, pending, pmask, lane, qi, r, best_d2, best_idx, best_spos);
+    {
+        const bool               hard  = pending && r > a.r_hard;
+        const unsigned long long hmask = __ballot(hard), emask = pmask & ~hmask;
+        if (hmask)
+            push_lanes(a, 0, blockIdx.x / a.seg_waves, hard, hmask, lane, qi, r, best_d2, best_idx, best_spos);
+        if (emask)
+            push_lanes(a, 2, blockIdx.x / a.seg_waves, pending && !hard, emask, lane, qi, r, best_d2, best_idx,
+                       best_spos);
+    }
 
     emit_wave(a, s_claim, lane, valid && !pending, qi, orig, active, thr, best_d2, best_idx, best_spos, lb2_keep);
 
@@ -586,14 +601,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const uint32_t  tile  = blockIdx.x;
     // the grid covers the worst case (every query pending): tiles_per_seg tiles for each segment of
     // the pending list; those beyond their segment's count leave at once
-    const uint32_t  seg    = tile / a.tiles_per_seg, tk = tile - seg * a.tiles_per_seg;
-    const uint32_t  n_pend = a.q_counters[(size_t)seg * NN_CNT_STRIDE];
+    const uint32_t  tiles_per_list = a.n_seg * a.tiles_per_seg;
+    const uint32_t  cls    = tile >= tiles_per_list ? 1u : 0u;  // 0 = hard (first), 1 = easy
+    const uint32_t  tl     = tile - cls * tiles_per_list;
+    const uint32_t  seg    = tl / a.tiles_per_seg, tk = tl - seg * a.tiles_per_seg;
+    const uint32_t  n_pend = a.q_counters[((size_t)(cls ? 2 : 0) * NN_MAX_SEG + seg) * NN_CNT_STRIDE];
     if (tk * (uint32_t)Q >= n_pend) return;
     const unsigned long long tl0 = wall_clock64();
     const int       qslot = lane & (Q - 1);
     const int       slice = (Q == 64) ? 0 : lane / Q;
     const bool      valid = tk * Q + qslot < n_pend;
-    const size_t    pslot = (size_t)seg * a.seg_cap + tk * Q + qslot;
+    const size_t    pslot = (size_t)cls * a.list_cap + (size_t)seg * a.seg_cap + tk * Q + qslot;
 
     // the lane kernel did the per-query set-up (visit list, MatchState, warm start); a pending
     // query arrives with its radius and the best candidate so far
@@ -1160,7 +1178,7 @@ __global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
 }
 
 // resets the segment counters of the two query lists
-__global__ __launch_bounds__(2 * NN_MAX_SEG) void nn_reset_kernel(uint32_t* q_counters)
+__global__ __launch_bounds__(NN_LISTS * NN_MAX_SEG) void nn_reset_kernel(uint32_t* q_counters)
 {
     q_counters[(size_t)threadIdx.x * NN_CNT_STRIDE] = 0u;
 }
@@ -1245,11 +1263,11 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     const size_t   list_cap  = (size_t)n_seg * seg_cap;
     MP2P_TRY_HIP(ctx, ctx->work.ensure(list_cap));
     MP2P_TRY_HIP(ctx, ctx->work_spos.ensure(list_cap));
-    MP2P_TRY_HIP(ctx, ctx->pend.ensure(list_cap));
-    MP2P_TRY_HIP(ctx, ctx->pend_spos.ensure(list_cap));
-    if (ctx->q_counters.n < (size_t)2 * NN_MAX_SEG * NN_CNT_STRIDE)
+    MP2P_TRY_HIP(ctx, ctx->pend.ensure(2 * list_cap));  // hard class, then easy class
+    MP2P_TRY_HIP(ctx, ctx->pend_spos.ensure(2 * list_cap));
+    if (ctx->q_counters.n < (size_t)NN_LISTS * NN_MAX_SEG * NN_CNT_STRIDE)
     {
-        MP2P_TRY_HIP(ctx, ctx->q_counters.ensure((size_t)2 * NN_MAX_SEG * NN_CNT_STRIDE));
+        MP2P_TRY_HIP(ctx, ctx->q_counters.ensure((size_t)NN_LISTS * NN_MAX_SEG * NN_CNT_STRIDE));
         ctx->q_counters_clean = false;
     }
     ctx->last_q       = Q;
@@ -1298,7 +1316,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.pend_spos    = ctx->pend_spos.p;
     a.q_counters   = ctx->q_counters.p;
     a.n_seg = n_seg, a.seg_waves = seg_waves, a.seg_cap = seg_cap, a.tiles_per_seg = seg_cap / Q;
-    const uint32_t n_tiles = n_seg * a.tiles_per_seg;  // worst case: every query pending
+    a.list_cap = (uint32_t)list_cap;
+    a.r_hard   = cell0 * 0.01f * (float)ctx->tune.hard_radius_pct;
+    const uint32_t n_tiles = 2u * n_seg * a.tiles_per_seg;  // worst case for each class: every query in it
     ctx->last_n_tiles = n_tiles;
     for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->hint_pose[i];
     for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->hint_pose[9 + i];
@@ -1331,7 +1351,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     ctx->last_n_boxes = n_waves;
     // the list counters: cleared by the previous call's fused compaction, or here
     if (!ctx->q_counters_clean)
-        hipLaunchKernelGGL(nn_reset_kernel, dim3(1), dim3(2 * NN_MAX_SEG), 0, ctx->stream, a.q_counters);
+        hipLaunchKernelGGL(nn_reset_kernel, dim3(1), dim3(NN_LISTS * NN_MAX_SEG), 0, ctx->stream, a.q_counters);
     ctx->q_counters_clean = false;
     // ev[0]..ev[1] brackets exactly the search kernels (the roofline kernels of bench.py)
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));

@@ -231,11 +231,12 @@ def make_scan_union_pair(n_local, n_global, seed, map_scan_points=None, spacing=
         yaw = 0.05 * math.cos(x / 35.0)
         return (x, y, 0.0), yaw
 
-    # ~55 % of a scan's points survive thinning against its neighbours at the target density
+    # scans are added until the thinned union holds enough points; the union is thinned incrementally
+    # ("first in input order" per voxel, so accumulating a thinned prefix changes nothing)
     vox = 0.05
     raw, n_scans, k = [], 0, 0
-    est = 0
-    while est < n_global * 1.15 and k < max_scans:
+    acc = np.zeros((0, 3), np.float32)
+    while acc.shape[0] < n_global * 1.1 and k < max_scans:
         (sx, sy, sz), yaw = pose_at(k)
         if sx > scene.length + 20.0:
             break
@@ -249,12 +250,14 @@ def make_scan_union_pair(n_local, n_global, seed, map_scan_points=None, spacing=
         k += 1
         n_scans = k
         if k % 4 == 0 or k < 4:
-            est = _voxel_thin(np.concatenate(raw, 0), vox).shape[0]
-    allp = np.concatenate(raw, 0)
-    thin = _voxel_thin(allp, vox)
-    while thin.shape[0] < n_global and vox > 0.004:  # not enough voxels: thin less
-        vox *= 0.7
-        thin = _voxel_thin(allp, vox)
+            acc = _voxel_thin(np.concatenate([acc] + raw[-(4 if k % 4 == 0 else 1):], 0) if k >= 4
+                              else np.concatenate(raw, 0), vox)
+    thin = _voxel_thin(np.concatenate(raw, 0), vox) if acc.shape[0] < n_global or k % 4 else acc
+    if thin.shape[0] < n_global:
+        allp = np.concatenate(raw, 0)
+        while thin.shape[0] < n_global and vox > 0.004:  # not enough voxels: thin less
+            vox *= 0.7
+            thin = _voxel_thin(allp, vox)
     if thin.shape[0] < n_global:
         raise RuntimeError(f"scene too small for a {n_global}-point map ({thin.shape[0]} after {n_scans} scans)")
     sel = np.sort(rng.choice(thin.shape[0], n_global, replace=False))

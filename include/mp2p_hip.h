@@ -122,6 +122,21 @@ int  mp2p_hip_mstate_download(mp2p_hip_ctx* ctx, const mp2p_hip_mstate* ms,
 int  mp2p_hip_mstate_upload(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms, const uint8_t* global_taken,
                             const uint8_t* local_taken);
 
+/* The same two bit-fields PACKED, bit i = bit (i & 63) of word i / 64: the storage of libstdc++'s
+ * std::vector<bool>, which pointcloud_bitfield_t::DenseOrSparseBitField wraps (pointcloud_bitfield.h:
+ * 46-92).  ceil(n / 64) words each; either pointer may be NULL (that field is left as it is).  A
+ * 10 M-point layer is 1.25 MB this way instead of 10 MB -- and a caller whose fields are all clear
+ * calls mp2p_hip_mstate_reset (no transfer at all). */
+int  mp2p_hip_mstate_upload_bits(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms, const uint64_t* global_words,
+                                 const uint64_t* local_words);
+int  mp2p_hip_mstate_download_bits(mp2p_hip_ctx* ctx, const mp2p_hip_mstate* ms, uint64_t* global_words,
+                                   uint64_t* local_words);
+
+/* page-locked host memory (device transfers into it run at the full link rate and without a
+ * staging copy); for callers that control where their host containers live */
+void* mp2p_hip_host_alloc(mp2p_hip_ctx* ctx, size_t bytes);
+void  mp2p_hip_host_free(mp2p_hip_ctx* ctx, void* p);
+
 /* ---- Pairings (Pairings.h:84-169), device resident ------------------------------------ */
 /* host images, byte-compatible with the reference containers */
 typedef struct
@@ -169,6 +184,15 @@ int  mp2p_hip_pairs_download_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
 int  mp2p_hip_pairs_download_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
                                    mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx,
                                    size_t capacity, size_t* n_out);
+/* the entries [first, count) only: what ONE matcher call appended (the marks a matcher leaves in the
+ * MatchState are exactly the localIdx / globalIdx of these entries, so a host MatchState is brought
+ * up to date from this list -- no per-point transfer).  potential may be NULL. */
+int  mp2p_hip_pairs_download_pt2pt_from(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first,
+                                        mp2p_hip_pair_pt2pt* out, size_t capacity, size_t* n_out,
+                                        uint64_t* potential);
+int  mp2p_hip_pairs_download_pt2pl_from(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first,
+                                        mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx,
+                                        size_t capacity, size_t* n_out, uint64_t* potential);
 /* paired_pt2ln / paired_pl2pl: produced on the host by Matcher_Point2Line /
  * Matcher_Planes_Normals (not on this path), consumed by the Gauss-Newton solver
  * (optimal_tf_gauss_newton.cpp:184-202, 289-308).  Replaces both lists (n = 0 empties one);

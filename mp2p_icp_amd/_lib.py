@@ -177,6 +177,14 @@ SIGNATURES = {
     "mp2p_hip_mstate_free": (None, [_P, _P]),
     "mp2p_hip_mstate_download": (C.c_int, [_P, _P, _u8p, _u8p]),
     "mp2p_hip_mstate_upload": (C.c_int, [_P, _P, _u8p, _u8p]),
+    "mp2p_hip_mstate_upload_bits": (C.c_int, [_P, _P, _u64p, _u64p]),
+    "mp2p_hip_mstate_download_bits": (C.c_int, [_P, _P, _u64p, _u64p]),
+    "mp2p_hip_host_alloc": (_P, [_P, C.c_size_t]),
+    "mp2p_hip_host_free": (None, [_P, _P]),
+    "mp2p_hip_pairs_download_pt2pt_from": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_size_t),
+                                                     _u64p]),
+    "mp2p_hip_pairs_download_pt2pl_from": (C.c_int, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_uint32), C.c_size_t,
+                                                     C.POINTER(C.c_size_t), _u64p]),
     "mp2p_hip_pairs_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, _PP]),
     "mp2p_hip_pairs_free": (None, [_P, _P]),
     "mp2p_hip_pairs_clear": (C.c_int, [_P, _P]),

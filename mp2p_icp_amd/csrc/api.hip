@@ -360,6 +360,90 @@ int mp2p_hip_mstate_upload(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms, const uint8_t
     return MP2P_HIP_OK;
 }
 
+// packed bit-fields <-> one byte per point
+__global__ __launch_bounds__(256) void bits_to_bytes_kernel(const unsigned long long* __restrict__ words, size_t n,
+                                                            unsigned char* __restrict__ bytes)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bytes[i] = (unsigned char)((words[i >> 6] >> (i & 63)) & 1ull);
+}
+__global__ __launch_bounds__(256) void bytes_to_bits_kernel(const unsigned char* __restrict__ bytes, size_t n,
+                                                            unsigned long long* __restrict__ words)
+{
+    const size_t i    = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one wave = one word
+    const bool   set  = i < n && bytes[i] != 0;
+    const unsigned long long m = __ballot(set);
+    if ((threadIdx.x & 63) == 0 && (i >> 6) < (n + 63) / 64) words[i >> 6] = m;
+}
+
+int mp2p_hip_mstate_upload_bits(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms, const uint64_t* global_words,
+                                const uint64_t* local_words)
+{
+    if (!ctx || !ms) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ng = ms->global_taken.n, nl = ms->local_taken.n;
+    const size_t wg = (ng + 63) / 64, wl = (nl + 63) / 64;
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure((wg + wl) * 8 + 16));
+    auto* dw = reinterpret_cast<unsigned long long*>(ctx->aos_stage.p);
+    if (global_words)
+    {
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(dw, global_words, wg * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(bits_to_bytes_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, ctx->stream, dw, ng,
+                           ms->global_taken.p);
+    }
+    if (local_words)
+    {
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(dw + wg, local_words, wl * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(bits_to_bytes_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, dw + wg,
+                           nl, ms->local_taken.p);
+    }
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));  // the sources are caller memory
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_mstate_download_bits(mp2p_hip_ctx* ctx, const mp2p_hip_mstate* ms, uint64_t* global_words,
+                                  uint64_t* local_words)
+{
+    if (!ctx || !ms) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ng = ms->global_taken.n, nl = ms->local_taken.n;
+    const size_t wg = (ng + 63) / 64, wl = (nl + 63) / 64;
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure((wg + wl) * 8 + 16));
+    auto* dw = reinterpret_cast<unsigned long long*>(ctx->aos_stage.p);
+    if (global_words)
+    {
+        hipLaunchKernelGGL(bytes_to_bits_kernel, dim3((unsigned)(wg * 64 / 256 + 1)), dim3(256), 0, ctx->stream,
+                           ms->global_taken.p, ng, dw);
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(global_words, dw, wg * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (local_words)
+    {
+        hipLaunchKernelGGL(bytes_to_bits_kernel, dim3((unsigned)(wl * 64 / 256 + 1)), dim3(256), 0, ctx->stream,
+                           ms->local_taken.p, nl, dw + wg);
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(local_words, dw + wg, wl * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
+    return MP2P_HIP_OK;
+}
+
+void* mp2p_hip_host_alloc(mp2p_hip_ctx* ctx, size_t bytes)
+{
+    if (!ctx || !bytes) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void mp2p_hip_host_free(mp2p_hip_ctx* ctx, void* p)
+{
+    (void)ctx;
+    if (p) (void)hipHostFree(p);
+}
+
 // ---- Matcher_Points_DistanceThreshold ----------------------------------------------------------
 static int check_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
                        const mp2p_hip_pt2pt_params* prm, const mp2p_hip_mstate* ms)

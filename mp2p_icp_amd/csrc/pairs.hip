@@ -507,16 +507,17 @@ int launch_add_potential(mp2p_hip_ctx* ctx, mp2p_hip_pairs* out, unsigned long l
 __global__ __launch_bounds__(256) void pack_pt2pt_kernel(
     const uint32_t* lidx, const uint32_t* gidx, const float* lx, const float* ly, const float* lz,
     const float* gx, const float* gy, const float* gz, const float* err, uint32_t n,
-    mp2p_hip_pair_pt2pt* out)
+    mp2p_hip_pair_pt2pt* out, uint32_t first = 0)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = first + k;
     mp2p_hip_pair_pt2pt p;
     p.globalIdx = gidx[i], p.localIdx = lidx[i];
     p.global_xyz[0] = gx[i], p.global_xyz[1] = gy[i], p.global_xyz[2] = gz[i];
     p.local_xyz[0] = lx[i], p.local_xyz[1] = ly[i], p.local_xyz[2] = lz[i];
     p.errorSquareAfterTransformation = err[i];
-    out[i]                           = p;
+    out[k]                           = p;
 }
 
 __global__ __launch_bounds__(256) void unpack_pt2pt_kernel(const mp2p_hip_pair_pt2pt* in,
@@ -537,16 +538,17 @@ __global__ __launch_bounds__(256) void unpack_pt2pt_kernel(const mp2p_hip_pair_p
 __global__ __launch_bounds__(256) void pack_pt2pl_kernel(const double* coef, const double* cen,
                                                          const float* lx, const float* ly,
                                                          const float* lz, uint32_t n,
-                                                         mp2p_hip_pair_pt2pl* out)
+                                                         mp2p_hip_pair_pt2pl* out, uint32_t first = 0)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = first + j;
     mp2p_hip_pair_pt2pl p;
     for (int k = 0; k < 4; k++) p.plane[k] = coef[(size_t)i * 4 + k];
     for (int k = 0; k < 3; k++) p.centroid[k] = cen[(size_t)i * 3 + k];
     p.pt_local[0] = lx[i], p.pt_local[1] = ly[i], p.pt_local[2] = lz[i];
     p._pad = 0.f;
-    out[i] = p;
+    out[j] = p;
 }
 
 __global__ __launch_bounds__(256) void unpack_pt2pl_kernel(const mp2p_hip_pair_pt2pl* in,
@@ -732,6 +734,72 @@ int mp2p_hip_pairs_download_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
         MP2P_TRY_HIP(ctx, hipMemcpyAsync(out_local_idx, p->pl_lidx.p, n * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, ctx->stream));
     MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MP2P_HIP_OK;
+}
+
+// counts through the pinned buffer, waited for by polling (one per matcher call on the host path)
+static int read_counts(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, unsigned long long h[8])
+{
+    if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->pinned, p->counts.p, 8 * sizeof(unsigned long long),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
+    memcpy(h, ctx->pinned, 8 * sizeof(unsigned long long));
+    if (h[4])
+        return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "Pairings capacity exceeded (cap_pt2pt=%zu cap_pt2pl=%zu)",
+                       p->cap_pt2pt, p->cap_pt2pl);
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_download_pt2pt_from(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first,
+                                       mp2p_hip_pair_pt2pt* out, size_t capacity, size_t* n_out,
+                                       uint64_t* potential)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[8];
+    if (const int rc = read_counts(ctx, p, h)) return rc;
+    if (potential) *potential = h[2];
+    MP2P_REQUIRE(ctx, first <= h[0], "download_pt2pt_from: first is beyond the list");
+    const size_t n = (size_t)h[0] - first;
+    if (n_out) *n_out = n;
+    if (n == 0) return MP2P_HIP_OK;
+    if (!out || capacity < n)
+        return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "download_pt2pt_from: capacity %zu < %zu", capacity, n);
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pt)));
+    auto* d = reinterpret_cast<mp2p_hip_pair_pt2pt*>(ctx->aos_stage.p);
+    hipLaunchKernelGGL(pack_pt2pt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->lidx.p,
+                       p->gidx.p, p->lx.p, p->ly.p, p->lz.p, p->gx.p, p->gy.p, p->gz.p, p->err.p, (uint32_t)n, d,
+                       (uint32_t)first);
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, d, n * sizeof(mp2p_hip_pair_pt2pt), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_download_pt2pl_from(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first,
+                                       mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx, size_t capacity,
+                                       size_t* n_out, uint64_t* potential)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[8];
+    if (const int rc = read_counts(ctx, p, h)) return rc;
+    if (potential) *potential = h[2];
+    MP2P_REQUIRE(ctx, first <= h[1], "download_pt2pl_from: first is beyond the list");
+    const size_t n = (size_t)h[1] - first;
+    if (n_out) *n_out = n;
+    if (n == 0) return MP2P_HIP_OK;
+    if (!out || capacity < n)
+        return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "download_pt2pl_from: capacity %zu < %zu", capacity, n);
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pl)));
+    auto* d = reinterpret_cast<mp2p_hip_pair_pt2pl*>(ctx->aos_stage.p);
+    hipLaunchKernelGGL(pack_pt2pl_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->pl_coef.p,
+                       p->pl_cen.p, p->pl_lx.p, p->pl_ly.p, p->pl_lz.p, (uint32_t)n, d, (uint32_t)first);
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, d, n * sizeof(mp2p_hip_pair_pt2pl), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_local_idx)
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(out_local_idx, p->pl_lidx.p + first, n * sizeof(uint32_t),
+                                         hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
     return MP2P_HIP_OK;
 }
 

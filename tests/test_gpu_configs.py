@@ -84,7 +84,8 @@ def test_c2_scan_vs_2M_map_pt2pt_horn_chain(amd, oracle):
         out = amd.OptimalTF_Result()
         assert s.optimal_pose(pairs, out, sc)
         pose_h = out.optimalPose
-        pose_o = oracle.optimal_tf_horn(want)
+        pose_o, ok = oracle.optimal_tf_horn(want)
+        assert ok
         dt, dr = oracle.pose_err_split(pose_h, pose_o)
         assert dt < 1e-5 and dr < 1e-5, (it, dt, dr)
     e1 = np.linalg.norm(amd.se3.log(amd.se3.inverse_compose(pose_h, d["T_gt"])))

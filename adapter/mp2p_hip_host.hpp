@@ -1,0 +1,398 @@
+// mp2p_hip_host.hpp -- the reference-side binding of libmp2p_hip.so WITHOUT the MRPT types.
+//
+// Everything the plugin (mp2p_hip_plugin.cpp) does per matcher / solver call, written against plain
+// host containers: SoA float buffers (CPointsMap::getPointsBufferRef_{x,y,z}), packed bit-fields
+// (the storage of the std::vector<bool> inside pointcloud_bitfield_t::DenseOrSparseBitField) and
+// vectors of the byte-compatible pair records.  The plugin only converts MRPT containers to these
+// views; tests/test_gpu_boundary_hostpath.py and bench.py drive the SAME code through
+// adapter/hostpath_capi.cpp, so the host path that is measured is the host path that ships.
+//
+// Per matcher call on the host (N_g = global points, N_l = local points, P = pairs emitted):
+//   * MatchState in : one pass over the PACKED words (N/64 words; 0.17 M words for 10 M + 1 M points)
+//                     to see whether anything is marked; nothing marked -> device reset, no transfer;
+//                     otherwise the packed words are uploaded (1.4 MB instead of 11 MB of bytes)
+//   * MatchState out: the marks a matcher leaves ARE the localIdx / globalIdx of the pairs it emitted
+//                     (Matcher_Points_DistanceThreshold.cpp:116-120), so the host bit-fields are
+//                     updated from the downloaded pair list: O(P), no per-point transfer
+//   * Pairings      : only the P entries this call appended are downloaded (36 B / 72 B each)
+// Nothing is O(N_g) per call except the read of the packed global bit-field.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "mp2p_hip.h"
+
+namespace mp2p_hip_host
+{
+struct Error : std::runtime_error
+{
+    using std::runtime_error::runtime_error;
+};
+
+// ---- packed bit-field view (bit i = bit (i & 63) of word i / 64) ---------------------------------
+struct BitView
+{
+    uint64_t* words = nullptr;
+    size_t    nbits = 0;
+    size_t    nwords() const { return (nbits + 63) / 64; }
+    bool      valid() const { return words != nullptr || nbits == 0; }
+    bool      any() const
+    {
+        const size_t full = nbits / 64;
+        uint64_t     acc  = 0;
+        for (size_t i = 0; i < full; i++) acc |= words[i];
+        if (nbits & 63) acc |= words[full] & ((1ull << (nbits & 63)) - 1ull);
+        return acc != 0;
+    }
+    void set(size_t i) const { words[i >> 6] |= 1ull << (i & 63); }
+    bool test(size_t i) const { return (words[i >> 6] >> (i & 63)) & 1ull; }
+};
+
+// ---- content fingerprints of a point layer -------------------------------------------------------
+// full: every byte (threads share the work); sampled: 1024 evenly strided points.  ICP::align holds
+// its maps const for the whole call, so the plugin verifies a layer in full at ICP iteration 0 and
+// with the sampled fingerprint (+ size + buffer addresses) afterwards.
+inline uint64_t mix64(uint64_t h, uint64_t v)
+{
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xFF51AFD7ED558CCDull;
+    return h ^ (h >> 32);
+}
+inline uint64_t hash_span(const float* p, size_t n)
+{
+    uint64_t     h = 0x243F6A8885A308D3ull;
+    const size_t n2 = n / 2;
+    for (size_t i = 0; i < n2; i++)
+    {
+        uint64_t v;
+        std::memcpy(&v, p + 2 * i, 8);
+        h = mix64(h, v);
+    }
+    if (n & 1)
+    {
+        uint32_t v;
+        std::memcpy(&v, p + n - 1, 4);
+        h = mix64(h, v);
+    }
+    return h;
+}
+inline uint64_t full_fingerprint(const float* x, const float* y, const float* z, size_t n, unsigned threads = 8)
+{
+    if (n == 0) return 0;
+    threads = std::max(1u, std::min<unsigned>(threads, (unsigned)(n / 65536 + 1)));
+    std::vector<uint64_t>    part(3 * threads, 0);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; t++)
+        th.emplace_back(
+            [&, t]()
+            {
+                const size_t b = n * t / threads, e = n * (t + 1) / threads;
+                part[3 * t] = hash_span(x + b, e - b), part[3 * t + 1] = hash_span(y + b, e - b),
+                         part[3 * t + 2] = hash_span(z + b, e - b);
+            });
+    for (auto& t : th) t.join();
+    uint64_t h = n;
+    for (uint64_t v : part) h = mix64(h, v);
+    return h;
+}
+inline uint64_t sampled_fingerprint(const float* x, const float* y, const float* z, size_t n)
+{
+    uint64_t     h = mix64(n, (uint64_t)(uintptr_t)x ^ ((uint64_t)(uintptr_t)y << 1) ^ ((uint64_t)(uintptr_t)z << 2));
+    const size_t S = std::min<size_t>(n, 1024);
+    for (size_t k = 0; k < S; k++)
+    {
+        const size_t i = S > 1 ? (n - 1) * k / (S - 1) : 0;
+        uint32_t     a, b, c;
+        std::memcpy(&a, x + i, 4), std::memcpy(&b, y + i, 4), std::memcpy(&c, z + i, 4);
+        h = mix64(h, ((uint64_t)a << 32) | b), h = mix64(h, c);
+    }
+    return h;
+}
+
+// running checksum of a Pairings' point / plane lists (a plain sequential fold: folding two chunks one
+// after the other equals folding their concatenation).  It decides whether the device-resident list
+// the matchers of this plugin left behind is the list a solver was handed (run_matchers copies
+// Pairings by value, Matcher.cpp:74-77, so identity cannot be carried by the container)
+constexpr uint64_t SUM_PT_SEED = 0x13198A2E03707344ull, SUM_PL_SEED = 0xA4093822299F31D0ull;
+inline uint64_t pairs_checksum(const mp2p_hip_pair_pt2pt* p, size_t n, uint64_t h = SUM_PT_SEED)
+{
+    for (size_t i = 0; i < n; i++)
+    {
+        uint32_t e;
+        std::memcpy(&e, &p[i].errorSquareAfterTransformation, 4);
+        h = mix64(h, ((uint64_t)p[i].globalIdx << 32) | p[i].localIdx), h = mix64(h, e);
+    }
+    return h;
+}
+inline uint64_t planes_checksum(const mp2p_hip_pair_pt2pl* p, size_t n, uint64_t h = SUM_PL_SEED)
+{
+    for (size_t i = 0; i < n; i++)
+    {
+        uint64_t a, b;
+        std::memcpy(&a, &p[i].plane[3], 8), std::memcpy(&b, &p[i].pt_local[0], 8);
+        h = mix64(h, a), h = mix64(h, b);
+    }
+    return h;
+}
+
+// ---- one context + handle caches per thread (ICP::align is single-threaded per object) ----------
+class Runtime
+{
+   public:
+    mp2p_hip_ctx* ctx = nullptr;
+
+    static Runtime& get()
+    {
+        static thread_local Runtime r;
+        if (!r.ctx)
+        {
+            const int rc = mp2p_hip_ctx_create(0, nullptr, &r.ctx);
+            if (rc) throw Error(std::string("mp2p_hip_ctx_create: ") + mp2p_hip_last_error(nullptr));
+        }
+        return r;
+    }
+    void check(int rc) const
+    {
+        if (rc) throw Error(std::string("libmp2p_hip: ") + mp2p_hip_last_error(ctx));
+    }
+
+    // ---- point layers, keyed by the layer object's address.  full_check: verify every byte (the
+    //      plugin asks for it at ICP iteration 0 and for layers it has not seen); otherwise size,
+    //      buffer addresses and 1024 sampled points decide.  A changed layer is uploaded again --
+    //      the role of nn_prepare_for_3d_queries() after mark_as_modified().
+    struct Layer
+    {
+        void*    handle  = nullptr;
+        size_t   n       = 0;
+        uint64_t sampled = 0, full = 0;
+        bool     full_known = false;
+    };
+    mp2p_hip_map* global_layer(const void* key, const float* x, const float* y, const float* z, size_t n,
+                               bool full_check)
+    {
+        Layer& e = maps_[key];
+        if (!current(e, x, y, z, n, full_check))
+        {
+            if (e.handle) mp2p_hip_map_free(ctx, (mp2p_hip_map*)e.handle);
+            e.handle = nullptr;
+            mp2p_hip_map* h = nullptr;
+            check(mp2p_hip_map_upload(ctx, x, y, z, n, nullptr, &h));
+            e.handle = h;
+            n_map_uploads++;
+        }
+        return (mp2p_hip_map*)e.handle;
+    }
+    mp2p_hip_cloud* local_layer(const void* key, const float* x, const float* y, const float* z, size_t n,
+                                bool full_check)
+    {
+        Layer& e = clouds_[key];
+        if (!current(e, x, y, z, n, full_check))
+        {
+            if (e.handle) mp2p_hip_cloud_free(ctx, (mp2p_hip_cloud*)e.handle);
+            e.handle = nullptr;
+            mp2p_hip_cloud* h = nullptr;
+            check(mp2p_hip_cloud_upload(ctx, x, y, z, n, &h));
+            e.handle = h;
+            n_cloud_uploads++;
+        }
+        return (mp2p_hip_cloud*)e.handle;
+    }
+    // a caller that edited a layer in place between two ICP iterations of its own loop
+    void invalidate_layers()
+    {
+        for (auto& kv : maps_) kv.second.sampled = ~kv.second.sampled, kv.second.full_known = false;
+        for (auto& kv : clouds_) kv.second.sampled = ~kv.second.sampled, kv.second.full_known = false;
+    }
+
+    // ---- MatchState: one device object per (N_g, N_l), brought to the host fields' content --------
+    mp2p_hip_mstate* match_state(BitView g, BitView l)
+    {
+        auto& ms = mstates_[std::make_pair(g.nbits, l.nbits)];
+        if (!ms) check(mp2p_hip_mstate_create(ctx, g.nbits, l.nbits, &ms));  // created clear
+        const bool anyG = g.words && g.any(), anyL = l.words && l.any();
+        if (!anyG && !anyL) check(mp2p_hip_mstate_reset(ctx, ms));
+        else
+        {
+            if (!anyG || !anyL) check(mp2p_hip_mstate_reset(ctx, ms));
+            check(mp2p_hip_mstate_upload_bits(ctx, ms, anyG ? g.words : nullptr, anyL ? l.words : nullptr));
+            n_mstate_uploads++;
+        }
+        return ms;
+    }
+
+    // ---- device-resident Pairings shared by the matchers and solvers of one ICP iteration ----------
+    mp2p_hip_pairs* pairs(size_t cap_pt, size_t cap_pl)
+    {
+        cap_pt = std::max<size_t>(cap_pt, 1);
+        if (!dev_pairs_) check(mp2p_hip_pairs_create(ctx, cap_pt, cap_pl, &dev_pairs_));
+        else check(mp2p_hip_pairs_reserve(ctx, dev_pairs_, cap_pt, cap_pl));
+        cap_pt_ = std::max(cap_pt_, cap_pt), cap_pl_ = std::max(cap_pl_, cap_pl);
+        return dev_pairs_;
+    }
+    mp2p_hip_pairs* conv_pairs(size_t cap)
+    {
+        if (!conv_pairs_) check(mp2p_hip_pairs_create(ctx, std::max<size_t>(cap, 1), 0, &conv_pairs_));
+        else check(mp2p_hip_pairs_reserve(ctx, conv_pairs_, cap, 0));
+        check(mp2p_hip_pairs_clear(ctx, conv_pairs_));
+        return conv_pairs_;
+    }
+    size_t cap_pl() const { return cap_pl_; }
+
+    // what the device list holds, as the matchers of this plugin built it
+    struct Token
+    {
+        bool     valid = false;
+        size_t   n_pt = 0, n_pl = 0;
+        uint64_t sum_pt = SUM_PT_SEED, sum_pl = SUM_PL_SEED;
+        // the run_matchers call the list belongs to: (MatchState address, ICP iteration)
+        const void* ms_key = nullptr;
+        uint32_t    iteration = 0;
+    } token;
+    bool has_lines_planes = false;
+
+    // counters for tests / the bench's host_boundary block
+    size_t n_map_uploads = 0, n_cloud_uploads = 0, n_mstate_uploads = 0, n_pair_uploads = 0;
+
+    ~Runtime()
+    {  // process exit: the HIP runtime may already be gone, nothing is freed explicitly
+    }
+
+   private:
+    static bool current(Layer& e, const float* x, const float* y, const float* z, size_t n, bool full_check)
+    {
+        const uint64_t s = sampled_fingerprint(x, y, z, n);
+        bool           ok = e.handle && e.n == n && e.sampled == s;
+        uint64_t       f  = 0;
+        if (full_check || !ok)
+        {
+            f = full_fingerprint(x, y, z, n);
+            if (ok && e.full_known && e.full != f) ok = false;
+        }
+        if (!ok || full_check) e.full = f, e.full_known = true;
+        e.n = n, e.sampled = s;
+        return ok;
+    }
+    std::map<const void*, Layer>                             maps_, clouds_;
+    std::map<std::pair<size_t, size_t>, mp2p_hip_mstate*>    mstates_;
+    mp2p_hip_pairs *dev_pairs_ = nullptr, *conv_pairs_ = nullptr;
+    size_t          cap_pt_ = 0, cap_pl_ = 0;
+};
+
+// ---- per-call glue shared by the matchers ---------------------------------------------------------
+struct MatchCall
+{
+    const void* ms_key    = nullptr;  // address of the MatchState (one run_matchers call = one state)
+    uint32_t    iteration = 0;        // MatchContext::icpIteration
+    BitView     gbits, lbits;         // packed host bit-fields of this (global layer, local layer)
+};
+
+// start of a matcher call: the device list is continued when it belongs to the same run_matchers call
+// (same MatchState, same ICP iteration) and cleared otherwise
+inline mp2p_hip_pairs* begin_match(Runtime& rt, const MatchCall& c, size_t add_pt, size_t add_pl)
+{
+    auto&      tk   = rt.token;
+    const bool same = tk.valid && tk.ms_key == c.ms_key && tk.iteration == c.iteration;
+    if (!same) tk = Runtime::Token();
+    mp2p_hip_pairs* dp = rt.pairs(tk.n_pt + add_pt, std::max(rt.cap_pl(), tk.n_pl + add_pl));
+    if (!same) rt.check(mp2p_hip_pairs_clear(rt.ctx, dp));
+    tk.ms_key = c.ms_key, tk.iteration = c.iteration;
+    return dp;
+}
+
+// Matcher_Points_DistanceThreshold::implMatchOneLayer on host containers.  `out` (a vector of records
+// layout-compatible with mp2p_hip_pair_pt2pt, e.g. mrpt::tfest::TMatchingPairList) is appended to.
+// Returns the number of pairs added; *potential_add = what the reference adds to potential_pairings.
+template <class PairVec>
+size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2p_hip_cloud* cloud,
+                         const double pose[12], const mp2p_hip_pt2pt_params& prm, const uint32_t* visit,
+                         size_t n_visit, PairVec& out)
+{
+    static_assert(sizeof(typename PairVec::value_type) == sizeof(mp2p_hip_pair_pt2pt), "pair record layout");
+    const size_t    n_l = mp2p_hip_cloud_size(cloud);
+    mp2p_hip_pairs* dp  = begin_match(rt, c, n_l * prm.pairingsPerPoint, 0);
+    auto&           tk  = rt.token;
+    rt.check(mp2p_hip_cloud_set_visit_order(rt.ctx, cloud, n_visit ? visit : nullptr, n_visit));
+    mp2p_hip_mstate* ms = rt.match_state(c.gbits, c.lbits);
+    rt.check(mp2p_hip_match_pt2pt(rt.ctx, map, cloud, pose, &prm, ms, dp));
+    // the new list length first (24 bytes, one wait), then exactly the new entries into the caller's vector
+    uint64_t n_pt = 0;
+    rt.check(mp2p_hip_pairs_counts(rt.ctx, dp, &n_pt, nullptr, nullptr));
+    const size_t n0 = out.size(), n = (size_t)n_pt - tk.n_pt;
+    out.resize(n0 + n);
+    auto* dst = reinterpret_cast<mp2p_hip_pair_pt2pt*>(out.data()) + n0;
+    if (n) rt.check(mp2p_hip_pairs_copy_pt2pt(rt.ctx, dp, tk.n_pt, n, dst));
+    // the marks this matcher leaves (only when global re-use is forbidden, :116-120)
+    if (!prm.allowMatchAlreadyMatchedGlobalPoints)
+        for (size_t i = 0; i < n; i++)
+        {
+            if (c.lbits.words) c.lbits.set(dst[i].localIdx);
+            if (c.gbits.words) c.gbits.set(dst[i].globalIdx);
+        }
+    tk.sum_pt = pairs_checksum(dst, n, tk.sum_pt);
+    tk.n_pt += n, tk.valid = true;
+    return n;
+}
+
+// Matcher_Point2Plane::implMatchOneLayer on host containers: planes into `out` (records layout-
+// compatible with mp2p_hip_pair_pt2pl are produced into a scratch vector and handed to `emit`)
+template <class Emit>
+size_t match_pt2pl_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2p_hip_cloud* cloud,
+                         const double pose[12], const mp2p_hip_pt2pl_params& prm, const uint32_t* visit,
+                         size_t n_visit, Emit&& emit)
+{
+    const size_t    n_l = mp2p_hip_cloud_size(cloud);
+    mp2p_hip_pairs* dp  = begin_match(rt, c, 0, n_l);
+    auto&           tk  = rt.token;
+    rt.check(mp2p_hip_cloud_set_visit_order(rt.ctx, cloud, n_visit ? visit : nullptr, n_visit));
+    mp2p_hip_mstate* ms = rt.match_state(BitView{nullptr, c.gbits.nbits}, c.lbits);  // global marks are not read (:87-90)
+    rt.check(mp2p_hip_match_pt2pl(rt.ctx, map, cloud, pose, &prm, ms, dp));
+    uint64_t n_pl = 0;
+    rt.check(mp2p_hip_pairs_counts(rt.ctx, dp, nullptr, &n_pl, nullptr));
+    const size_t n = (size_t)n_pl - tk.n_pl;
+    static thread_local std::vector<mp2p_hip_pair_pt2pl> rec;
+    static thread_local std::vector<uint32_t>            idx;
+    rec.resize(n), idx.resize(n);
+    if (n) rt.check(mp2p_hip_pairs_copy_pt2pl(rt.ctx, dp, tk.n_pl, n, rec.data(), idx.data()));
+    for (size_t i = 0; i < n; i++)
+    {
+        emit(rec[i]);
+        if (c.lbits.words) c.lbits.set(idx[i]);  // Matcher_Point2Plane.cpp:109
+    }
+    tk.sum_pl = planes_checksum(rec.data(), n, tk.sum_pl);
+    tk.n_pl += n, tk.valid = true;
+    return n;
+}
+
+// Pairings -> the device handle a solver reads.  The lists the matchers of this plugin produced in the
+// same ICP iteration are still in HBM: recognised by size + checksum; anything else is uploaded.  The
+// token is consumed: the next solver call without a matcher call in between uploads again.
+inline mp2p_hip_pairs* pairings_to_device(Runtime& rt, const mp2p_hip_pair_pt2pt* pt, size_t n_pt,
+                                          const mp2p_hip_pair_pt2pl* pl, size_t n_pl,
+                                          const mp2p_hip_pair_pt2ln* ln, size_t n_ln,
+                                          const mp2p_hip_pair_pl2pl* pp, size_t n_pp)
+{
+    auto& tk = rt.token;
+    bool  resident = tk.valid && tk.n_pt == n_pt && tk.n_pl == n_pl && (n_pt + n_pl) > 0;
+    if (resident && n_pt) resident = pairs_checksum(pt, n_pt) == tk.sum_pt;
+    if (resident && n_pl) resident = planes_checksum(pl, n_pl) == tk.sum_pl;
+    mp2p_hip_pairs* dp = rt.pairs(n_pt, std::max(rt.cap_pl(), n_pl));
+    if (!resident)
+    {
+        rt.check(mp2p_hip_pairs_upload(rt.ctx, dp, pt, n_pt, pl, n_pl));
+        rt.n_pair_uploads++;
+    }
+    tk = Runtime::Token();  // consumed
+    if (n_ln || n_pp || rt.has_lines_planes)
+        rt.check(mp2p_hip_pairs_upload_lines_planes(rt.ctx, dp, ln, n_ln, pp, n_pp));
+    rt.has_lines_planes = n_ln || n_pp;
+    return dp;
+}
+
+}  // namespace mp2p_hip_host

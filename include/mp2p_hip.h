@@ -193,6 +193,12 @@ int  mp2p_hip_pairs_download_pt2pt_from(mp2p_hip_ctx* ctx, const mp2p_hip_pairs*
 int  mp2p_hip_pairs_download_pt2pl_from(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first,
                                         mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx,
                                         size_t capacity, size_t* n_out, uint64_t* potential);
+/* ... and without the count read-back, for a caller that already knows the range (entries
+ * [first, first + n) must exist: it read the counts itself) */
+int  mp2p_hip_pairs_copy_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
+                               mp2p_hip_pair_pt2pt* out);
+int  mp2p_hip_pairs_copy_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
+                               mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx);
 /* paired_pt2ln / paired_pl2pl: produced on the host by Matcher_Point2Line /
  * Matcher_Planes_Normals (not on this path), consumed by the Gauss-Newton solver
  * (optimal_tf_gauss_newton.cpp:184-202, 289-308).  Replaces both lists (n = 0 empties one);

@@ -580,6 +580,20 @@ static int grow_buf(mp2p_hip_ctx* ctx, DevBuf<T>& b, size_t new_count, size_t ke
 
 using namespace mp2p;
 
+// counts through the pinned buffer, waited for by polling (one per matcher call on the host path)
+static int read_counts(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, unsigned long long h[8])
+{
+    if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->pinned, p->counts.p, 8 * sizeof(unsigned long long),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
+    memcpy(h, ctx->pinned, 8 * sizeof(unsigned long long));
+    if (h[4])
+        return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "Pairings capacity exceeded (cap_pt2pt=%zu cap_pt2pl=%zu)",
+                       p->cap_pt2pt, p->cap_pt2pl);
+    return MP2P_HIP_OK;
+}
+
 extern "C" {
 
 int mp2p_hip_pairs_create(mp2p_hip_ctx* ctx, size_t cap_pt2pt, size_t cap_pt2pl,
@@ -677,15 +691,10 @@ int mp2p_hip_pairs_counts(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, uint64_t* 
 {
     if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
     unsigned long long h[8];
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync(h, p->counts.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (const int rc = read_counts(ctx, p, h)) return rc;
     if (n_pt2pt) *n_pt2pt = h[0];
     if (n_pt2pl) *n_pt2pl = h[1];
     if (potential) *potential = h[2];
-    if (h[4])
-        return set_err(ctx, MP2P_HIP_ERR_CAPACITY,
-                       "Pairings capacity exceeded (cap_pt2pt=%zu cap_pt2pl=%zu)", p->cap_pt2pt,
-                       p->cap_pt2pl);
     return MP2P_HIP_OK;
 }
 
@@ -737,17 +746,39 @@ int mp2p_hip_pairs_download_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
     return MP2P_HIP_OK;
 }
 
-// counts through the pinned buffer, waited for by polling (one per matcher call on the host path)
-static int read_counts(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, unsigned long long h[8])
+int mp2p_hip_pairs_copy_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
+                              mp2p_hip_pair_pt2pt* out)
 {
-    if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->pinned, p->counts.p, 8 * sizeof(unsigned long long),
-                                     hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    if (n == 0) return MP2P_HIP_OK;
+    MP2P_REQUIRE(ctx, out && first + n <= p->cap_pt2pt, "copy_pt2pt: range outside the list");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pt)));
+    auto* d = reinterpret_cast<mp2p_hip_pair_pt2pt*>(ctx->aos_stage.p);
+    hipLaunchKernelGGL(pack_pt2pt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->lidx.p,
+                       p->gidx.p, p->lx.p, p->ly.p, p->lz.p, p->gx.p, p->gy.p, p->gz.p, p->err.p, (uint32_t)n, d,
+                       (uint32_t)first);
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, d, n * sizeof(mp2p_hip_pair_pt2pt), hipMemcpyDeviceToHost, ctx->stream));
     MP2P_TRY_HIP(ctx, stream_wait(ctx));
-    memcpy(h, ctx->pinned, 8 * sizeof(unsigned long long));
-    if (h[4])
-        return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "Pairings capacity exceeded (cap_pt2pt=%zu cap_pt2pl=%zu)",
-                       p->cap_pt2pt, p->cap_pt2pl);
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_copy_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
+                              mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    if (n == 0) return MP2P_HIP_OK;
+    MP2P_REQUIRE(ctx, out && first + n <= p->cap_pt2pl, "copy_pt2pl: range outside the list");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pl)));
+    auto* d = reinterpret_cast<mp2p_hip_pair_pt2pl*>(ctx->aos_stage.p);
+    hipLaunchKernelGGL(pack_pt2pl_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->pl_coef.p,
+                       p->pl_cen.p, p->pl_lx.p, p->pl_ly.p, p->pl_lz.p, (uint32_t)n, d, (uint32_t)first);
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, d, n * sizeof(mp2p_hip_pair_pt2pl), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_local_idx)
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(out_local_idx, p->pl_lidx.p + first, n * sizeof(uint32_t),
+                                         hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
     return MP2P_HIP_OK;
 }
 

@@ -54,5 +54,39 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# ---- the host-path library: adapter/mp2p_hip_host.hpp (the MRPT-free part of the reference-side
+#      plugin) behind a C ABI, for tests/ and bench.py.  Plain g++, links libmp2p_hip.so. ------------
+ADAPTER_DIR = os.path.join(HERE, "..", "adapter")
+HOSTPATH_SRC = os.path.join(ADAPTER_DIR, "hostpath_capi.cpp")
+HOSTPATH_LIB = os.path.join(HERE, "libmp2p_hip_hostpath.so")
+
+
+def hostpath_needs_build():
+    if not os.path.exists(HOSTPATH_LIB):
+        return True
+    t = os.path.getmtime(HOSTPATH_LIB)
+    deps = [HOSTPATH_SRC, os.path.join(ADAPTER_DIR, "mp2p_hip_host.hpp"),
+            os.path.join(HERE, "..", "include", "mp2p_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hostpath(force=False, verbose=False):
+    if not force and not hostpath_needs_build():
+        return HOSTPATH_LIB
+    build()  # links against the HIP library
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", HOSTPATH_SRC,
+           "-I" + os.path.join(HERE, "..", "include"), "-I" + ADAPTER_DIR, "-L" + HERE, "-lmp2p_hip",
+           "-Wl,-rpath,$ORIGIN", "-lpthread", "-o", HOSTPATH_LIB + ".tmp"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed on the host-path library:\n" + r.stderr[-8000:])
+    os.replace(HOSTPATH_LIB + ".tmp", HOSTPATH_LIB)
+    if verbose:
+        print("built", HOSTPATH_LIB)
+    return HOSTPATH_LIB
+
+
 if __name__ == "__main__":
     build(force=True, verbose=True)
+    build_hostpath(force=True, verbose=True)

@@ -122,3 +122,30 @@ def test_no_device_fails_loudly():
     with pytest.raises(mp2p_icp_amd.Mp2pHipError) as e:
         mp2p_icp_amd.Context(0)
     assert e.value.code == -5 and "no CPU fallback" in str(e.value)
+
+
+def test_hostpath_library_builds_loads_and_exports():
+    """adapter/mp2p_hip_host.hpp (the reference-side plugin's MRPT-free host layer) compiles with g++
+    behind adapter/hostpath_capi.cpp and exports every entry the Python binding declares; without a
+    GPU its first compute call fails loudly (no CPU fallback anywhere on the product path)."""
+    import numpy as np
+    import torch
+    from mp2p_icp_amd import _lib, hostpath
+    L = hostpath.load()
+    for name in hostpath.SIGNATURES:
+        assert hasattr(L, name), name
+    g = np.zeros((8, 3), np.float32)
+    s = hostpath.Session(g, g)
+    s.begin_iteration()
+    assert s.pairs_pt2pt().size == 0 and not s.bits(0).any() and s.bits(1).size == 8
+    m = np.zeros(8, bool)
+    m[[1, 5]] = True
+    s.set_bits(1, m)
+    assert np.array_equal(s.bits(1), m)
+    if not torch.cuda.is_available():
+        p = _lib.Pt2PtParams()
+        p.threshold, p.pairingsPerPoint = 1.0, 1
+        with pytest.raises(hostpath.HostPathError) as e:
+            s.match_pt2pt(np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0.0]), p)
+        assert "no CPU fallback" in str(e.value)
+    s.close()

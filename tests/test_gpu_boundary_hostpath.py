@@ -1,0 +1,229 @@
+"""The HOST path of the drop-in boundary: the reference-side adapter's per-call logic
+(adapter/mp2p_hip_host.hpp, through adapter/hostpath_capi.cpp) against host containers -- packed
+MatchState bit-fields in and out, 36-byte / 72-byte pair records out, a solver handed host Pairings --
+checked against the CPU oracle, plus what it may and may not transfer per call."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _xyz(a):
+    return a[:, 0], a[:, 1], a[:, 2]
+
+
+def _same_pt2pt(got, want):
+    assert len(got) == len(want), (len(got), len(want))
+    assert np.array_equal(got["localIdx"], want["localIdx"])
+    assert np.array_equal(got["globalIdx"], want["globalIdx"])
+    assert np.array_equal(got["errorSquareAfterTransformation"].view(np.uint32), want["errSq"].view(np.uint32))
+    assert np.array_equal(got["local"], np.stack([want["lx"], want["ly"], want["lz"]], 1))
+    assert np.array_equal(got["global"], np.stack([want["gx"], want["gy"], want["gz"]], 1))
+
+
+def _pt2pt_prm(threshold, **kw):
+    from mp2p_icp_amd import _lib
+    p = _lib.Pt2PtParams()
+    p.threshold, p.thresholdAngularDeg, p.pairingsPerPoint = threshold, 0.0, 1
+    p.bounding_box_intersection_check_epsilon = 0.20
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _gn_prm(iters=3):
+    from mp2p_icp_amd import _lib
+    g = _lib.GNParams()
+    g.maxInnerLoopIterations, g.minDelta, g.maxCost = iters, 1e-7, 0.0
+    g.kernel, g.kernelParam = _lib.KERNEL_GEMANMCCLURE, 0.15
+    g.w_pt2pt = g.w_pt2pl = 1.0
+    return g
+
+
+def test_icp_chain_through_host_containers(oracle):
+    from mp2p_icp_amd import hostpath, synthetic
+    d = synthetic.make_pair(120_000, 500_000, 31)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(*_xyz(g))
+    s = hostpath.Session(g, l)
+    c0 = hostpath.counters()
+    prm, gnp = _pt2pt_prm(1.5), _gn_prm()
+    oprm = oracle.make_gn_params(3, kernel=oracle.KERNEL_GEMANMCCLURE, kernelParam=0.15)
+    pose_h, pose_o = d["T_init"].copy(), d["T_init"].copy()
+    for it in range(4):
+        s.begin_iteration()
+        n = s.match_pt2pt(pose_h, prm, icp_iteration=it)
+        lt, gt = np.zeros(l.shape[0], np.uint8), np.zeros(g.shape[0], np.uint8)
+        want, pot = oracle.match_pt2pt(*_xyz(g), *_xyz(l), pose_o, 1.5, 0.0, tree=tree, local_taken=lt, global_taken=gt)
+        got = s.pairs_pt2pt()
+        assert n == len(got)
+        _same_pt2pt(got, want)
+        assert s.potential_pairings == pot
+        # the host MatchState carries the marks of the emitted pairs (:116-120), set from the pair list
+        assert np.array_equal(s.bits(1), lt.astype(bool)) and np.array_equal(s.bits(0), gt.astype(bool))
+        pose_h, iters = s.solve_gn(pose_h, gnp)
+        pose_o, *_ = oracle.optimal_tf_gauss_newton(want, None, None, pose_o, oprm)
+        dt, dr = oracle.pose_err_split(pose_h, pose_o)
+        assert dt < 1e-5 and dr < 1e-5, (it, dt, dr)
+    c1 = hostpath.counters()
+    # layers uploaded once, no MatchState transfer (the fields were clear), no Pairings upload (the
+    # solver recognised the device-resident list by size + checksum)
+    assert c1["map_uploads"] - c0["map_uploads"] == 1 and c1["cloud_uploads"] - c0["cloud_uploads"] == 1
+    assert c1["mstate_uploads"] == c0["mstate_uploads"] and c1["pairings_uploads"] == c0["pairings_uploads"]
+    s.close()
+
+
+@pytest.mark.parametrize("allow_local,allow_global", [(False, False), (True, False), (False, True)])
+def test_premarked_match_state_and_marks(oracle, allow_local, allow_global):
+    from mp2p_icp_amd import hostpath, synthetic
+    d = synthetic.random_cloud_pair(20_000, 60_000, 11, outlier_frac=0.1)
+    g, l = d["glob"], d["local"]
+    rng = np.random.default_rng(4)
+    lt0, gt0 = rng.random(l.shape[0]) < 0.3, rng.random(g.shape[0]) < 0.2
+    tree = oracle.KDTree(*_xyz(g))
+    s = hostpath.Session(g, l)
+    c0 = hostpath.counters()
+    s.begin_iteration()
+    s.set_bits(1, lt0), s.set_bits(0, gt0)
+    prm = _pt2pt_prm(0.8, allowMatchAlreadyMatchedPoints=int(allow_local),
+                     allowMatchAlreadyMatchedGlobalPoints=int(allow_global))
+    s.match_pt2pt(d["T_init"], prm)
+    lt, gt = lt0.astype(np.uint8), gt0.astype(np.uint8)
+    want, _ = oracle.match_pt2pt(*_xyz(g), *_xyz(l), d["T_init"], 0.8, 0.0, tree=tree, local_taken=lt, global_taken=gt,
+                                 allowMatchAlreadyMatchedPoints=allow_local,
+                                 allowMatchAlreadyMatchedGlobalPoints=allow_global)
+    _same_pt2pt(s.pairs_pt2pt(), want)
+    assert np.array_equal(s.bits(1), lt.astype(bool)) and np.array_equal(s.bits(0), gt.astype(bool))
+    assert hostpath.counters()["mstate_uploads"] == c0["mstate_uploads"] + 1  # packed words went up once
+    s.close()
+
+
+def test_two_matchers_one_solver_and_foreign_pairings(oracle):
+    """Matcher_Point2Plane then Matcher_Points_DistanceThreshold on ONE MatchState (one run_matchers
+    call): the device list is continued, the solver finds it resident.  Pairings from elsewhere are
+    uploaded."""
+    from mp2p_icp_amd import _lib, hostpath, synthetic
+    d = synthetic.make_pair(30_000, 300_000, 9)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(*_xyz(g))
+    PL = dict(distanceThreshold=0.25, searchRadius=0.5, knn=6, minimumPlanePoints=5, planeEigenThreshold=0.05)
+    plp = _lib.Pt2PlParams()
+    plp.distanceThreshold, plp.searchRadius, plp.knn = PL["distanceThreshold"], PL["searchRadius"], PL["knn"]
+    plp.minimumPlanePoints, plp.planeEigenThreshold = PL["minimumPlanePoints"], PL["planeEigenThreshold"]
+    plp.bounding_box_intersection_check_epsilon = 0.20
+    s = hostpath.Session(g, l)
+    c0 = hostpath.counters()
+    s.begin_iteration()
+    s.match_pt2pl(d["T_init"], plp)
+    s.match_pt2pt(d["T_init"], _pt2pt_prm(1.0))
+    lt = np.zeros(l.shape[0], np.uint8)
+    w_pl, w_idx, pot1 = oracle.match_pt2pl(*_xyz(g), *_xyz(l), d["T_init"], tree=tree, local_taken=lt, **PL)
+    gt = np.zeros(g.shape[0], np.uint8)
+    w_pt, pot2 = oracle.match_pt2pt(*_xyz(g), *_xyz(l), d["T_init"], 1.0, 0.0, tree=tree, local_taken=lt, global_taken=gt)
+    _same_pt2pt(s.pairs_pt2pt(), w_pt)
+    got_pl = s.pairs_pt2pl()
+    assert len(got_pl) == len(w_pl) and np.allclose(got_pl["plane"], w_pl["plane"], rtol=0, atol=1e-9)
+    assert np.array_equal(got_pl["pt_local"], np.stack([w_pl["lx"], w_pl["ly"], w_pl["lz"]], 1))
+    assert s.potential_pairings == pot1 + pot2
+    assert np.array_equal(s.bits(1), lt.astype(bool)) and np.array_equal(s.bits(0), gt.astype(bool))
+    gnp = _gn_prm()
+    oprm = oracle.make_gn_params(3, kernel=oracle.KERNEL_GEMANMCCLURE, kernelParam=0.15)
+    pose, _ = s.solve_gn(d["T_init"], gnp)
+    want, *_ = oracle.optimal_tf_gauss_newton(w_pt, w_pl, None, d["T_init"], oprm)
+    dt, dr = oracle.pose_err_split(pose, want)
+    assert dt < 1e-5 and dr < 1e-5
+    assert hostpath.counters()["pairings_uploads"] == c0["pairings_uploads"]
+    # the token is consumed: the same solver call again uploads (nothing vouches for the device list)
+    pose2, _ = s.solve_gn(d["T_init"], gnp)
+    assert np.allclose(pose2, pose, atol=1e-12) and hostpath.counters()["pairings_uploads"] == c0["pairings_uploads"] + 1
+    # pairings produced elsewhere
+    sub = s.pairs_pt2pt()[::2].copy()
+    s.set_pairings(sub, None)
+    pose3, _ = s.solve_gn(d["T_init"], gnp)
+    o = np.zeros(len(sub), oracle.PAIR_PT2PT)
+    o["globalIdx"], o["localIdx"] = sub["globalIdx"], sub["localIdx"]
+    o["gx"], o["gy"], o["gz"] = sub["global"].T
+    o["lx"], o["ly"], o["lz"] = sub["local"].T
+    o["errSq"] = sub["errorSquareAfterTransformation"]
+    want3, *_ = oracle.optimal_tf_gauss_newton(o, None, None, d["T_init"], oprm)
+    dt, dr = oracle.pose_err_split(pose3, want3)
+    assert dt < 1e-5 and dr < 1e-5
+    assert hostpath.counters()["pairings_uploads"] == c0["pairings_uploads"] + 2
+    s.close()
+
+
+def test_layer_change_detection(oracle):
+    """a layer edited in place: found by the full fingerprint at ICP iteration 0 (and after
+    invalidate_layers()); later iterations of one align only pay the sampled check"""
+    from mp2p_icp_amd import hostpath, synthetic
+    d = synthetic.random_cloud_pair(5000, 20000, 3)
+    g, l = d["glob"], d["local"].copy()
+    s = hostpath.Session(g, l)
+    prm = _pt2pt_prm(0.8)
+    s.begin_iteration()
+    s.match_pt2pt(d["T_init"], prm, icp_iteration=0)
+    c0 = hostpath.counters()
+    s.begin_iteration()
+    s.match_pt2pt(d["T_init"], prm, icp_iteration=0)  # unchanged: nothing re-uploaded
+    assert hostpath.counters() == c0
+    before = s.pairs_pt2pt()
+    # an interior point that the 1024-point sample does not see, moved far away
+    k = 1237
+    s._l[0][k] += 50.0
+    lm = np.stack(s._l, 1)
+    tree = oracle.KDTree(*_xyz(g))
+    s.begin_iteration()
+    s.match_pt2pt(d["T_init"], prm, icp_iteration=0)
+    assert hostpath.counters()["cloud_uploads"] == c0["cloud_uploads"] + 1
+    want, _ = oracle.match_pt2pt(*_xyz(g), *_xyz(lm), d["T_init"], 0.8, 0.0, tree=tree)
+    _same_pt2pt(s.pairs_pt2pt(), want)
+    assert len(before) != len(want) or not np.array_equal(before["localIdx"], want["localIdx"])
+    s.close()
+
+
+@pytest.mark.timeout(600)
+def test_host_path_cost_at_full_size(oracle):
+    """1 M x 10 M: a step through host containers (fresh MatchState, pairs into a host vector, marks,
+    solver finding the list resident) stays within 2.5x of the device-resident step; the lists are the
+    device-resident path's lists."""
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import core, hostpath, synthetic
+    d = synthetic.make_pair(1_000_000, 10_000_000, 1)
+    g, l = d["glob"], d["local"]
+    s = hostpath.Session(g, l)
+    prm, gnp = _pt2pt_prm(2.0), _gn_prm()
+    ctx = core.default_context()
+    gmap = core.GlobalMap(ctx, *_xyz(g))
+    cloud = core.LocalCloud(ctx, *_xyz(l))
+    pairs = core.DevicePairs(ctx, l.shape[0], 0)
+
+    def chain(step, n=8):
+        pose, ts = d["T_init"].copy(), []
+        for it in range(n):
+            t0 = time.perf_counter()
+            pose = step(pose, it)
+            ts.append(time.perf_counter() - t0)
+        return pose, float(np.median(ts[2:]))
+
+    def host_step(pose, it):
+        s.begin_iteration()
+        s.match_pt2pt(pose, prm, icp_iteration=it)
+        return s.solve_gn(pose, gnp)[0]
+
+    def dev_step(pose, it):
+        pairs.clear()
+        core.match_pt2pt(ctx, gmap, cloud, pose, prm, None, pairs)
+        return np.array(core.gn_solve(ctx, pairs, pose, gnp).pose)
+
+    pose_d, t_dev = chain(dev_step)
+    c0 = hostpath.counters()
+    pose_h, t_host = chain(host_step)
+    c1 = hostpath.counters()
+    assert np.allclose(pose_h, pose_d, atol=1e-9)
+    assert c1["mstate_uploads"] == c0["mstate_uploads"] and c1["pairings_uploads"] == c0["pairings_uploads"]
+    assert c1["map_uploads"] - c0["map_uploads"] <= 1 and c1["cloud_uploads"] - c0["cloud_uploads"] <= 1
+    print(f"\n[host path] device-resident step {t_dev * 1e3:.3f} ms, host-container step {t_host * 1e3:.3f} ms")
+    assert t_host < 2.5 * t_dev + 2e-4, (t_host, t_dev)
+    s.close()

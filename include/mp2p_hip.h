@@ -379,6 +379,23 @@ int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
                          const double pose[12], const mp2p_hip_pt2pl_params* prm,
                          mp2p_hip_mstate* ms, mp2p_hip_pairs* out);
 
+/* ---- NearestPlaneCapable::nn_search_pt2pl (NearestPlaneCapable.h:33-52) for ONE query: the contract
+ *      a CMetricMap layer type must offer for the reference's own Matcher_Point2Plane to run on it
+ *      (MapToNP, metricmap.cpp:804-822).  `point` is already in the map's frame.  Same k-NN / plane fit
+ *      as mp2p_hip_match_pt2pl with distanceThreshold = max_search_distance; prm->searchRadius <= 0
+ *      means max_search_distance.  One launch + one 100-byte read-back per call (~0.1 ms): the contract,
+ *      not the fast path -- the plugin's own Matcher_Point2Plane class batches the whole layer. ------ */
+typedef struct
+{
+    int32_t found;        /* NearestPlaneResult::pairing.has_value() */
+    double  plane[4];     /* pl_global.plane  */
+    double  centroid[3];  /* pl_global.centroid */
+    float   distance;     /* |plane.distance(point)| */
+} mp2p_hip_nearest_plane;
+int mp2p_hip_nn_search_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const float point[3],
+                             float max_search_distance, const mp2p_hip_pt2pl_params* prm,
+                             mp2p_hip_nearest_plane* out);
+
 /* ---- optimal_tf_gauss_newton (optimal_tf_gauss_newton.cpp:36-372) as called by
  *      Solver_GaussNewton::impl_optimal_pose (Solver_GaussNewton.cpp:42-67).
  *      Kernels K6, K7, K8.  H and g are rebuilt at every inner iteration (TBB-build

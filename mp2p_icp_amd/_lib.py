@@ -107,6 +107,11 @@ class Pt2PlParams(C.Structure):
                 ("initial_radius_cells", C.c_float), ("queries_per_wave", C.c_uint32)]
 
 
+class NearestPlane(C.Structure):
+    _fields_ = [("found", C.c_int32), ("plane", C.c_double * 4), ("centroid", C.c_double * 3),
+                ("distance", C.c_float)]
+
+
 class GNParams(C.Structure):
     _fields_ = [("maxInnerLoopIterations", C.c_uint32), ("minDelta", C.c_double),
                 ("maxCost", C.c_double), ("kernel", C.c_int32), ("kernelParam", C.c_double),
@@ -222,6 +227,7 @@ SIGNATURES = {
     "mp2p_hip_match_adaptive": (C.c_int, [_P, _P, _P, _dp, C.POINTER(AdaptiveParams), _P, _P,
                                           C.POINTER(C.c_double), C.POINTER(AdaptiveHist)]),
     "mp2p_hip_match_pt2pl": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PlParams), _P, _P]),
+    "mp2p_hip_nn_search_pt2pl": (C.c_int, [_P, _P, _fp, C.c_float, C.POINTER(Pt2PlParams), C.POINTER(NearestPlane)]),
     "mp2p_hip_gn_solve": (C.c_int, [_P, _P, _dp, C.POINTER(GNParams), C.POINTER(GNResult)]),
     "mp2p_hip_gn_begin": (C.c_int, [_P, _P, _dp, C.POINTER(GNParams)]),
     "mp2p_hip_gn_accumulate": (C.c_int, [_P]),

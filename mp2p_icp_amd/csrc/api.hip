@@ -167,6 +167,8 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->q1_pairs) mp2p_hip_pairs_free(nullptr, ctx->q1_pairs);
+    if (ctx->q1_cloud) mp2p_hip_cloud_free(nullptr, ctx->q1_cloud);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -724,6 +726,71 @@ int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
         }
     }
     return rc;
+}
+
+// ---- NearestPlaneCapable::nn_search_pt2pl, one query -----------------------------------------------
+__global__ void set_point_kernel(float4* sorted, float* x, float* y, float* z, uint32_t* pos, float px, float py,
+                                 float pz)
+{
+    sorted[0] = make_float4(px, py, pz, __uint_as_float(0u));
+    x[0] = px, y[0] = py, z[0] = pz, pos[0] = 0u;
+}
+
+int mp2p_hip_nn_search_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const float point[3],
+                             float max_search_distance, const mp2p_hip_pt2pl_params* prm,
+                             mp2p_hip_nearest_plane* out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, map && point && prm && out, "null argument");
+    MP2P_REQUIRE(ctx, map->ctx == ctx, "handle belongs to another context");
+    MP2P_REQUIRE(ctx, max_search_distance > 0.f, "max_search_distance must be > 0");
+    MP2P_REQUIRE(ctx, prm->knn >= 3 && prm->knn <= 16, "knn must be in [3,16]");
+    memset(out, 0, sizeof(*out));
+    if (map->n == 0) return MP2P_HIP_OK;
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->q1_cloud)
+    {  // a one-point local layer, re-pointed at every query
+        auto* c = new mp2p_hip_cloud();
+        c->ctx = ctx, c->n = 1;
+        MP2P_TRY_HIP(ctx, c->sorted.alloc(1));
+        MP2P_TRY_HIP(ctx, c->pos.alloc(1));
+        MP2P_TRY_HIP(ctx, c->x.alloc(1));
+        MP2P_TRY_HIP(ctx, c->y.alloc(1));
+        MP2P_TRY_HIP(ctx, c->z.alloc(1));
+        ctx->q1_cloud = c;
+        int rc = mp2p_hip_pairs_create(ctx, 1, 1, &ctx->q1_pairs);
+        if (rc) return rc;
+    }
+    mp2p_hip_cloud* c = ctx->q1_cloud;
+    hipLaunchKernelGGL(set_point_kernel, dim3(1), dim3(1), 0, ctx->stream, c->sorted.p, c->x.p, c->y.p, c->z.p,
+                       c->pos.p, point[0], point[1], point[2]);
+    int rc = mp2p_hip_pairs_clear(ctx, ctx->q1_pairs);
+    if (rc) return rc;
+    mp2p_hip_pt2pl_params q = *prm;
+    q.distanceThreshold = max_search_distance;
+    if (!(q.searchRadius > 0.0)) q.searchRadius = max_search_distance;
+    q.allowMatchAlreadyMatchedPoints = 1;
+    const double I[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    const int    prof  = ctx->profiling;
+    ctx->profiling     = 0;
+    rc                 = launch_match_pt2pl(ctx, map, c, I, &q, nullptr, ctx->q1_pairs);
+    ctx->profiling     = prof;
+    if (rc) return rc;
+    if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
+    auto* h = reinterpret_cast<unsigned char*>(ctx->pinned);
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(h, ctx->q1_pairs->counts.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(h + 64, ctx->q1_pairs->pl_coef.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(h + 96, ctx->q1_pairs->pl_cen.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
+    unsigned long long cnt[8];
+    memcpy(cnt, h, 64);
+    if (cnt[1] == 0) return MP2P_HIP_OK;
+    out->found = 1;
+    memcpy(out->plane, h + 64, 32), memcpy(out->centroid, h + 96, 24);
+    // TPlane::distance of the (float) query, narrowed like NearestPlaneResult::distance
+    out->distance = (float)fabs(out->plane[0] * (double)point[0] + out->plane[1] * (double)point[1] +
+                                out->plane[2] * (double)point[2] + out->plane[3]);
+    return MP2P_HIP_OK;
 }
 
 // ---- Solver_GaussNewton ------------------------------------------------------------------------

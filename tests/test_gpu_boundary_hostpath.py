@@ -207,10 +207,14 @@ def test_host_path_cost_at_full_size(oracle):
             ts.append(time.perf_counter() - t0)
         return pose, float(np.median(ts[2:]))
 
+    trace = []
+
     def host_step(pose, it):
         s.begin_iteration()
-        s.match_pt2pt(pose, prm, icp_iteration=it)
-        return s.solve_gn(pose, gnp)[0]
+        n = s.match_pt2pt(pose, prm, icp_iteration=it)
+        out = s.solve_gn(pose, gnp)[0]
+        trace.append((it, n, hostpath.counters()["pairings_uploads"], s.last_ms()))
+        return out
 
     def dev_step(pose, it):
         pairs.clear()
@@ -222,7 +226,8 @@ def test_host_path_cost_at_full_size(oracle):
     pose_h, t_host = chain(host_step)
     c1 = hostpath.counters()
     assert np.allclose(pose_h, pose_d, atol=1e-9)
-    assert c1["mstate_uploads"] == c0["mstate_uploads"] and c1["pairings_uploads"] == c0["pairings_uploads"]
+    print("\n[host path] (iteration, pairs, pairings uploads so far, (match ms, solve ms)):", trace)
+    assert c1["mstate_uploads"] == c0["mstate_uploads"] and c1["pairings_uploads"] == c0["pairings_uploads"], trace
     assert c1["map_uploads"] - c0["map_uploads"] <= 1 and c1["cloud_uploads"] - c0["cloud_uploads"] <= 1
     print(f"\n[host path] device-resident step {t_dev * 1e3:.3f} ms, host-container step {t_host * 1e3:.3f} ms")
     assert t_host < 2.5 * t_dev + 2e-4, (t_host, t_dev)

@@ -116,30 +116,37 @@ inline uint64_t sampled_fingerprint(const float* x, const float* y, const float*
     return h;
 }
 
-// running checksum of a Pairings' point / plane lists (a plain sequential fold: folding two chunks one
-// after the other equals folding their concatenation).  It decides whether the device-resident list
+// running checksum of a Pairings' point / plane lists.  Four interleaved multiply-add streams (entry i
+// feeds stream i & 3: a single stream is one long dependency chain, ~1 ms per 10^5 pairs), each order-
+// sensitive; folding two chunks one after the other -- the second starting at the absolute index where
+// the first ended -- equals folding their concatenation.  It decides whether the device-resident list
 // the matchers of this plugin left behind is the list a solver was handed (run_matchers copies
-// Pairings by value, Matcher.cpp:74-77, so identity cannot be carried by the container)
-constexpr uint64_t SUM_PT_SEED = 0x13198A2E03707344ull, SUM_PL_SEED = 0xA4093822299F31D0ull;
-inline uint64_t pairs_checksum(const mp2p_hip_pair_pt2pt* p, size_t n, uint64_t h = SUM_PT_SEED)
+// Pairings by value, Matcher.cpp:74-77, so identity cannot be carried by the container).
+struct Sum
+{
+    uint64_t h[4] = {0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull, 0x452821E638D01377ull};
+    bool operator==(const Sum& o) const { return h[0] == o.h[0] && h[1] == o.h[1] && h[2] == o.h[2] && h[3] == o.h[3]; }
+};
+inline void sum_feed(Sum& s, size_t i, uint64_t v) { s.h[i & 3] = s.h[i & 3] * 0x9E3779B97F4A7C15ull + (v ^ (v >> 29)); }
+inline Sum pairs_checksum(const mp2p_hip_pair_pt2pt* p, size_t n, Sum s = Sum(), size_t first = 0)
 {
     for (size_t i = 0; i < n; i++)
     {
         uint32_t e;
         std::memcpy(&e, &p[i].errorSquareAfterTransformation, 4);
-        h = mix64(h, ((uint64_t)p[i].globalIdx << 32) | p[i].localIdx), h = mix64(h, e);
+        sum_feed(s, first + i, (((uint64_t)p[i].globalIdx << 32) | p[i].localIdx) + ((uint64_t)e << 17));
     }
-    return h;
+    return s;
 }
-inline uint64_t planes_checksum(const mp2p_hip_pair_pt2pl* p, size_t n, uint64_t h = SUM_PL_SEED)
+inline Sum planes_checksum(const mp2p_hip_pair_pt2pl* p, size_t n, Sum s = Sum(), size_t first = 0)
 {
     for (size_t i = 0; i < n; i++)
     {
         uint64_t a, b;
         std::memcpy(&a, &p[i].plane[3], 8), std::memcpy(&b, &p[i].pt_local[0], 8);
-        h = mix64(h, a), h = mix64(h, b);
+        sum_feed(s, first + i, a + (b << 1));
     }
-    return h;
+    return s;
 }
 
 // ---- one context + handle caches per thread (ICP::align is single-threaded per object) ----------
@@ -212,11 +219,10 @@ class Runtime
     }
 
     // ---- MatchState: one device object per (N_g, N_l), brought to the host fields' content --------
-    mp2p_hip_mstate* match_state(BitView g, BitView l)
+    mp2p_hip_mstate* match_state(BitView g, BitView l, bool anyG, bool anyL)
     {
         auto& ms = mstates_[std::make_pair(g.nbits, l.nbits)];
         if (!ms) check(mp2p_hip_mstate_create(ctx, g.nbits, l.nbits, &ms));  // created clear
-        const bool anyG = g.words && g.any(), anyL = l.words && l.any();
         if (!anyG && !anyL) check(mp2p_hip_mstate_reset(ctx, ms));
         else
         {
@@ -250,7 +256,7 @@ class Runtime
     {
         bool     valid = false;
         size_t   n_pt = 0, n_pl = 0;
-        uint64_t sum_pt = SUM_PT_SEED, sum_pl = SUM_PL_SEED;
+        Sum      sum_pt, sum_pl;
         // the run_matchers call the list belongs to: (MatchState address, ICP iteration)
         const void* ms_key = nullptr;
         uint32_t    iteration = 0;
@@ -294,11 +300,14 @@ struct MatchCall
 };
 
 // start of a matcher call: the device list is continued when it belongs to the same run_matchers call
-// (same MatchState, same ICP iteration) and cleared otherwise
-inline mp2p_hip_pairs* begin_match(Runtime& rt, const MatchCall& c, size_t add_pt, size_t add_pl)
+// (same MatchState object, same ICP iteration, and that state carries marks: a state without any is
+// what run_matchers starts from -- Matcher.cpp:57-66 -- and clearing needlessly only costs the solver
+// an upload, whereas continuing a list of an earlier call would grow it for nothing) and cleared
+// otherwise.  Whatever is decided here, the solver trusts the device list only on size + checksum.
+inline mp2p_hip_pairs* begin_match(Runtime& rt, const MatchCall& c, bool fresh_state, size_t add_pt, size_t add_pl)
 {
     auto&      tk   = rt.token;
-    const bool same = tk.valid && tk.ms_key == c.ms_key && tk.iteration == c.iteration;
+    const bool same = tk.valid && !fresh_state && tk.ms_key == c.ms_key && tk.iteration == c.iteration;
     if (!same) tk = Runtime::Token();
     mp2p_hip_pairs* dp = rt.pairs(tk.n_pt + add_pt, std::max(rt.cap_pl(), tk.n_pl + add_pl));
     if (!same) rt.check(mp2p_hip_pairs_clear(rt.ctx, dp));
@@ -315,11 +324,12 @@ size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
                          size_t n_visit, PairVec& out)
 {
     static_assert(sizeof(typename PairVec::value_type) == sizeof(mp2p_hip_pair_pt2pt), "pair record layout");
-    const size_t    n_l = mp2p_hip_cloud_size(cloud);
-    mp2p_hip_pairs* dp  = begin_match(rt, c, n_l * prm.pairingsPerPoint, 0);
-    auto&           tk  = rt.token;
+    const size_t    n_l  = mp2p_hip_cloud_size(cloud);
+    const bool      anyG = c.gbits.words && c.gbits.any(), anyL = c.lbits.words && c.lbits.any();
+    mp2p_hip_pairs* dp   = begin_match(rt, c, !anyG && !anyL, n_l * prm.pairingsPerPoint, 0);
+    auto&           tk   = rt.token;
     rt.check(mp2p_hip_cloud_set_visit_order(rt.ctx, cloud, n_visit ? visit : nullptr, n_visit));
-    mp2p_hip_mstate* ms = rt.match_state(c.gbits, c.lbits);
+    mp2p_hip_mstate* ms = rt.match_state(c.gbits, c.lbits, anyG, anyL);
     rt.check(mp2p_hip_match_pt2pt(rt.ctx, map, cloud, pose, &prm, ms, dp));
     // the new list length first (24 bytes, one wait), then exactly the new entries into the caller's vector
     uint64_t n_pt = 0;
@@ -335,7 +345,7 @@ size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
             if (c.lbits.words) c.lbits.set(dst[i].localIdx);
             if (c.gbits.words) c.gbits.set(dst[i].globalIdx);
         }
-    tk.sum_pt = pairs_checksum(dst, n, tk.sum_pt);
+    tk.sum_pt = pairs_checksum(dst, n, tk.sum_pt, tk.n_pt);
     tk.n_pt += n, tk.valid = true;
     return n;
 }
@@ -347,11 +357,13 @@ size_t match_pt2pl_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
                          const double pose[12], const mp2p_hip_pt2pl_params& prm, const uint32_t* visit,
                          size_t n_visit, Emit&& emit)
 {
-    const size_t    n_l = mp2p_hip_cloud_size(cloud);
-    mp2p_hip_pairs* dp  = begin_match(rt, c, 0, n_l);
-    auto&           tk  = rt.token;
+    const size_t    n_l  = mp2p_hip_cloud_size(cloud);
+    const bool      anyG = c.gbits.words && c.gbits.any(), anyL = c.lbits.words && c.lbits.any();
+    mp2p_hip_pairs* dp   = begin_match(rt, c, !anyG && !anyL, 0, n_l);
+    auto&           tk   = rt.token;
     rt.check(mp2p_hip_cloud_set_visit_order(rt.ctx, cloud, n_visit ? visit : nullptr, n_visit));
-    mp2p_hip_mstate* ms = rt.match_state(BitView{nullptr, c.gbits.nbits}, c.lbits);  // global marks are not read (:87-90)
+    // global marks are neither read nor set by this matcher (:87-90)
+    mp2p_hip_mstate* ms = rt.match_state(BitView{nullptr, c.gbits.nbits}, c.lbits, false, anyL);
     rt.check(mp2p_hip_match_pt2pl(rt.ctx, map, cloud, pose, &prm, ms, dp));
     uint64_t n_pl = 0;
     rt.check(mp2p_hip_pairs_counts(rt.ctx, dp, nullptr, &n_pl, nullptr));
@@ -365,7 +377,7 @@ size_t match_pt2pl_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
         emit(rec[i]);
         if (c.lbits.words) c.lbits.set(idx[i]);  // Matcher_Point2Plane.cpp:109
     }
-    tk.sum_pl = planes_checksum(rec.data(), n, tk.sum_pl);
+    tk.sum_pl = planes_checksum(rec.data(), n, tk.sum_pl, tk.n_pl);
     tk.n_pl += n, tk.valid = true;
     return n;
 }

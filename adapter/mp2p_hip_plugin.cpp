@@ -8,149 +8,192 @@
 //       - class: mp2p_icp_hip::Matcher_Points_DistanceThreshold
 //         plugin: libmp2p_icp_hip_plugin.so            # ICP.cpp:540-547, load_plugin.cpp:70-134
 //         params: { threshold: 2.0, thresholdAngularDeg: 0 }
+//       - class: mp2p_icp_hip::Matcher_Point2Plane
+//         plugin: libmp2p_icp_hip_plugin.so
+//         params: { distanceThreshold: 0.4, searchRadius: 0.4, knn: 5, minimumPlanePoints: 5, planeEigenThreshold: 0.05 }
 //     solvers:
 //       - class: mp2p_icp_hip::Solver_GaussNewton
 //         plugin: libmp2p_icp_hip_plugin.so            # ICP.cpp:501-508
 //         params: { maxIterations: 3, robustKernel: 'RobustKernel::GemanMcClure', robustKernelParam: 0.15 }
 //
-// It needs MRPT >= 2.11.5 and mp2p_icp to build (neither exists in the development image of
-// this repository, so this file is NOT compiled by __graft_entry__.build(); see
-// adapter/CMakeLists.txt and INTEGRATION.md).  All numerics happen behind the C ABI of
-// include/mp2p_hip.h; this file only converts containers.
+// It needs MRPT >= 2.11.5 and mp2p_icp to build (neither exists in the development image of this
+// repository, so this file is NOT compiled by __graft_entry__.build(); adapter/CMakeLists.txt and
+// INTEGRATION.md).  tests/test_adapter_syntax.py compiles it with g++ -fsyntax-only against
+// declaration-only stand-ins of the MRPT / mp2p_icp types it touches (tests/adapter_stubs/).
+// All numerics happen behind the C ABI of include/mp2p_hip.h; all per-call host logic (what is
+// transferred when) lives in mp2p_hip_host.hpp, which IS compiled, tested and timed here.  This file
+// only converts MRPT containers into the plain views that header works on.
 //
 // Interfaces implemented (reference file:line):
-//   Matcher_Points_Base::implMatchOneLayer     Matcher_Points_Base.h:125-128 (private virtual)
-//   Solver::impl_optimal_pose                  Solver.h:100-101   (Gauss-Newton, Horn)
-//   Matcher::initialize / Solver::initialize   Matcher.h:88, Solver.h:80
-//   registration                               register.cpp:43-69
+//   Matcher::match (virtual)                    Matcher.h:93-96    -> captures MatchContext::icpIteration
+//   Matcher_Points_Base::implMatchOneLayer      Matcher_Points_Base.h:125-128 (private virtual)
+//   Solver::impl_optimal_pose                   Solver.h:100-101   (Gauss-Newton, Horn)
+//   Matcher::initialize / Solver::initialize    Matcher.h:88, Solver.h:80
+//   NearestPlaneCapable::nn_search_pt2pl        NearestPlaneCapable.h:49-50  (PointsMapPlanes layer)
+//   registration                                register.cpp:43-69
 #include <mp2p_icp/Matcher_Points_Base.h>
-#include <mp2p_icp/Solver.h>
+#include <mp2p_icp/NearestPlaneCapable.h>
 #include <mp2p_icp/PairWeights.h>
+#include <mp2p_icp/Solver.h>
 #include <mp2p_icp/WeightParameters.h>
-#include <mp2p_icp/robust_kernels.h>
 #include <mp2p_icp/metricmap.h>
+#include <mp2p_icp/pointcloud_bitfield.h>
+#include <mp2p_icp/robust_kernels.h>
 #include <mrpt/core/initializer.h>
 #include <mrpt/maps/CPointsMap.h>
+#include <mrpt/maps/CSimplePointsMap.h>
 #include <mrpt/random/random_shuffle.h>
 #include <mrpt/rtti/CObject.h>
 
 #include <chrono>
 #include <cstring>
 #include <numeric>
+#include <optional>
 #include <random>
-#include <map>
-#include <memory>
-#include <stdexcept>
+#include <vector>
 
 #include "mp2p_hip.h"
+#include "mp2p_hip_host.hpp"
 
 static_assert(sizeof(mrpt::tfest::TMatchingPair) == sizeof(mp2p_hip_pair_pt2pt),
               "TMatchingPair layout changed: update mp2p_hip_pair_pt2pt");
 
 namespace mp2p_icp_hip
 {
-// ---- one context + handle caches per thread (ICP::align is single-threaded per object) --------
-struct Runtime
-{
-    mp2p_hip_ctx* ctx = nullptr;
-    struct MapEntry
-    {
-        mp2p_hip_map* h = nullptr;
-        size_t        n = 0;
-        float         probe[6] = {0, 0, 0, 0, 0, 0};  // first/last point: cheap change detector
-    };
-    struct CloudEntry
-    {
-        mp2p_hip_cloud* h = nullptr;
-        size_t          n = 0;
-        float           probe[6] = {0, 0, 0, 0, 0, 0};
-    };
-    std::map<const void*, MapEntry>   maps;
-    std::map<const void*, CloudEntry> clouds;
-    // the Pairings the last matcher call left in HBM, so that the solver of the same ICP
-    // iteration need not upload them again (run_matchers copies Pairings by value,
-    // Matcher.cpp:74-77, so a derived container type would not survive)
-    mp2p_hip_pairs* dev_pairs = nullptr;
-    mp2p_hip_pairs* conv_pairs = nullptr;  // Solver_Horn: output of pt2ln_pl_to_pt2pt
-    size_t          dev_cap_pt = 0, dev_cap_pl = 0;
-    size_t          token_n_pt = 0, token_n_pl = 0;
-    bool            has_lines_planes = false;
-    uint32_t        token_first = 0, token_last = 0;
+using mp2p_hip_host::BitView;
+using mp2p_hip_host::MatchCall;
+using mp2p_hip_host::Runtime;
 
-    static Runtime& get()
+// ---- the packed words behind a DenseOrSparseBitField -------------------------------------------------
+// pointcloud_bitfield_t::DenseOrSparseBitField (pointcloud_bitfield.h:46-92) offers operator[] and
+// mark_as_set only; its dense form is a private std::optional<std::vector<bool>>.  Reading 10 M bits
+// through operator[] costs ~10 ms per matcher call, the words cost 30 us -- so the dense member is
+// reached through the explicit-instantiation idiom (access checks do not apply to the arguments of an
+// explicit template instantiation: standard C++, no reinterpret_cast of the object), and the word
+// pointer through libstdc++'s public iterator member.  Any other standard library, or the sparse form,
+// takes the generic route (a temporary packed copy filled through operator[]).
+namespace detail
+{
+using BitField = mp2p_icp::pointcloud_bitfield_t::DenseOrSparseBitField;
+template <typename Tag, typename Tag::type M>
+struct Rob
+{
+    friend typename Tag::type get(Tag) { return M; }
+};
+struct DenseTag
+{
+    using type = std::optional<std::vector<bool>> BitField::*;
+    friend type get(DenseTag);
+};
+template struct Rob<DenseTag, &BitField::dense_>;
+
+inline std::optional<std::vector<bool>>& dense_of(BitField& bf) { return bf.*get(DenseTag{}); }
+}  // namespace detail
+
+// a BitView over one bit-field for the duration of a matcher call; commit() carries new marks back
+// when the view is a temporary copy
+class BitAccess
+{
+   public:
+    BitAccess(detail::BitField& bf, size_t n) : bf_(bf), n_(n)
     {
-        static thread_local Runtime r;
-        if (!r.ctx)
+#if defined(__GLIBCXX__)
+        auto& d = detail::dense_of(bf);
+        if (d.has_value() && d->size() >= n)
         {
-            const int rc = mp2p_hip_ctx_create(0, nullptr, &r.ctx);
-            if (rc) throw std::runtime_error(std::string("mp2p_hip_ctx_create: ") + mp2p_hip_last_error(nullptr));
+            direct_ = true;
+            view_   = BitView{reinterpret_cast<uint64_t*>(d->begin()._M_p), n};
+            static_assert(sizeof(*d->begin()._M_p) == sizeof(uint64_t), "std::vector<bool> word size");
+            return;
         }
-        return r;
+#endif
+        tmp_.assign((n + 63) / 64 + 1, 0);
+        for (size_t i = 0; i < n; i++)
+            if (bf[i]) tmp_[i >> 6] |= 1ull << (i & 63);
+        before_ = tmp_;
+        view_   = BitView{tmp_.data(), n};
     }
-    void check(int rc) const
+    BitView view() const { return view_; }
+    void    commit()
     {
-        if (rc) throw std::runtime_error(std::string("libmp2p_hip: ") + mp2p_hip_last_error(ctx));
-    }
-    static void fill_probe(const mrpt::maps::CPointsMap& m, float p[6])
-    {
-        const auto &x = m.getPointsBufferRef_x(), &y = m.getPointsBufferRef_y(), &z = m.getPointsBufferRef_z();
-        const size_t n = x.size();
-        if (!n) return;
-        p[0] = x[0], p[1] = y[0], p[2] = z[0], p[3] = x[n - 1], p[4] = y[n - 1], p[5] = z[n - 1];
-    }
-    mp2p_hip_map* global_layer(const mrpt::maps::CPointsMap& m)
-    {
-        auto& e = maps[&m];
-        float p[6] = {0, 0, 0, 0, 0, 0};
-        fill_probe(m, p);
-        if (!e.h || e.n != m.size() || std::memcmp(p, e.probe, sizeof(p)) != 0)
-        {  // (re)build the index: the role of nn_prepare_for_3d_queries() after mark_as_modified()
-            if (e.h) mp2p_hip_map_free(ctx, e.h);
-            e.h = nullptr;
-            check(mp2p_hip_map_upload(ctx, m.getPointsBufferRef_x().data(), m.getPointsBufferRef_y().data(),
-                                      m.getPointsBufferRef_z().data(), m.size(), nullptr, &e.h));
-            e.n = m.size();
-            std::memcpy(e.probe, p, sizeof(p));
-        }
-        return e.h;
-    }
-    mp2p_hip_cloud* local_layer(const mrpt::maps::CPointsMap& m)
-    {
-        auto& e = clouds[&m];
-        float p[6] = {0, 0, 0, 0, 0, 0};
-        fill_probe(m, p);
-        if (!e.h || e.n != m.size() || std::memcmp(p, e.probe, sizeof(p)) != 0)
+        if (direct_) return;
+        for (size_t w = 0; w < tmp_.size(); w++)
         {
-            if (e.h) mp2p_hip_cloud_free(ctx, e.h);
-            e.h = nullptr;
-            check(mp2p_hip_cloud_upload(ctx, m.getPointsBufferRef_x().data(), m.getPointsBufferRef_y().data(),
-                                        m.getPointsBufferRef_z().data(), m.size(), &e.h));
-            e.n = m.size();
-            std::memcpy(e.probe, p, sizeof(p));
+            uint64_t m = tmp_[w] & ~before_[w];
+            while (m)
+            {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                bf_.mark_as_set(w * 64 + (size_t)b);
+            }
         }
-        return e.h;
     }
-    mp2p_hip_pairs* pairs(size_t cap_pt, size_t cap_pl)
+
+   private:
+    detail::BitField&     bf_;
+    size_t                n_;
+    bool                  direct_ = false;
+    BitView               view_;
+    std::vector<uint64_t> tmp_, before_;
+};
+
+static void fill_pose(const mrpt::poses::CPose3D& P, double T[12])
+{
+    const auto& R = P.getRotationMatrix();
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) T[i * 3 + j] = R(i, j);
+    T[9] = P.x(), T[10] = P.y(), T[11] = P.z();
+}
+static mrpt::poses::CPose3D make_pose(const double T[12])
+{
+    mrpt::math::CMatrixDouble33 R;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R(i, j) = T[i * 3 + j];
+    return mrpt::poses::CPose3D(R, mrpt::math::TPoint3D(T[9], T[10], T[11]));
+}
+
+// maxLocalPointsPerLayer: the SAME list the reference would visit (Matcher_Points_Base.cpp:222-232),
+// drawn with MRPT's own shuffle and handed to the library
+static std::vector<uint32_t> visit_list(size_t n_local, uint64_t maxLocalPoints, uint64_t seed0)
+{
+    std::vector<uint32_t> visit;
+    if (maxLocalPoints != 0 && n_local > maxLocalPoints)
     {
-        if (!dev_pairs) check(mp2p_hip_pairs_create(ctx, cap_pt, cap_pl, &dev_pairs));
-        else check(mp2p_hip_pairs_reserve(ctx, dev_pairs, cap_pt, cap_pl));
-        dev_cap_pt = std::max(dev_cap_pt, cap_pt), dev_cap_pl = std::max(dev_cap_pl, cap_pl);
-        return dev_pairs;
+        std::vector<std::size_t> idxs(maxLocalPoints);
+        std::iota(idxs.begin(), idxs.end(), 0);
+        const unsigned int seed =
+            seed0 != 0 ? (unsigned int)seed0 : (unsigned int)std::chrono::system_clock::now().time_since_epoch().count();
+        mrpt::random::partial_shuffle(idxs.begin(), idxs.end(), std::default_random_engine(seed), maxLocalPoints);
+        visit.assign(idxs.begin(), idxs.end());
+    }
+    return visit;
+}
+
+// what both matchers share: the ICP iteration and MatchState of the running run_matchers call
+class MatcherCallContext
+{
+   protected:
+    mutable uint32_t    cur_iteration_ = 0;
+    mutable const void* cur_ms_        = nullptr;
+    void note_call(const mp2p_icp::MatchContext& mc, const mp2p_icp::MatchState& ms) const
+    {
+        cur_iteration_ = mc.icpIteration, cur_ms_ = &ms;
+    }
+    // handles of the two layers: verified in full at ICP iteration 0 (ICP::align holds its maps const
+    // afterwards), by size + buffer addresses + 1024 sampled points otherwise
+    void layers(Runtime& rt, const mrpt::maps::CPointsMap& gl, const mrpt::maps::CPointsMap& lc, mp2p_hip_map*& m,
+                mp2p_hip_cloud*& c) const
+    {
+        const bool full = cur_iteration_ == 0;
+        m = rt.global_layer(&gl, gl.getPointsBufferRef_x().data(), gl.getPointsBufferRef_y().data(),
+                            gl.getPointsBufferRef_z().data(), gl.size(), full);
+        c = rt.local_layer(&lc, lc.getPointsBufferRef_x().data(), lc.getPointsBufferRef_y().data(),
+                           lc.getPointsBufferRef_z().data(), lc.size(), full);
     }
 };
 
-// MatchState bit-fields <-> one byte per point (mp2p_hip_mstate)
-static void bits_to_bytes(const mp2p_icp::pointcloud_bitfield_t::DenseOrSparseBitField& bf, size_t n,
-                          std::vector<uint8_t>& out, bool& any)
-{
-    out.assign(n ? n : 1, 0);
-    any = false;
-    for (size_t i = 0; i < n; i++)
-        if (bf[i]) out[i] = 1, any = true;
-}
-
 // ================================================================================================
-class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base
+class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base, protected MatcherCallContext
 {
     DEFINE_MRPT_OBJECT(Matcher_Points_DistanceThreshold, mp2p_icp_hip)
    public:
@@ -160,6 +203,13 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base
         DECLARE_PARAMETER_REQ(params, threshold);            // Matcher_Points_DistanceThreshold.cpp:43
         DECLARE_PARAMETER_REQ(params, thresholdAngularDeg);  // :44
         DECLARE_PARAMETER_OPT(params, pairingsPerPoint);     // :45
+    }
+    bool match(const mp2p_icp::metric_map_t& pcGlobal, const mp2p_icp::metric_map_t& pcLocal,
+               const mrpt::poses::CPose3D& localPose, const mp2p_icp::MatchContext& mc, mp2p_icp::MatchState& ms,
+               mp2p_icp::Pairings& out) const override
+    {
+        note_call(mc, ms);
+        return mp2p_icp::Matcher::match(pcGlobal, pcLocal, localPose, mc, ms, out);
     }
     double   threshold           = 0.50;
     double   thresholdAngularDeg = 0.50;
@@ -179,137 +229,204 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base
         const auto* gl = mp2p_icp::MapToPointsMap(pcGlobal);
         if (!gl) THROW_EXCEPTION("HIP matcher: the global layer must be a CPointsMap");
 
-        auto& rt = Runtime::get();
-        // maxLocalPointsPerLayer: the SAME list the reference would visit (Matcher_Points_Base.cpp:
-        // 222-232), drawn here with MRPT's own shuffle and handed to the library
-        std::vector<uint32_t> visit;
-        if (maxLocalPointsPerLayer_ != 0 && pcLocal.size() > maxLocalPointsPerLayer_)
-        {
-            std::vector<std::size_t> idxs(maxLocalPointsPerLayer_);
-            std::iota(idxs.begin(), idxs.end(), 0);
-            const unsigned int seed = localPointsSampleSeed_ != 0
-                                          ? localPointsSampleSeed_
-                                          : std::chrono::system_clock::now().time_since_epoch().count();
-            mrpt::random::partial_shuffle(idxs.begin(), idxs.end(), std::default_random_engine(seed),
-                                          maxLocalPointsPerLayer_);
-            visit.assign(idxs.begin(), idxs.end());
-        }
-        const size_t nVisited = visit.empty() ? pcLocal.size() : visit.size();
-        out.potential_pairings += nVisited * pairingsPerPoint;  // :64 (the library adds the
-        if (pcGlobal.isEmpty() || pcLocal.empty()) return;     //  same amount on its side)
+        out.potential_pairings += pcLocal.size() * pairingsPerPoint;  // :64 (the whole layer)
+        if (pcGlobal.isEmpty() || pcLocal.empty()) return;            // :67
 
         mp2p_hip_pt2pt_params prm;
         std::memset(&prm, 0, sizeof(prm));
         prm.threshold = threshold, prm.thresholdAngularDeg = thresholdAngularDeg;
-        prm.pairingsPerPoint = pairingsPerPoint;
+        prm.pairingsPerPoint                     = pairingsPerPoint;
         prm.allowMatchAlreadyMatchedPoints       = allowMatchAlreadyMatchedPoints_;
         prm.allowMatchAlreadyMatchedGlobalPoints = allowMatchAlreadyMatchedGlobalPoints_;
         prm.bounding_box_intersection_check_epsilon = bounding_box_intersection_check_epsilon_;
-
-        // pose: R row-major + t
         double T[12];
-        const auto& R = localPose.getRotationMatrix();
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) T[i * 3 + j] = R(i, j);
-        T[9] = localPose.x(), T[10] = localPose.y(), T[11] = localPose.z();
+        fill_pose(localPose, T);
 
-        // MatchState -> device (only when something is already marked)
-        mp2p_hip_mstate*     dms = nullptr;
-        std::vector<uint8_t> gtaken, ltaken;
-        bool                 anyG = false, anyL = false;
-        auto& gbf = ms.globalPairedBitField.point_layers.at(globalName);
-        auto& lbf = ms.localPairedBitField.point_layers.at(localName);
-        bits_to_bytes(gbf, gl->size(), gtaken, anyG);
-        bits_to_bytes(lbf, pcLocal.size(), ltaken, anyL);
-        rt.check(mp2p_hip_mstate_create(rt.ctx, gl->size(), pcLocal.size(), &dms));
-        if (anyG || anyL) rt.check(mp2p_hip_mstate_upload(rt.ctx, dms, gtaken.data(), ltaken.data()));
-
-        mp2p_hip_pairs* dp = rt.pairs(out.paired_pt2pt.size() + pcLocal.size() * pairingsPerPoint, rt.dev_cap_pl);
-        if (out.paired_pt2pt.empty() && out.paired_pt2pl.empty()) rt.check(mp2p_hip_pairs_clear(rt.ctx, dp));
-        mp2p_hip_cloud* dl = rt.local_layer(pcLocal);
-        rt.check(mp2p_hip_cloud_set_visit_order(rt.ctx, dl, visit.empty() ? nullptr : visit.data(), visit.size()));
-        const int rc = mp2p_hip_match_pt2pt(rt.ctx, rt.global_layer(*gl), dl, T, &prm, dms, dp);
-        if (rc)
-        {
-            mp2p_hip_mstate_free(rt.ctx, dms);
-            rt.check(rc);
-        }
-        // host containers (ICP::align needs them: .empty(), quality, covariance, logs)
-        uint64_t n64 = 0;
-        rt.check(mp2p_hip_pairs_counts(rt.ctx, dp, &n64, nullptr, nullptr));
-        size_t n = static_cast<size_t>(n64);
-        out.paired_pt2pt.resize(n);  // the device list already holds what `out` held before
-        if (n)
-            rt.check(mp2p_hip_pairs_download_pt2pt(
-                rt.ctx, dp, reinterpret_cast<mp2p_hip_pair_pt2pt*>(out.paired_pt2pt.data()), n, &n));
-        // marks back to the host MatchState (only left when global re-use is forbidden, :116-120)
-        if (!allowMatchAlreadyMatchedGlobalPoints_)
-        {
-            rt.check(mp2p_hip_mstate_download(rt.ctx, dms, gtaken.data(), ltaken.data()));
-            for (size_t i = 0; i < gl->size(); i++)
-                if (gtaken[i]) gbf.mark_as_set(i);
-            for (size_t i = 0; i < pcLocal.size(); i++)
-                if (ltaken[i]) lbf.mark_as_set(i);
-        }
-        mp2p_hip_mstate_free(rt.ctx, dms);
-        rt.token_n_pt  = n;
-        rt.token_first = n ? out.paired_pt2pt.front().localIdx : 0;
-        rt.token_last  = n ? out.paired_pt2pt.back().localIdx : 0;
+        auto&                       rt    = Runtime::get();
+        const std::vector<uint32_t> visit = visit_list(pcLocal.size(), maxLocalPointsPerLayer_, localPointsSampleSeed_);
+        mp2p_hip_map*               m;
+        mp2p_hip_cloud*             c;
+        layers(rt, *gl, pcLocal, m, c);
+        BitAccess gbits(ms.globalPairedBitField.point_layers.at(globalName), gl->size());
+        BitAccess lbits(ms.localPairedBitField.point_layers.at(localName), pcLocal.size());
+        MatchCall call;
+        call.ms_key = cur_ms_ ? cur_ms_ : &ms, call.iteration = cur_iteration_;
+        call.gbits = gbits.view(), call.lbits = lbits.view();
+        // mrpt::tfest::TMatchingPairList derives std::vector<TMatchingPair>: appended in place
+        mp2p_hip_host::match_pt2pt_layer(rt, call, m, c, T, prm, visit.data(), visit.size(), out.paired_pt2pt);
+        gbits.commit(), lbits.commit();
     }
 };
 
-// Pairings -> the device handle the solvers read.  Point pairings produced by this plugin's matcher
-// in the same ICP iteration are still in HBM (Runtime::token_*): only lists from other matchers
-// are uploaded.
+// ================================================================================================
+// Matcher_Point2Plane (Matcher_Point2Plane.cpp:41-114) with the plane search batched over the whole
+// local layer on the device.  The reference delegates the plane construction to the global layer's
+// nn_search_pt2pl (no implementor in its own tree); here it is the k-NN + covariance + eigen rule
+// declared in oracle/mp2p_oracle.c, with its parameters exposed in the YAML (defaults = those of
+// the PointsMapPlanes layer below, so both routes pair the same points).
+class Matcher_Point2Plane : public mp2p_icp::Matcher_Points_Base, protected MatcherCallContext
+{
+    DEFINE_MRPT_OBJECT(Matcher_Point2Plane, mp2p_icp_hip)
+   public:
+    void initialize(const mrpt::containers::yaml& params) override
+    {
+        Matcher_Points_Base::initialize(params);
+        DECLARE_PARAMETER_REQ(params, distanceThreshold);  // Matcher_Point2Plane.cpp:38
+        DECLARE_PARAMETER_OPT(params, searchRadius);
+        MCP_LOAD_OPT(params, knn);
+        MCP_LOAD_OPT(params, minimumPlanePoints);
+        MCP_LOAD_OPT(params, planeEigenThreshold);
+    }
+    bool match(const mp2p_icp::metric_map_t& pcGlobal, const mp2p_icp::metric_map_t& pcLocal,
+               const mrpt::poses::CPose3D& localPose, const mp2p_icp::MatchContext& mc, mp2p_icp::MatchState& ms,
+               mp2p_icp::Pairings& out) const override
+    {
+        note_call(mc, ms);
+        return mp2p_icp::Matcher::match(pcGlobal, pcLocal, localPose, mc, ms, out);
+    }
+    double   distanceThreshold   = 0.50;
+    double   searchRadius        = 0.0;  // 0: distanceThreshold
+    uint32_t knn                 = 5;
+    uint32_t minimumPlanePoints  = 5;
+    double   planeEigenThreshold = 0.05;
+
+   private:
+    void implMatchOneLayer(const mrpt::maps::CMetricMap& pcGlobal, const mrpt::maps::CPointsMap& pcLocal,
+                           const mrpt::poses::CPose3D& localPose, mp2p_icp::MatchState& ms,
+                           const mp2p_icp::layer_name_t& globalName, const mp2p_icp::layer_name_t& localName,
+                           mp2p_icp::Pairings& out) const override
+    {
+        checkAllParametersAreRealized();
+        ASSERT_GT_(distanceThreshold, .0);
+        ASSERT_(knn >= 3 && knn <= 16);
+        const auto* gl = mp2p_icp::MapToPointsMap(pcGlobal);
+        if (!gl) THROW_EXCEPTION("HIP point-to-plane matcher: the global layer must be a CPointsMap");
+        out.potential_pairings += pcLocal.size();           // :54
+        if (pcGlobal.isEmpty() || pcLocal.empty()) return;  // :57
+
+        mp2p_hip_pt2pl_params prm;
+        std::memset(&prm, 0, sizeof(prm));
+        prm.distanceThreshold = distanceThreshold;
+        prm.searchRadius      = searchRadius > 0 ? searchRadius : distanceThreshold;
+        prm.knn = knn, prm.minimumPlanePoints = minimumPlanePoints, prm.planeEigenThreshold = planeEigenThreshold;
+        prm.allowMatchAlreadyMatchedPoints          = allowMatchAlreadyMatchedPoints_;
+        prm.bounding_box_intersection_check_epsilon = bounding_box_intersection_check_epsilon_;
+        double T[12];
+        fill_pose(localPose, T);
+
+        auto&                       rt    = Runtime::get();
+        const std::vector<uint32_t> visit = visit_list(pcLocal.size(), maxLocalPointsPerLayer_, localPointsSampleSeed_);
+        mp2p_hip_map*               m;
+        mp2p_hip_cloud*             c;
+        layers(rt, *gl, pcLocal, m, c);
+        BitAccess lbits(ms.localPairedBitField.point_layers.at(localName), pcLocal.size());
+        MatchCall call;
+        call.ms_key = cur_ms_ ? cur_ms_ : &ms, call.iteration = cur_iteration_;
+        call.gbits = BitView{nullptr, gl->size()}, call.lbits = lbits.view();  // global marks: not read, not set (:87-90)
+        (void)globalName;
+        mp2p_hip_host::match_pt2pl_layer(
+            rt, call, m, c, T, prm, visit.data(), visit.size(),
+            [&](const mp2p_hip_pair_pt2pl& r)
+            {
+                auto& p = out.paired_pt2pl.emplace_back();
+                p.pt_local = {r.pt_local[0], r.pt_local[1], r.pt_local[2]};
+                for (int k = 0; k < 4; k++) p.pl_global.plane.coefs[k] = r.plane[k];
+                p.pl_global.centroid = {r.centroid[0], r.centroid[1], r.centroid[2]};
+            });
+        lbits.commit();
+    }
+};
+
+// ================================================================================================
+// A point layer type that also offers NearestPlaneCapable (NearestPlaneCapable.h:33-52), so that the
+// reference's OWN Matcher_Point2Plane runs on it (MapToNP is a dynamic_cast, metricmap.cpp:804-822).
+// One device call per query (~0.1 ms): the contract, not the fast path -- a pipeline that wants speed
+// names mp2p_icp_hip::Matcher_Point2Plane, which batches the whole layer.
+class PointsMapPlanes : public mrpt::maps::CSimplePointsMap, public mp2p_icp::NearestPlaneCapable
+{
+    DEFINE_SERIALIZABLE(PointsMapPlanes, mp2p_icp_hip)
+   public:
+    uint32_t knn                 = 5;
+    uint32_t minimumPlanePoints  = 5;
+    double   planeEigenThreshold = 0.05;
+    double   searchRadius        = 0.0;  // 0: the max_search_distance of the query
+
+    NearestPlaneResult nn_search_pt2pl(const mrpt::math::TPoint3Df& point, const float max_search_distance) const override
+    {
+        NearestPlaneResult res;
+        if (this->empty()) return res;
+        auto&         rt = Runtime::get();
+        mp2p_hip_map* m  = rt.global_layer(this, getPointsBufferRef_x().data(), getPointsBufferRef_y().data(),
+                                           getPointsBufferRef_z().data(), size(), /*full_check=*/false);
+        mp2p_hip_pt2pl_params prm;
+        std::memset(&prm, 0, sizeof(prm));
+        prm.searchRadius = searchRadius, prm.knn = knn, prm.minimumPlanePoints = minimumPlanePoints;
+        prm.planeEigenThreshold                     = planeEigenThreshold;
+        prm.bounding_box_intersection_check_epsilon = 0.20;
+        const float            q[3] = {point.x, point.y, point.z};
+        mp2p_hip_nearest_plane np;
+        rt.check(mp2p_hip_nn_search_pt2pl(rt.ctx, m, q, max_search_distance, &prm, &np));
+        if (!np.found) return res;
+        mp2p_icp::point_plane_pair_t pr;
+        for (int k = 0; k < 4; k++) pr.pl_global.plane.coefs[k] = np.plane[k];
+        pr.pl_global.centroid = {np.centroid[0], np.centroid[1], np.centroid[2]};
+        pr.pt_local           = point;
+        res.pairing           = pr;
+        res.distance          = np.distance;
+        return res;
+    }
+};
+
+uint8_t PointsMapPlanes::serializeGetVersion() const { return 0; }
+void    PointsMapPlanes::serializeTo(mrpt::serialization::CArchive& out) const
+{
+    out << knn << minimumPlanePoints << planeEigenThreshold << searchRadius;
+    mrpt::maps::CSimplePointsMap::serializeTo(out);
+}
+void PointsMapPlanes::serializeFrom(mrpt::serialization::CArchive& in, uint8_t version)
+{
+    if (version != 0) MRPT_THROW_UNKNOWN_SERIALIZATION_VERSION(version);
+    in >> knn >> minimumPlanePoints >> planeEigenThreshold >> searchRadius;
+    uint8_t base_version = 0;
+    in >> base_version;
+    mrpt::maps::CSimplePointsMap::serializeFrom(in, base_version);
+}
+
+// ================================================================================================
+// Pairings -> the device handle the solvers read (mp2p_hip_host::pairings_to_device decides whether
+// the list this plugin's matchers left in HBM is the list handed over)
 static mp2p_hip_pairs* pairings_to_device(Runtime& rt, const mp2p_icp::Pairings& pairings)
 {
-    const size_t n1 = pairings.paired_pt2pt.size(), n2 = pairings.paired_pt2pl.size();
-    mp2p_hip_pairs* dp = rt.pairs(std::max<size_t>(n1, 1), n2);
-    const bool resident = n2 == 0 && n1 == rt.token_n_pt && n1 > 0 &&
-                          pairings.paired_pt2pt.front().localIdx == rt.token_first &&
-                          pairings.paired_pt2pt.back().localIdx == rt.token_last;
-    if (!resident)
-    {  // pairings this plugin did not produce (or pt2pl from another matcher): upload them
-        std::vector<mp2p_hip_pair_pt2pl> pl(n2);
-        for (size_t i = 0; i < n2; i++)
-        {
-            const auto& p = pairings.paired_pt2pl[i];
-            for (int k = 0; k < 4; k++) pl[i].plane[k] = p.pl_global.plane.coefs[k];
-            pl[i].centroid[0] = p.pl_global.centroid.x, pl[i].centroid[1] = p.pl_global.centroid.y,
-            pl[i].centroid[2] = p.pl_global.centroid.z;
-            pl[i].pt_local[0] = p.pt_local.x, pl[i].pt_local[1] = p.pt_local.y, pl[i].pt_local[2] = p.pt_local.z;
-            pl[i]._pad = 0;
-        }
-        rt.check(mp2p_hip_pairs_upload(
-            rt.ctx, dp, reinterpret_cast<const mp2p_hip_pair_pt2pt*>(pairings.paired_pt2pt.data()), n1,
-            pl.data(), n2));
-        rt.token_n_pt = 0;
+    const size_t                     n2 = pairings.paired_pt2pl.size();
+    std::vector<mp2p_hip_pair_pt2pl> pl(n2);
+    for (size_t i = 0; i < n2; i++)
+    {
+        const auto& p = pairings.paired_pt2pl[i];
+        for (int k = 0; k < 4; k++) pl[i].plane[k] = p.pl_global.plane.coefs[k];
+        pl[i].centroid[0] = p.pl_global.centroid.x, pl[i].centroid[1] = p.pl_global.centroid.y,
+        pl[i].centroid[2] = p.pl_global.centroid.z;
+        pl[i].pt_local[0] = p.pt_local.x, pl[i].pt_local[1] = p.pt_local.y, pl[i].pt_local[2] = p.pt_local.z;
+        pl[i]._pad = 0;
     }
-
-    {  // paired_pt2ln / paired_pl2pl always come from host matchers: (re)upload, also when empty
-        std::vector<mp2p_hip_pair_pt2ln> ln(pairings.paired_pt2ln.size());
-        for (size_t i = 0; i < ln.size(); i++)
-        {
-            const auto& q = pairings.paired_pt2ln[i];
-            for (int k = 0; k < 3; k++)
-                ln[i].ln_base[k] = q.ln_global.pBase[k], ln[i].ln_director[k] = q.ln_global.director[k],
-                ln[i].pt_local[k] = q.pt_local[k];
-        }
-        std::vector<mp2p_hip_pair_pl2pl> pp(pairings.paired_pl2pl.size());
-        for (size_t i = 0; i < pp.size(); i++)
-        {
-            const auto& q = pairings.paired_pl2pl[i];
-            for (int k = 0; k < 4; k++)
-                pp[i].pl_global[k] = q.p_global.plane.coefs[k], pp[i].pl_local[k] = q.p_local.plane.coefs[k];
-            for (int k = 0; k < 3; k++)
-                pp[i].c_global[k] = q.p_global.centroid[k], pp[i].c_local[k] = q.p_local.centroid[k];
-        }
-        if (!ln.empty() || !pp.empty() || rt.has_lines_planes)
-            rt.check(mp2p_hip_pairs_upload_lines_planes(rt.ctx, dp, ln.data(), ln.size(), pp.data(), pp.size()));
-        rt.has_lines_planes = !ln.empty() || !pp.empty();
+    std::vector<mp2p_hip_pair_pt2ln> ln(pairings.paired_pt2ln.size());
+    for (size_t i = 0; i < ln.size(); i++)
+    {
+        const auto& q = pairings.paired_pt2ln[i];
+        for (int k = 0; k < 3; k++)
+            ln[i].ln_base[k] = q.ln_global.pBase[k], ln[i].ln_director[k] = q.ln_global.director[k],
+            ln[i].pt_local[k] = q.pt_local[k];
     }
-
-    return dp;
+    std::vector<mp2p_hip_pair_pl2pl> pp(pairings.paired_pl2pl.size());
+    for (size_t i = 0; i < pp.size(); i++)
+    {
+        const auto& q = pairings.paired_pl2pl[i];
+        for (int k = 0; k < 4; k++)
+            pp[i].pl_global[k] = q.p_global.plane.coefs[k], pp[i].pl_local[k] = q.p_local.plane.coefs[k];
+        for (int k = 0; k < 3; k++) pp[i].c_global[k] = q.p_global.centroid[k], pp[i].c_local[k] = q.p_local.centroid[k];
+    }
+    return mp2p_hip_host::pairings_to_device(
+        rt, reinterpret_cast<const mp2p_hip_pair_pt2pt*>(pairings.paired_pt2pt.data()), pairings.paired_pt2pt.size(),
+        pl.data(), pl.size(), ln.data(), ln.size(), pp.data(), pp.size());
 }
 
 // ================================================================================================
@@ -339,7 +456,9 @@ class Solver_GaussNewton : public mp2p_icp::Solver
         out = mp2p_icp::OptimalTF_Result();
         ASSERT_(sc.guessRelativePose.has_value());
         if (!pairings.paired_ln2ln.empty())
-            THROW_EXCEPTION("HIP Gauss-Newton: paired_ln2ln is not supported");
+            THROW_EXCEPTION("HIP Gauss-Newton: paired_ln2ln is not supported");  // DESIGN.md section 2
+        if (pairings.point_weights.size() > 8)
+            THROW_EXCEPTION("HIP Gauss-Newton: more than 8 point_weights blocks are not supported");
         auto& rt = Runtime::get();
 
         mp2p_hip_pairs* dp = pairings_to_device(rt, pairings);
@@ -352,17 +471,9 @@ class Solver_GaussNewton : public mp2p_icp::Solver
         p.kernelParam = robustKernelParam;
         p.w_pt2pt = pairWeights.pt2pt, p.w_pt2pl = pairWeights.pt2pl;
         p.w_pt2ln = pairWeights.pt2ln, p.w_pl2pl = pairWeights.pl2pl;
-        ASSERT_(pairings.point_weights.size() <= 8);
         p.n_weight_blocks = static_cast<uint32_t>(pairings.point_weights.size());
         for (size_t i = 0; i < pairings.point_weights.size(); i++)
             p.weight_block_count[i] = pairings.point_weights[i].first, p.weight_block_w[i] = pairings.point_weights[i].second;
-        auto fill_pose = [](const mrpt::poses::CPose3D& P, double T[12])
-        {
-            const auto& R = P.getRotationMatrix();
-            for (int i = 0; i < 3; i++)
-                for (int j = 0; j < 3; j++) T[i * 3 + j] = R(i, j);
-            T[9] = P.x(), T[10] = P.y(), T[11] = P.z();
-        };
         if (sc.prior.has_value())
         {
             p.has_prior = 1;
@@ -374,10 +485,7 @@ class Solver_GaussNewton : public mp2p_icp::Solver
         fill_pose(mrpt::poses::CPose3D(sc.guessRelativePose.value()), T0);
         mp2p_hip_gn_result res;
         rt.check(mp2p_hip_gn_solve(rt.ctx, dp, T0, &p, &res));
-        mrpt::math::CMatrixDouble33 R;
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) R(i, j) = res.pose[i * 3 + j];
-        out.optimalPose = mrpt::poses::CPose3D(R, mrpt::math::TPoint3D(res.pose[9], res.pose[10], res.pose[11]));
+        out.optimalPose = make_pose(res.pose);
         return true;  // optimal_tf_gauss_newton.cpp:369
     }
 };
@@ -404,28 +512,19 @@ class Solver_Horn : public mp2p_icp::Solver
     {
         out = mp2p_icp::OptimalTF_Result();
         if (!pairings.paired_ln2ln.empty()) THROW_EXCEPTION("HIP Horn: paired_ln2ln is not supported");
+        if (pairings.point_weights.size() > 8) THROW_EXCEPTION("HIP Horn: more than 8 point_weights blocks are not supported");
         auto&                 rt  = Runtime::get();
         const mp2p_hip_pairs* eff = pairings_to_device(rt, pairings);
         const auto&           wp  = pairingsWeightParameters;
-        auto fill_pose = [](const mrpt::poses::CPose3D& P, double T[12])
-        {
-            const auto& R = P.getRotationMatrix();
-            for (int i = 0; i < 3; i++)
-                for (int j = 0; j < 3; j++) T[i * 3 + j] = R(i, j);
-            T[9] = P.x(), T[10] = P.y(), T[11] = P.z();
-        };
         const bool converted = !pairings.paired_pt2ln.empty() || !pairings.paired_pt2pl.empty();
         if (converted)
         {  // Solver_Horn.cpp:51-55: a fresh Pairings with the converted point pairings only
             ASSERT_(sc.guessRelativePose.has_value());
-            const size_t cap = pairings.paired_pt2ln.size() + pairings.paired_pt2pl.size();
-            if (!rt.conv_pairs) rt.check(mp2p_hip_pairs_create(rt.ctx, cap, 0, &rt.conv_pairs));
-            else rt.check(mp2p_hip_pairs_reserve(rt.ctx, rt.conv_pairs, cap, 0));
-            rt.check(mp2p_hip_pairs_clear(rt.ctx, rt.conv_pairs));
-            double T[12];
+            mp2p_hip_pairs* conv = rt.conv_pairs(pairings.paired_pt2ln.size() + pairings.paired_pt2pl.size());
+            double          T[12];
             fill_pose(mrpt::poses::CPose3D(sc.guessRelativePose.value()), T);
-            rt.check(mp2p_hip_pairs_pt2ln_pl_to_pt2pt(rt.ctx, eff, T, rt.conv_pairs));
-            eff = rt.conv_pairs;
+            rt.check(mp2p_hip_pairs_pt2ln_pl_to_pt2pt(rt.ctx, eff, T, conv));
+            eff = conv;
         }
         mp2p_hip_horn_params w;
         std::memset(&w, 0, sizeof(w));
@@ -448,10 +547,7 @@ class Solver_Horn : public mp2p_icp::Solver
         mp2p_hip_horn_result res;
         rt.check(mp2p_hip_horn_solve_wp(rt.ctx, eff, &w, &res));
         if (!res.solved) return false;  // optimal_tf_horn.cpp:98
-        mrpt::math::CMatrixDouble33 R;
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) R(i, j) = res.pose[i * 3 + j];
-        out.optimalPose = mrpt::poses::CPose3D(R, mrpt::math::TPoint3D(res.pose[9], res.pose[10], res.pose[11]));
+        out.optimalPose = make_pose(res.pose);
         if (res.n_outliers)
         {  // OptimalTF_Result::outliers (OutlierIndices::point2point)
             uint64_t n64 = 0;
@@ -465,9 +561,14 @@ class Solver_Horn : public mp2p_icp::Solver
     }
 };
 
+// a caller that edits a layer in place between the iterations of its OWN loop (ICP::align never does)
+void invalidate_layers() { Runtime::get().invalidate_layers(); }
+
 IMPLEMENTS_MRPT_OBJECT(Matcher_Points_DistanceThreshold, mp2p_icp::Matcher, mp2p_icp_hip)
+IMPLEMENTS_MRPT_OBJECT(Matcher_Point2Plane, mp2p_icp::Matcher, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(Solver_Horn, mp2p_icp::Solver, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(Solver_GaussNewton, mp2p_icp::Solver, mp2p_icp_hip)
+IMPLEMENTS_SERIALIZABLE(PointsMapPlanes, CSimplePointsMap, mp2p_icp_hip)
 
 }  // namespace mp2p_icp_hip
 
@@ -475,6 +576,8 @@ MRPT_INITIALIZER(register_mp2p_icp_hip)
 {
     using mrpt::rtti::registerClass;
     registerClass(CLASS_ID(mp2p_icp_hip::Matcher_Points_DistanceThreshold));
+    registerClass(CLASS_ID(mp2p_icp_hip::Matcher_Point2Plane));
     registerClass(CLASS_ID(mp2p_icp_hip::Solver_GaussNewton));
     registerClass(CLASS_ID(mp2p_icp_hip::Solver_Horn));
+    registerClass(CLASS_ID(mp2p_icp_hip::PointsMapPlanes));
 }

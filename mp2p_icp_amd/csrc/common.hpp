@@ -184,6 +184,8 @@ struct mp2p_hip_ctx
     uint32_t last_n_tiles = 0;
     uint32_t last_q       = 64;
     void*    pinned       = nullptr;  // 4 KB of page-locked host memory for the small read-backs
+    void*    pinned_big   = nullptr;  // ... and a growable one for the pair lists handed to host containers
+    size_t   pinned_big_bytes = 0;
     mp2p_hip_cloud* q1_cloud = nullptr;  // mp2p_hip_nn_search_pt2pl: the one-point query layer
     mp2p_hip_pairs* q1_pairs = nullptr;
 };

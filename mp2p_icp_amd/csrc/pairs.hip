@@ -6,6 +6,8 @@
 //   already paired; emitting marks i and g.  A skipped candidate has no side effect, hence
 //   winner(g) = min{ i : NN(i)=g, d2 < thr } -- exactly what the atomicMin claims of
 //   nn_query.hip computed -- and the output order is ascending i (stable compaction).
+#include <thread>
+
 #include "device_utils.hpp"
 
 namespace mp2p
@@ -594,6 +596,43 @@ static int read_counts(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, unsigned long
     return MP2P_HIP_OK;
 }
 
+// device -> caller memory.  The caller's containers are pageable (std::vector storage): a direct copy
+// is staged by the runtime through its own bounce buffers; here: one DMA into a page-locked buffer of
+// the context (full link rate), then the host copy, split over a few threads when it is large.
+static int copy_out(mp2p_hip_ctx* ctx, const void* dev, void* out, size_t bytes)
+{
+    if (bytes < (256u << 10))
+    {
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MP2P_TRY_HIP(ctx, stream_wait(ctx));
+        return MP2P_HIP_OK;
+    }
+    if (ctx->pinned_big_bytes < bytes)
+    {
+        if (ctx->pinned_big) (void)hipHostFree(ctx->pinned_big);
+        ctx->pinned_big = nullptr, ctx->pinned_big_bytes = 0;
+        const size_t want = bytes + bytes / 4;
+        MP2P_TRY_HIP(ctx, hipHostMalloc(&ctx->pinned_big, want, hipHostMallocDefault));
+        ctx->pinned_big_bytes = want;
+    }
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->pinned_big, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
+    const unsigned nt = bytes >= (2u << 20) ? 4u : 1u;
+    if (nt == 1)
+        memcpy(out, ctx->pinned_big, bytes);
+    else
+    {
+        std::thread th[4];
+        for (unsigned t = 0; t < nt; t++)
+        {
+            const size_t b = bytes * t / nt, e = bytes * (t + 1) / nt;
+            th[t] = std::thread([=]() { memcpy((char*)out + b, (const char*)ctx->pinned_big + b, e - b); });
+        }
+        for (unsigned t = 0; t < nt; t++) th[t].join();
+    }
+    return MP2P_HIP_OK;
+}
+
 extern "C" {
 
 int mp2p_hip_pairs_create(mp2p_hip_ctx* ctx, size_t cap_pt2pt, size_t cap_pt2pl,
@@ -758,9 +797,7 @@ int mp2p_hip_pairs_copy_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t
     hipLaunchKernelGGL(pack_pt2pt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->lidx.p,
                        p->gidx.p, p->lx.p, p->ly.p, p->lz.p, p->gx.p, p->gy.p, p->gz.p, p->err.p, (uint32_t)n, d,
                        (uint32_t)first);
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, d, n * sizeof(mp2p_hip_pair_pt2pt), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, stream_wait(ctx));
-    return MP2P_HIP_OK;
+    return copy_out(ctx, d, out, n * sizeof(mp2p_hip_pair_pt2pt));
 }
 
 int mp2p_hip_pairs_copy_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
@@ -774,12 +811,10 @@ int mp2p_hip_pairs_copy_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t
     auto* d = reinterpret_cast<mp2p_hip_pair_pt2pl*>(ctx->aos_stage.p);
     hipLaunchKernelGGL(pack_pt2pl_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->pl_coef.p,
                        p->pl_cen.p, p->pl_lx.p, p->pl_ly.p, p->pl_lz.p, (uint32_t)n, d, (uint32_t)first);
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, d, n * sizeof(mp2p_hip_pair_pt2pl), hipMemcpyDeviceToHost, ctx->stream));
     if (out_local_idx)
         MP2P_TRY_HIP(ctx, hipMemcpyAsync(out_local_idx, p->pl_lidx.p + first, n * sizeof(uint32_t),
                                          hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, stream_wait(ctx));
-    return MP2P_HIP_OK;
+    return copy_out(ctx, d, out, n * sizeof(mp2p_hip_pair_pt2pl));
 }
 
 int mp2p_hip_pairs_download_pt2pt_from(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first,

@@ -1,0 +1,13 @@
+#pragma once
+// stand-in: mp2p_icp_common Parameterizable.h:169-184 (DECLARE_PARAMETER_*: formula-capable parameters)
+#include <mrpt/containers/yaml.h>
+namespace mp2p_icp
+{
+class Parameterizable
+{
+   public:
+    void checkAllParametersAreRealized() const;
+};
+}  // namespace mp2p_icp
+#define DECLARE_PARAMETER_REQ(Yaml__, Var__) Var__ = (Yaml__)[#Var__].as<decltype(Var__)>()
+#define DECLARE_PARAMETER_OPT(Yaml__, Var__) Var__ = (Yaml__).getOrDefault<decltype(Var__)>(#Var__, Var__)

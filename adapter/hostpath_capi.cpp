@@ -191,6 +191,18 @@ void mp2p_hostpath_last_ms(void* h, double out[2])
     auto* s = static_cast<Session*>(h);
     out[0] = s->last_ms[0], out[1] = s->last_ms[1];
 }
+// stages of the last matcher call of this thread's runtime (mp2p_hip_host::Runtime::stage_ms)
+void mp2p_hostpath_stage_ms(double out[6])
+{
+    try
+    {
+        Runtime& rt = Runtime::get();
+        for (int i = 0; i < 6; i++) out[i] = rt.stage_ms[i];
+    }
+    catch (...)
+    {
+    }
+}
 void mp2p_hostpath_invalidate_layers(void)
 {
     try

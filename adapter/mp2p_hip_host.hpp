@@ -18,6 +18,7 @@
 // Nothing is O(N_g) per call except the read of the packed global bit-field.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -265,6 +266,13 @@ class Runtime
 
     // counters for tests / the bench's host_boundary block
     size_t n_map_uploads = 0, n_cloud_uploads = 0, n_mstate_uploads = 0, n_pair_uploads = 0;
+    // wall time of the stages of the last matcher call [ms]: {layers + MatchState in, device work until
+    // the list length is known, container resize, pair copy-out, marks, checksum}
+    double stage_ms[6] = {0, 0, 0, 0, 0, 0};
+    static double now_ms()
+    {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
 
     ~Runtime()
     {  // process exit: the HIP runtime may already be gone, nothing is freed explicitly
@@ -325,19 +333,24 @@ size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
 {
     static_assert(sizeof(typename PairVec::value_type) == sizeof(mp2p_hip_pair_pt2pt), "pair record layout");
     const size_t    n_l  = mp2p_hip_cloud_size(cloud);
+    double          t0   = Runtime::now_ms(), t1;
     const bool      anyG = c.gbits.words && c.gbits.any(), anyL = c.lbits.words && c.lbits.any();
     mp2p_hip_pairs* dp   = begin_match(rt, c, !anyG && !anyL, n_l * prm.pairingsPerPoint, 0);
     auto&           tk   = rt.token;
     rt.check(mp2p_hip_cloud_set_visit_order(rt.ctx, cloud, n_visit ? visit : nullptr, n_visit));
     mp2p_hip_mstate* ms = rt.match_state(c.gbits, c.lbits, anyG, anyL);
+    rt.stage_ms[0] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
     rt.check(mp2p_hip_match_pt2pt(rt.ctx, map, cloud, pose, &prm, ms, dp));
     // the new list length first (24 bytes, one wait), then exactly the new entries into the caller's vector
     uint64_t n_pt = 0;
     rt.check(mp2p_hip_pairs_counts(rt.ctx, dp, &n_pt, nullptr, nullptr));
+    rt.stage_ms[1] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
     const size_t n0 = out.size(), n = (size_t)n_pt - tk.n_pt;
     out.resize(n0 + n);
+    rt.stage_ms[2] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
     auto* dst = reinterpret_cast<mp2p_hip_pair_pt2pt*>(out.data()) + n0;
     if (n) rt.check(mp2p_hip_pairs_copy_pt2pt(rt.ctx, dp, tk.n_pt, n, dst));
+    rt.stage_ms[3] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
     // the marks this matcher leaves (only when global re-use is forbidden, :116-120)
     if (!prm.allowMatchAlreadyMatchedGlobalPoints)
         for (size_t i = 0; i < n; i++)
@@ -345,8 +358,10 @@ size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
             if (c.lbits.words) c.lbits.set(dst[i].localIdx);
             if (c.gbits.words) c.gbits.set(dst[i].globalIdx);
         }
+    rt.stage_ms[4] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
     tk.sum_pt = pairs_checksum(dst, n, tk.sum_pt, tk.n_pt);
     tk.n_pt += n, tk.valid = true;
+    rt.stage_ms[5] = Runtime::now_ms() - t0;
     return n;
 }
 

@@ -35,6 +35,7 @@ SIGNATURES = {
     "mp2p_hostpath_counters": (C.c_int, [C.POINTER(C.c_size_t)]),
     "mp2p_hostpath_last_ms": (None, [_P, _dp]),
     "mp2p_hostpath_invalidate_layers": (None, []),
+    "mp2p_hostpath_stage_ms": (None, [_dp]),
 }
 
 
@@ -166,6 +167,14 @@ def counters():
     out = (C.c_size_t * 4)()
     _check(load().mp2p_hostpath_counters(out))
     return dict(map_uploads=out[0], cloud_uploads=out[1], mstate_uploads=out[2], pairings_uploads=out[3])
+
+
+def stage_ms():
+    """wall time [ms] of the stages of the last matcher call: layers + MatchState in, device work until the
+    list length is known, container resize, pair copy-out, marks, checksum"""
+    out = (C.c_double * 6)()
+    load().mp2p_hostpath_stage_ms(out)
+    return dict(zip(("state_in", "device", "resize", "copy_out", "marks", "checksum"), [float(v) for v in out]))
 
 
 def invalidate_layers():

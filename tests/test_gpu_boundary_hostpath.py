@@ -213,7 +213,8 @@ def test_host_path_cost_at_full_size(oracle):
         s.begin_iteration()
         n = s.match_pt2pt(pose, prm, icp_iteration=it)
         out = s.solve_gn(pose, gnp)[0]
-        trace.append((it, n, hostpath.counters()["pairings_uploads"], s.last_ms()))
+        trace.append((it, n, hostpath.counters()["pairings_uploads"], s.last_ms(),
+                      {k: round(v, 3) for k, v in hostpath.stage_ms().items()}))
         return out
 
     def dev_step(pose, it):

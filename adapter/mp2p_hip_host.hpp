@@ -351,17 +351,19 @@ size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
     auto* dst = reinterpret_cast<mp2p_hip_pair_pt2pt*>(out.data()) + n0;
     if (n) rt.check(mp2p_hip_pairs_copy_pt2pt(rt.ctx, dp, tk.n_pt, n, dst));
     rt.stage_ms[3] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
-    // the marks this matcher leaves (only when global re-use is forbidden, :116-120)
-    if (!prm.allowMatchAlreadyMatchedGlobalPoints)
-        for (size_t i = 0; i < n; i++)
-        {
-            if (c.lbits.words) c.lbits.set(dst[i].localIdx);
-            if (c.gbits.words) c.gbits.set(dst[i].globalIdx);
-        }
-    rt.stage_ms[4] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
-    tk.sum_pt = pairs_checksum(dst, n, tk.sum_pt, tk.n_pt);
+    // one pass over the new entries: the marks this matcher leaves (only when global re-use is
+    // forbidden, :116-120) and the running checksum of the device list
+    const bool marks = !prm.allowMatchAlreadyMatchedGlobalPoints;
+    for (size_t i = 0; i < n; i++)
+    {
+        if (marks && c.lbits.words) c.lbits.set(dst[i].localIdx);
+        if (marks && c.gbits.words) c.gbits.set(dst[i].globalIdx);
+        uint32_t e;
+        std::memcpy(&e, &dst[i].errorSquareAfterTransformation, 4);
+        sum_feed(tk.sum_pt, tk.n_pt + i, (((uint64_t)dst[i].globalIdx << 32) | dst[i].localIdx) + ((uint64_t)e << 17));
+    }
     tk.n_pt += n, tk.valid = true;
-    rt.stage_ms[5] = Runtime::now_ms() - t0;
+    rt.stage_ms[4] = Runtime::now_ms() - t0, rt.stage_ms[5] = 0.0;
     return n;
 }
 

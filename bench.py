@@ -10,11 +10,22 @@ real ICP chain (step s starts from the pose step s-1 produced, restarting from t
 initial guess every 10 steps), and every step ends with the 96-byte pose read-back the
 reference's outer loop needs for its termination test.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5]
+
+The default line (no --config) carries, next to the contract's fields:
+  roofline       the search kernels (K1+K3) against the HBM roofline
+  cpu_baseline   the oracle (CPU port of the reference's algorithm class) on all host threads, plus its
+                 single-thread figure
+  step_ms        min / median / max of the K timed steps; `stability` = 200 more chained steps
+  host_boundary  the same step through HOST containers, i.e. through the reference-side adapter's code
+                 (adapter/mp2p_hip_host.hpp): fresh MatchState, pairs into a host vector, marks, solver
+  scene_b        the same metric on the SURVEY.md 8d scene (map = union of consecutive scans, voxel-
+                 thinned; scan and map densities match and the chain converges); `value` stays on
+                 scene A (scan vs surface-sampled map) for continuity with round 1
 N > 1 is launched by torch.distributed.run (one rank per GPU); the local layer is sharded
-(weak scaling: every rank holds its own 1 M-point slice of an N x 1 M-point local layer), the
-10 M-point global layer is replicated, and the exchange steps of mp2p_icp_amd/distributed.py
-run over RCCL.  Rank 0 prints ONE JSON line.
+(weak scaling: every rank holds its own 1 M-point slice of an N x 1 M-point local layer; the block
+`strong_scaling` times ONE 1 M-point scan split N ways), the 10 M-point global layer is replicated,
+and the exchange steps of mp2p_icp_amd/distributed.py run over RCCL.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -34,21 +45,27 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_inputs(n_local, n_global, seed, rank, world):
+# ---------------------------------------------------------------------------------------------------
+def build_inputs(n_local, n_global, seed, rank, world, scene="a"):
+    """scene a: ray-cast scan vs a map sampled uniformly on the surfaces (round 1's scene);
+    scene b: SURVEY.md 8d -- the map is the voxel-thinned union of consecutive scans"""
     from mp2p_icp_amd import synthetic, se3
+    if scene == "b":
+        return synthetic.make_scan_union_pair(n_local, n_global, seed + 100 * rank,
+                                              map_scan_points=max(n_local, 120_000))
     cache = f"/tmp/mp2p_bench_{n_local}_{n_global}_{seed}_{rank}_{world}.npz"
     if os.path.exists(cache):
         z = np.load(cache)
         return dict(local=z["local"], glob=z["glob"], T_gt=z["T_gt"], T_init=z["T_init"])
-    scene = synthetic.Scene(seed)
+    sc = synthetic.Scene(seed)
     n_rings, n_az = synthetic.rings_for(int(n_local * 1.25))
-    sensor = (scene.length * 0.5, 0.0, 0.0)
+    sensor = (sc.length * 0.5, 0.0, 0.0)
     yaw = 0.05
     # rank r scans with its own noise stream: its slice of the N x 1M-point local layer
-    loc = scene.scan(sensor, yaw, n_rings, n_az, seed + 1 + 1000 * rank)
+    loc = sc.scan(sensor, yaw, n_rings, n_az, seed + 1 + 1000 * rank)
     if loc.shape[0] > n_local:
         loc = loc[np.linspace(0, loc.shape[0] - 1, n_local).astype(np.int64)]
-    glob = scene.sample_map(n_global, seed + 2)  # identical on every rank
+    glob = sc.sample_map(n_global, seed + 2)  # identical on every rank
     T_gt = se3.from_xyzypr(sensor[0], sensor[1], sensor[2], yaw, 0.0, 0.0)
     T_init = se3.compose(T_gt, se3.from_xyzypr(*synthetic.perturbation(seed + 3)))
     d = dict(local=np.ascontiguousarray(loc), glob=glob, T_gt=T_gt, T_init=T_init)
@@ -60,36 +77,350 @@ def build_inputs(n_local, n_global, seed, rank, world):
 
 
 def cpu_baseline(d, threshold, gn_iters, kernel_param, sample, cores):
-    """The oracle (CPU port of the reference's algorithm class: exact KD-tree + GN), timed on
-    this host's cores on a bounded sample of the same workload."""
+    """The oracle (CPU port of the reference's algorithm class: exact KD-tree + GN), timed on this
+    host's cores on a bounded sample of the same workload; plus the single-thread figure (the
+    reference's deterministic, sequential semantics) on a smaller sample."""
     import oracle as orc
     g, l = d["glob"], d["local"]
     t0 = time.time()
     tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
     t_build = time.time() - t0
+
+    def run(n_s, threads):
+        ls = l[np.linspace(0, l.shape[0] - 1, n_s).astype(np.int64)]
+        tm = ts = npairs = 0.0
+        for pose in (d["T_init"], d["T_gt"]):
+            t0 = time.time()
+            pairs, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], ls[:, 0], ls[:, 1], ls[:, 2], pose,
+                                       threshold, 0.0, tree=tree, threads=threads)
+            tm += time.time() - t0
+            prm = orc.make_gn_params(gn_iters, kernel=orc.KERNEL_GEMANMCCLURE, kernelParam=kernel_param)
+            t0 = time.time()
+            orc.optimal_tf_gauss_newton(pairs, None, None, pose, prm, threads=threads)
+            ts += time.time() - t0
+            npairs += len(pairs)
+        scale = l.shape[0] / n_s
+        t_iter = (tm + ts) / 2 * scale  # mean of the hard (initial) and easy (converged) pose
+        return 1.0 / t_iter, npairs / 2 * scale / t_iter, tm / 2 * scale, ts / 2 * scale
+
     n_s = min(sample, l.shape[0])
-    ls = l[np.linspace(0, l.shape[0] - 1, n_s).astype(np.int64)]
-    best = None
-    for pose in (d["T_init"], d["T_gt"]):
-        t0 = time.time()
-        pairs, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], ls[:, 0], ls[:, 1], ls[:, 2], pose,
-                                   threshold, 0.0, tree=tree, threads=cores)
-        t_match = time.time() - t0
-        prm = orc.make_gn_params(gn_iters, kernel=orc.KERNEL_GEMANMCCLURE, kernelParam=kernel_param)
-        t0 = time.time()
-        orc.optimal_tf_gauss_newton(pairs, None, None, pose, prm, threads=cores)
-        t_solve = time.time() - t0
-        best = (t_match, t_solve, len(pairs)) if best is None else (
-            best[0] + t_match, best[1] + t_solve, best[2] + len(pairs))
-    scale = l.shape[0] / n_s
-    t_iter = (best[0] + best[1]) / 2 * scale  # mean of the hard (initial) and easy (converged) pose
-    return {"value": 1.0 / t_iter, "unit": "iterations/s", "cores": cores, "kind": "port",
+    v, pps, tm, ts = run(n_s, cores)
+    n_1 = min(max(2000, sample // 10), l.shape[0])
+    v1, pps1, tm1, ts1 = run(n_1, 0)  # threads=0: the sequential loop
+    return {"value": v, "unit": "iterations/s", "cores": cores, "kind": "port",
             "sample": f"{n_s} of {l.shape[0]} local points (uniform subsample) vs the full "
                       f"{g.shape[0]}-point map; mean of initial-guess and converged pose; "
                       f"KD-tree build {t_build:.1f}s excluded (amortised per map)",
-            "pairs_per_s": best[2] / 2 * scale / t_iter}
+            "pairs_per_s": pps, "matcher_s_per_iteration": tm, "solver_s_per_iteration": ts,
+            "single_thread": {"value": v1, "unit": "iterations/s", "cores": 1, "pairs_per_s": pps1,
+                              "sample": f"{n_1} of {l.shape[0]} local points, sequential loop",
+                              "matcher_s_per_iteration": tm1, "solver_s_per_iteration": ts1}}
 
 
+# ---------------------------------------------------------------------------------------------------
+class Rig:
+    """the device-resident pipeline of one scene on one rank"""
+
+    def __init__(self, args, d, rank, world, dist, local_rank, stream, n_offset):
+        import mp2p_icp_amd as amd
+        from mp2p_icp_amd import _lib, core
+        from mp2p_icp_amd.distributed import HipBackend, ShardedRegistration
+        self.amd, self.d = amd, d
+        self.ctx = amd.Context(local_rank, stream=stream)
+        g, l = d["glob"], d["local"]
+        t0 = time.time()
+        self.gmap = core.GlobalMap(self.ctx, g[:, 0], g[:, 1], g[:, 2], cell_size=args.cell,
+                                   target_per_cell=args.target_per_cell, no_occupancy_bitmap=args.no_bitmap)
+        self.info = self.gmap.info()
+        self.t_index = time.time() - t0
+        self.cloud = core.LocalCloud(self.ctx, l[:, 0], l[:, 1], l[:, 2])
+        self.n_l = l.shape[0]
+        self.prm = _lib.Pt2PtParams(args.threshold, 0.0, 1, 0, 0, 0.20, n_offset, args.r0, args.q, args.grp,
+                                    args.budget, args.defer, int(args.cold), args.bricks, 0)
+        gnp = _lib.GNParams()
+        gnp.maxInnerLoopIterations = args.gn_iters
+        gnp.minDelta, gnp.maxCost = 1e-7, 0.0
+        gnp.kernel, gnp.kernelParam = _lib.KERNEL_GEMANMCCLURE, 0.15
+        gnp.w_pt2pt = gnp.w_pt2pl = 1.0
+        self.gnp = gnp
+        self.pairs = core.DevicePairs(self.ctx, self.n_l, 0)
+        self.reg = ShardedRegistration(HipBackend(self.ctx, self.gmap, self.cloud, self.prm, gnp, self.pairs), dist)
+        self.state = {"pose": d["T_init"].copy(), "s": 0}
+
+    def restart(self):
+        self.state = {"pose": self.d["T_init"].copy(), "s": 0}
+
+    def one_step(self):
+        st = self.state
+        if st["s"] % CYCLE == 0:
+            st["pose"] = self.d["T_init"].copy()
+        st["pose"], _ = self.reg.step(st["pose"])  # ends with the pose read-back (sync)
+        st["s"] += 1
+
+
+def timed_chain(rig, steps, warmup, barrier, events=True):
+    """W untimed steps, then exactly K steps between two barrier+synchronize brackets"""
+    rig.restart()
+    for _ in range(warmup):
+        rig.one_step()
+    rig.ctx.set_profiling(3 if events else 0)
+    nn_ms, step_s = [], []
+    barrier()
+    t0 = time.perf_counter()
+    tp = t0
+    for _ in range(steps):
+        rig.one_step()
+        if events:
+            nn_ms.append(rig.ctx.stats()["ms_nn"])  # the step already ended with a stream sync (pose read-back)
+        tn = time.perf_counter()
+        step_s.append(tn - tp)
+        tp = tn
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rig.ctx.set_profiling(0)
+    return elapsed, nn_ms, step_s
+
+
+def replay(rig, steps, warmup):
+    """untimed replay of the same pose chain: per-kernel time and pair counts"""
+    rig.restart()
+    for _ in range(warmup):
+        rig.one_step()
+    out = {k: [] for k in ("lane", "tile", "single", "compact", "gn", "nn", "pairs")}
+    rig.ctx.set_profiling(1)
+    for _ in range(steps):
+        rig.one_step()
+        st = rig.ctx.stats()
+        out["nn"].append(st["ms_nn"]), out["lane"].append(st["ms_nn_lane"]), out["tile"].append(st["ms_nn_tile"])
+        out["single"].append(st["ms_nn_single"]), out["compact"].append(st["ms_compact"]), out["gn"].append(st["ms_gn"])
+        out["pairs"].append(rig.pairs.counts()[0])
+    rig.ctx.set_profiling(0)
+    return out
+
+
+def instrumented(rig, n_steps, rank, tag):
+    """the device counters of one chain cycle: distinct global points touched, candidates, passes"""
+    amd, d = rig.amd, rig.d
+    rig.restart()
+    st_ = rig.state
+    rig.ctx.set_profiling(2)
+    rows = []
+    for _ in range(n_steps):
+        if st_["s"] % CYCLE == 0:
+            st_["pose"] = d["T_init"].copy()
+        rig.reg.match(st_["pose"])
+        st = rig.ctx.stats()
+        _e = amd.se3.log(amd.se3.inverse_compose(st_["pose"], d["T_gt"]))
+        rows.append(dict(touched=st["nn_points_staged"], cand=st["nn_candidates_tested"],
+                         passes=st["nn_passes"] / max(1, st["nn_tiles"]), maxcand=st["nn_max_candidates_one_tile"],
+                         maxpass=st["nn_max_passes_one_tile"], pending=st["nn_lane_pending"],
+                         skipped=st["nn_lane_skipped"], deferred=st["nn_single_queries"],
+                         err_t=float(np.linalg.norm(_e[:3])), err_r=float(np.linalg.norm(_e[3:]))))
+        log(f"[bench r{rank}] {tag} chain step {st_['s']}: err=({rows[-1]['err_t']:.3f} m, "
+            f"{np.degrees(rows[-1]['err_r']):.2f} deg) pairs={rig.pairs.counts()[0]} "
+            f"pending={st['nn_lane_pending']} finished-without-search={st['nn_lane_skipped']} "
+            f"deferred={st['nn_single_queries']} single_cand/q="
+            f"{st['nn_single_candidates'] / max(1, st['nn_single_queries']):.0f} "
+            f"tile_cand/tile={st['nn_candidates_tested'] / max(1, st['nn_tiles']):.0f} "
+            f"passes/tile={st['nn_passes'] / max(1, st['nn_tiles']):.2f}")
+        st_["pose"], _ = rig.reg.solve(st_["pose"])
+        st_["s"] += 1
+    rig.ctx.set_profiling(0)
+    final_err = amd.se3.log(amd.se3.inverse_compose(st_["pose"], d["T_gt"]))
+    return rows, final_err
+
+
+def stats_ms(xs):
+    a = np.asarray(xs, dtype=np.float64) * 1e3
+    return {"min": float(a.min()), "median": float(np.median(a)), "max": float(a.max())}
+
+
+def roofline_block(n_l, touched_mean, nn_ms_avg, tag):
+    # algorithmic bytes of the search kernels per launch (SURVEY.md section 8d):
+    #   12 B/query read + 12 B per distinct global point in a visited voxel + 8 B/query written
+    alg_bytes = 12.0 * n_l + 12.0 * touched_mean + 8.0 * n_l
+    achieved = alg_bytes / (max(nn_ms_avg, 1e-9) * 1e-3) / 1e9
+    out = {"bound": "hbm",
+           "kernel": "nn_lane_kernel + nn_tile_kernel + nn_single_kernel (K1+K3: transform + exact NN search)",
+           "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+           "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": nn_ms_avg,
+           "traffic": None, "traffic_from_profiles": None}
+    # HBM traffic of the search kernels from the committed rocprofv3 PMC passes of this same command
+    # (FETCH_SIZE x2 correction for gfx950 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"): a cited constant
+    # from profiles/, not a measurement of this run
+    try:
+        import csv
+        f = os.path.join(ROOT, "profiles", f"r02_bench_{tag}_hbm_pmc.csv")
+        t = 0.0
+        for r in csv.DictReader(open(f)):
+            if "mp2p::nn_" in r["kernel"] and "true>" not in r["kernel"]:
+                t += float(r["fetch_bytes_avg_corrected_x2"]) + float(r["write_bytes_avg"])
+        if t > 0:
+            out["traffic_from_profiles"] = t
+            out["traffic_source"] = os.path.relpath(f, ROOT) + " (rocprofv3 --pmc; committed, not measured in this run)"
+    except Exception:
+        pass
+    return out
+
+
+def host_boundary(args, d, dev_ms):
+    """one ICP iteration through HOST containers (adapter/mp2p_hip_host.hpp via hostpath_capi.cpp):
+    fresh MatchState, pairs into a host vector, marks from the pair list, solver handed the host list"""
+    from mp2p_icp_amd import _lib, hostpath
+    s = hostpath.Session(d["glob"], d["local"])
+    prm = _lib.Pt2PtParams()
+    prm.threshold, prm.thresholdAngularDeg, prm.pairingsPerPoint = args.threshold, 0.0, 1
+    prm.bounding_box_intersection_check_epsilon = 0.20
+    gnp = _lib.GNParams()
+    gnp.maxInnerLoopIterations, gnp.minDelta, gnp.maxCost = args.gn_iters, 1e-7, 0.0
+    gnp.kernel, gnp.kernelParam, gnp.w_pt2pt, gnp.w_pt2pl = _lib.KERNEL_GEMANMCCLURE, 0.15, 1.0, 1.0
+    c0 = hostpath.counters()
+    ts, stages, npairs = [], [], []
+    pose = d["T_init"].copy()
+    n = args.warmup + args.steps
+    for it in range(n):
+        k = it % CYCLE
+        if k == 0:
+            pose = d["T_init"].copy()
+        t0 = time.perf_counter()
+        s.begin_iteration()
+        # chain position 0 = ICP iteration 0 of a new ICP::align: both layers are verified in full there
+        npairs.append(s.match_pt2pt(pose, prm, icp_iteration=k))
+        pose, _ = s.solve_gn(pose, gnp)
+        ts.append(time.perf_counter() - t0)
+        stages.append(hostpath.stage_ms())
+    c1 = hostpath.counters()
+    keep = [i for i in range(args.warmup, n) if i % CYCLE != 0]
+    first = [i for i in range(args.warmup, n) if i % CYCLE == 0]
+    ms = float(np.mean([ts[i] for i in keep])) * 1e3
+    out = {"ms_per_step": ms, "iterations_per_s": 1e3 / ms,
+           "vs_device_resident_step": ms / dev_ms,
+           "ms_per_step_at_icp_iteration_0": float(np.mean([ts[i] for i in first])) * 1e3 if first else None,
+           "stage_ms": {k: float(np.mean([stages[i][k] for i in keep])) for k in stages[0]},
+           "pairs_per_step": float(np.mean([npairs[i] for i in keep])),
+           "transfers": {k: c1[k] - c0[k] for k in c0},
+           "note": "through adapter/mp2p_hip_host.hpp (the plugin's MRPT-free host layer): packed MatchState "
+                   "bit-fields in (none uploaded: the fields are clear), 36 B per emitted pair out, marks set "
+                   "from the pair list, the solver recognising the device-resident list by size + checksum; "
+                   "ms_per_step excludes chain position 0, where both layers are fingerprinted in full "
+                   "(120 MB) like at ICP iteration 0 of any new ICP::align"}
+    s.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+def bench_config(args, which, local_rank, stream):
+    """--config c2|c3|c5: the other BASELINE configs as bench lines of their own"""
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import _lib, core, synthetic
+    ctx = amd.Context(local_rank, stream=stream)
+    if which == "c2":
+        d = synthetic.make_scan_union_pair(120_000, 2_000_000, 2001, map_scan_points=120_000)
+        label = "KITTI-shape scan (~120 k pts) vs 2 M-pt map, Matcher_Points_DistanceThreshold + Solver_Horn"
+    elif which == "c3":
+        d = synthetic.make_scan_union_pair(120_000, 10_000_000, 3001, map_scan_points=1_000_000)
+        label = "KITTI-shape scan (~120 k pts) vs 10 M-pt map, Matcher_Point2Plane (knn 5, r 0.4) + Solver_GaussNewton"
+    else:
+        d = synthetic.make_scan_union_pair(5_000_000, 5_000_000, 5001, map_scan_points=1_000_000, outlier_frac=0.30)
+        label = ("5 M-pt scan (30 % uniform outliers) vs 5 M-pt map, Matcher_Point2Plane + "
+                 "Matcher_Points_DistanceThreshold into one Solver_GaussNewton (Cauchy 0.15)")
+    g, l = d["glob"], d["local"]
+    gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])
+    cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    n_l = l.shape[0]
+    pairs = core.DevicePairs(ctx, n_l, n_l if which != "c2" else 0)
+    ms_dev = core.DeviceMatchState(ctx, g.shape[0], n_l) if which == "c5" else None
+    pt = _lib.Pt2PtParams()
+    pt.threshold, pt.thresholdAngularDeg, pt.pairingsPerPoint = (2.0 if which == "c2" else 1.0), 0.0, 1
+    pt.bounding_box_intersection_check_epsilon = 0.20
+    pl = _lib.Pt2PlParams()
+    pl.distanceThreshold = 0.4 if which == "c3" else 0.25
+    pl.searchRadius, pl.knn, pl.minimumPlanePoints, pl.planeEigenThreshold = 0.4, 5, 5, 0.05
+    pl.bounding_box_intersection_check_epsilon = 0.20
+    gnp = _lib.GNParams()
+    gnp.maxInnerLoopIterations, gnp.minDelta, gnp.maxCost = 3, 1e-7, 0.0
+    gnp.kernel = _lib.KERNEL_CAUCHY if which == "c5" else _lib.KERNEL_GEMANMCCLURE
+    gnp.kernelParam, gnp.w_pt2pt, gnp.w_pt2pl = 0.15, 1.0, 1.0
+
+    def step(pose):
+        pairs.clear()
+        if which == "c2":
+            core.match_pt2pt(ctx, gmap, cloud, pose, pt, None, pairs)
+            T, ok = core.horn_solve(ctx, pairs)
+            return np.asarray(T)
+        if which == "c3":
+            core.match_pt2pl(ctx, gmap, cloud, pose, pl, None, pairs)
+        else:
+            ms_dev.reset()
+            core.match_pt2pl(ctx, gmap, cloud, pose, pl, ms_dev, pairs)
+            core.match_pt2pt(ctx, gmap, cloud, pose, pt, ms_dev, pairs)
+        return np.array(core.gn_solve(ctx, pairs, pose, gnp).pose)
+
+    import torch
+    pose, k = d["T_init"].copy(), 0
+
+    def one():
+        nonlocal pose, k
+        if k % CYCLE == 0:
+            pose = d["T_init"].copy()
+        pose = step(pose)
+        k += 1
+
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ts = []
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # kernel breakdown + pairs from a replay with events
+    pose, k = d["T_init"].copy(), 0
+    for _ in range(args.warmup):
+        one()
+    ctx.set_profiling(1)
+    nn, cp, gn, npt, npl = [], [], [], [], []
+    for _ in range(min(args.steps, CYCLE)):
+        one()
+        st = ctx.stats()
+        nn.append(st["ms_nn"]), cp.append(st["ms_compact"]), gn.append(st["ms_gn"])
+        a, b, _ = pairs.counts()
+        npt.append(a), npl.append(b)
+    ctx.set_profiling(0)
+    err = amd.se3.log(amd.se3.inverse_compose(pose, d["T_gt"]))
+    nn_ms = float(np.mean(nn))
+    knn = 5
+    # lower bound of the distinct global points touched (SURVEY.md 8d: N_g,touched >= N_pairs): the
+    # pairs' own neighbours; the fraction below is therefore a LOWER bound of the roofline fraction
+    touched_lb = float(np.mean(npt)) + min(float(g.shape[0]), knn * float(np.mean(npl)))
+    out_bytes = 8.0 * n_l if which == "c2" else 72.0 * float(np.mean(npl)) + (8.0 * n_l if which == "c5" else 0.0)
+    alg = 12.0 * n_l * (2 if which == "c5" else 1) + 12.0 * touched_lb + out_bytes
+    ach = alg / (nn_ms * 1e-3) / 1e9
+    return {
+        "metric": "icp_iterations_per_sec", "value": args.steps / elapsed, "unit": "iterations/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 search / f64 plane fit and normal equations",
+        "data": "synthetic (seeded KITTI-shape street scene; map = voxel-thinned union of consecutive scans, SURVEY.md 8d)",
+        "config": {"workload": label, "n_local": int(n_l), "n_global": int(g.shape[0]), "baseline_config": which.upper(),
+                   "pose_chain": f"real ICP chain, restart from perturbed guess every {CYCLE} steps"},
+        "step_ms": stats_ms(ts),
+        "kernel_ms": {"search_last_matcher": nn_ms, "compact_last_matcher": float(np.mean(cp)), "solver": float(np.mean(gn)),
+                      "note": "hipEvents of the LAST matcher call of the step (c5 runs two matchers)"},
+        "pairs_per_step": {"pt2pt": float(np.mean(npt)), "pt2pl": float(np.mean(npl))},
+        "matched_pairs_per_sec": (float(np.mean(npt)) + float(np.mean(npl))) * args.steps / elapsed,
+        "final_pose_error": {"trans_m": float(np.linalg.norm(err[:3])), "rot_rad": float(np.linalg.norm(err[3:]))},
+        "roofline": {"bound": "hbm", "kernel": "search kernel(s) of the last matcher of the step",
+                     "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": nn_ms, "traffic": None,
+                     "note": "N_g,touched replaced by its lower bound (the pairs' own neighbours): frac is a lower bound"},
+    }
+
+
+# ---------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +431,9 @@ def main():
     ap.add_argument("--threshold", type=float, default=2.0)
     ap.add_argument("--gn-iters", type=int, default=3)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--config", choices=["c2", "c3", "c5"], default=None,
+                    help="another BASELINE config as a bench line of its own (1 GPU)")
+    ap.add_argument("--scene", choices=["a", "b"], default="a", help="scene of `value` (see the module docstring)")
     ap.add_argument("--q", type=int, default=0, help="queries per wave (tuning)")
     ap.add_argument("--r0", type=float, default=0.0, help="initial radius in cells (tuning)")
     ap.add_argument("--grp", type=float, default=0.0, help="group radius factor (tuning)")
@@ -107,12 +441,12 @@ def main():
     ap.add_argument("--no-bitmap", action="store_true", help="build the map without occupancy bitmaps")
     ap.add_argument("--no-events", action="store_true", help="timed loop without hipEvents (overhead probe)")
     ap.add_argument("--cold", action="store_true", help="disable the warm start from the previous iteration")
-    ap.add_argument("--tile-order", action="store_true", help="launch the tiles longest-first (by the previous iteration's durations) instead of in Morton order")
     ap.add_argument("--defer", type=float, default=0.0, help="defer radius in cells (tuning)")
     ap.add_argument("--budget", type=int, default=0, help="voxel budget per search box (tuning)")
     ap.add_argument("--cell", type=float, default=0.0, help="voxel edge [m] (0 = automatic)")
     ap.add_argument("--target-per-cell", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip scene_b / host_boundary / stability (tuning runs)")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     args = ap.parse_args()
 
@@ -140,44 +474,17 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
 
-    import mp2p_icp_amd as amd
-    from mp2p_icp_amd import _lib, core
-    from mp2p_icp_amd.distributed import HipBackend, ShardedRegistration
-
-    t0 = time.time()
-    d = build_inputs(args.n_local, args.n_global, args.seed, rank, world)
-    log(f"[bench r{rank}] inputs ready in {time.time() - t0:.1f}s: local {d['local'].shape}, "
-        f"global {d['glob'].shape}")
-
     # one HIP stream shared with torch so that RCCL collectives are ordered with our kernels: a
     # dedicated torch stream made current (torch's default stream is the null stream, raw value 0)
     tstream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    ctx = amd.Context(local_rank, stream=stream)
-    g, l = d["glob"], d["local"]
-    t0 = time.time()
-    gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2], cell_size=args.cell,
-                          target_per_cell=args.target_per_cell, no_occupancy_bitmap=args.no_bitmap)
-    info = gmap.info()
-    t_index = time.time() - t0
-    t0 = time.time()
-    cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
-    t_cloud = time.time() - t0
-    log(f"[bench r{rank}] index: cell {info['cell_size']:.3f} m, {info['n_levels']} levels, "
-        f"{info['n_cells_level0']} voxels, {info['device_bytes'] / 1e6:.0f} MB, build "
-        f"{info['build_ms']:.1f} ms (upload+build {t_index * 1e3:.0f} ms); cloud {t_cloud * 1e3:.0f} ms")
 
-    n_l = l.shape[0]
-    prm = _lib.Pt2PtParams(args.threshold, 0.0, 1, 0, 0, 0.20, rank * n_l, args.r0, args.q, args.grp, args.budget, args.defer, int(args.cold), args.bricks,
-                           int(args.tile_order))
-    gnp = _lib.GNParams()
-    gnp.maxInnerLoopIterations = args.gn_iters
-    gnp.minDelta, gnp.maxCost = 1e-7, 0.0
-    gnp.kernel, gnp.kernelParam = _lib.KERNEL_GEMANMCCLURE, 0.15
-    gnp.w_pt2pt = gnp.w_pt2pl = 1.0
-    pairs = core.DevicePairs(ctx, n_l, 0)
-    reg = ShardedRegistration(HipBackend(ctx, gmap, cloud, prm, gnp, pairs), dist)
+    if args.config:
+        if world != 1:
+            raise SystemExit("--config lines are single-GPU")
+        print(json.dumps(bench_config(args, args.config, local_rank, stream)), flush=True)
+        return
 
     def barrier():
         torch.cuda.synchronize()
@@ -185,90 +492,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    state = {"pose": d["T_init"].copy(), "s": 0}
+    t0 = time.time()
+    d = build_inputs(args.n_local, args.n_global, args.seed, rank, world, args.scene)
+    log(f"[bench r{rank}] inputs ready in {time.time() - t0:.1f}s: local {d['local'].shape}, global {d['glob'].shape}")
+    n_l = d["local"].shape[0]
+    rig = Rig(args, d, rank, world, dist, local_rank, stream, rank * n_l)
+    info = rig.info
+    log(f"[bench r{rank}] index: cell {info['cell_size']:.3f} m, {info['n_levels']} levels, "
+        f"{info['n_cells_level0']} voxels, {info['device_bytes'] / 1e6:.0f} MB, build "
+        f"{info['build_ms']:.1f} ms (upload+build {rig.t_index * 1e3:.0f} ms)")
 
-    def one_step():
-        if state["s"] % CYCLE == 0:
-            state["pose"] = d["T_init"].copy()
-        state["pose"], _ = reg.step(state["pose"])  # ends with the pose read-back (sync)
-        state["s"] += 1
-
-    for _ in range(args.warmup):
-        one_step()
     # ---- timed region: exactly K steps between two barrier+synchronize brackets --------------
-    # two hipEvents per step around the search kernels (the roofline kernel), read back lazily;
-    # the per-kernel breakdown comes from the untimed replay below (a full set of events costs
-    # about 5 % of the step)
-    ctx.set_profiling(0 if args.no_events else 3)
-    nn_ms = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-        nn_ms.append(ctx.stats()["ms_nn"])  # the step already ended with a stream sync (pose read-back)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.set_profiling(0)
+    # two hipEvents per step around the search kernels (the roofline kernels), read back lazily;
+    # the per-kernel breakdown comes from the untimed replay below
+    elapsed, nn_ms, step_s = timed_chain(rig, args.steps, args.warmup, barrier, events=not args.no_events)
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # ---- untimed replay of the same pose chain: per-kernel time, pairs, touched points --------
-    state = {"pose": d["T_init"].copy(), "s": 0}
-    for _ in range(args.warmup):
-        one_step()
-    touched, cand, passes, pair_counts, maxcand, maxpass = [], [], [], [], [], []
-    nn_tile_ms, nn_single_ms, cp_ms, gn_ms, nn_ms_replay, nn_lane_ms = [], [], [], [], [], []
-    lane_stats = []
-    ctx.set_profiling(1)
-    for _ in range(args.steps):
-        one_step()
-        st = ctx.stats()
-        nn_ms_replay.append(st["ms_nn"])
-        nn_tile_ms.append(st["ms_nn_tile"])
-        nn_lane_ms.append(st["ms_nn_lane"])
-        nn_single_ms.append(st["ms_nn_single"])
-        cp_ms.append(st["ms_compact"])
-        gn_ms.append(st["ms_gn"])
-        pair_counts.append(pairs.counts()[0])
-    ctx.set_profiling(0)
+    rp = replay(rig, args.steps, args.warmup)
     log(f"[bench r{rank}] per-step kernel ms (replay; chain position = (warmup + i) % {CYCLE}): lane="
-        f"{[round(v, 3) for v in nn_lane_ms]} tile="
-        f"{[round(v, 3) for v in nn_tile_ms]} single={[round(v, 3) for v in nn_single_ms]} "
-        f"gn={[round(v, 3) for v in gn_ms]}; search in the timed loop: {[round(v, 3) for v in nn_ms]}")
-    state = {"pose": d["T_init"].copy(), "s": 0}
-    ctx.set_profiling(2)
-    for _ in range(min(CYCLE, args.warmup + args.steps)):
-        if state["s"] % CYCLE == 0:
-            state["pose"] = d["T_init"].copy()
-        reg.match(state["pose"])
-        st = ctx.stats()
-        touched.append(st["nn_points_staged"])
-        cand.append(st["nn_candidates_tested"])
-        passes.append(st["nn_passes"] / max(1, st["nn_tiles"]))
-        maxcand.append(st["nn_max_candidates_one_tile"])
-        maxpass.append(st["nn_max_passes_one_tile"])
-        lane_stats.append((st["nn_lane_searched"], st["nn_lane_pending"], st["nn_lane_skipped"],
-                           st["nn_lane_candidates"], st["nn_lane_voxels"]))
-        _e = amd.se3.log(amd.se3.inverse_compose(state["pose"], d["T_gt"]))
-        log(f"[bench r{rank}] chain step {state['s']}: err=({np.linalg.norm(_e[:3]):.3f} m, "
-            f"{np.degrees(np.linalg.norm(_e[3:])):.2f} deg) pairs={pairs.counts()[0]} "
-            f"lane: searched={st['nn_lane_searched']} skipped={st['nn_lane_skipped']} pending={st['nn_lane_pending']} "
-            f"cand/q={st['nn_lane_candidates'] / max(1, st['nn_lane_searched']):.1f} "
-            f"vox/q={st['nn_lane_voxels'] / max(1, st['nn_lane_searched']):.1f}; "
-            f"deferred={st['nn_single_queries']} single_cand/q="
-            f"{st['nn_single_candidates'] / max(1, st['nn_single_queries']):.0f} "
-            f"tile_cand/tile={st['nn_candidates_tested'] / max(1, st['nn_tiles']):.0f} "
-            f"passes/tile={st['nn_passes'] / max(1, st['nn_tiles']):.2f}")
-        state["pose"], _ = reg.solve(state["pose"])
-        state["s"] += 1
-    ctx.set_profiling(0)
-    final_err = amd.se3.log(amd.se3.inverse_compose(state["pose"], d["T_gt"]))
+        f"{[round(v, 3) for v in rp['lane']]} tile={[round(v, 3) for v in rp['tile']]} "
+        f"single={[round(v, 3) for v in rp['single']]} gn={[round(v, 3) for v in rp['gn']]}; "
+        f"search in the timed loop: {[round(v, 3) for v in nn_ms]}")
+    rows, final_err = instrumented(rig, min(CYCLE, args.warmup + args.steps), rank, "scene " + args.scene)
 
-    pairs_total = torch.tensor([float(np.sum(pair_counts))], dtype=torch.float64, device="cuda")
+    pairs_total = torch.tensor([float(np.sum(rp["pairs"]))], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(pairs_total, op=dist.ReduceOp.SUM)
+
+    # ---- N > 1: strong scaling of ONE scan (every rank a contiguous 1/N of rank 0's scan) -------
+    strong = None
+    if world > 1:
+        try:
+            d0 = build_inputs(args.n_local, args.n_global, args.seed, 0, world, args.scene)
+            from mp2p_icp_amd.distributed import shard_range
+            b, e = shard_range(d0["local"].shape[0], rank, world)
+            ds = dict(d0, local=np.ascontiguousarray(d0["local"][b:e]))
+            rig_s = Rig(args, ds, rank, world, dist, local_rank, stream, b)
+            el_s, _, _ = timed_chain(rig_s, args.steps, args.warmup, barrier, events=False)
+            ts_ = torch.tensor([el_s], dtype=torch.float64, device="cuda")
+            dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+            strong = {"scaling": "strong", "workload": f"ONE {d0['local'].shape[0]}-pt scan split x{world} vs the replicated map",
+                      "value": args.steps / float(ts_.item()), "unit": "iterations/s",
+                      "ms_per_step": float(ts_.item()) / args.steps * 1e3}
+        except Exception as ex:  # never lose the headline line to the extra block
+            strong = {"error": repr(ex)}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -281,11 +551,10 @@ def main():
     # n_local local points -- hence the whole-job aggregate is world / t_step; the plain step rate
     # is reported next to it.
     iters_per_s = world * args.steps / elapsed
-    nn_ms_avg = max(float(np.mean(nn_ms)), 1e-9)  # 0 only with --no-events (overhead probe)
-    # algorithmic bytes of the search kernel per launch:
-    #   12 B/query read + 12 B per distinct global point in a visited voxel + 8 B/query written
-    alg_bytes = 12.0 * n_l + 12.0 * float(np.mean(touched)) + 8.0 * n_l
-    achieved = alg_bytes / (nn_ms_avg * 1e-3) / 1e9
+    nn_ms_avg = max(float(np.mean(nn_ms)) if nn_ms else 0.0, 1e-9)  # 0 only with --no-events (overhead probe)
+    g = d["glob"]
+    scene_txt = {"a": "ray-cast scan vs surface-sampled map",
+                 "b": "ray-cast scan vs voxel-thinned union of consecutive scans (SURVEY.md 8d)"}
     out = {
         "metric": "icp_iterations_per_sec",
         "value": iters_per_s,
@@ -298,16 +567,18 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32 search / f64 normal equations",
-        "data": "synthetic (seeded KITTI-shape street scene: ray-cast scan vs surface-sampled map)",
+        "data": f"synthetic (seeded KITTI-shape street scene: {scene_txt[args.scene]})",
         "config": {
             "workload": f"{n_l * world}-pt local ({world} x {n_l}) vs {g.shape[0]}-pt global, "
                         "Matcher_Points_DistanceThreshold + Solver_GaussNewton",
+            "scene": args.scene,
             "threshold_m": args.threshold, "thresholdAngularDeg": 0.0,
             "gn_inner_iterations": args.gn_iters, "robust_kernel": "GemanMcClure(0.15)",
             "unique_global_filter": True,
             "pose_chain": f"real ICP chain, restart from perturbed guess every {CYCLE} steps",
             "parallelism": f"local layer sharded x{world}, map replicated",
         },
+        "step_ms": stats_ms(step_s),
         "steps_per_sec_wall": args.steps / elapsed,
         "unit_of_work": f"one outer ICP iteration (match + Gauss-Newton solve) over {n_l} local points vs "
                         f"{g.shape[0]} global points; a step does {world} of them jointly",
@@ -316,51 +587,75 @@ def main():
         "pairs_per_step": float(pairs_total.item()) / args.steps,
         "kernel_ms": {"note": "nn_search: hipEvents in the timed loop; the others: same chain replayed "
                               "with an event around every stage",
-                      "nn_search": nn_ms_avg, "nn_search_replay": float(np.mean(nn_ms_replay)),
-                      "nn_lane_kernel": float(np.mean(nn_lane_ms)),
-                      "nn_tile_kernel": float(np.mean(nn_tile_ms)),
-                      "nn_single_kernel": float(np.mean(nn_single_ms)),
-                      "compact": float(np.mean(cp_ms)),
-                      "gn_solve_all_inner": float(np.mean(gn_ms))},
-        "nn_stats": {"lane_kernel_searched_frac": float(np.mean([a[0] for a in lane_stats])) / n_l,
-                     "lane_kernel_pending_frac": float(np.mean([a[1] for a in lane_stats])) / n_l,
-                     "lane_kernel_finished_without_search_frac": float(np.mean([a[2] for a in lane_stats])) / n_l,
-                     "avg_passes_per_tile": float(np.mean(passes)),
-                     "candidates_tested_per_query": float(np.mean(cand)) / n_l,
-                     "global_points_touched": float(np.mean(touched)),
-                     "max_candidates_one_tile": int(np.max(maxcand)),
-                     "max_passes_one_tile": int(np.max(maxpass)),
+                      "nn_search": nn_ms_avg, "nn_search_replay": float(np.mean(rp["nn"])),
+                      "nn_lane_kernel": float(np.mean(rp["lane"])),
+                      "nn_tile_kernel": float(np.mean(rp["tile"])),
+                      "nn_single_kernel": float(np.mean(rp["single"])),
+                      "compact": float(np.mean(rp["compact"])),
+                      "gn_solve_all_inner": float(np.mean(rp["gn"]))},
+        "nn_stats": {"pending_after_prologue_frac": float(np.mean([r["pending"] for r in rows])) / n_l,
+                     "finished_without_search_frac": float(np.mean([r["skipped"] for r in rows])) / n_l,
+                     "deferred_to_one_query_kernel_frac": float(np.mean([r["deferred"] for r in rows])) / n_l,
+                     "avg_passes_per_tile": float(np.mean([r["passes"] for r in rows])),
+                     "candidates_tested_per_query": float(np.mean([r["cand"] for r in rows])) / n_l,
+                     "global_points_touched": float(np.mean([r["touched"] for r in rows])),
+                     "max_candidates_one_tile": int(np.max([r["maxcand"] for r in rows])),
+                     "max_passes_one_tile": int(np.max([r["maxpass"] for r in rows])),
                      "voxel_m": info["cell_size"]},
         "index_build_ms": info["build_ms"],
         "final_pose_error": {"trans_m": float(np.linalg.norm(final_err[:3])),
                              "rot_rad": float(np.linalg.norm(final_err[3:]))},
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "nn_lane_kernel + nn_tile_kernel + nn_single_kernel (K1+K3: transform + exact NN search)",
-            "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": nn_ms_avg,
-            "traffic": None,
-        },
+        "roofline": roofline_block(n_l, float(np.mean([r["touched"] for r in rows])), nn_ms_avg, "scene_" + args.scene),
     }
-    # HBM traffic of the search kernels from the committed rocprofv3 PMC passes of this same
-    # command (FETCH_SIZE x2 correction for gfx950 + WRITE_SIZE, MI355X_MICROARCH.md "HBM")
-    try:
-        import csv
-        t = 0.0
-        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_bench_hbm_pmc.csv"))):
-            if r["kernel"].strip('"').startswith(("void mp2p::nn_tile_kernel<32, false>",
-                                                   "void mp2p::nn_single_kernel<false>")):
-                t += float(r["fetch_bytes_avg_corrected_x2"]) + float(r["write_bytes_avg"])
-        if t > 0 and args.n_local == 1_000_000 and args.n_global == 10_000_000 and world == 1:
-            out["roofline"]["traffic"] = t
-            out["roofline"]["traffic_source"] = "profiles/r01_bench_hbm_pmc.csv (rocprofv3 --pmc)"
-    except Exception:
-        pass
+    if strong is not None:
+        out["strong_scaling"] = strong
+    if world == 1 and not args.no_extras:
+        # ---- 200 more chained steps: run-to-run / step-to-step spread ------------------------------
+        el2, _, st2 = timed_chain(rig, 200, args.warmup, barrier, events=False)
+        a = np.asarray(st2) * 1e3
+        out["stability"] = {"steps": 200, "iterations_per_s": 200 / el2, "ms_per_step_mean": float(a.mean()),
+                            "p5": float(np.percentile(a, 5)), "p50": float(np.percentile(a, 50)),
+                            "p95": float(np.percentile(a, 95)), "max": float(a.max()),
+                            "note": "no hipEvents in this loop; chain position 0 (the restart from the perturbed guess, "
+                                    "stale warm start) is the slow step of every cycle"}
+        # ---- the boundary through host containers ------------------------------------------------------
+        try:
+            out["host_boundary"] = host_boundary(args, d, ms_per_step)
+        except Exception as ex:
+            out["host_boundary"] = {"error": repr(ex)}
+        # ---- the other scene ---------------------------------------------------------------------------
+        other = "b" if args.scene == "a" else "a"
+        try:
+            t0 = time.time()
+            d2 = build_inputs(args.n_local, args.n_global, args.seed, 0, 1, other)
+            t_gen = time.time() - t0
+            rig2 = Rig(args, d2, 0, 1, None, local_rank, stream, 0)
+            el, nn2, st2 = timed_chain(rig2, args.steps, args.warmup, barrier)
+            rp2 = replay(rig2, args.steps, args.warmup)
+            rows2, ferr2 = instrumented(rig2, min(CYCLE, args.warmup + args.steps), 0, "scene " + other)
+            n2 = d2["local"].shape[0]
+            out["scene_" + other] = {
+                "data": scene_txt[other], "n_local": int(n2), "n_global": int(d2["glob"].shape[0]),
+                "value": args.steps / el, "unit": "iterations/s", "ms_per_step": el / args.steps * 1e3,
+                "step_ms": stats_ms(st2), "pairs_per_step": float(np.mean(rp2["pairs"])),
+                "matched_pairs_per_sec": float(np.sum(rp2["pairs"])) / el,
+                "kernel_ms": {"nn_search": float(np.mean(nn2)), "nn_lane_kernel": float(np.mean(rp2["lane"])),
+                              "nn_tile_kernel": float(np.mean(rp2["tile"])), "nn_single_kernel": float(np.mean(rp2["single"])),
+                              "compact": float(np.mean(rp2["compact"])), "gn_solve_all_inner": float(np.mean(rp2["gn"]))},
+                "nn_stats": {"pending_after_prologue_frac": float(np.mean([r["pending"] for r in rows2])) / n2,
+                             "finished_without_search_frac": float(np.mean([r["skipped"] for r in rows2])) / n2,
+                             "global_points_touched": float(np.mean([r["touched"] for r in rows2]))},
+                "pose_error_along_the_chain_m": [round(r["err_t"], 4) for r in rows2],
+                "final_pose_error": {"trans_m": float(np.linalg.norm(ferr2[:3])), "rot_rad": float(np.linalg.norm(ferr2[3:]))},
+                "roofline": roofline_block(n2, float(np.mean([r["touched"] for r in rows2])), float(np.mean(nn2)), "scene_" + other),
+                "input_generation_s": t_gen,
+            }
+        except Exception as ex:
+            out["scene_" + other] = {"error": repr(ex)}
     if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only
         cores = os.cpu_count() or 1
         t0 = time.time()
-        out["cpu_baseline"] = cpu_baseline(d, args.threshold, args.gn_iters, 0.15,
-                                           args.cpu_sample, cores)
+        out["cpu_baseline"] = cpu_baseline(d, args.threshold, args.gn_iters, 0.15, args.cpu_sample, cores)
         out["cpu_baseline"]["wall_s"] = time.time() - t0
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out), flush=True)

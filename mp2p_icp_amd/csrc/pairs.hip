@@ -596,40 +596,18 @@ static int read_counts(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, unsigned long
     return MP2P_HIP_OK;
 }
 
-// device -> caller memory.  The caller's containers are pageable (std::vector storage): a direct copy
-// is staged by the runtime through its own bounce buffers; here: one DMA into a page-locked buffer of
-// the context (full link rate), then the host copy, split over a few threads when it is large.
+// device -> caller memory.  The caller's containers are pageable (std::vector storage).  Measured on
+// the MI355X host for 3.9 MB (tools/copy_probe.hip): page-lock the destination for the duration of the
+// copy, one DMA, unlock = 0.11 ms; a plain hipMemcpy into never-seen pages 0.51 ms (0.10 once the
+// runtime has seen them); DMA into an own pinned buffer + host copy 0.19-0.27 ms.
 static int copy_out(mp2p_hip_ctx* ctx, const void* dev, void* out, size_t bytes)
 {
-    if (bytes < (256u << 10))
-    {
-        MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        MP2P_TRY_HIP(ctx, stream_wait(ctx));
-        return MP2P_HIP_OK;
-    }
-    if (ctx->pinned_big_bytes < bytes)
-    {
-        if (ctx->pinned_big) (void)hipHostFree(ctx->pinned_big);
-        ctx->pinned_big = nullptr, ctx->pinned_big_bytes = 0;
-        const size_t want = bytes + bytes / 4;
-        MP2P_TRY_HIP(ctx, hipHostMalloc(&ctx->pinned_big, want, hipHostMallocDefault));
-        ctx->pinned_big_bytes = want;
-    }
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->pinned_big, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, stream_wait(ctx));
-    const unsigned nt = bytes >= (2u << 20) ? 4u : 1u;
-    if (nt == 1)
-        memcpy(out, ctx->pinned_big, bytes);
-    else
-    {
-        std::thread th[4];
-        for (unsigned t = 0; t < nt; t++)
-        {
-            const size_t b = bytes * t / nt, e = bytes * (t + 1) / nt;
-            th[t] = std::thread([=]() { memcpy((char*)out + b, (const char*)ctx->pinned_big + b, e - b); });
-        }
-        for (unsigned t = 0; t < nt; t++) th[t].join();
-    }
+    const bool lock = bytes >= (256u << 10) && hipHostRegister(out, bytes, hipHostRegisterDefault) == hipSuccess;
+    if (!lock) (void)hipGetLastError();
+    hipError_t e = hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = stream_wait(ctx);
+    if (lock) (void)hipHostUnregister(out);
+    MP2P_TRY_HIP(ctx, e);
     return MP2P_HIP_OK;
 }
 

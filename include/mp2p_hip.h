@@ -490,6 +490,43 @@ int mp2p_hip_horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, double w
 int mp2p_hip_pairs_pt2ln_pl_to_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* in, const double guess[12],
                                      mp2p_hip_pairs* out);
 
+/* ---- multi-GPU: RCCL inside the boundary (SURVEY.md sections 8b, 8e (ii)).  One process per GPU, one
+ *      context per process.  The local layer is sharded in contiguous ranges of the visiting order
+ *      (every rank passes its shard's whole-layer offset in mp2p_hip_pt2pt_params::local_index_offset),
+ *      the map and its index are replicated.  The reference has no distributed code; a C++
+ *      host shards with:
+ *
+ *        rank 0: mp2p_hip_comm_get_unique_id(id); ship the 128 bytes to the other ranks (MPI, a file, ...)
+ *        every rank: mp2p_hip_comm_init(ctx, id, rank, nranks);           // ncclCommInitRank
+ *        per ICP iteration: mp2p_hip_step_sharded(ctx, map, shard, pose, ...)  // same pose out on all ranks
+ *
+ *      mp2p_hip_step_sharded = phase1 ; ncclAllReduce(MAX, f64[8]) ; ncclAllGather(claim records) ;
+ *      phase2 ; { accumulate ; ncclAllReduce(SUM, f64[48]) ; step } x maxInnerLoopIterations -- all on the
+ *      context's stream.  librccl is opened at run time, by mp2p_hip_comm_init only. ------------------ */
+#define MP2P_HIP_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+int mp2p_hip_comm_get_unique_id(void* id_out /* MP2P_HIP_COMM_ID_BYTES */);
+int mp2p_hip_comm_init(mp2p_hip_ctx* ctx, const void* unique_id, int rank, int nranks);
+/* caller-provided collectives instead of RCCL (another transport; tests).  Both act IN PLACE / into recv
+ * on DEVICE buffers and must be ordered with `stream`; return 0 on success.
+ *   allreduce(user, buf, n_doubles, op (0 sum, 1 max), stream)
+ *   allgather(user, send, recv, n_u64_per_rank, stream)        recv holds nranks * n words, by rank */
+typedef int (*mp2p_hip_allreduce_fn)(void* user, void* dev_buf, size_t n, int op, void* stream);
+typedef int (*mp2p_hip_allgather_fn)(void* user, const void* dev_send, void* dev_recv, size_t n, void* stream);
+int mp2p_hip_comm_init_hooks(mp2p_hip_ctx* ctx, int rank, int nranks, mp2p_hip_allreduce_fn allreduce,
+                             mp2p_hip_allgather_fn allgather, void* user);
+int mp2p_hip_comm_destroy(mp2p_hip_ctx* ctx);
+int mp2p_hip_comm_rank(const mp2p_hip_ctx* ctx);
+int mp2p_hip_comm_size(const mp2p_hip_ctx* ctx);
+/* the path's all-reduce on its own (device double[n], in place, on the context's stream) */
+int mp2p_hip_comm_allreduce_f64(mp2p_hip_ctx* ctx, void* dev_buf, size_t n, int op_max);
+/* one outer ICP iteration of a sharded local layer: Matcher_Points_DistanceThreshold (pairingsPerPoint
+ * 1) + Solver_GaussNewton; `pairs` receives THIS rank's pairings, `out` the pose every rank agrees on
+ * (sums re-associated across ranks: equal to ~1e-12 relative).  *redone = 1 when the claim-record lists
+ * outgrew their predicted length and the iteration was repeated with the exact one (may be NULL). */
+int mp2p_hip_step_sharded(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                          const double pose[12], const mp2p_hip_pt2pt_params* prm, const mp2p_hip_gn_params* gn,
+                          mp2p_hip_pairs* pairs, mp2p_hip_gn_result* out, int32_t* redone);
+
 /* ---- instrumentation ------------------------------------------------------------------ */
 typedef struct
 {

@@ -160,6 +160,10 @@ _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)
 _u64p = C.POINTER(C.c_uint64)
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+COMM_ID_BYTES = 128
+
 # name -> (restype, argtypes).  tests/test_abi.py checks this table against include/mp2p_hip.h.
 SIGNATURES = {
     "mp2p_hip_abi_version": (C.c_int, []),
@@ -238,6 +242,15 @@ SIGNATURES = {
     "mp2p_hip_horn_solve_wp": (C.c_int, [_P, _P, C.POINTER(HornParams), C.POINTER(HornResult)]),
     "mp2p_hip_horn_outlier_flags": (C.c_int, [_P, C.POINTER(C.c_uint8), C.c_size_t]),
     "mp2p_hip_pairs_pt2ln_pl_to_pt2pt": (C.c_int, [_P, _P, _dp, _P]),
+    "mp2p_hip_comm_get_unique_id": (C.c_int, [_P]),
+    "mp2p_hip_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "mp2p_hip_comm_init_hooks": (C.c_int, [_P, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, _P]),
+    "mp2p_hip_comm_destroy": (C.c_int, [_P]),
+    "mp2p_hip_comm_rank": (C.c_int, [_P]),
+    "mp2p_hip_comm_size": (C.c_int, [_P]),
+    "mp2p_hip_comm_allreduce_f64": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
+    "mp2p_hip_step_sharded": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PtParams), C.POINTER(GNParams), _P,
+                                        C.POINTER(GNResult), C.POINTER(C.c_int32)]),
     "mp2p_hip_set_profiling": (C.c_int, [_P, C.c_int]),
     "mp2p_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "mp2p_hip_get_timeline": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t),

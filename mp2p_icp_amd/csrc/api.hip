@@ -166,6 +166,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->pend.release(), ctx->pend_spos.release(), ctx->q_counters.release(), ctx->nn_rec.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    (void)mp2p_hip_comm_destroy(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_big) (void)hipHostFree(ctx->pinned_big);
     if (ctx->q1_pairs) mp2p_hip_pairs_free(nullptr, ctx->q1_pairs);

@@ -114,6 +114,18 @@ struct Tune
     int      compact_fused = 1;     // compaction: bounding-box reduction folded in
 };
 
+// multi-GPU communicator of a context (comm.hip): RCCL, or caller-provided collectives
+struct Comm
+{
+    void* nccl = nullptr;  // ncclComm_t
+    int   rank = 0, nranks = 0;
+    mp2p_hip_allreduce_fn hook_allreduce = nullptr;
+    mp2p_hip_allgather_fn hook_allgather = nullptr;
+    void*                 hook_user      = nullptr;
+    size_t                cap_guess      = 0;  // record-list length predicted for the next iteration (0: ask)
+    DevBuf<unsigned long long> pad, gathered;
+};
+
 struct GnState
 {
     const mp2p_hip_pairs* pairs = nullptr;
@@ -181,6 +193,7 @@ struct mp2p_hip_ctx
     const void*                      hint_cloud = nullptr;
     size_t                           hint_n     = 0;
     mp2p::GnState                    gn;
+    mp2p::Comm                       comm;
     uint32_t last_n_tiles = 0;
     uint32_t last_q       = 64;
     void*    pinned       = nullptr;  // 4 KB of page-locked host memory for the small read-backs

@@ -755,6 +755,13 @@ int gn_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[
 {
     MP2P_REQUIRE(ctx, pairs && pose0 && prm, "null argument");
     MP2P_REQUIRE(ctx, prm->n_weight_blocks <= 8, "at most 8 point_weights blocks are supported");
+    // Pairings::point_weights semantics of this build: block b covers the next
+    // weight_block_count[b] point pairings, at EVERY inner iteration.  The reference's cursor
+    // (optimal_tf_gauss_newton.cpp:66-68, 159-167) is not reset between inner iterations (from the
+    // second one on it reads past its list) and steps over an empty block one point late; an empty
+    // block is therefore refused rather than given either meaning.
+    for (uint32_t b = 0; b < prm->n_weight_blocks; b++)
+        MP2P_REQUIRE(ctx, prm->weight_block_count[b] > 0, "point_weights: a block of zero pairings");
     MP2P_TRY_HIP(ctx, ctx->gn_partials.ensure((size_t)GN_BLOCKS * NS));
     MP2P_TRY_HIP(ctx, ctx->gn_sums.ensure(NS));
     MP2P_TRY_HIP(ctx, ctx->gn_state.ensure(ST_SIZE));

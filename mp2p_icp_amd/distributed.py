@@ -21,6 +21,8 @@ The class is written against a small backend protocol so that the *exchange logi
 exercised with gloo on CPU (tests/test_distributed_gloo.py plugs the CPU oracle in); the only
 product backend is HipBackend below.
 """
+import os
+
 import numpy as np
 
 
@@ -125,19 +127,68 @@ class HipBackend:
     def n_pairs(self):
         return self.pairs.counts()[0]
 
+    # ---- RCCL inside the C boundary (include/mp2p_hip.h, "multi-GPU") -------------------------------
+    def init_native_comm(self, dist, group=None):
+        """One communicator per context, created from an ncclUniqueId that rank 0 draws and the process
+        group carries to the others (128 bytes, the only use of torch.distributed on this route).  From
+        then on step_native() runs the whole sharded iteration -- both all-reduces and the all-gather --
+        inside libmp2p_hip on the context's stream."""
+        import ctypes as C
+        from . import _lib
+        torch = self.torch
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        if rank == 0:
+            _lib.check(self.ctx._L.mp2p_hip_comm_get_unique_id(buf))
+        dev = self.dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0, group=group)
+        raw = bytes(t.cpu().tolist())
+        idb = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(raw)
+        _lib.check(self.ctx._L.mp2p_hip_comm_init(self.ctx.handle, idb, rank, world), self.ctx.handle)
+        self.native = True
+
+    def step_native(self, pose):
+        import ctypes as C
+        from . import _lib
+        T = np.ascontiguousarray(pose, dtype=np.float64)
+        res, redone = _lib.GNResult(), C.c_int32(0)
+        _lib.check(self.ctx._L.mp2p_hip_step_sharded(self.ctx.handle, self.gmap.handle, self.cloud.handle,
+                                                     T.ctypes.data_as(C.POINTER(C.c_double)), C.byref(self.prm),
+                                                     C.byref(self.gn_prm), self.pairs.handle, C.byref(res),
+                                                     C.byref(redone)), self.ctx.handle)
+        self.redone_steps = getattr(self, "redone_steps", 0) + int(redone.value)
+        return np.array(res.pose), int(res.iterations)
+
     @property
     def max_inner(self):
         return int(self.gn_prm.maxInnerLoopIterations)
 
 
 class ShardedRegistration:
-    """match (pt2pt) + Gauss-Newton over a local layer sharded across the process group."""
+    """match (pt2pt) + Gauss-Newton over a local layer sharded across the process group.
 
-    def __init__(self, backend, dist=None, group=None):
+    Two routes to the same exchange steps: the product route runs them INSIDE libmp2p_hip
+    (mp2p_hip_step_sharded over RCCL; chosen when the backend offers it and the process group is nccl),
+    this class's own match()/solve() run them through torch.distributed collectives -- the protocol the
+    gloo tests exercise on CPU with the oracle as the per-rank compute, and the fallback when the native
+    communicator cannot be created."""
+
+    def __init__(self, backend, dist=None, group=None, native=None):
         self.b = backend
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group) if dist is not None else 1
+        if native is None:
+            native = os.environ.get("MP2P_HIP_NATIVE_COMM", "1") != "0"
+        if (native and self.world > 1 and hasattr(backend, "init_native_comm")
+                and dist.get_backend(group) == "nccl"):
+            try:
+                backend.init_native_comm(dist, group)
+            except Exception as ex:  # stay on the torch.distributed route
+                import sys
+                print(f"[mp2p_icp_amd] native RCCL communicator unavailable ({ex}); using torch.distributed",
+                      file=sys.stderr)
 
     def _allreduce(self, t, op):
         if self.dist is not None and self.world > 1:
@@ -197,6 +248,8 @@ class ShardedRegistration:
         if self.world == 1:
             self.match(pose)
             return self.solve(pose)
+        if getattr(self.b, "native", False):  # RCCL inside the C boundary
+            return self.b.step_native(pose)
         guess = getattr(self, "_cap_guess", None)
         exch, cap = self.match(pose, predicted_cap=guess)
         out = self.solve(pose)

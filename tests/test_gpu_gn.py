@@ -177,6 +177,31 @@ def test_point_weight_blocks(amd, oracle):
     assert np.allclose(out.gn["H"], H, rtol=1e-9, atol=1e-9 * np.abs(H).max())
 
 
+def test_point_weight_blocks_over_several_inner_iterations(amd, oracle):
+    """several inner iterations: block b covers its pairings at EVERY iteration (the oracle's
+    reset_weight_cursor_each_iter mode; the reference's own cursor runs off its list from the second
+    iteration on -- DESIGN.md section 2); an empty block is refused"""
+    rng = np.random.default_rng(10)
+    n = 4000
+    l = rng.uniform(-10, 10, (n, 3))
+    g = l + rng.normal(0, 0.05, (n, 3)) + np.array([0.2, -0.1, 0.05])
+    pt = np.zeros(n, oracle.PAIR_PT2PT)
+    pt["lx"], pt["ly"], pt["lz"] = l.T.astype(np.float32)
+    pt["gx"], pt["gy"], pt["gz"] = g.T.astype(np.float32)
+    blocks = [(700, 0.25), (2300, 3.0), (1000, 1.0)]
+    for iters in (2, 4):
+        out = _solve(amd, pt, None, None, {"maxIterations": iters, "robustKernel": "RobustKernel::Cauchy",
+                                           "robustKernelParam": 0.5}, point_weights=blocks)
+        To, it, H, gg = oracle.optimal_tf_gauss_newton(
+            pt, None, None, oracle.pose_identity(),
+            oracle.make_gn_params(iters, kernel=oracle.KERNEL_CAUCHY, kernelParam=0.5, weight_blocks=blocks,
+                                  reset_weight_cursor_each_iter=1))
+        assert _close(oracle, out.optimalPose, To)
+        assert np.allclose(out.gn["H"], H, rtol=1e-9, atol=1e-9 * np.abs(H).max())
+    with pytest.raises(amd.Mp2pHipError):
+        _solve(amd, pt, None, None, {"maxIterations": 1}, point_weights=[(1000, 0.5), (0, 2.0), (3000, 1.0)])
+
+
 def test_convergence_flags_and_empty(amd, oracle):
     # exact pairs at the linearisation point: cost 0 -> break before solving (:344-346)
     from test_oracle_kat import make_prior_kat

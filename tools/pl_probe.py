@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time Matcher_Point2Plane (K5) + Gauss-Newton on BASELINE config 3 shape.
-usage: pl_probe.py [n_local n_global]"""
+usage: pl_probe.py [n_local n_global [r0_cells [a|b]]]"""
 import os, sys, time, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,11 @@ import bench
 
 n_l = int(sys.argv[1]) if len(sys.argv) > 1 else 120_000
 n_g = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
-d = bench.build_inputs(n_l, n_g, 3001, 0, 1)
+if len(sys.argv) > 4 and sys.argv[4] == "b":  # SURVEY.md 8d scene: map = voxel-thinned union of scans (the C3 test's)
+    from mp2p_icp_amd import synthetic
+    d = synthetic.make_scan_union_pair(n_l, n_g, 3001, map_scan_points=1_000_000)
+else:
+    d = bench.build_inputs(n_l, n_g, 3001, 0, 1)
 ctx = amd.Context(0)
 g, l = d["glob"], d["local"]
 gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])

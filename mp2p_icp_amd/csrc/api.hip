@@ -58,6 +58,7 @@ static void parse_tune(Tune& t)
             else if (k == "tile_time_cap_us") t.tile_time_cap_us = (uint32_t)v;
             else if (k == "hard_radius_pct") t.hard_radius_pct = (uint32_t)v;
             else if (k == "sync_spin") t.sync_spin = (int)v;
+            else if (k == "pl_q") t.pl_q = (v == 8 || v == 32) ? (uint32_t)v : 0u;
             else if (k == "claim_dedup") t.claim_dedup = (int)v;
             else if (k == "claim_peek") t.claim_peek = (int)v;
             else if (k == "gn_ticket") t.gn_ticket = (int)v;
@@ -161,7 +162,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->nn_spos.release(), ctx->nn_d2.release(), ctx->tile_bbox.release();
     ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release();
     ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release(), ctx->gn_ticket.release();
-    ctx->aos_stage.release(), ctx->pl_slots.release();
+    ctx->aos_stage.release(), ctx->pl_slots.release(), ctx->pl_knn.release();
     ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();
     ctx->pend.release(), ctx->pend_spos.release(), ctx->q_counters.release(), ctx->nn_rec.release();
     for (auto& ev : ctx->ev)

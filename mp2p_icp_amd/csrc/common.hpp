@@ -105,6 +105,7 @@ struct Tune
     uint32_t tile_time_cap_us = 50; // ... and microseconds after which it does
     uint32_t hard_radius_pct = 100; // pending queries with a radius above this % of a level-0 voxel are "hard":
                                     // their tiles are dispatched first (nn_query.hip)
+    uint32_t pl_q          = 0;     // point-to-plane search: queries per wave (0 = by layer size: 8 up to 400 k points, else 32)
     int      sync_spin     = 1;     // wait for the stream by polling hipStreamQuery (lower wake-up latency)
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
     int      claim_peek    = 1;     // plain look at the claim word before the atomic
@@ -173,6 +174,7 @@ struct mp2p_hip_ctx
     bool                             gn_ticket_zeroed = false;
     mp2p::DevBuf<unsigned char>      aos_stage;    // download staging
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
+    mp2p::DevBuf<uint32_t>           pl_knn;       // pt2pl neighbour lists [n_local][K] (search -> fit kernel)
     mp2p::DevBuf<unsigned long long> timeline;     // profiling level 4: {start, end} ticks per workgroup
     size_t                           timeline_tiles = 0, timeline_singles = 0;
     mp2p::DevBuf<unsigned char>      horn_flags;   // Horn: scale-outlier flag per point pairing

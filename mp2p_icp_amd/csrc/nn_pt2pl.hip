@@ -36,6 +36,7 @@ struct PlArgs
     uint32_t      knn;  // <= K (template capacity of the register k-list)
     const unsigned char* local_taken;
     const uint32_t*      rank;      // visit rank per original local index (NONE = not visited) or null
+    uint32_t*            out_knn;   // [n_l][K capacity] neighbour lists by original local index (search -> fit)
     unsigned char*       out_flag;  // [n_l] by original local index
     double*              out_rec;   // [n_l][7] plane(4) + centroid(3)
     float*               tile_bbox;
@@ -415,7 +416,12 @@ __device__ __forceinline__ bool plane_of_points(const float (&px)[K], const floa
 
 constexpr int PL_Q = 32;  // queries per wave (2 candidate slices)
 
-template <int K>
+// Search and plane fit are two kernels: the search holds a query on 64 / Q lanes, the fit needs one
+// lane per query (fp64 Jacobi, thousands of instructions) -- fused, the fit ran on Q of 64 lanes.
+// Q = 32 for large local layers (a staged bucket serves 32 queries); Q = 8 when the layer is too small
+// to fill the chip with 32-query tiles (a KITTI scan of 120 k points = 3 750 tiles for 5 120 wave
+// slots: the kernel then lasts as long as its slowest tile; 8-query tiles cut that tile's work 4x).
+template <int K, int Q>
 __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
 {
     __shared__ float4   s_cand[PL_CAP];
@@ -429,56 +435,71 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
     bool            valid, visited;
     uint32_t        orig, vrank;
     float           qx, qy, qz;
-    transform_tile<PL_Q>(a.pose, a.lpts, a.n_l, a.rank, a.tile_bbox, lane, valid, visited, orig, vrank, qx, qy, qz);
+    transform_tile<Q>(a.pose, a.lpts, a.n_l, a.rank, a.tile_bbox, lane, valid, visited, orig, vrank, qx, qy, qz);
     const float fin    = fadd(fadd(qx, qy), qz);
     bool        active = visited && (fin - fin == 0.0f);
     if (active && a.local_taken && a.local_taken[orig]) active = false;  // Matcher_Point2Plane.cpp:83-85
 
     float    kd2[K];
     uint32_t kidx[K], kspos[K];
-    knn_search<K, false, PL_Q>(g, lane, qx, qy, qz, active, a.radSq, a.rad * 1.002f + g.slack, a.r0, a.knn,
-                         a.grp_factor, a.cell_budget, a.dbg, s_hit, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
+    knn_search<K, false, Q>(g, lane, qx, qy, qz, active, a.radSq, a.rad * 1.002f + g.slack, a.r0, a.knn,
+                            a.grp_factor, a.cell_budget, a.dbg, s_hit, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
+    // the neighbour list (sorted positions, ascending (d2, idx); NONE beyond its end) for the fit kernel
+    if (!valid || lane >= Q) return;
+    uint32_t* o = a.out_knn + (size_t)orig * K;
+#pragma unroll
+    for (int j = 0; j < K; j++) o[j] = (active && kidx[j] != NONE_U32) ? kspos[j] : NONE_U32;
+}
 
-    // ---- plane fit (one lane per query) ---------------------------------------------------------
-    if (!valid || lane >= PL_Q) return;
-    unsigned char flag = 0;
-    if (active)
+// ---- plane fit: one thread per local point (original index) -----------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void pt2pl_fit_kernel(const PlArgs a, const float* __restrict__ lx,
+                                                        const float* __restrict__ ly, const float* __restrict__ lz)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_l) return;
+    const GridView& g = a.g;
+    const uint32_t* o = a.out_knn + (size_t)i * K;
+    uint32_t        ks[K];
+    int             m = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++)
     {
-        int m = 0;
+        ks[j] = o[j];
+        if (ks[j] != NONE_U32) m++;  // all stored entries satisfy d2 <= radSq
+    }
+    unsigned char flag = 0;
+    if (m >= (int)a.minPts && m >= 3)
+    {
+        float qx, qy, qz;
+        compose_point_f(a.pose, lx[i], ly[i], lz[i], qx, qy, qz);
+        float px[K], py[K], pz[K];
 #pragma unroll
         for (int j = 0; j < K; j++)
-            if (kidx[j] != NONE_U32) m++;  // all stored entries satisfy d2 <= radSq
-        if (m >= (int)a.minPts && m >= 3)
         {
-            float px[K], py[K], pz[K];
-#pragma unroll
-            for (int j = 0; j < K; j++)
+            if (j < m)
             {
-                if (j < m)
-                {
-                    const float4 p = g.pts[kspos[j]];
-                    px[j] = p.x, py[j] = p.y, pz[j] = p.z;
-                }
+                const float4 p = g.pts[ks[j]];
+                px[j] = p.x, py[j] = p.y, pz[j] = p.z;
             }
-            float  mx, my, mz;
-            double n[3];
-            if (plane_of_points<K>(px, py, pz, m, a.eigThr, n, mx, my, mz))
+        }
+        float  mx, my, mz;
+        double n[3];
+        if (plane_of_points<K>(px, py, pz, m, a.eigThr, n, mx, my, mz))
+        {
+            const double c0 = (double)mx, c1 = (double)my, c2 = (double)mz;
+            const double d  = -(n[0] * c0 + n[1] * c1 + n[2] * c2);
+            const float  dist = (float)fabs(n[0] * (double)qx + n[1] * (double)qy + n[2] * (double)qz + d);
+            if (!(dist > a.distThr))
             {
-                const double c0 = (double)mx, c1 = (double)my, c2 = (double)mz;
-                const double d  = -(n[0] * c0 + n[1] * c1 + n[2] * c2);
-                const float  dist =
-                    (float)fabs(n[0] * (double)qx + n[1] * (double)qy + n[2] * (double)qz + d);
-                if (!(dist > a.distThr))
-                {
-                    flag      = 1;
-                    double* o = a.out_rec + (size_t)orig * 7;
-                    o[0] = n[0], o[1] = n[1], o[2] = n[2], o[3] = d;
-                    o[4] = c0, o[5] = c1, o[6] = c2;
-                }
+                flag       = 1;
+                double* r7 = a.out_rec + (size_t)i * 7;
+                r7[0] = n[0], r7[1] = n[1], r7[2] = n[2], r7[3] = d;
+                r7[4] = c0, r7[5] = c1, r7[6] = c2;
             }
         }
     }
-    a.out_flag[orig] = flag;
+    a.out_flag[i] = flag;
 }
 
 // ---- Matcher_Points_DistanceThreshold with pairingsPerPoint > 1 ----------------------------------
@@ -636,9 +657,13 @@ __global__ __launch_bounds__(PC_THREADS) void pl_write_kernel(const PlCompactArg
 }
 
 template <int K>
-static void launch_k(const PlArgs& a, uint32_t n_tiles, hipStream_t st)
+static void launch_k(const PlArgs& a, uint32_t q, const mp2p_hip_cloud* cloud, hipStream_t st)
 {
-    hipLaunchKernelGGL(pt2pl_tile_kernel<K>, dim3(n_tiles), dim3(64), 0, st, a);
+    const uint32_t n_tiles = (a.n_l + q - 1) / q;
+    if (q == 8) hipLaunchKernelGGL((pt2pl_tile_kernel<K, 8>), dim3(n_tiles), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((pt2pl_tile_kernel<K, PL_Q>), dim3(n_tiles), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(pt2pl_fit_kernel<K>, dim3((a.n_l + 255) / 256), dim3(256), 0, st, a, cloud->x.p, cloud->y.p,
+                       cloud->z.p);
 }
 
 int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
@@ -646,10 +671,14 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
                        mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
 {
     const size_t   n_l     = cloud->n;
-    const uint32_t n_tiles = (uint32_t)((n_l + PL_Q - 1) / PL_Q);
+    // tile size: see pt2pl_tile_kernel (MP2P_HIP_TUNE pl_q = 8 / 32 forces one)
+    const uint32_t Q       = ctx->tune.pl_q ? ctx->tune.pl_q : (n_l <= 400000 ? 8u : (uint32_t)PL_Q);
+    const uint32_t n_tiles = (uint32_t)((n_l + Q - 1) / Q);
+    const uint32_t Kcap    = prm->knn <= 5 ? 5u : prm->knn <= 8 ? 8u : prm->knn <= 12 ? 12u : 16u;
     MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_tiles * 6));
     MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
     MP2P_TRY_HIP(ctx, ctx->pl_slots.ensure(n_l * (7 * sizeof(double) + 1) + 64));
+    MP2P_TRY_HIP(ctx, ctx->pl_knn.ensure(n_l * Kcap));
     // layout: [n_l][7] doubles, then [n_l] flags
     double*        rec  = reinterpret_cast<double*>(ctx->pl_slots.p);
     unsigned char* flag = ctx->pl_slots.p + n_l * 7 * sizeof(double);
@@ -671,6 +700,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     a.local_taken = (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
     a.rank     = cloud->n_visit ? cloud->rank.p : nullptr;
     a.out_flag = flag, a.out_rec = rec, a.tile_bbox = ctx->tile_bbox.p;
+    a.out_knn  = ctx->pl_knn.p;
     a.dbg = nullptr;
     if (ctx->profiling == 2)
     {
@@ -681,11 +711,10 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
 
     ctx->pending_lane = 0;
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    const uint32_t K = prm->knn;
-    if (K <= 5) launch_k<5>(a, n_tiles, ctx->stream);
-    else if (K <= 8) launch_k<8>(a, n_tiles, ctx->stream);
-    else if (K <= 12) launch_k<12>(a, n_tiles, ctx->stream);
-    else launch_k<16>(a, n_tiles, ctx->stream);
+    if (Kcap == 5) launch_k<5>(a, Q, cloud, ctx->stream);
+    else if (Kcap == 8) launch_k<8>(a, Q, cloud, ctx->stream);
+    else if (Kcap == 12) launch_k<12>(a, Q, cloud, ctx->stream);
+    else launch_k<16>(a, Q, cloud, ctx->stream);
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     {

@@ -5,12 +5,12 @@ summaries kept under profiles/:
   <tag>_bench_hbm_pmc.csv       per-kernel average FETCH_SIZE / WRITE_SIZE per dispatch, in bytes
                                 (both counters tick in KB units; FETCH_SIZE x2 on gfx950 --
                                 /opt/skills/guides/MI355X_MICROARCH.md, HBM section)
-usage: summarize_prof.py <tag>        e.g. r01"""
+usage: summarize_prof.py <tag> [<prof dir under gpurun_out>]       e.g. r02_bench_scene_a r2k/prof"""
 import csv, glob, os, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-prof = os.path.join(ROOT, "gpurun_out", "prof")
+prof = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "prof")
 
 
 def one(pattern):
@@ -24,7 +24,7 @@ def one(pattern):
 src = one("bench_kt/**/*kernel_stats.csv")
 rows = list(csv.DictReader(open(src)))
 keep = [r for r in rows if "rocprim" not in r["Name"] or True]
-with open(os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
+with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()
     for r in keep:
@@ -46,7 +46,7 @@ def counter(dirname, name):
 
 
 fetch, write = counter("bench_fetch", "FETCH_SIZE"), counter("bench_write", "WRITE_SIZE")
-with open(os.path.join(ROOT, "profiles", f"{tag}_bench_hbm_pmc.csv"), "w", newline="") as f:
+with open(os.path.join(ROOT, "profiles", f"{tag}_hbm_pmc.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "dispatches", "FETCH_SIZE_avg_KB_raw", "fetch_bytes_avg_corrected_x2",
                 "WRITE_SIZE_avg_KB_raw", "write_bytes_avg"])
@@ -55,4 +55,4 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_bench_hbm_pmc.csv"), "w", newli
         wn, wt = write.get(k, [1, 0.0])
         wk = wt / max(1, wn)
         w.writerow([k, n, f"{fk:.1f}", int(fk * 1024 * 2), f"{wk:.1f}", int(wk * 1024)])
-print("written profiles/%s_bench_kernel_stats.csv and profiles/%s_bench_hbm_pmc.csv" % (tag, tag))
+print("written profiles/%s_kernel_stats.csv and profiles/%s_hbm_pmc.csv" % (tag, tag))

@@ -239,6 +239,7 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base, p
         prm.allowMatchAlreadyMatchedPoints       = allowMatchAlreadyMatchedPoints_;
         prm.allowMatchAlreadyMatchedGlobalPoints = allowMatchAlreadyMatchedGlobalPoints_;
         prm.bounding_box_intersection_check_epsilon = bounding_box_intersection_check_epsilon_;
+        prm.multi_search_radius_mode = 1;  // pairingsPerPoint > 1: the shipped (TBB) build's nn_radius_search (:172-177)
         double T[12];
         fill_pose(localPose, T);
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MP2P_HIP_ABI_VERSION 1
+#define MP2P_HIP_ABI_VERSION 2
 
 enum
 {
@@ -221,7 +221,7 @@ typedef struct
 {
     double   threshold;           /* [m]   Matcher_Points_DistanceThreshold.cpp:43 (formula) */
     double   thresholdAngularDeg; /* [deg] :44 */
-    uint32_t pairingsPerPoint;    /* :45 (only 1 is implemented in this round) */
+    uint32_t pairingsPerPoint;    /* :45 (1 .. 16) */
     int32_t  allowMatchAlreadyMatchedPoints;       /* Matcher_Points_Base.cpp:168-169 */
     int32_t  allowMatchAlreadyMatchedGlobalPoints; /* :171-172 */
     double   bounding_box_intersection_check_epsilon; /* :179-180, default 0.20 */
@@ -244,10 +244,16 @@ typedef struct
                                      nearest neighbour (exactness is unaffected) */
     uint32_t brick_budget;        /* 4x4x4-voxel bricks of the occupancy bitmap a deferred query
                                      enumerates per pass before it moves to a coarser level; 0 = 128 */
-    int32_t  tile_order;          /* 1: a warm call (see disable_warm_start) launches the tiles
-                                     of the local layer longest-first, by their measured duration
-                                     in the previous call (results are unaffected; off by default:
-                                     the sort currently costs more than the shorter tail saves) */
+    int32_t  tile_order;          /* ignored since round 2 (kept for layout): the tile kernel now works
+                                     on the list of queries the prologue left pending, hard ones first */
+    int32_t  multi_search_radius_mode; /* pairingsPerPoint > 1 only.  1: the shipped (TBB) build's search,
+                                     nn_radius_search(maxDistSq, ..., k) (Matcher_Points_DistanceThreshold.cpp:
+                                     172-177): neighbours with d2 < maxDistSq, the angular term never widens
+                                     it.  0: the sequential build's nn_multiple_search (:246-248) followed by
+                                     the threshold rule.  Identical when thresholdAngularDeg == 0.  The
+                                     adapter and the Python mirror pass 1 (policy: where the two builds of
+                                     the reference differ, follow the shipped one -- as for H, g in
+                                     optimal_tf_gauss_newton) */
 } mp2p_hip_pt2pt_params;
 
 /* ms may be NULL (fresh MatchState with nothing marked, marks discarded). */

@@ -95,7 +95,7 @@ class Pt2PtParams(C.Structure):
                 ("queries_per_wave", C.c_uint32), ("group_radius_factor", C.c_float),
                 ("cell_budget", C.c_uint32), ("defer_radius_cells", C.c_float),
                 ("disable_warm_start", C.c_int32), ("brick_budget", C.c_uint32),
-                ("tile_order", C.c_int32)]
+                ("tile_order", C.c_int32), ("multi_search_radius_mode", C.c_int32)]
 
 
 class Pt2PlParams(C.Structure):
@@ -299,7 +299,7 @@ def load():
         fn = getattr(L, name)  # AttributeError = symbol missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if L.mp2p_hip_abi_version() != 1:
+    if L.mp2p_hip_abi_version() != 2:
         raise ImportError("libmp2p_hip.so ABI version mismatch")
     _lib = L
     return L

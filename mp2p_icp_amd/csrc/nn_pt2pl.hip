@@ -268,12 +268,16 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                     kth = kth_d2(kd2, knn);
                     hq  = 0;
                 };
-                for (uint32_t j = (uint32_t)(lane / Q); j < m; j += 64 / Q)
+                // (uniform trip count: the flush inside is a wave-wide operation -- DPP / readlane
+                //  reductions -- and must be reached by every lane together)
+                for (uint32_t j0 = 0; j0 < m; j0 += 64 / Q)
                 {
-                    const float4 c  = s_cand[j];
-                    const float  d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
-                    const bool   in = STRICT ? (d2 < lim2) : (d2 <= lim2);
-                    if (grp && in && d2 <= kth) s_hit[hq * 64 + lane] = j, hq++;
+                    const uint32_t j  = j0 + (uint32_t)(lane / Q);
+                    const bool     jv = j < m;
+                    const float4   c  = s_cand[jv ? j : 0u];
+                    const float    d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
+                    const bool     in = STRICT ? (d2 < lim2) : (d2 <= lim2);
+                    if (jv && grp && in && d2 <= kth) s_hit[hq * 64 + lane] = j, hq++;
                     if (__ballot(hq >= (uint32_t)PL_HITQ) != 0ull) flush();
                 }
                 if (__ballot(hq > 0u) != 0ull) flush();
@@ -772,6 +776,10 @@ int launch_nn_pt2pt_knn(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_h
     a.maxDistSq = (float)(prm->threshold * prm->threshold);                 // :82
     const double ang = prm->thresholdAngularDeg * 3.14159265358979323846 / 180.0;
     a.angSq          = (float)(ang * ang);                                  // :83
+    // the shipped (TBB) build searches with nn_radius_search(maxDistSq, ..., k) for pairingsPerPoint > 1
+    // (:172-177): a neighbour is returned only if d2 < maxDistSq, so the angular term (which can only
+    // raise the threshold above maxDistSq) never admits anything further
+    if (prm->multi_search_radius_mode) a.angSq = 0.0f;
     const float cell0 = map->view.hf * (float)(1u << map->view.shift0);
     a.r0  = cell0 * (prm->initial_radius_cells > 0 ? prm->initial_radius_cells : 1.5f);
     a.knn = K;

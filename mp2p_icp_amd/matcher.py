@@ -203,6 +203,7 @@ class Matcher_Points_Base(Matcher):
         self.defer_radius_cells = 0.0
         self.disable_warm_start = False
         self.tile_order = False
+        self.multi_search_radius_mode = True
         self.brick_budget = 0
 
     def initialize(self, params):
@@ -236,6 +237,9 @@ class Matcher_Points_Base(Matcher):
         self.defer_radius_cells = float(params.get("hip_defer_radius_cells", 0.0))
         self.disable_warm_start = bool(params.get("hip_disable_warm_start", False))
         self.tile_order = bool(params.get("hip_tile_order", False))
+        # pairingsPerPoint > 1: the shipped (TBB) build's nn_radius_search meaning by default
+        # (Matcher_Points_DistanceThreshold.cpp:172-177); False = the sequential build's nn_multiple_search
+        self.multi_search_radius_mode = bool(params.get("hip_multi_search_radius_mode", True))
         self.brick_budget = int(params.get("hip_brick_budget", 0))
 
     # maxLocalPointsPerLayer (Matcher_Points_Base.cpp:222-246): when the local layer is larger,
@@ -343,7 +347,7 @@ class Matcher_Points_DistanceThreshold(Matcher_Points_Base):
             float(self.initial_radius_cells), int(self.queries_per_wave),
             float(self.group_radius_factor), int(self.cell_budget),
             float(self.defer_radius_cells), int(self.disable_warm_start), int(self.brick_budget),
-            int(self.tile_order))
+            int(self.tile_order), int(self.multi_search_radius_mode))
 
     def implMatchOneLayer(self, ctx, gLayer, lLayer, localPose, ms, glName, lcName, out):
         self.checkAllParametersAreRealized()

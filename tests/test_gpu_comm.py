@@ -135,7 +135,7 @@ def test_sharded_step_through_hooks(oracle, world, allow_global):
     import mp2p_icp_amd as amd
     from mp2p_icp_amd import _lib, core, synthetic
     from mp2p_icp_amd.distributed import shard_range
-    d = synthetic.make_pair(60_000, 400_000, 8)
+    d = synthetic.make_pair(250_000, 300_000, 8)  # enough claim records per rank to outgrow a predicted length
     g, l = d["glob"], d["local"]
     tree = oracle.KDTree(*_xyz(g))
     dev = torch.device("cuda", 0)

@@ -241,9 +241,12 @@ def test_warm_start_pose_sequence(amd, oracle):
 
 @pytest.mark.parametrize("K", [2, 3, 5, 8, 13, 16])
 @pytest.mark.parametrize("allow_global", [False, True])
-def test_pairings_per_point(amd, oracle, K, allow_global):
+@pytest.mark.parametrize("radius_mode", [True, False])
+def test_pairings_per_point(amd, oracle, K, allow_global, radius_mode):
     """pairingsPerPoint > 1 (Matcher_Points_DistanceThreshold.cpp:242-265): the k nearest in
-    ascending d2 up to the threshold, first claimant of a global point wins."""
+    ascending d2 up to the threshold, first claimant of a global point wins -- with the search of the
+    shipped TBB build (nn_radius_search, :172-177; the default) and of the sequential build
+    (nn_multiple_search, :246-248); thresholdAngularDeg > 0 tells them apart."""
     from mp2p_icp_amd import synthetic
     d = synthetic.random_cloud_pair(3000, 12000, 40 + K, outlier_frac=0.1)
     g, l = d["glob"], d["local"]
@@ -253,10 +256,12 @@ def test_pairings_per_point(amd, oracle, K, allow_global):
     for pose in (d["T_gt"], d["T_init"]):
         want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose,
                                        0.6, 0.2, pairingsPerPoint=K, tree=tree,
-                                       allowMatchAlreadyMatchedGlobalPoints=allow_global)
+                                       allowMatchAlreadyMatchedGlobalPoints=allow_global,
+                                       multi_search_radius_mode=int(radius_mode))
         pairs, _ = _hip_match(amd, pcG, pcL, pose,
                               {"threshold": 0.6, "thresholdAngularDeg": 0.2, "pairingsPerPoint": K,
-                               "allowMatchAlreadyMatchedGlobalPoints": allow_global})
+                               "allowMatchAlreadyMatchedGlobalPoints": allow_global,
+                               "hip_multi_search_radius_mode": radius_mode})
         _assert_same_pairs(pairs.paired_pt2pt, want)
         assert pairs.potential_pairings == pot == l.shape[0] * K
 

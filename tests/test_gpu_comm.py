@@ -135,7 +135,9 @@ def test_sharded_step_through_hooks(oracle, world, allow_global):
     import mp2p_icp_amd as amd
     from mp2p_icp_amd import _lib, core, synthetic
     from mp2p_icp_amd.distributed import shard_range
-    d = synthetic.make_pair(250_000, 300_000, 8)  # enough claim records per rank to outgrow a predicted length
+    # most local points win a global point of their own: tens of thousands of claim records per rank,
+    # enough to outgrow a length predicted from an iteration that had none
+    d = synthetic.random_cloud_pair(90_000, 120_000, 8, outlier_frac=0.05)
     g, l = d["glob"], d["local"]
     tree = oracle.KDTree(*_xyz(g))
     dev = torch.device("cuda", 0)

@@ -953,8 +953,11 @@ __device__ __forceinline__ void scan_batch(const NNArgs& a, const GridView& g, i
 
 constexpr int NN_VLIST = 1024;  // occupied voxels listed per round (LDS)
 
-template <bool INSTR>
-__global__ __launch_bounds__(64) void nn_single_kernel(const NNArgs a)
+// W = waves per SIMD the register allocation aims at (__launch_bounds__' second argument; 1 = the
+// compiler's own choice, 96-98 VGPRs = 5 waves): the kernel is a chain of dependent loads per query, so
+// queries in flight per CU is what it is bound by (measured variants: MP2P_HIP_TUNE single_waves)
+template <bool INSTR, int W>
+__global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
 {
     __shared__ uint32_t s_cstart[64];
     __shared__ uint32_t s_coff[64];
@@ -1374,8 +1377,12 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
 #undef MP2P_LAUNCH_TILE
         if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         // deferred queries: the count lives on the device; a fixed grid strides over it
-        if (instr) hipLaunchKernelGGL(nn_single_kernel<true>, dim3(single_blocks), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(nn_single_kernel<false>, dim3(single_blocks), dim3(64), 0, ctx->stream, a);
+        const uint32_t sb = ctx->tune.single_blocks_per_cu ? std::min<uint32_t>((uint32_t)n_l, 256u * ctx->tune.single_blocks_per_cu)
+                                                           : single_blocks;
+        if (instr) hipLaunchKernelGGL((nn_single_kernel<true, 1>), dim3(sb), dim3(64), 0, ctx->stream, a);
+        else if (ctx->tune.single_waves == 6) hipLaunchKernelGGL((nn_single_kernel<false, 6>), dim3(sb), dim3(64), 0, ctx->stream, a);
+        else if (ctx->tune.single_waves == 8) hipLaunchKernelGGL((nn_single_kernel<false, 8>), dim3(sb), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((nn_single_kernel<false, 1>), dim3(sb), dim3(64), 0, ctx->stream, a);
     }
     else if (ctx->prof_all())
     {

@@ -526,7 +526,8 @@ int mp2p_hip_comm_size(const mp2p_hip_ctx* ctx);
 /* the path's all-reduce on its own (device double[n], in place, on the context's stream) */
 int mp2p_hip_comm_allreduce_f64(mp2p_hip_ctx* ctx, void* dev_buf, size_t n, int op_max);
 /* one outer ICP iteration of a sharded local layer: Matcher_Points_DistanceThreshold (pairingsPerPoint
- * 1) + Solver_GaussNewton; `pairs` receives THIS rank's pairings, `out` the pose every rank agrees on
+ * 1) + Solver_GaussNewton (Pairings cleared first); without a communicator it is the single-GPU step
+ * in one call.  `pairs` receives THIS rank's pairings, `out` the pose every rank agrees on
  * (sums re-associated across ranks: equal to ~1e-12 relative).  *redone = 1 when the claim-record lists
  * outgrew their predicted length and the iteration was repeated with the exact one (may be NULL). */
 int mp2p_hip_step_sharded(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,

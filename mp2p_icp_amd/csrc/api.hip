@@ -59,6 +59,7 @@ static void parse_tune(Tune& t)
             else if (k == "hard_radius_pct") t.hard_radius_pct = (uint32_t)v;
             else if (k == "sync_spin") t.sync_spin = (int)v;
             else if (k == "single_waves") t.single_waves = (uint32_t)v;
+            else if (k == "xcd_map") t.xcd_map = (int)v;
             else if (k == "single_blocks_per_cu") t.single_blocks_per_cu = (uint32_t)v;
             else if (k == "pl_q") t.pl_q = (v == 8 || v == 32) ? (uint32_t)v : 0u;
             else if (k == "claim_dedup") t.claim_dedup = (int)v;

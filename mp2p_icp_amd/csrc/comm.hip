@@ -91,10 +91,14 @@ static size_t round_cap(double n)
 static int sharded_match(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud, const double pose[12],
                          const mp2p_hip_pt2pt_params* prm, mp2p_hip_pairs* out, size_t cap, size_t* cap_used)
 {
-    Comm& c  = ctx->comm;
-    int   rc = mp2p_hip_match_pt2pt_phase1(ctx, map, cloud, pose, prm, nullptr);
+    Comm& c = ctx->comm;
+    if (c.nranks <= 1)
+    {  // one GPU: the unsplit matcher (bounding-box reduction folded into the compaction)
+        if (cap_used) *cap_used = 0;
+        return mp2p_hip_match_pt2pt(ctx, map, cloud, pose, prm, nullptr, out);
+    }
+    int rc = mp2p_hip_match_pt2pt_phase1(ctx, map, cloud, pose, prm, nullptr);
     if (rc) return rc;
-    if (c.nranks > 1)
     {
         void * exch = nullptr, *list = nullptr;
         size_t list_len = 0;
@@ -221,7 +225,8 @@ int mp2p_hip_step_sharded(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;
     MP2P_REQUIRE(ctx, map && cloud && pose && prm && gn && pairs && out, "null argument");
-    MP2P_REQUIRE(ctx, ctx->comm.nranks >= 1, "no communicator: call mp2p_hip_comm_init (nranks may be 1)");
+    // no communicator = one rank: the same call is the single-GPU step (one boundary crossing per
+    // outer ICP iteration instead of three)
     MP2P_REQUIRE(ctx, prm->pairingsPerPoint == 1, "the sharded step implements pairingsPerPoint == 1");
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     Comm& c = ctx->comm;

@@ -100,6 +100,7 @@ struct NNArgs
     // covered by the short, uniform easy tiles.  It also keeps far queries out of the easy tiles' boxes.
     uint32_t             list_cap;
     float                r_hard;
+    int                  xcd_map;
     const uint32_t*      rank;  // visit rank per original local index (NONE = not visited) or null
     int                  use_hint;
     PoseRt               prev_pose;
@@ -601,10 +602,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const uint32_t  tile  = blockIdx.x;
     // the grid covers the worst case (every query pending): tiles_per_seg tiles for each segment of
     // the pending list; those beyond their segment's count leave at once
-    const uint32_t  tiles_per_list = a.n_seg * a.tiles_per_seg;
+    // workgroup b runs on XCD b % 8 (observed placement; each XCD has its own L2): a segment -- ~3 900
+    // Morton-consecutive queries, i.e. one neighbourhood of the map -- is served by ONE XCD, and
+    // consecutive segments go round the XCDs (fine-grained enough to stay balanced)
+    const uint32_t  segs8          = (a.n_seg + 7u) / 8u;               // segments per XCD
+    const uint32_t  tiles_per_list = segs8 * 8u * a.tiles_per_seg;
     const uint32_t  cls    = tile >= tiles_per_list ? 1u : 0u;  // 0 = hard (first), 1 = easy
     const uint32_t  tl     = tile - cls * tiles_per_list;
-    const uint32_t  seg    = tl / a.tiles_per_seg, tk = tl - seg * a.tiles_per_seg;
+    uint32_t        seg, tk;
+    if (a.xcd_map)
+    {
+        const uint32_t x = tl & 7u, j = tl >> 3;
+        const uint32_t sl = j / a.tiles_per_seg;
+        tk = j - sl * a.tiles_per_seg, seg = sl * 8u + x;
+    }
+    else
+        seg = tl / a.tiles_per_seg, tk = tl - seg * a.tiles_per_seg;
+    if (seg >= a.n_seg) return;
     const uint32_t  n_pend = a.q_counters[((size_t)(cls ? 2 : 0) * NN_MAX_SEG + seg) * NN_CNT_STRIDE];
     if (tk * (uint32_t)Q >= n_pend) return;
     const unsigned long long tl0 = wall_clock64();
@@ -1321,7 +1335,8 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.n_seg = n_seg, a.seg_waves = seg_waves, a.seg_cap = seg_cap, a.tiles_per_seg = seg_cap / Q;
     a.list_cap = (uint32_t)list_cap;
     a.r_hard   = cell0 * 0.01f * (float)ctx->tune.hard_radius_pct;
-    const uint32_t n_tiles = 2u * n_seg * a.tiles_per_seg;  // worst case for each class: every query in it
+    a.xcd_map  = ctx->tune.xcd_map;
+    const uint32_t n_tiles = 2u * ((n_seg + 7u) / 8u) * 8u * a.tiles_per_seg;  // worst case for each class: every query in it
     ctx->last_n_tiles = n_tiles;
     for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->hint_pose[i];
     for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->hint_pose[9 + i];

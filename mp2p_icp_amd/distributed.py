@@ -245,11 +245,11 @@ class ShardedRegistration:
         the matcher nothing waits for the host: the record-list length comes from the previous
         iteration (+25 %); the true length is checked after the solve, when the stream is idle
         anyway, and the (rare) iteration whose lists did not fit is redone with the exact length."""
+        if hasattr(self.b, "step_native") and (self.world == 1 or getattr(self.b, "native", False)):
+            return self.b.step_native(pose)  # one call into libmp2p_hip (RCCL inside when sharded)
         if self.world == 1:
             self.match(pose)
             return self.solve(pose)
-        if getattr(self.b, "native", False):  # RCCL inside the C boundary
-            return self.b.step_native(pose)
         guess = getattr(self, "_cap_guess", None)
         exch, cap = self.match(pose, predicted_cap=guess)
         out = self.solve(pose)

@@ -165,6 +165,9 @@ def timed_chain(rig, steps, warmup, barrier, events=True):
         rig.one_step()
     rig.ctx.set_profiling(3 if events else 0)
     nn_ms, step_s = [], []
+    import gc
+    gc.collect()
+    gc.disable()  # as timeit does: a collection inside a 0.4 ms step is a 1 ms outlier
     barrier()
     t0 = time.perf_counter()
     tp = t0
@@ -177,6 +180,7 @@ def timed_chain(rig, steps, warmup, barrier, events=True):
         tp = tn
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     rig.ctx.set_profiling(0)
     return elapsed, nn_ms, step_s
 
@@ -506,6 +510,7 @@ def main():
     # two hipEvents per step around the search kernels (the roofline kernels), read back lazily;
     # the per-kernel breakdown comes from the untimed replay below
     elapsed, nn_ms, step_s = timed_chain(rig, args.steps, args.warmup, barrier, events=not args.no_events)
+    log("timed steps [ms]:", " ".join("%.3f" % (1e3 * t) for t in step_s))
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

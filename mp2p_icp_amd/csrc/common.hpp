@@ -112,9 +112,6 @@ struct Tune
     int      sync_spin     = 1;     // wait for the stream by polling hipStreamQuery (lower wake-up latency)
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
     int      claim_peek    = 1;     // plain look at the claim word before the atomic
-    int      gn_ticket     = 0;     // Gauss-Newton: the last block to arrive reduces and steps (one launch per inner
-                                    // iteration): 1 = release/acquire fences, 2 = agent-scope atomic stores/loads.
-                                    // Measured slower than the extra launches (0.103 vs 0.070 ms for 3 iterations)
     int      compact_fused = 1;     // compaction: bounding-box reduction folded in
 };
 
@@ -173,8 +170,6 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<double>             gn_partials;  // [GN_BLOCKS][NSUMS]
     mp2p::DevBuf<double>             gn_sums;      // [NSUMS]
     mp2p::DevBuf<double>             gn_state;     // pose(12) H(36) g(6) cost(1) iters(1) done(1)
-    mp2p::DevBuf<unsigned int>       gn_ticket;    // arrival counter of the fused iteration kernel
-    bool                             gn_ticket_zeroed = false;
     mp2p::DevBuf<unsigned char>      aos_stage;    // download staging
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
     mp2p::DevBuf<uint32_t>           pl_knn;       // pt2pl neighbour lists [n_local][K] (search -> fit kernel)

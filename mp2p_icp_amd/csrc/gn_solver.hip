@@ -41,6 +41,12 @@ struct GnKernelPrm
     double             blk_w[8];
 };
 
+// the linearisation point of the first inner iteration, as a kernel argument
+struct GnInit
+{
+    double pose[12];
+};
+
 // robust_kernels.h:57-94 (weight on the SQUARED error)
 __device__ __forceinline__ double robust_w(const GnKernelPrm& p, double esq)
 {
@@ -131,15 +137,15 @@ __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pt_kernel(
     const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ lz,
     const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz,
     const unsigned long long* __restrict__ counts, const double* __restrict__ state,
-    const GnKernelPrm prm, double* __restrict__ partials)
+    const GnKernelPrm prm, double* __restrict__ partials, const GnInit init, const int first)
 {
-    const bool done = state[ST_DONE] != 0.0;
+    const bool done = first ? false : state[ST_DONE] != 0.0;
     const unsigned long long n = done ? 0ull : counts[0];
     double R[9], t[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = state[ST_POSE + k];
+    for (int k = 0; k < 9; k++) R[k] = first ? init.pose[k] : state[ST_POSE + k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) t[k] = state[ST_POSE + 9 + k];
+    for (int k = 0; k < 3; k++) t[k] = first ? init.pose[9 + k] : state[ST_POSE + 9 + k];
     accum_pt2pt_body(lx, ly, lz, gx, gy, gz, n, R, t, prm, partials);
 }
 
@@ -270,28 +276,35 @@ __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pl_kernel(
     const double* __restrict__ coef, const float* __restrict__ lx, const float* __restrict__ ly,
     const float* __restrict__ lz, const mp2p_hip_pair_pt2ln* __restrict__ lines,
     const mp2p_hip_pair_pl2pl* __restrict__ planes, const unsigned long long* __restrict__ counts,
-    const double* __restrict__ state, const GnKernelPrm prm, double* __restrict__ partials)
+    const double* __restrict__ state, const GnKernelPrm prm, double* __restrict__ partials,
+    const GnInit init, const int first)
 {
-    const bool done = state[ST_DONE] != 0.0;
+    const bool done = first ? false : state[ST_DONE] != 0.0;
     double R[9], t[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = state[ST_POSE + k];
+    for (int k = 0; k < 9; k++) R[k] = first ? init.pose[k] : state[ST_POSE + k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) t[k] = state[ST_POSE + 9 + k];
+    for (int k = 0; k < 3; k++) t[k] = first ? init.pose[9 + k] : state[ST_POSE + 9 + k];
     accum_pt2pl_body(coef, lx, ly, lz, lines, planes, counts, done, R, t, prm, partials);
 }
 
 // fixed-order sum of the block partials -> sums[48] (16 interleaved partial sums per quantity,
-// combined as a fixed tree: deterministic run to run)
+// combined as a fixed tree: deterministic run to run).  The 16 loads of a thread are independent (one
+// round trip, not 16); the result goes to global memory (the all-reduce buffer) and to s_sums (LDS).
 __device__ __forceinline__ void gn_sums_body(const double* __restrict__ partials, bool done,
-                                             int use_pt, int use_pl, double* __restrict__ sums)
+                                             int use_pt, int use_pl, double* __restrict__ sums,
+                                             double* s_sums)
 {
     __shared__ double s[16][NS];
     const int         q = threadIdx.x & 63, part = threadIdx.x >> 6;
-    double            t = 0;
     const bool mine = q < NS && ((q < NS_PT && use_pt) || (q >= NS_PT && q < NS_PT + NS_PL && use_pl));
-    if (mine && !done)
-        for (int b = part; b < GN_BLOCKS; b += 16) t += partials[(size_t)b * NS + q];
+    double     v[GN_BLOCKS / 16];
+#pragma unroll
+    for (int k = 0; k < GN_BLOCKS / 16; k++)
+        v[k] = (mine && !done) ? partials[(size_t)(part + 16 * k) * NS + q] : 0.0;
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < GN_BLOCKS / 16; k++) t += v[k];
     if (q < NS) s[part][q] = t;
     __syncthreads();
     if (threadIdx.x < NS)
@@ -299,7 +312,9 @@ __device__ __forceinline__ void gn_sums_body(const double* __restrict__ partials
         const int i = threadIdx.x;
         double    r[8];
         for (int k = 0; k < 8; k++) r[k] = s[2 * k][i] + s[2 * k + 1][i];
-        sums[i] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        const double tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        sums[i] = tot;
+        if (s_sums) s_sums[i] = tot;
     }
 }
 
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(1024) void gn_sums_kernel(const double* __restrict_
                                                        int use_pt, int use_pl,
                                                        double* __restrict__ sums)
 {
-    gn_sums_body(partials, state[ST_DONE] != 0.0, use_pt, use_pl, sums);
+    gn_sums_body(partials, state[ST_DONE] != 0.0, use_pt, use_pl, sums, nullptr);
 }
 
 // ---- small dense helpers (single thread) -----------------------------------------------------
@@ -415,65 +430,91 @@ __device__ void d_se3_log(const double* T, double* xi)
     xi[3] = w[0], xi[4] = w[1], xi[5] = w[2];
 }
 
-// LDL^T with diagonal pivoting (role of Eigen's H.ldlt().solve(g), :351)
-// ws: >= 78 doubles of workspace (the callers pass LDS: indexed private arrays would live in
-// scratch memory, i.e. a global-memory round trip per element -- this solve used to cost 12 us)
-__device__ void d_ldlt6_solve(const double* H, const double* g, double* x, double* ws)
+// LDL^T with diagonal pivoting (role of Eigen's H.ldlt().solve(g), :351), run by ONE WAVE: lane
+// 6 i + j holds A(i,j) and L(i,j); pivots, D and the permutation are wave-uniform (v_readlane); the row /
+// column exchanges are two ds_bpermute.  Same operations per element and in the same order as the
+// textbook serial loop, which it replaced: that loop, run by one thread on an LDS copy of the matrix
+// (indexed private arrays would live in scratch memory), was a chain of ~300 dependent LDS round trips,
+// ~10 us of the 15 us gn_sums_step_kernel used to take.
+__device__ __forceinline__ double readlane_d(double v, int l)
 {
-    const int n = 6;
-    double *  A = ws, *L = ws + 36, *D = ws + 72;
-    int       perm[6];
-    for (int i = 0; i < 36; i++) A[i] = H[i], L[i] = 0;
-    for (int i = 0; i < n; i++) perm[i] = i, D[i] = 0;
-    for (int k = 0; k < n; k++)
+    const unsigned long long u  = __builtin_bit_cast(unsigned long long, v);
+    const unsigned int       lo = (unsigned int)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), l);
+    const unsigned int       hi = (unsigned int)__builtin_amdgcn_readlane((int)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// H (6x6 row-major) and g in LDS; x is returned in every lane
+__device__ __forceinline__ void wave_ldlt6_solve(const double* H, const double* g, double (&x)[6])
+{
+    const int lane = threadIdx.x & 63;
+    const int l    = lane < 36 ? lane : 35;
+    const int i = l / 6, j = l % 6;
+    double    a = H[l], Lv = 0.0;
+    const double gv = g[j];            // lanes 0..5 hold g[0..5]
+    int          pv = lane < 6 ? lane : 0;  // lanes 0..5 hold perm[0..5]
+    double       D[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
     {
         int    piv  = k;
-        double best = fabs(A[k * n + k]);
-        for (int i = k + 1; i < n; i++)
-            if (fabs(A[i * n + i]) > best) best = fabs(A[i * n + i]), piv = i;
-        if (piv != k)
+        double best = fabs(readlane_d(a, k * 7));
+#pragma unroll
+        for (int r = k + 1; r < 6; r++)
         {
-            for (int j = 0; j < n; j++)
-            {
-                const double t = A[k * n + j];
-                A[k * n + j] = A[piv * n + j], A[piv * n + j] = t;
-            }
-            for (int i = 0; i < n; i++)
-            {
-                const double t = A[i * n + k];
-                A[i * n + k] = A[i * n + piv], A[i * n + piv] = t;
-            }
-            for (int j = 0; j < k; j++)
-            {
-                const double t = L[k * n + j];
-                L[k * n + j] = L[piv * n + j], L[piv * n + j] = t;
-            }
-            const int t = perm[k];
-            perm[k] = perm[piv], perm[piv] = t;
+            const double d = fabs(readlane_d(a, r * 7));
+            if (d > best) best = d, piv = r;
         }
-        D[k]         = A[k * n + k];
-        L[k * n + k] = 1.0;
-        if (D[k] == 0.0) continue;
-        for (int i = k + 1; i < n; i++) L[i * n + k] = A[i * n + k] / D[k];
-        for (int i = k + 1; i < n; i++)
-            for (int j = k + 1; j < n; j++) A[i * n + j] -= L[i * n + k] * D[k] * L[j * n + k];
+        if (piv != k)  // wave-uniform
+        {
+            const int pi = (i == k) ? piv : (i == piv) ? k : i;
+            const int pj = (j == k) ? piv : (j == piv) ? k : j;
+            a            = __shfl(a, pi * 6 + pj, 64);
+            Lv           = __shfl(Lv, pi * 6 + j, 64);  // columns >= k of both rows are still zero
+            const int pk = __builtin_amdgcn_readlane(pv, k), pp = __builtin_amdgcn_readlane(pv, piv);
+            pv           = (lane == k) ? pp : (lane == piv) ? pk : pv;
+        }
+        const double Dk = readlane_d(a, k * 7);
+        D[k]            = Dk;
+        if (i == k && j == k) Lv = 1.0;
+        if (Dk == 0.0) continue;
+        const double lik = __shfl(a, i * 6 + k, 64) / Dk;
+        const double ljk = __shfl(a, j * 6 + k, 64) / Dk;
+        if (j == k && i > k) Lv = lik;
+        if (i > k && j > k) a -= lik * Dk * ljk;
     }
-    double b[6], y[6], z[6];
-    for (int i = 0; i < n; i++) b[i] = g[perm[i]];
-    for (int i = 0; i < n; i++)
+    double Lr[6][6];
+#pragma unroll
+    for (int r = 1; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < r; c++) Lr[r][c] = readlane_d(Lv, r * 6 + c);
+    int    perm[6];
+    double y[6], z[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
     {
-        double s = b[i];
-        for (int j = 0; j < i; j++) s -= L[i * n + j] * y[j];
-        y[i] = s;
+        perm[r]  = __builtin_amdgcn_readlane(pv, r);
+        double q = readlane_d(gv, perm[r]);  // b[r] = g[perm[r]]
+#pragma unroll
+        for (int c = 0; c < r; c++) q -= Lr[r][c] * y[c];
+        y[r] = q;
     }
-    for (int i = 0; i < n; i++) z[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
-    for (int i = n - 1; i >= 0; i--)
+#pragma unroll
+    for (int r = 0; r < 6; r++) z[r] = (D[r] != 0.0) ? y[r] / D[r] : 0.0;
+#pragma unroll
+    for (int r = 5; r >= 0; r--)
     {
-        double s = z[i];
-        for (int j = i + 1; j < n; j++) s -= L[j * n + i] * y[j];
-        y[i] = s;
+        double q = z[r];
+#pragma unroll
+        for (int c = r + 1; c < 6; c++) q -= Lr[c][r] * y[c];
+        y[r] = q;
     }
-    for (int i = 0; i < n; i++) x[perm[i]] = y[i];
+    double xt = 0.0;  // lane t < 6: x[t]
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+        if (perm[r] == lane) xt = y[r];
+#pragma unroll
+    for (int r = 0; r < 6; r++) x[r] = readlane_d(xt, r);
 }
 
 struct GnStepPrm
@@ -485,16 +526,14 @@ struct GnStepPrm
     int    use_pt, use_pl;
 };
 
-// ---- K8: assemble H,g from the sums, prior, solve, retract (one thread) -----------------------
-constexpr int GN_STEP_WS = 36 + 6 + 78 + 2;  // H, g, LDLT workspace
+// ---- K8: assemble H,g from the sums and the prior (one thread), solve and retract (one wave) ----
+constexpr int GN_STEP_WS = 36 + 6 + 2;  // H, g, cost
+static_assert(ST_SIZE == 64, "the state vector is stored by one wave");
 
-__device__ void gn_step_body(const double* __restrict__ sums, double* __restrict__ state,
-                             const GnStepPrm& prm, double* ws)
+template <bool PRIOR>
+__device__ void gn_assemble(const double* sums, const double (&T)[12], const GnStepPrm& prm, double* ws)
 {
-    if (state[ST_DONE] != 0.0) return;
-    double T[12];
-    for (int i = 0; i < 12; i++) T[i] = state[ST_POSE + i];
-    double *H = ws, *g = ws + 36;  // LDS workspace (see d_ldlt6_solve)
+    double *H = ws, *g = ws + 36;
     for (int i = 0; i < 36; i++) H[i] = 0;
     for (int i = 0; i < 6; i++) g[i] = 0;
     double cost = 0;
@@ -537,7 +576,7 @@ __device__ void gn_step_body(const double* __restrict__ sums, double* __restrict
         for (int p = 0; p < 6; p++) g[p] += s[21 + p];
         cost += s[27];
     }
-    if (prm.has_prior)
+    if (PRIOR)  // a kernel variant of its own: its 6x6 temporaries cost registers and scratch memory
     {
         // :311-341  err = log(prior^-1 * pose); J = d log(A exp(eps))/d eps (central differences)
         double Pinv[12], A[12], err[6], J[36];
@@ -579,142 +618,98 @@ __device__ void gn_step_body(const double* __restrict__ sums, double* __restrict
             }
         }
     }
-    for (int i = 0; i < 36; i++) state[ST_H + i] = H[i];
-    for (int i = 0; i < 6; i++) state[ST_G + i] = g[i];
-    state[ST_COST] = cost;
-    state[ST_ITERS] += 1.0;
-    if (sqrt(cost) <= prm.maxCost)  // :344-346
-    {
-        state[ST_DONE] = 1.0;
-        return;
-    }
-    double delta[6];
-    d_ldlt6_solve(H, g, delta, ws + 42);
-    for (int i = 0; i < 6; i++) delta[i] = -delta[i];  // :351
-    double dE[12], Tn[12];
-    d_se3_exp(delta, dE);       // :354
-    d_pose_compose(T, dE, Tn);  // :356
-    for (int i = 0; i < 12; i++) state[ST_POSE + i] = Tn[i];
-    double nrm = 0;
-    for (int i = 0; i < 6; i++) nrm += delta[i] * delta[i];
-    if (sqrt(nrm) < prm.minDelta) state[ST_DONE] = 1.0;  // :365
+    ws[42] = cost;
 }
 
-__global__ void gn_step_kernel(const double* __restrict__ sums, double* __restrict__ state,
-                               const GnStepPrm prm)
+// Called by every thread of the block (it contains a barrier).  s_sums: the 48 sums in LDS; T, iters: the
+// current iterate (from the kernel argument at the first iteration: the state vector needs no launch of
+// its own); ws: GN_STEP_WS + ST_SIZE doubles of LDS.  The whole state vector leaves as one 512-byte store.
+template <bool PRIOR>
+__device__ void gn_step_block(const double* s_sums, double* __restrict__ state, const GnStepPrm& prm,
+                              double* ws, const double (&T)[12], double iters)
 {
-    __shared__ double ws[GN_STEP_WS];
-    if (threadIdx.x == 0 && blockIdx.x == 0) gn_step_body(sums, state, prm, ws);
+    if (threadIdx.x == 0) gn_assemble<PRIOR>(s_sums, T, prm, ws);
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int    lane  = threadIdx.x;
+    double*      s_out = ws + GN_STEP_WS;
+    const double cost  = ws[42];
+    bool         done  = sqrt(cost) <= prm.maxCost;  // :344-346
+    double       Tn[12];
+    for (int i = 0; i < 12; i++) Tn[i] = T[i];
+    if (!done)
+    {
+        double delta[6], dE[12];
+        wave_ldlt6_solve(ws, ws + 36, delta);
+        for (int i = 0; i < 6; i++) delta[i] = -delta[i];  // :351
+        d_se3_exp(delta, dE);                              // :354
+        d_pose_compose(T, dE, Tn);                         // :356
+        double nrm = 0;
+        for (int i = 0; i < 6; i++) nrm += delta[i] * delta[i];
+        done = sqrt(nrm) < prm.minDelta;  // :365
+    }
+    if (lane < 36) s_out[ST_H + lane] = ws[lane];
+    if (lane < 6) s_out[ST_G + lane] = ws[36 + lane];
+    if (lane >= ST_DONE + 1) s_out[lane] = 0.0;
+    if (lane == 0)
+    {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s_out[ST_POSE + i] = Tn[i];
+        s_out[ST_COST] = cost, s_out[ST_ITERS] = iters + 1.0, s_out[ST_DONE] = done ? 1.0 : 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    state[lane] = s_out[lane];  // ST_SIZE == 64
+}
+
+// split form (an all-reduce sits between the sums and the step)
+template <bool PRIOR>
+__global__ __launch_bounds__(64) void gn_step_kernel(const double* __restrict__ sums, double* __restrict__ state,
+                                                     const GnStepPrm prm)
+{
+    __shared__ double ws[GN_STEP_WS + ST_SIZE];
+    __shared__ double s_sums[NS];
+    if (state[ST_DONE] != 0.0) return;
+    double T[12];
+    for (int i = 0; i < 12; i++) T[i] = state[ST_POSE + i];
+    const double iters = state[ST_ITERS];
+    if (threadIdx.x < NS) s_sums[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+    gn_step_block<PRIOR>(s_sums, state, prm, ws, T, iters);
 }
 
 // single-GPU form: final reduction and the 6x6 step in one launch (no all-reduce in between)
+template <bool PRIOR>
 __global__ __launch_bounds__(1024) void gn_sums_step_kernel(const double* __restrict__ partials,
                                                             double* __restrict__ state, int use_pt,
                                                             int use_pl, double* __restrict__ sums,
-                                                            const GnStepPrm prm)
+                                                            const GnStepPrm prm, const GnInit init,
+                                                            const int first)
 {
-    __shared__ double ws[GN_STEP_WS];
-    gn_sums_body(partials, state[ST_DONE] != 0.0, use_pt, use_pl, sums);
-    __syncthreads();  // sums[] written by this block are visible to its thread 0
-    if (threadIdx.x == 0) gn_step_body(sums, state, prm, ws);
+    __shared__ double ws[GN_STEP_WS + ST_SIZE];
+    __shared__ double s_sums[NS];
+    // the iterate is read while the partials are on their way
+    double T[12], iters = 0.0;
+    bool   done = false;
+    if (first)
+        for (int i = 0; i < 12; i++) T[i] = init.pose[i];
+    else
+    {
+        done = state[ST_DONE] != 0.0;
+        for (int i = 0; i < 12; i++) T[i] = state[ST_POSE + i];
+        iters = state[ST_ITERS];
+    }
+    if (done) return;  // block-uniform
+    gn_sums_body(partials, false, use_pt, use_pl, sums, s_sums);
+    __syncthreads();
+    gn_step_block<PRIOR>(s_sums, state, prm, ws, T, iters);
 }
 
-struct GnInit
-{
-    double pose[12];
-};
-// the linearisation point travels as a kernel argument: no H2D copy, no host synchronisation
 __global__ void gn_init_kernel(double* __restrict__ state, const GnInit init)
 {
     const int i = threadIdx.x;
     if (i < ST_SIZE) state[i] = (i < 12) ? init.pose[i] : 0.0;
-}
-
-// ---- one launch per inner iteration (single GPU): every block accumulates its share of the pairs
-//      and takes a ticket; the LAST block to arrive adds the block partials in a fixed order and runs
-//      the 6x6 step.  The first iteration takes the linearisation point from the kernel arguments
-//      (no init launch).  Hand-off between the blocks = the agent-scope release / acquire pair of
-//      MI355X_MICROARCH.md ("inter-workgroup visibility"): plain stores, __syncthreads, one lane's
-//      release fence + s_waitcnt, relaxed ticket atomic; the last block: one acquire fence,
-//      __syncthreads, plain loads.  ~2 us per side against ~8 us per saved launch boundary.
-struct GnIterArgs
-{
-    const float *lx, *ly, *lz, *gx, *gy, *gz;        // pt2pt SoA
-    const double* coef;                              // pt2pl
-    const float * pl_lx, *pl_ly, *pl_lz;
-    const mp2p_hip_pair_pt2ln* lines;
-    const mp2p_hip_pair_pl2pl* planes;
-    const unsigned long long*  counts;
-    double *     state, *partials, *sums;
-    unsigned int* ticket;
-    GnKernelPrm  kprm;
-    GnStepPrm    sprm;
-    GnInit       init;
-    int          first, use_pt, use_pl;
-};
-
-template <bool AGENT>
-__global__ __launch_bounds__(GN_THREADS) void gn_iter_kernel(const GnIterArgs a)
-{
-    __shared__ int    s_last;
-    __shared__ double s_part[GN_THREADS / 64][NS];
-    __shared__ double s_ws[GN_STEP_WS];
-    const bool done = a.first ? false : (a.state[ST_DONE] != 0.0);
-    double     R[9], t[3];
-#pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = a.first ? a.init.pose[k] : a.state[ST_POSE + k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) t[k] = a.first ? a.init.pose[9 + k] : a.state[ST_POSE + 9 + k];
-
-    if (a.use_pt)
-        accum_pt2pt_body<AGENT>(a.lx, a.ly, a.lz, a.gx, a.gy, a.gz, done ? 0ull : a.counts[0], R, t, a.kprm,
-                                a.partials);
-    if (a.use_pl)
-        accum_pt2pl_body<AGENT>(a.coef, a.pl_lx, a.pl_ly, a.pl_lz, a.lines, a.planes, a.counts, done, R, t,
-                                a.kprm, a.partials);
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        if (!AGENT)
-        {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const unsigned int tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (tk == gridDim.x - 1u) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0)
-    {
-        if (!AGENT) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *a.ticket = 0u;  // for the next launch (ordered by the kernel boundary)
-    }
-    __syncthreads();
-    // fixed-order sum of the block partials: 4 interleaved partial sums per quantity, then a fixed tree
-    {
-        const int  q = threadIdx.x & 63, part = threadIdx.x >> 6;
-        const bool mine = q < NS && ((q < NS_PT && a.use_pt) || (q >= NS_PT && q < NS_PT + NS_PL && a.use_pl));
-        double     v = 0;
-        if (mine && !done)
-            for (int b = part; b < GN_BLOCKS; b += GN_THREADS / 64)
-                v += AGENT ? __hip_atomic_load(a.partials + (size_t)b * NS + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                           : a.partials[(size_t)b * NS + q];
-        if (q < NS) s_part[part][q] = v;
-        __syncthreads();
-        if (threadIdx.x < NS)
-        {
-            const int i = threadIdx.x;
-            a.sums[i]   = (s_part[0][i] + s_part[1][i]) + (s_part[2][i] + s_part[3][i]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-    {
-        if (a.first)
-            for (int i = 0; i < ST_SIZE; i++) a.state[i] = (i < 12) ? a.init.pose[i] : 0.0;
-        gn_step_body(a.sums, a.state, a.sprm, s_ws);
-    }
 }
 
 static GnKernelPrm make_kernel_prm(const mp2p_hip_gn_params& p)
@@ -737,14 +732,19 @@ static GnKernelPrm make_kernel_prm(const mp2p_hip_gn_params& p)
     return k;
 }
 
+static GnInit make_init(const mp2p_hip_ctx* ctx)
+{
+    GnInit init;
+    for (int i = 0; i < 12; i++) init.pose[i] = ctx->gn.pose0[i];
+    return init;
+}
+
 // the state vector starts as {pose0, zeros}: written by a launch of its own (split form), or by the
 // first fused iteration
 static int gn_ensure_state(mp2p_hip_ctx* ctx)
 {
     if (ctx->gn.state_ready) return MP2P_HIP_OK;
-    GnInit init;
-    for (int i = 0; i < 12; i++) init.pose[i] = ctx->gn.pose0[i];
-    hipLaunchKernelGGL(gn_init_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->gn_state.p, init);
+    hipLaunchKernelGGL(gn_init_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->gn_state.p, make_init(ctx));
     ctx->gn.state_ready = true;
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
@@ -788,26 +788,29 @@ static GnStepPrm make_step_prm(mp2p_hip_ctx* ctx)
     return s;
 }
 
-static void launch_partials(mp2p_hip_ctx* ctx, int& use_pt, int& use_pl)
+// first: the state vector is not written yet; the kernels take the linearisation point from `init`
+static void launch_partials(mp2p_hip_ctx* ctx, int& use_pt, int& use_pl, int first)
 {
+    const GnInit init = make_init(ctx);
     const mp2p_hip_pairs* P = ctx->gn.pairs;
     const GnKernelPrm     k = make_kernel_prm(ctx->gn.prm);
     use_pt = P->cap_pt2pt > 0, use_pl = P->cap_pt2pl > 0 || P->ln.p || P->pp.p;
     if (use_pt)
         hipLaunchKernelGGL(gn_accum_pt2pt_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
                            P->lx.p, P->ly.p, P->lz.p, P->gx.p, P->gy.p, P->gz.p, P->counts.p,
-                           ctx->gn_state.p, k, ctx->gn_partials.p);
+                           ctx->gn_state.p, k, ctx->gn_partials.p, init, first);
     if (use_pl)
         hipLaunchKernelGGL(gn_accum_pt2pl_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
                            P->cap_pt2pl > 0 ? P->pl_coef.p : nullptr, P->pl_lx.p, P->pl_ly.p, P->pl_lz.p,
-                           P->ln.p, P->pp.p, P->counts.p, ctx->gn_state.p, k, ctx->gn_partials.p);
+                           P->ln.p, P->pp.p, P->counts.p, ctx->gn_state.p, k, ctx->gn_partials.p, init, first);
 }
 
 int gn_accumulate(mp2p_hip_ctx* ctx)
 {
     MP2P_REQUIRE(ctx, ctx->gn.active, "gn_accumulate without gn_begin");
+    if (const int rc = gn_ensure_state(ctx)) return rc;
     int use_pt, use_pl;
-    launch_partials(ctx, use_pt, use_pl);
+    launch_partials(ctx, use_pt, use_pl, 0);
     hipLaunchKernelGGL(gn_sums_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->gn_partials.p,
                        ctx->gn_state.p, use_pt, use_pl, ctx->gn_sums.p);
     MP2P_TRY_HIP(ctx, hipGetLastError());
@@ -817,8 +820,11 @@ int gn_accumulate(mp2p_hip_ctx* ctx)
 int gn_step(mp2p_hip_ctx* ctx)
 {
     MP2P_REQUIRE(ctx, ctx->gn.active, "gn_step without gn_begin");
-    hipLaunchKernelGGL(gn_step_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->gn_sums.p,
-                       ctx->gn_state.p, make_step_prm(ctx));
+    const GnStepPrm sp = make_step_prm(ctx);
+    if (sp.has_prior)
+        hipLaunchKernelGGL(gn_step_kernel<true>, dim3(1), dim3(64), 0, ctx->stream, ctx->gn_sums.p, ctx->gn_state.p, sp);
+    else
+        hipLaunchKernelGGL(gn_step_kernel<false>, dim3(1), dim3(64), 0, ctx->stream, ctx->gn_sums.p, ctx->gn_state.p, sp);
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
 }
@@ -827,41 +833,17 @@ int gn_step(mp2p_hip_ctx* ctx)
 int gn_iterate_fused(mp2p_hip_ctx* ctx)
 {
     MP2P_REQUIRE(ctx, ctx->gn.active, "gn_iterate_fused without gn_begin");
-    if (ctx->tune.gn_ticket)
-    {
-        const mp2p_hip_pairs* P = ctx->gn.pairs;
-        MP2P_TRY_HIP(ctx, ctx->gn_ticket.ensure(1));
-        if (!ctx->gn_ticket_zeroed)
-        {
-            MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->gn_ticket.p, 0, sizeof(unsigned int), ctx->stream));
-            ctx->gn_ticket_zeroed = true;
-        }
-        GnIterArgs a;
-        memset(&a, 0, sizeof(a));
-        a.lx = P->lx.p, a.ly = P->ly.p, a.lz = P->lz.p, a.gx = P->gx.p, a.gy = P->gy.p, a.gz = P->gz.p;
-        a.coef  = P->cap_pt2pl > 0 ? P->pl_coef.p : nullptr;
-        a.pl_lx = P->pl_lx.p, a.pl_ly = P->pl_ly.p, a.pl_lz = P->pl_lz.p;
-        a.lines = P->ln.p, a.planes = P->pp.p, a.counts = P->counts.p;
-        a.state = ctx->gn_state.p, a.partials = ctx->gn_partials.p, a.sums = ctx->gn_sums.p;
-        a.ticket = ctx->gn_ticket.p;
-        a.kprm = make_kernel_prm(ctx->gn.prm), a.sprm = make_step_prm(ctx);
-        a.use_pt = a.sprm.use_pt, a.use_pl = a.sprm.use_pl;
-        a.first = ctx->gn.state_ready ? 0 : 1;
-        for (int i = 0; i < 12; i++) a.init.pose[i] = ctx->gn.pose0[i];
-        if (ctx->tune.gn_ticket == 2)
-            hipLaunchKernelGGL(gn_iter_kernel<true>, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(gn_iter_kernel<false>, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream, a);
-        ctx->gn.state_ready = true;
-        MP2P_TRY_HIP(ctx, hipGetLastError());
-        return MP2P_HIP_OK;
-    }
-    if (const int rc = gn_ensure_state(ctx)) return rc;
-    int use_pt, use_pl;
-    launch_partials(ctx, use_pt, use_pl);
-    hipLaunchKernelGGL(gn_sums_step_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                       ctx->gn_partials.p, ctx->gn_state.p, use_pt, use_pl, ctx->gn_sums.p,
-                       make_step_prm(ctx));
+    const int first = ctx->gn.state_ready ? 0 : 1;
+    int       use_pt, use_pl;
+    launch_partials(ctx, use_pt, use_pl, first);
+    const GnStepPrm sp = make_step_prm(ctx);
+    if (sp.has_prior)
+        hipLaunchKernelGGL(gn_sums_step_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, ctx->gn_partials.p,
+                           ctx->gn_state.p, use_pt, use_pl, ctx->gn_sums.p, sp, make_init(ctx), first);
+    else
+        hipLaunchKernelGGL(gn_sums_step_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, ctx->gn_partials.p,
+                           ctx->gn_state.p, use_pt, use_pl, ctx->gn_sums.p, sp, make_init(ctx), first);
+    ctx->gn.state_ready = true;
     MP2P_TRY_HIP(ctx, hipGetLastError());
     return MP2P_HIP_OK;
 }

@@ -64,6 +64,9 @@ def test_fuzz_pt2pt(oracle, seed):
     params = {"threshold": thr, "thresholdAngularDeg": ang, "pairingsPerPoint": K,
               "hip_queries_per_wave": int(rng.choice([0, 16, 32, 64])),
               "allowMatchAlreadyMatchedGlobalPoints": bool(rng.random() < 0.3)}
+    # K > 1: the nn_radius_search meaning (TBB build, the default here) or nn_multiple_search (sequential build)
+    radius_mode = bool((seed // len(KINDS)) % 2 == 0)
+    params["hip_multi_search_radius_mode"] = radius_mode
     tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
     pcG = amd.metric_map_t({"raw": amd.PointLayer(g, **layer_kw)})
     pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
@@ -74,7 +77,7 @@ def test_fuzz_pt2pt(oracle, seed):
         xi = np.concatenate([rng.normal(0, 0.02 * scale, 3), rng.normal(0, 0.02, 3)]) * (step > 0)
         T = amd.se3.compose(T, amd.se3.exp(xi))
         want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, thr, ang,
-                                       pairingsPerPoint=K, tree=tree,
+                                       pairingsPerPoint=K, tree=tree, multi_search_radius_mode=int(radius_mode),
                                        allowMatchAlreadyMatchedGlobalPoints=params["allowMatchAlreadyMatchedGlobalPoints"])
         pairs = amd.Pairings()
         assert m.match(pcG, pcL, T, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)

@@ -66,7 +66,10 @@ typedef struct
     float    cell_size;       /* finest voxel edge [m]; <=0 = choose from the point density   */
     float    target_per_cell; /* density target for the automatic choice (<=0 -> 6)           */
     uint32_t max_levels;      /* 0 -> default (12)                                            */
-    uint32_t no_occupancy_bitmap; /* 1 = do not build the dense occupancy bitmaps (probe only) */
+    uint32_t no_occupancy_bitmap; /* index variants (results are identical; for tests and measurements):
+                                     1 = hash probes only (no occupancy bitmaps, no dense voxel directories),
+                                     2 = bitmaps but no dense voxel directories,
+                                     4 = no dense voxel directory for the finest level only                 */
 } mp2p_hip_map_params;
 
 typedef struct

@@ -63,6 +63,7 @@ static void parse_tune(Tune& t)
             else if (k == "single_blocks_per_cu") t.single_blocks_per_cu = (uint32_t)v;
             else if (k == "pl_q") t.pl_q = (v == 8 || v == 32) ? (uint32_t)v : 0u;
             else if (k == "claim_dedup") t.claim_dedup = (int)v;
+            else if (k == "dir_budget_mb") t.dir_budget_mb = (uint32_t)v;
             else if (k == "claim_peek") t.claim_peek = (int)v;
             else if (k == "compact_fused") t.compact_fused = (int)v;
             else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
@@ -165,8 +166,8 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release();
     ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release();
     ctx->aos_stage.release(), ctx->pl_slots.release(), ctx->pl_knn.release();
-    ctx->work.release(), ctx->work_spos.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();
-    ctx->pend.release(), ctx->pend_spos.release(), ctx->q_counters.release(), ctx->nn_rec.release();
+    ctx->work.release(), ctx->work_q.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();
+    ctx->pend.release(), ctx->pend_q.release(), ctx->q_counters.release(), ctx->nn_rec.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     (void)mp2p_hip_comm_destroy(ctx);

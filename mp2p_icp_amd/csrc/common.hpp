@@ -44,8 +44,16 @@ struct GridView
     const unsigned long long* occ;          // all levels in one allocation, or null
     uint32_t                  occ_off[16];  // first word of level l, OCC_NONE = no bitmap for it
     uint32_t                  occ_bx[16], occ_by[16], occ_bz[16];  // bricks per axis
+    // dense voxel directory: {first, one-past-last} sorted position of every voxel of the level's grid
+    // (4 occ_bx x 4 occ_by x 4 occ_bz voxels, x fastest), empty voxels {0, 0}.  ONE load answers "which
+    // points does this voxel hold" -- the bitmap test and the hash probe behind it are two dependent round
+    // trips, and the search kernels are bound by exactly that chain.  64 x the bitmap's size: kept for the
+    // levels that fit the budget (MP2P_HIP_TUNE dir_budget_mb; HBM is 288 GB), the hash table serves the rest.
+    const uint2*              dir;
+    unsigned long long        dir_off[16];  // first entry of level l, DIR_NONE = no directory for it
 };
-constexpr uint32_t OCC_NONE = 0xFFFFFFFFu;
+constexpr uint32_t           OCC_NONE = 0xFFFFFFFFu;
+constexpr unsigned long long DIR_NONE = ~0ull;
 
 // ---------------------------------------------------------------------------------------
 // host-side objects behind the opaque C handles
@@ -113,6 +121,7 @@ struct Tune
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
     int      claim_peek    = 1;     // plain look at the claim word before the atomic
     int      compact_fused = 1;     // compaction: bounding-box reduction folded in
+    uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
 };
 
 // multi-GPU communicator of a context (comm.hip): RCCL, or caller-provided collectives
@@ -185,7 +194,7 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<uint4>              nn_rec;       // [n_local] result + warm-start records of the pt2pt search
                                                    // (Morton order of the local layer; see nn_query.hip)
     mp2p::DevBuf<uint4>              work, pend;   // deferred / pending queries of the NN search
-    mp2p::DevBuf<uint32_t>           work_spos, pend_spos;
+    mp2p::DevBuf<uint4>              work_q, pend_q;  // {qx, qy, qz, best_spos} of the list entries
     mp2p::DevBuf<uint32_t>           q_counters;   //   {#pending, #deferred}
     mp2p::Tune                       tune;         // MP2P_HIP_TUNE (experiments; defaults otherwise)
     double                           hint_pose[12] = {};
@@ -211,6 +220,7 @@ struct mp2p_hip_map
     mp2p::DevBuf<mp2p::Cell>         table;
     mp2p::DevBuf<unsigned long long> claims;  // [n] indexed by SORTED position
     mp2p::DevBuf<unsigned long long> occ;     // occupancy bitmaps of all levels
+    mp2p::DevBuf<uint2>              dir;     // dense voxel directories of the levels that fit
     mp2p::GridView                   view{};
     mp2p_hip_map_info                info{};
 };

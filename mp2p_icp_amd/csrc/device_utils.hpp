@@ -320,4 +320,22 @@ __device__ __forceinline__ bool cell_lookup(const GridView& g, unsigned long lon
     }
 }
 
+// true and [start, end) when voxel (cx, cy, cz) of level lev holds points.  occ_checked: the caller has
+// already seen the voxel's occupancy bit set (the hash path then skips that test).
+__device__ __forceinline__ bool voxel_range(const GridView& g, uint32_t lev, uint32_t cx, uint32_t cy,
+                                            uint32_t cz, uint32_t& start, uint32_t& end, bool occ_checked)
+{
+    const unsigned long long off = g.dir_off[lev];
+    if (off != DIR_NONE)
+    {
+        const uint32_t nx = g.occ_bx[lev] * 4u, ny = g.occ_by[lev] * 4u, nz = g.occ_bz[lev] * 4u;
+        if (cx >= nx || cy >= ny || cz >= nz) return false;
+        const uint2 e = g.dir[off + ((size_t)cz * ny + cy) * nx + cx];
+        start = e.x, end = e.y;
+        return e.y > e.x;
+    }
+    if (!occ_checked && !occ_maybe(g, lev, cx, cy, cz)) return false;
+    return cell_lookup(g, cell_key(lev, cx, cy, cz), start, end);
+}
+
 }  // namespace mp2p

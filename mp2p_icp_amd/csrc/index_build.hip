@@ -150,6 +150,8 @@ struct OccBuild
 {
     unsigned long long* words;
     uint32_t            off[16], bx[16], by[16];
+    uint2*              dir;  // dense voxel directory (GridView::dir)
+    unsigned long long  dir_off[16];
 };
 
 template <int PASS>
@@ -178,6 +180,8 @@ __global__ __launch_bounds__(256) void cells_kernel(const unsigned long long* __
                 atomicOr(&occ.words[(size_t)occ.off[l] +
                                     ((size_t)(cz >> 2) * occ.by[l] + (cy >> 2)) * occ.bx[l] + (cx >> 2)],
                          1ull << (((cz & 3u) << 4) | ((cy & 3u) << 2) | (cx & 3u)));
+            if (occ.dir_off[l] != DIR_NONE)
+                occ.dir[occ.dir_off[l] + ((size_t)cz * (occ.by[l] * 4u) + cy) * (occ.bx[l] * 4u) + cx].x = i;
         }
     }
     else
@@ -193,6 +197,8 @@ __global__ __launch_bounds__(256) void cells_kernel(const unsigned long long* __
         {
             const uint32_t s = shift0 + l;
             hash_set_end(table, mask, cell_key(l, fx >> s, fy >> s, fz >> s), i + 1);
+            if (occ.dir_off[l] != DIR_NONE)
+                occ.dir[occ.dir_off[l] + ((size_t)(fz >> s) * (occ.by[l] * 4u) + (fy >> s)) * (occ.bx[l] * 4u) + (fx >> s)].y = i + 1;
         }
     }
 }
@@ -328,7 +334,7 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
     OccBuild ob;
     memset(&ob, 0, sizeof(ob));
     {
-        const unsigned long long budget = (prm && prm->no_occupancy_bitmap) ? 0ull : (1ull << 27);  // words = 1 GB
+        const unsigned long long budget = (prm && (prm->no_occupancy_bitmap & 1u)) ? 0ull : (1ull << 27);  // words = 1 GB
         unsigned long long       total  = 0;
         uint32_t nf[3];
         for (int d = 0; d < 3; d++)
@@ -352,6 +358,26 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
         }
         ob.words = map->occ.p;
         for (int l = 0; l < 16; l++) ob.off[l] = g.occ_off[l], ob.bx[l] = g.occ_bx[l], ob.by[l] = g.occ_by[l];
+        // dense voxel directories, finest level first (it serves nearly every lookup of a warm ICP
+        // iteration; each coarser level is 1/8 of the one below)
+        const uint32_t     variant  = prm ? prm->no_occupancy_bitmap : 0u;
+        unsigned long long dir_left = (variant & 3u) ? 0ull : (unsigned long long)ctx->tune.dir_budget_mb * (1ull << 20) / sizeof(uint2);
+        unsigned long long dir_total = 0;
+        for (int l = 0; l < 16; l++)
+        {
+            g.dir_off[l] = DIR_NONE;
+            if (l >= (int)n_levels || (l == 0 && (variant & 4u))) continue;
+            const unsigned long long v = 64ull * g.occ_bx[l] * g.occ_by[l] * g.occ_bz[l];
+            if (v > dir_left) continue;
+            g.dir_off[l] = dir_total, dir_total += v, dir_left -= v;
+        }
+        if (dir_total)
+        {
+            MP2P_TRY_HIP(ctx, map->dir.alloc(dir_total));
+            MP2P_TRY_HIP(ctx, hipMemsetAsync(map->dir.p, 0, dir_total * sizeof(uint2), ctx->stream));
+        }
+        ob.dir = map->dir.p;
+        for (int l = 0; l < 16; l++) ob.dir_off[l] = g.dir_off[l];
     }
     hipLaunchKernelGGL(cells_kernel<0>, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, keys.p,
                        map->pts.p, (uint32_t)n, mn[0], mn[1], mn[2], inv_hf, shift0, n_levels,
@@ -367,6 +393,7 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
     g.pts = map->pts.p, g.n = (uint32_t)n;
     g.table = map->table.p, g.mask = cap - 1;
     g.occ   = map->occ.p;
+    g.dir   = map->dir.p;
     g.ox = mn[0], g.oy = mn[1], g.oz = mn[2];
     g.hf = hf, g.inv_hf = inv_hf;
     g.shift0 = shift0, g.n_levels = n_levels;
@@ -381,7 +408,7 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
     info.n_cells_total  = total_cells;
     info.n_cells_level0 = cells[shift0];
     info.hash_capacity  = cap;
-    info.device_bytes   = map->pts.bytes() + map->table.bytes() + map->claims.bytes() + map->occ.bytes();
+    info.device_bytes   = map->pts.bytes() + map->table.bytes() + map->claims.bytes() + map->occ.bytes() + map->dir.bytes();
     info.build_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MP2P_HIP_OK;

@@ -202,10 +202,11 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                 const float dx = fmaxf(0.f, fmaxf(vx0 - qhx, qlx - (vx0 + hs)));
                 const float dy = fmaxf(0.f, fmaxf(vy0 - qhy, qly - (vy0 + hs)));
                 const float dz = fmaxf(0.f, fmaxf(vz0 - qhz, qlz - (vz0 + hs)));
-                if (dx * dx + dy * dy + dz * dz <= prune2 && occ_maybe(g, lev, cx, cy, cz))
+                if (dx * dx + dy * dy + dz * dz <= prune2)
                 {
                     uint32_t e = 0;
-                    if (cell_lookup(g, cell_key(lev, cx, cy, cz), start, e)) cnt = e - start;
+                    if (voxel_range(g, lev, cx, cy, cz, start, e, false)) cnt = e - start;
+                    else start = 0;
                 }
             }
             const uint32_t incl  = wave_incl_scan(cnt, lane);

@@ -81,16 +81,16 @@ struct NNArgs
     uint4*               rec;
     float*               tile_bbox;  // [n_waves of the lane kernel][6]
     // pending queries (lane kernel -> tile kernel) and deferred queries (-> one-query-per-wave
-    // kernel): {sorted local idx, r, best_d2, best_idx} + best_spos.  A device-scope atomic is a
+    // kernel): {sorted local idx, r, best_d2, best_idx} + {qx, qy, qz, best_spos}.  A device-scope atomic is a
     // round trip to the memory side and atomics on ONE address serialise there (~12 ns each: one
     // counter bumped by every wave set the duration of the whole kernel), so each list is cut into
     // n_seg SEGMENTS of seg_cap entries, one counter per segment on its own 128-byte line; the waves
     // of seg_waves consecutive workgroups of the lane kernel share a segment (Morton-consecutive
     // queries stay together).  q_counters[(list * NN_MAX_SEG + seg) * NN_CNT_STRIDE]
     uint4*               pend;
-    uint32_t*            pend_spos;
-    uint4*               work;
-    uint32_t*            work_spos;
+    uint4*               pend_q;  // {qx, qy, qz (the transformed point), best_spos}: a pending query is read in
+    uint4*               work;    // ONE round trip (its point would otherwise be a dependent second one)
+    uint4*               work_q;
     uint32_t*            q_counters;
     uint32_t             n_seg, seg_waves, seg_cap, tiles_per_seg;
     // the pending list comes in two classes, hard (list 0: radius above r_hard) and easy (list 2, stored
@@ -185,10 +185,11 @@ __device__ __forceinline__ void lookup_voxel(const GridView& g, const PassBox& b
     const float dy = fmaxf(0.f, fmaxf(vy0 - qhy, qly - (vy0 + b.hs)));
     const float dz = fmaxf(0.f, fmaxf(vz0 - qhz, qlz - (vz0 + b.hs)));
     md2 = dx * dx + dy * dy + dz * dz;
-    if (md2 <= prune2 && occ_maybe(g, b.lev, cx, cy, cz))
+    if (md2 <= prune2)
     {
         uint32_t e = 0;
-        if (cell_lookup(g, cell_key(b.lev, cx, cy, cz), start, e)) cnt = e - start;
+        if (voxel_range(g, b.lev, cx, cy, cz, start, e, false)) cnt = e - start;
+        else start = 0;
     }
 }
 
@@ -243,16 +244,16 @@ __device__ __forceinline__ void claim_global(const NNArgs& a, uint32_t spos, uin
 // do_emit: this lane writes the record of query qi.  s_claim: NN_CLAIM_SLOTS words of LDS.
 __device__ __forceinline__ void emit_wave(const NNArgs& a, unsigned long long* s_claim, int lane, bool do_emit,
                                           uint32_t qi, uint32_t orig, bool active, float thr, float best_d2,
-                                          uint32_t best_idx, uint32_t best_spos, float lb2_keep)
+                                          uint32_t best_idx, uint32_t best_spos, float lb2_all)
 {
     bool acc = do_emit && active && best_idx != NONE_U32 && best_d2 < thr;  // :259
     if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;     // :98-101
     if (do_emit)
     {
         // next call's warm start: the raw nearest neighbour (even if rejected) and what this search
-        // proved: no map point is nearer than min(best, threshold) (every point that could pass the
-        // threshold was examined), or than the bound that let the search be skipped
-        const float lb2 = active ? fmaxf(fminf(best_d2, thr), lb2_keep) : 0.f;
+        // proved: no map point is nearer than lb2_all (min(best, threshold): every point that could pass
+        // the threshold was examined; or the bound that let the search be skipped)
+        const float lb2 = active ? lb2_all : 0.f;
         a.rec[qi] = make_uint4(best_spos, __float_as_uint(best_d2), __float_as_uint(lb2), acc ? 1u : 0u);
     }
     if (!a.claims) return;               // uniform
@@ -284,10 +285,11 @@ __device__ __forceinline__ void emit_wave(const NNArgs& a, unsigned long long* s
 // push the lanes of `push` (at most one per query) onto segment `seg` of a query list
 __device__ __forceinline__ uint32_t push_lanes(const NNArgs& a, int list, uint32_t seg, bool mine,
                                                unsigned long long push, int lane, uint32_t qi, float r,
-                                               float best_d2, uint32_t best_idx, uint32_t best_spos)
+                                               float best_d2, uint32_t best_idx, uint32_t best_spos,
+                                               float qx, float qy, float qz)
 {
-    uint4*    l_rec  = list == 1 ? a.work : a.pend + (list == 2 ? a.list_cap : 0u);
-    uint32_t* l_spos = list == 1 ? a.work_spos : a.pend_spos + (list == 2 ? a.list_cap : 0u);
+    uint4* l_rec = list == 1 ? a.work : a.pend + (list == 2 ? a.list_cap : 0u);
+    uint4* l_q   = list == 1 ? a.work_q : a.pend_q + (list == 2 ? a.list_cap : 0u);
     const int npush     = __popcll(push);
     uint32_t  base_slot = 0;
     if (lane == 0)
@@ -297,8 +299,8 @@ __device__ __forceinline__ uint32_t push_lanes(const NNArgs& a, int list, uint32
     {
         // a segment holds every query of its workgroups: base_slot + rank < seg_cap by construction
         const size_t slot = (size_t)seg * a.seg_cap + base_slot + (uint32_t)__popcll(push & ((1ull << lane) - 1ull));
-        l_rec[slot]  = make_uint4(qi, __float_as_uint(r), __float_as_uint(best_d2), best_idx);
-        l_spos[slot] = best_spos;
+        l_rec[slot] = make_uint4(qi, __float_as_uint(r), __float_as_uint(best_d2), best_idx);
+        l_q[slot]   = make_uint4(__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz), best_spos);
     }
     return (uint32_t)npush;
 }
@@ -308,10 +310,12 @@ __device__ __forceinline__ uint32_t push_lanes(const NNArgs& a, int list, uint32
 template <int Q>
 __device__ __forceinline__ uint32_t defer_lanes(const NNArgs& a, uint32_t seg, bool mine, unsigned long long mask,
                                                 int lane, int slice, uint32_t qi, float r,
-                                                float best_d2, uint32_t best_idx, uint32_t best_spos)
+                                                float best_d2, uint32_t best_idx, uint32_t best_spos,
+                                                float qx, float qy, float qz)
 {
     const unsigned long long slot_mask = (Q < 64) ? ((1ull << (Q & 63)) - 1ull) : ~0ull;
-    return push_lanes(a, 1, seg, mine && slice == 0, mask & slot_mask, lane, qi, r, best_d2, best_idx, best_spos);
+    return push_lanes(a, 1, seg, mine && slice == 0, mask & slot_mask, lane, qi, r, best_d2, best_idx, best_spos,
+                      qx, qy, qz);
 }
 
 // ---- per-lane search helpers -------------------------------------------------------------------
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     //      nothing within the threshold finish without a search; (1) gives the radius that is
     //      certain to conclude.  The ball that decides the result is still searched completely,
     //      so the result is the cold result. ---------------------------------------------------
-    float lb2_keep = 0.f;
+    float lb2_out = -1.f;  // >= 0: the record's bound when this kernel concludes without a search
     if (a.use_hint && active)
     {
         float       ox, oy, oz;
@@ -433,8 +437,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
         if (lb * 0.999f > sqrtf(thr))
         {  // fl(d2) >= thr for every map point: nothing to pair, nothing to search
-            done     = true;
-            lb2_keep = (lb * 0.9999f) * (lb * 0.9999f);
+            done    = true;
+            lb2_out = (lb * 0.9999f) * (lb * 0.9999f);
         }
         else if (lb > r * (1.0f - 1.0f / 1024.0f) - g.slack)
             r = fminf(fmaxf(hr > 0.f ? fminf(hr, 2.0f * lb) : 2.0f * lb, r), rmax);
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 if (md2 <= fminf(prune2, voxel_limit(best_d2, g.slack)))
                 {
                     uint32_t s0 = 0, e0 = 0;
-                    if (cell_lookup(g, cell_key(0u, cx, cy, cz), s0, e0)) p = s0, pe = e0;
+                    if (voxel_range(g, 0u, cx, cy, cz, s0, e0, true)) p = s0, pe = e0;
                     if (INSTR) st_vox++;
                 }
             }
@@ -555,18 +559,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const bool               hard  = pending && r > a.r_hard;
         const unsigned long long hmask = __ballot(hard), emask = pmask & ~hmask;
         if (hmask)
-            push_lanes(a, 0, blockIdx.x / a.seg_waves, hard, hmask, lane, qi, r, best_d2, best_idx, best_spos);
+            push_lanes(a, 0, blockIdx.x / a.seg_waves, hard, hmask, lane, qi, r, best_d2, best_idx, best_spos, qx, qy,
+                       qz);
         if (emask)
             push_lanes(a, 2, blockIdx.x / a.seg_waves, pending && !hard, emask, lane, qi, r, best_d2, best_idx,
-                       best_spos);
+                       best_spos, qx, qy, qz);
     }
 
-    emit_wave(a, s_claim, lane, valid && !pending, qi, orig, active, thr, best_d2, best_idx, best_spos, lb2_keep);
+    // a query this lane searched itself: all that could pass the threshold was examined
+    emit_wave(a, s_claim, lane, valid && !pending, qi, orig, active, thr, best_d2, best_idx, best_spos,
+              lb2_out >= 0.f ? lb2_out : fminf(best_d2, thr));
 
     if (INSTR)
     {
         const uint32_t n_fast = (uint32_t)__popcll(__ballot(fast && !empty_cube));
-        const uint32_t n_skip = (uint32_t)__popcll(__ballot(active && lb2_keep > 0.f));
+        const uint32_t n_skip = (uint32_t)__popcll(__ballot(active && lb2_out >= 0.f));
         const uint32_t cand   = wave_sum_u32(st_cand), vox = wave_sum_u32(st_vox);
         if (lane == 0)
         {
@@ -629,17 +636,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 
     // the lane kernel did the per-query set-up (visit list, MatchState, warm start); a pending
     // query arrives with its radius and the best candidate so far
-    uint4    w  = make_uint4(0u, 0u, __float_as_uint(INFINITY), NONE_U32);
-    uint32_t ws = NONE_U32;
-    if (valid) w = a.pend[pslot], ws = a.pend_spos[pslot];
+    uint4 w  = make_uint4(0u, 0u, __float_as_uint(INFINITY), NONE_U32);
+    uint4 wq = make_uint4(0u, 0u, 0u, NONE_U32);
+    if (valid) w = a.pend[pslot], wq = a.pend_q[pslot];
     const uint32_t qi = w.x;
-    float4 lp = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) lp = a.lpts[qi];
-    const uint32_t orig = __float_as_uint(lp.w);
-
-    // ---- K1 again (cheaper than carrying three more words per pending query) ------------------
-    float qx, qy, qz;
-    compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
+    const uint32_t ws = wq.w;
+    // the original index is needed only for the claim at the very end: its load (dependent on the entry)
+    // is in flight during the search
+    uint32_t orig = 0u;
+    if (valid) orig = __float_as_uint(a.lpts[qi].w);
+    const float qx = __uint_as_float(wq.x), qy = __uint_as_float(wq.y), qz = __uint_as_float(wq.z);
     const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));
     const float thr    = fadd(a.maxDistSq, fmul(a.angSq, normSq));
     const float rmax   = sqrtf(thr) * 1.002f + g.slack;
@@ -650,7 +656,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     bool       deferred = false;
     float      best_d2  = __uint_as_float(w.z);
     uint32_t   best_idx = w.w, best_spos = ws;
-    const float lb2_keep = 0.f;
 
     // a query whose radius already exceeds what a tile should carry goes straight to the
     // one-query-per-wave kernel
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         const unsigned long long wmask = __ballot(wide);
         if (wmask)
         {
-            defer_lanes<Q>(a, seg, wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
+            defer_lanes<Q>(a, seg, wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
             if (wide) done = true, deferred = true;
         }
     }
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         // ---- a group of a few isolated queries goes to the one-query-per-wave kernel -----------
         if (__popcll(gmask) <= NN_COOP_MAX * S)
         {
-            st_defer += defer_lanes<Q>(a, seg, grp, gmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
+            st_defer += defer_lanes<Q>(a, seg, grp, gmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
             if (grp) done = true, deferred = true;
             continue;
         }
@@ -854,14 +859,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         const unsigned long long wmask = __ballot(too_wide);
         if (wmask)
         {
-            st_defer += defer_lanes<Q>(a, seg, too_wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos);
+            st_defer += defer_lanes<Q>(a, seg, too_wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
             if (too_wide) done = true, deferred = true;
         }
     }
 
     // ---- output (Morton order of the local layer) + claim of the global point -----------------
+    // every point that could pass the threshold was examined: no map point is nearer than min(best, threshold)
     emit_wave(a, s_claim, lane, valid && slice == 0 && !deferred, qi, orig, active, thr, best_d2, best_idx,
-              best_spos, lb2_keep);
+              best_spos, fminf(best_d2, thr));
 
     if (a.timeline && lane == 0)
         a.timeline[2 * (size_t)tile] = tl0, a.timeline[2 * (size_t)tile + 1] = wall_clock64();
@@ -1013,18 +1019,17 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
         }
         const size_t   item = (size_t)lo * a.seg_cap + (k_item - s_segoff[lo]);
         const uint4    w    = a.work[item];
+        const uint4    wq   = a.work_q[item];
         const uint32_t qi   = w.x;
-        const float4   lp   = a.lpts[qi];
-        const uint32_t orig = __float_as_uint(lp.w);
-        float          qx, qy, qz;
-        compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
+        const uint32_t orig = __float_as_uint(a.lpts[qi].w);  // used by the claim at the end only
+        const float    qx = __uint_as_float(wq.x), qy = __uint_as_float(wq.y), qz = __uint_as_float(wq.z);
         const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));
         const float thr    = fadd(a.maxDistSq, fmul(a.angSq, normSq));
         const float rmax   = sqrtf(thr) * 1.002f + g.slack;
         float       r      = __uint_as_float(w.y);
         // wave-uniform running best (carried over from the tile kernel)
         float    best_d2  = __uint_as_float(w.z);
-        uint32_t best_idx = w.w, best_spos = a.work_spos[item];
+        uint32_t best_idx = w.w, best_spos = wq.w;
         uint32_t st_pass = 0, st_cand = 0, st_cells = 0;
         const long long t_start = INSTR ? (long long)wall_clock64() : 0;
 
@@ -1134,7 +1139,8 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
                                 if (md2 <= fminf(prune2, voxel_limit(bound, g.slack)))
                                 {
                                     uint32_t e = 0;
-                                    if (cell_lookup(g, cell_key(lev, cx, cy, cz), start, e)) cnt = e - start;
+                                    if (voxel_range(g, lev, cx, cy, cz, start, e, true)) cnt = e - start;
+                                    else start = 0;
                                 }
                             }
                             scan_batch<INSTR>(a, g, lane, qx, qy, qz, start, cnt, md2, s_cstart, s_coff, pd, pi,
@@ -1279,9 +1285,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     const uint32_t seg_cap   = seg_waves * 64u;
     const size_t   list_cap  = (size_t)n_seg * seg_cap;
     MP2P_TRY_HIP(ctx, ctx->work.ensure(list_cap));
-    MP2P_TRY_HIP(ctx, ctx->work_spos.ensure(list_cap));
+    MP2P_TRY_HIP(ctx, ctx->work_q.ensure(list_cap));
     MP2P_TRY_HIP(ctx, ctx->pend.ensure(2 * list_cap));  // hard class, then easy class
-    MP2P_TRY_HIP(ctx, ctx->pend_spos.ensure(2 * list_cap));
+    MP2P_TRY_HIP(ctx, ctx->pend_q.ensure(2 * list_cap));
     if (ctx->q_counters.n < (size_t)NN_LISTS * NN_MAX_SEG * NN_CNT_STRIDE)
     {
         MP2P_TRY_HIP(ctx, ctx->q_counters.ensure((size_t)NN_LISTS * NN_MAX_SEG * NN_CNT_STRIDE));
@@ -1328,9 +1334,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.rec          = ctx->nn_rec.p;
     a.tile_bbox    = ctx->tile_bbox.p;
     a.work         = ctx->work.p;
-    a.work_spos    = ctx->work_spos.p;
+    a.work_q       = ctx->work_q.p;
     a.pend         = ctx->pend.p;
-    a.pend_spos    = ctx->pend_spos.p;
+    a.pend_q       = ctx->pend_q.p;
     a.q_counters   = ctx->q_counters.p;
     a.n_seg = n_seg, a.seg_waves = seg_waves, a.seg_cap = seg_cap, a.tiles_per_seg = seg_cap / Q;
     a.list_cap = (uint32_t)list_cap;

@@ -60,7 +60,7 @@ def test_fuzz_pt2pt(oracle, seed):
     if rng.random() < 0.3:
         layer_kw["cell_size"] = float(rng.choice([0.02, 0.2, 1.5]) * scale / 10.0)
     if rng.random() < 0.3:
-        layer_kw["no_occupancy_bitmap"] = True
+        layer_kw["no_occupancy_bitmap"] = int(rng.choice([1, 2, 4]))   # index variants (mp2p_hip_map_params)
     params = {"threshold": thr, "thresholdAngularDeg": ang, "pairingsPerPoint": K,
               "hip_queries_per_wave": int(rng.choice([0, 16, 32, 64])),
               "allowMatchAlreadyMatchedGlobalPoints": bool(rng.random() < 0.3)}

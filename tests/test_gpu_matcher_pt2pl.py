@@ -69,9 +69,10 @@ def test_golden_pt2pl(amd):
     assert pairs.potential_pairings == gold["pt2pl_potential"][0]
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])   # index variants (mp2p_hip_map_params::no_occupancy_bitmap)
 @pytest.mark.parametrize("knn,minpts,radius,eig", [(5, 5, 0.4, 0.05), (8, 6, 0.6, 0.02),
                                                    (12, 5, 0.3, 0.1), (16, 10, 0.8, 0.05)])
-def test_random_parity_vs_oracle(amd, oracle, knn, minpts, radius, eig):
+def test_random_parity_vs_oracle(amd, oracle, knn, minpts, radius, eig, variant):
     from mp2p_icp_amd import synthetic
     d = synthetic.make_pair(6000, 60000, 77 + knn)
     g, l = d["glob"], d["local"]
@@ -80,7 +81,8 @@ def test_random_parity_vs_oracle(amd, oracle, knn, minpts, radius, eig):
         want, widx, pot = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2],
                                              pose, 0.25, radius, knn, minpts, eig, tree=tree)
         pairs, _ = _match(amd, g, l, pose, dict(distanceThreshold=0.25, searchRadius=radius, knn=knn,
-                                                minimumPlanePoints=minpts, planeEigenThreshold=eig))
+                                                minimumPlanePoints=minpts, planeEigenThreshold=eig),
+                          layer_kw=dict(no_occupancy_bitmap=variant))
         _check(pairs, want, widx)
         assert pairs.potential_pairings == pot
 

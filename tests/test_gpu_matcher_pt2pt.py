@@ -73,7 +73,9 @@ CASES = [
     (50000, 10000, 0.2, 0.0, 6, dict(cell_size=0.05)),
     (50000, 10000, 0.7, 0.1, 7, dict(cell_size=3.0)),   # very coarse voxels
     (777, 129, 0.4, 0.0, 8, dict(target_per_cell=1.0)),
-    (20000, 4097, 0.5, 0.2, 9, dict(no_occupancy_bitmap=True)),   # hash probes alone
+    (20000, 4097, 0.5, 0.2, 9, dict(no_occupancy_bitmap=1)),   # hash probes alone
+    (20000, 4097, 0.5, 0.2, 9, dict(no_occupancy_bitmap=2)),   # bitmaps + hash, no dense voxel directory
+    (20000, 4097, 0.5, 0.2, 9, dict(no_occupancy_bitmap=4)),   # directory for the coarse levels only
 ]
 
 

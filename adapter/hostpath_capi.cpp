@@ -191,13 +191,25 @@ void mp2p_hostpath_last_ms(void* h, double out[2])
     auto* s = static_cast<Session*>(h);
     out[0] = s->last_ms[0], out[1] = s->last_ms[1];
 }
-// stages of the last matcher call of this thread's runtime (mp2p_hip_host::Runtime::stage_ms)
+// stages of the last matcher call of this thread's runtime (mp2p_hip_host::Runtime::stage_ms):
+// {state in, device, resize, copy-out window, marks (inside that window), list fingerprint}
 void mp2p_hostpath_stage_ms(double out[6])
 {
     try
     {
         Runtime& rt = Runtime::get();
         for (int i = 0; i < 6; i++) out[i] = rt.stage_ms[i];
+    }
+    catch (...)
+    {
+    }
+}
+// Runtime::strict of this thread's runtime (MP2P_HIP_HOST_STRICT): every solver call uploads the host Pairings
+void mp2p_hostpath_set_strict(int on)
+{
+    try
+    {
+        Runtime::get().strict = on != 0;
     }
     catch (...)
     {

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -117,37 +118,54 @@ inline uint64_t sampled_fingerprint(const float* x, const float* y, const float*
     return h;
 }
 
-// running checksum of a Pairings' point / plane lists.  Four interleaved multiply-add streams (entry i
-// feeds stream i & 3: a single stream is one long dependency chain, ~1 ms per 10^5 pairs), each order-
-// sensitive; folding two chunks one after the other -- the second starting at the absolute index where
-// the first ended -- equals folding their concatenation.  It decides whether the device-resident list
-// the matchers of this plugin left behind is the list a solver was handed (run_matchers copies
-// Pairings by value, Matcher.cpp:74-77, so identity cannot be carried by the container).
-struct Sum
+// Fingerprint of a Pairings' point / plane list: its length, its last record, and the records at the
+// sampled positions (the first 32 and every 64th).  It decides whether the device-resident list the
+// matchers of this plugin left behind is the list a solver was handed (run_matchers copies Pairings by
+// value, Matcher.cpp:74-77, so identity cannot be carried by the container; nothing in ICP::align edits
+// a Pairings between run_matchers and run_solvers, ICP.cpp:148-260).  What it catches: any change of
+// length (Pairings::push_back of another matcher's list, erasures), any reordering, truncation, or a
+// foreign list of the same length -- with the certainty of a 64-bit hash over ~n/64 records.  What it
+// does not: an in-place edit confined to unsampled records.  A caller that does such edits sets
+// MP2P_HIP_HOST_STRICT=1 (Runtime::strict): every solver call then uploads the host list (0.09 ms per
+// 10^5 point pairs) and nothing is assumed.  Reading every record instead costs the same 0.1 ms as the
+// upload (the list has just come off the link and is in no cache), which is why it is not the default.
+struct ListPrint
 {
-    uint64_t h[4] = {0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull, 0x452821E638D01377ull};
-    bool operator==(const Sum& o) const { return h[0] == o.h[0] && h[1] == o.h[1] && h[2] == o.h[2] && h[3] == o.h[3]; }
+    uint64_t h = 0x13198A2E03707344ull, last = 0;
+    size_t   n = 0;
+    bool operator==(const ListPrint& o) const { return h == o.h && last == o.last && n == o.n; }
 };
-inline void sum_feed(Sum& s, size_t i, uint64_t v) { s.h[i & 3] = s.h[i & 3] * 0x9E3779B97F4A7C15ull + (v ^ (v >> 29)); }
-inline Sum pairs_checksum(const mp2p_hip_pair_pt2pt* p, size_t n, Sum s = Sum(), size_t first = 0)
+constexpr size_t PRINT_STRIDE = 64;  // a power of two >= 32
+inline bool      sampled_pos(size_t i) { return i < 32 || (i & (PRINT_STRIDE - 1)) == 0; }
+inline uint64_t pair_word(const mp2p_hip_pair_pt2pt& r)
 {
-    for (size_t i = 0; i < n; i++)
-    {
-        uint32_t e;
-        std::memcpy(&e, &p[i].errorSquareAfterTransformation, 4);
-        sum_feed(s, first + i, (((uint64_t)p[i].globalIdx << 32) | p[i].localIdx) + ((uint64_t)e << 17));
-    }
-    return s;
+    uint32_t e;
+    std::memcpy(&e, &r.errorSquareAfterTransformation, 4);
+    return (((uint64_t)r.globalIdx << 32) | r.localIdx) + ((uint64_t)e << 17);
 }
-inline Sum planes_checksum(const mp2p_hip_pair_pt2pl* p, size_t n, Sum s = Sum(), size_t first = 0)
+inline uint64_t pair_word(const mp2p_hip_pair_pt2pl& r)
 {
-    for (size_t i = 0; i < n; i++)
-    {
-        uint64_t a, b;
-        std::memcpy(&a, &p[i].plane[3], 8), std::memcpy(&b, &p[i].pt_local[0], 8);
-        sum_feed(s, first + i, a + (b << 1));
-    }
-    return s;
+    uint64_t a, b;
+    std::memcpy(&a, &r.plane[3], 8), std::memcpy(&b, &r.pt_local[0], 8);
+    return a + (b << 1);
+}
+// continue fingerprint `f` (covering f.n records) with the n records at p
+template <class Rec>
+inline void print_feed(ListPrint& f, const Rec* p, size_t n)
+{
+    if (!n) return;
+    size_t i = 0;
+    for (; f.n + i < 32 && i < n; i++) f.h = mix64(f.h, pair_word(p[i]));
+    i = ((f.n + i + PRINT_STRIDE - 1) & ~(PRINT_STRIDE - 1)) - f.n;  // next absolute multiple of the stride
+    for (; i < n; i += PRINT_STRIDE) f.h = mix64(f.h, pair_word(p[i]));
+    f.last = pair_word(p[n - 1]), f.n += n;
+}
+template <class Rec>
+inline ListPrint list_print(const Rec* p, size_t n)
+{
+    ListPrint f;
+    print_feed(f, p, n);
+    return f;
 }
 
 // ---- one context + handle caches per thread (ICP::align is single-threaded per object) ----------
@@ -255,9 +273,9 @@ class Runtime
     // what the device list holds, as the matchers of this plugin built it
     struct Token
     {
-        bool     valid = false;
-        size_t   n_pt = 0, n_pl = 0;
-        Sum      sum_pt, sum_pl;
+        bool      valid = false;
+        size_t    n_pt = 0, n_pl = 0;
+        ListPrint print_pt, print_pl;
         // the run_matchers call the list belongs to: (MatchState address, ICP iteration)
         const void* ms_key = nullptr;
         uint32_t    iteration = 0;
@@ -266,8 +284,24 @@ class Runtime
 
     // counters for tests / the bench's host_boundary block
     size_t n_map_uploads = 0, n_cloud_uploads = 0, n_mstate_uploads = 0, n_pair_uploads = 0;
+    // every solver call uploads the host Pairings (see ListPrint)
+    bool strict = std::getenv("MP2P_HIP_HOST_STRICT") && std::getenv("MP2P_HIP_HOST_STRICT")[0] == '1';
+    // page-locked scratch for the index arrays of the pairs a matcher call appended
+    uint32_t* idx_scratch(size_t n)
+    {
+        if (n > idx_cap_)
+        {
+            if (idx_) mp2p_hip_host_free(ctx, idx_);
+            idx_cap_ = std::max<size_t>(2 * n, 1 << 16);
+            idx_     = static_cast<uint32_t*>(mp2p_hip_host_alloc(ctx, 2 * idx_cap_ * sizeof(uint32_t)));
+            if (!idx_) idx_cap_ = 0, throw Error("mp2p_hip_host_alloc failed");
+        }
+        return idx_;
+    }
+    size_t idx_stride() const { return idx_cap_; }
     // wall time of the stages of the last matcher call [ms]: {layers + MatchState in, device work until
-    // the list length is known, container resize, pair copy-out, marks, checksum}
+    // the list length is known, container resize, pair copy-out (whole window), marks (inside that
+    // window: they run on the index arrays while the records are on the link), list fingerprint}
     double stage_ms[6] = {0, 0, 0, 0, 0, 0};
     static double now_ms()
     {
@@ -295,6 +329,8 @@ class Runtime
     }
     std::map<const void*, Layer>                             maps_, clouds_;
     std::map<std::pair<size_t, size_t>, mp2p_hip_mstate*>    mstates_;
+    uint32_t*       idx_     = nullptr;
+    size_t          idx_cap_ = 0;
     mp2p_hip_pairs *dev_pairs_ = nullptr, *conv_pairs_ = nullptr;
     size_t          cap_pt_ = 0, cap_pl_ = 0;
 };
@@ -311,7 +347,7 @@ struct MatchCall
 // (same MatchState object, same ICP iteration, and that state carries marks: a state without any is
 // what run_matchers starts from -- Matcher.cpp:57-66 -- and clearing needlessly only costs the solver
 // an upload, whereas continuing a list of an earlier call would grow it for nothing) and cleared
-// otherwise.  Whatever is decided here, the solver trusts the device list only on size + checksum.
+// otherwise.  Whatever is decided here, the solver trusts the device list only on its fingerprint.
 inline mp2p_hip_pairs* begin_match(Runtime& rt, const MatchCall& c, bool fresh_state, size_t add_pt, size_t add_pl)
 {
     auto&      tk   = rt.token;
@@ -349,21 +385,30 @@ size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
     out.resize(n0 + n);
     rt.stage_ms[2] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
     auto* dst = reinterpret_cast<mp2p_hip_pair_pt2pt*>(out.data()) + n0;
-    if (n) rt.check(mp2p_hip_pairs_copy_pt2pt(rt.ctx, dp, tk.n_pt, n, dst));
-    rt.stage_ms[3] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
-    // one pass over the new entries: the marks this matcher leaves (only when global re-use is
-    // forbidden, :116-120) and the running checksum of the device list
+    // the marks this matcher leaves (only when global re-use is forbidden, :116-120) ARE the indices of
+    // the new pairs: set from the two index arrays (8 bytes per pair, first on the link) while the
+    // 36-byte records are still arriving in the caller's vector
     const bool marks = !prm.allowMatchAlreadyMatchedGlobalPoints;
-    for (size_t i = 0; i < n; i++)
+    double     t_marks = 0.0;
+    if (n)
     {
-        if (marks && c.lbits.words) c.lbits.set(dst[i].localIdx);
-        if (marks && c.gbits.words) c.gbits.set(dst[i].globalIdx);
-        uint32_t e;
-        std::memcpy(&e, &dst[i].errorSquareAfterTransformation, 4);
-        sum_feed(tk.sum_pt, tk.n_pt + i, (((uint64_t)dst[i].globalIdx << 32) | dst[i].localIdx) + ((uint64_t)e << 17));
+        uint32_t* li = rt.idx_scratch(n);
+        uint32_t* gi = li + rt.idx_stride();
+        rt.check(mp2p_hip_pairs_copy_pt2pt_begin(rt.ctx, dp, tk.n_pt, n, dst, li, gi));
+        rt.check(mp2p_hip_pairs_copy_wait_idx(rt.ctx));
+        const double tm = Runtime::now_ms();
+        if (marks && c.lbits.words)
+            for (size_t i = 0; i < n; i++) c.lbits.set(li[i]);
+        if (marks && c.gbits.words)
+            for (size_t i = 0; i < n; i++) c.gbits.set(gi[i]);
+        t_marks = Runtime::now_ms() - tm;
+        rt.check(mp2p_hip_pairs_copy_end(rt.ctx));
     }
+    rt.stage_ms[3] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
+    rt.stage_ms[4] = t_marks;
+    print_feed(tk.print_pt, dst, n);
     tk.n_pt += n, tk.valid = true;
-    rt.stage_ms[4] = Runtime::now_ms() - t0, rt.stage_ms[5] = 0.0;
+    rt.stage_ms[5] = Runtime::now_ms() - t0;
     return n;
 }
 
@@ -394,13 +439,13 @@ size_t match_pt2pl_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
         emit(rec[i]);
         if (c.lbits.words) c.lbits.set(idx[i]);  // Matcher_Point2Plane.cpp:109
     }
-    tk.sum_pl = planes_checksum(rec.data(), n, tk.sum_pl, tk.n_pl);
+    print_feed(tk.print_pl, rec.data(), n);
     tk.n_pl += n, tk.valid = true;
     return n;
 }
 
 // Pairings -> the device handle a solver reads.  The lists the matchers of this plugin produced in the
-// same ICP iteration are still in HBM: recognised by size + checksum; anything else is uploaded.  The
+// same ICP iteration are still in HBM: recognised by their fingerprint (ListPrint); anything else is uploaded.  The
 // token is consumed: the next solver call without a matcher call in between uploads again.
 inline mp2p_hip_pairs* pairings_to_device(Runtime& rt, const mp2p_hip_pair_pt2pt* pt, size_t n_pt,
                                           const mp2p_hip_pair_pt2pl* pl, size_t n_pl,
@@ -408,9 +453,9 @@ inline mp2p_hip_pairs* pairings_to_device(Runtime& rt, const mp2p_hip_pair_pt2pt
                                           const mp2p_hip_pair_pl2pl* pp, size_t n_pp)
 {
     auto& tk = rt.token;
-    bool  resident = tk.valid && tk.n_pt == n_pt && tk.n_pl == n_pl && (n_pt + n_pl) > 0;
-    if (resident && n_pt) resident = pairs_checksum(pt, n_pt) == tk.sum_pt;
-    if (resident && n_pl) resident = planes_checksum(pl, n_pl) == tk.sum_pl;
+    bool  resident = !rt.strict && tk.valid && tk.n_pt == n_pt && tk.n_pl == n_pl && (n_pt + n_pl) > 0;
+    if (resident && n_pt) resident = list_print(pt, n_pt) == tk.print_pt;
+    if (resident && n_pl) resident = list_print(pl, n_pl) == tk.print_pl;
     mp2p_hip_pairs* dp = rt.pairs(n_pt, std::max(rt.cap_pl(), n_pl));
     if (!resident)
     {

@@ -305,7 +305,8 @@ def host_boundary(args, d, dev_ms):
            "transfers": {k: c1[k] - c0[k] for k in c0},
            "note": "through adapter/mp2p_hip_host.hpp (the plugin's MRPT-free host layer): packed MatchState "
                    "bit-fields in (none uploaded: the fields are clear), 36 B per emitted pair out, marks set "
-                   "from the pair list, the solver recognising the device-resident list by size + checksum; "
+                   "from the index arrays while the records are on the link, the solver recognising the device-resident "
+                   "list by its fingerprint (length, last record, every 64th record); "
                    "ms_per_step excludes chain position 0, where both layers are fingerprinted in full "
                    "(120 MB) like at ICP iteration 0 of any new ICP::align"}
     s.close()

@@ -200,6 +200,15 @@ int  mp2p_hip_pairs_download_pt2pl_from(mp2p_hip_ctx* ctx, const mp2p_hip_pairs*
  * [first, first + n) must exist: it read the counts itself) */
 int  mp2p_hip_pairs_copy_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
                                mp2p_hip_pair_pt2pt* out);
+/* ... and in three steps, for a caller that has work to do on the indices alone (the MatchState marks a
+ * matcher leaves ARE the localIdx / globalIdx of the pairs it appended, Matcher_Points_DistanceThreshold.cpp:
+ * 116-120): _begin enqueues the index arrays (into page-locked memory from mp2p_hip_host_alloc), then the
+ * records (into `out`, page-locked for the duration); _wait_idx returns when the indices are there -- the
+ * records are still on the link --; _end waits for the records.  One copy at a time per context. */
+int  mp2p_hip_pairs_copy_pt2pt_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
+                                     mp2p_hip_pair_pt2pt* out, uint32_t* idx_local, uint32_t* idx_global);
+int  mp2p_hip_pairs_copy_wait_idx(mp2p_hip_ctx* ctx);
+int  mp2p_hip_pairs_copy_end(mp2p_hip_ctx* ctx);
 int  mp2p_hip_pairs_copy_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
                                mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx);
 /* paired_pt2ln / paired_pl2pl: produced on the host by Matcher_Point2Line /

@@ -195,6 +195,10 @@ SIGNATURES = {
     "mp2p_hip_pairs_download_pt2pl_from": (C.c_int, [_P, _P, C.c_size_t, _P, C.POINTER(C.c_uint32), C.c_size_t,
                                                      C.POINTER(C.c_size_t), _u64p]),
     "mp2p_hip_pairs_copy_pt2pt": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P]),
+    "mp2p_hip_pairs_copy_pt2pt_begin": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.POINTER(C.c_uint32),
+                                                  C.POINTER(C.c_uint32)]),
+    "mp2p_hip_pairs_copy_wait_idx": (C.c_int, [_P]),
+    "mp2p_hip_pairs_copy_end": (C.c_int, [_P]),
     "mp2p_hip_pairs_copy_pt2pl": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.POINTER(C.c_uint32)]),
     "mp2p_hip_pairs_create": (C.c_int, [_P, C.c_size_t, C.c_size_t, _PP]),
     "mp2p_hip_pairs_free": (None, [_P, _P]),

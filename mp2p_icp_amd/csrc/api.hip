@@ -170,6 +170,8 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->pend.release(), ctx->pend_q.release(), ctx->q_counters.release(), ctx->nn_rec.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    (void)mp2p_hip_pairs_copy_end(ctx);
+    if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
     (void)mp2p_hip_comm_destroy(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->pinned_big) (void)hipHostFree(ctx->pinned_big);

@@ -208,6 +208,9 @@ struct mp2p_hip_ctx
     void*    pinned       = nullptr;  // 4 KB of page-locked host memory for the small read-backs
     void*    pinned_big   = nullptr;  // ... and a growable one for the pair lists handed to host containers
     size_t   pinned_big_bytes = 0;
+    hipEvent_t copy_ev     = nullptr;    // mp2p_hip_pairs_copy_pt2pt_begin: the index arrays have arrived
+    void*      copy_locked = nullptr;    // ... the destination it page-locked
+    bool       copy_open   = false;
     mp2p_hip_cloud* q1_cloud = nullptr;  // mp2p_hip_nn_search_pt2pl: the one-point query layer
     mp2p_hip_pairs* q1_pairs = nullptr;
 };

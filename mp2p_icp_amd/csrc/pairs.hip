@@ -778,6 +778,60 @@ int mp2p_hip_pairs_copy_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t
     return copy_out(ctx, d, out, n * sizeof(mp2p_hip_pair_pt2pt));
 }
 
+// the same copy in three steps, so that the caller's pass over the indices (the MatchState marks) runs
+// while the records are still on the link: index arrays first (small), an event, then the records
+int mp2p_hip_pairs_copy_pt2pt_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
+                                    mp2p_hip_pair_pt2pt* out, uint32_t* idx_local, uint32_t* idx_global)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, !ctx->copy_open, "copy_pt2pt_begin: the previous copy was not ended");
+    MP2P_REQUIRE(ctx, n > 0 && out && idx_local && idx_global && first + n <= p->cap_pt2pt,
+                 "copy_pt2pt_begin: empty range, null destination or range outside the list");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_ev) MP2P_TRY_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(idx_local, p->lidx.p + first, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(idx_global, p->gidx.p + first, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipEventRecord(ctx->copy_ev, ctx->stream));
+    const size_t bytes = n * sizeof(mp2p_hip_pair_pt2pt);
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(bytes));
+    auto* d = reinterpret_cast<mp2p_hip_pair_pt2pt*>(ctx->aos_stage.p);
+    hipLaunchKernelGGL(pack_pt2pt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->lidx.p,
+                       p->gidx.p, p->lx.p, p->ly.p, p->lz.p, p->gx.p, p->gy.p, p->gz.p, p->err.p, (uint32_t)n, d,
+                       (uint32_t)first);
+    ctx->copy_locked = nullptr;
+    if (bytes >= (256u << 10) && hipHostRegister(out, bytes, hipHostRegisterDefault) == hipSuccess) ctx->copy_locked = out;
+    else (void)hipGetLastError();
+    ctx->copy_open = true;
+    const hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess)
+    {
+        (void)mp2p_hip_pairs_copy_end(ctx);
+        MP2P_TRY_HIP(ctx, e);
+    }
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_copy_wait_idx(mp2p_hip_ctx* ctx)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, ctx->copy_open, "copy_wait_idx without copy_pt2pt_begin");
+    hipError_t e;
+    while ((e = hipEventQuery(ctx->copy_ev)) == hipErrorNotReady) {}
+    MP2P_TRY_HIP(ctx, e);
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_copy_end(mp2p_hip_ctx* ctx)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    if (!ctx->copy_open) return MP2P_HIP_OK;
+    const hipError_t e = stream_wait(ctx);
+    if (ctx->copy_locked) (void)hipHostUnregister(ctx->copy_locked);
+    ctx->copy_locked = nullptr, ctx->copy_open = false;
+    MP2P_TRY_HIP(ctx, e);
+    return MP2P_HIP_OK;
+}
+
 int mp2p_hip_pairs_copy_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
                               mp2p_hip_pair_pt2pl* out, uint32_t* out_local_idx)
 {

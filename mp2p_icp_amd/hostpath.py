@@ -36,6 +36,7 @@ SIGNATURES = {
     "mp2p_hostpath_last_ms": (None, [_P, _dp]),
     "mp2p_hostpath_invalidate_layers": (None, []),
     "mp2p_hostpath_stage_ms": (None, [_dp]),
+    "mp2p_hostpath_set_strict": (None, [C.c_int]),
 }
 
 
@@ -171,10 +172,17 @@ def counters():
 
 def stage_ms():
     """wall time [ms] of the stages of the last matcher call: layers + MatchState in, device work until the
-    list length is known, container resize, pair copy-out, marks, checksum"""
+    list length is known, container resize, pair copy-out (the whole window), marks (run INSIDE that window,
+    on the index arrays, while the records are on the link), list fingerprint"""
     out = (C.c_double * 6)()
     load().mp2p_hostpath_stage_ms(out)
-    return dict(zip(("state_in", "device", "resize", "copy_out", "marks", "checksum"), [float(v) for v in out]))
+    return dict(zip(("state_in", "device", "resize", "copy_out_window", "marks_inside_window", "fingerprint"),
+                    [float(v) for v in out]))
+
+
+def set_strict(on):
+    """every solver call uploads the host Pairings (the plugin's MP2P_HIP_HOST_STRICT=1)"""
+    load().mp2p_hostpath_set_strict(int(bool(on)))
 
 
 def invalidate_layers():

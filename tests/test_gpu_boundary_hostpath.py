@@ -154,6 +154,78 @@ def test_two_matchers_one_solver_and_foreign_pairings(oracle):
     s.close()
 
 
+def test_resident_list_fingerprint_and_strict_mode(oracle):
+    """The solver takes the device-resident list only when the host list has its fingerprint (length, last
+    record, the first 32 and every 64th record): the matcher's own list -> no upload; the same records in
+    another order, a list cut short, a sampled record edited -> uploaded, and the solve is the solve of the
+    HOST list.  Strict mode uploads always."""
+    from mp2p_icp_amd import hostpath, synthetic
+    d = synthetic.make_pair(30_000, 300_000, 11)
+    g, l = d["glob"], d["local"]
+    s = hostpath.Session(g, l)
+    gnp = _gn_prm()
+    oprm = oracle.make_gn_params(3, kernel=oracle.KERNEL_GEMANMCCLURE, kernelParam=0.15)
+
+    def oracle_pose(P):
+        o = np.zeros(len(P), oracle.PAIR_PT2PT)
+        o["globalIdx"], o["localIdx"] = P["globalIdx"], P["localIdx"]
+        o["gx"], o["gy"], o["gz"] = P["global"].T
+        o["lx"], o["ly"], o["lz"] = P["local"].T
+        o["errSq"] = P["errorSquareAfterTransformation"]
+        return oracle.optimal_tf_gauss_newton(o, None, None, d["T_init"], oprm)[0]
+
+    def fresh():
+        s.begin_iteration()
+        assert s.match_pt2pt(d["T_init"], _pt2pt_prm(1.0)) > 1000
+        return s.pairs_pt2pt()
+
+    def uploads():
+        return hostpath.counters()["pairings_uploads"]
+
+    P = fresh()
+    u = uploads()
+    pose, _ = s.solve_gn(d["T_init"], gnp)
+    assert uploads() == u                                   # the matcher's own list
+    dt, dr = oracle.pose_err_split(pose, oracle_pose(P))
+    assert dt < 1e-5 and dr < 1e-5
+    for name, edit in (("reversed", lambda Q: Q[::-1].copy()),
+                       ("cut short", lambda Q: Q[:-1].copy()),
+                       ("two records swapped at a sampled position", lambda Q: _swap(Q, 64, 65)),
+                       ("last record edited", lambda Q: _poke(Q, len(Q) - 1))):
+        P = fresh()
+        Q = edit(P)
+        s.set_pairings(Q, None)
+        u = uploads()
+        pose, _ = s.solve_gn(d["T_init"], gnp)
+        assert uploads() == u + 1, name
+        dt, dr = oracle.pose_err_split(pose, oracle_pose(Q))
+        assert dt < 1e-5 and dr < 1e-5, name
+    hostpath.set_strict(True)
+    try:
+        P = fresh()
+        u = uploads()
+        pose, _ = s.solve_gn(d["T_init"], gnp)
+        assert uploads() == u + 1
+        dt, dr = oracle.pose_err_split(pose, oracle_pose(P))
+        assert dt < 1e-5 and dr < 1e-5
+    finally:
+        hostpath.set_strict(False)
+    s.close()
+
+
+def _swap(Q, i, j):
+    Q = Q.copy()
+    Q[[i, j]] = Q[[j, i]]
+    return Q
+
+
+def _poke(Q, i):
+    Q = Q.copy()
+    Q["local"][i] += np.float32(0.25)
+    Q["localIdx"][i] ^= 1
+    return Q
+
+
 def test_layer_change_detection(oracle):
     """a layer edited in place: found by the full fingerprint at ICP iteration 0 (and after
     invalidate_layers()); later iterations of one align only pay the sampled check"""
@@ -186,7 +258,7 @@ def test_layer_change_detection(oracle):
 @pytest.mark.timeout(600)
 def test_host_path_cost_at_full_size(oracle):
     """1 M x 10 M: a step through host containers (fresh MatchState, pairs into a host vector, marks,
-    solver finding the list resident) stays within 2.5x of the device-resident step; the lists are the
+    solver finding the list resident) stays close to the device-resident step (regression bound 2.3x); the lists are the
     device-resident path's lists."""
     import mp2p_icp_amd as amd
     from mp2p_icp_amd import core, hostpath, synthetic
@@ -231,5 +303,5 @@ def test_host_path_cost_at_full_size(oracle):
     assert c1["mstate_uploads"] == c0["mstate_uploads"] and c1["pairings_uploads"] == c0["pairings_uploads"], trace
     assert c1["map_uploads"] - c0["map_uploads"] <= 1 and c1["cloud_uploads"] - c0["cloud_uploads"] <= 1
     print(f"\n[host path] device-resident step {t_dev * 1e3:.3f} ms, host-container step {t_host * 1e3:.3f} ms")
-    assert t_host < 2.5 * t_dev + 2e-4, (t_host, t_dev)
+    assert t_host < 2.3 * t_dev + 1e-4, (t_host, t_dev)   # regression bound; bench.py host_boundary reports the ratio (1.8)
     s.close()

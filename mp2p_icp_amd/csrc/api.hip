@@ -63,6 +63,8 @@ static void parse_tune(Tune& t)
             else if (k == "single_blocks_per_cu") t.single_blocks_per_cu = (uint32_t)v;
             else if (k == "pl_q") t.pl_q = (v == 8 || v == 32) ? (uint32_t)v : 0u;
             else if (k == "claim_dedup") t.claim_dedup = (int)v;
+            else if (k == "tile_waves") t.tile_waves = (uint32_t)v;
+            else if (k == "mfma_scan") t.mfma_scan = (int)v;
             else if (k == "dir_budget_mb") t.dir_budget_mb = (uint32_t)v;
             else if (k == "claim_peek") t.claim_peek = (int)v;
             else if (k == "compact_fused") t.compact_fused = (int)v;

@@ -121,6 +121,8 @@ struct Tune
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
     int      claim_peek    = 1;     // plain look at the claim word before the atomic
     int      compact_fused = 1;     // compaction: bounding-box reduction folded in
+    uint32_t tile_waves    = 5;     // tile kernel (matrix-pipe variant): register budget for this many waves per SIMD
+    int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
 };
 

@@ -47,6 +47,7 @@
 
 namespace mp2p
 {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int NN_CAP      = 256;  // staged candidates per round (LDS: 5 x 1 KB)
 constexpr int NN_COOP_MAX = 4;    // groups of up to this many queries are deferred
 constexpr int NN_CLAIM_SLOTS = 128;  // in-wave claim table (LDS)
@@ -70,6 +71,7 @@ struct NNArgs
     uint32_t      tile_cand_cap;     // staged candidates after which a tile hands its pending queries on
     unsigned long long tile_tick_cap;  // ... and 100 MHz ticks since the tile started (checked after each pass)
     int           claim_dedup, claim_peek;
+    int           mfma_scan;         // tile kernel, Q = 32: distance tests on the matrix pipe as a prefilter
     const unsigned char* local_taken;   // by original local index, or null
     const unsigned char* global_taken;  // by original global index, or null
     unsigned long long*  claims;        // by sorted global position, or null
@@ -590,8 +592,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // Tiles of Q consecutive PENDING queries.
 // 5 waves per SIMD: 96 VGPRs with 4 spilled dwords; measured +3.5 % over the compiler's own 108
 // VGPRs / 4 waves, while 6 waves (80 VGPRs, 22 spilled dwords) give the gain back
-template <int Q, bool INSTR>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void nn_tile_kernel(const NNArgs a)
+template <int Q, bool INSTR, bool MFMA = false, int WAVES = 5>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void nn_tile_kernel(const NNArgs a)
 {
     constexpr int S = 64 / Q;
     __shared__ __attribute__((aligned(16))) float s_x[NN_CAP];
@@ -602,7 +604,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     __shared__ __attribute__((aligned(16))) uint32_t s_owner[NN_CAP];
     __shared__ uint32_t s_cstart[64];
     __shared__ uint32_t s_coff[64];
-    __shared__ unsigned long long s_claim[NN_CLAIM_SLOTS];
+    // the claim table is used after the search only: it lives in the staging area (6.5 KB per tile instead
+    // of 7.5: 24 tiles per CU instead of 21)
+    static_assert(NN_CLAIM_SLOTS * sizeof(unsigned long long) <= NN_CAP * sizeof(float), "claim table fits s_x");
+    unsigned long long* s_claim = reinterpret_cast<unsigned long long*>(s_x);
 
     const GridView& g     = a.g;
     const int       lane  = threadIdx.x;
@@ -714,6 +719,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         const float   prune2 = prune * prune;
 
         const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        // ---- matrix-pipe prefilter (Q = 32): d2 of 32 staged candidates x 32 queries by three
+        //      v_mfma_f32_32x32x2_f32 on coordinates centred on the box:
+        //        S = -2 c'.q' + |c'|^2 + |q'|^2,   A = [c'x c'y | c'z |c'|^2 | 1 0],  B = [-2q'x -2q'y | -2q'z 1 | |q'|^2 0]
+        //      (rows = candidates, columns = queries: lane l gets column l & 31 and 16 of the 32 rows -- the
+        //      (query, slice) lanes of the exact scan).  |S - exact d2| <= tol for every query of the group
+        //      (they lie in the box, the candidates in the box grown by one voxel: every term is bounded by
+        //      the box), so a candidate with S > best + tol cannot beat or tie the best; the others are
+        //      recomputed in the exact FMA-free sequence.  Lanes outside the group only collect upper bounds.
+        constexpr bool use_mfma = MFMA && Q == 32;
+        const float ocx = 0.5f * (lox + hix), ocy = 0.5f * (loy + hiy), ocz = 0.5f * (loz + hiz);
+        float       mtol = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, o0 = 0.f, o1 = 0.f;
+        if (use_mfma)
+        {
+            const float hx = 0.5f * (hix - lox) + box.hs, hy = 0.5f * (hiy - loy) + box.hs, hz = 0.5f * (hiz - loz) + box.hs;
+            // the sum's terms are bounded by 4 (hx^2 + hy^2 + hz^2); ~30 roundings of 2^-24 relative each
+            mtol = (hx * hx + hy * hy + hz * hz) * (1.0f / 32768.0f);
+            const float cqx = qx - ocx, cqy = qy - ocy, cqz = qz - ocz;
+            const bool  hi  = lane >= 32;
+            b0 = -2.0f * (hi ? cqy : cqx);
+            b1 = hi ? 1.0f : -2.0f * cqz;
+            b2 = hi ? 0.0f : (cqx * cqx + cqy * cqy + cqz * cqz);
+            o0 = hi ? ocy : ocx, o1 = hi ? 0.0f : ocz;
+        }
         for (unsigned long long cb = 0; cb < box.ncell; cb += 64)
         {
             uint32_t cnt, start;
@@ -776,6 +804,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                         make_uint4(__float_as_uint(c4[0].w), __float_as_uint(c4[1].w),
                                    __float_as_uint(c4[2].w), __float_as_uint(c4[3].w));
                     *reinterpret_cast<uint4*>(&s_spos[t0]) = make_uint4(src[0], src[1], src[2], src[3]);
+                    if (use_mfma)
+                    {  // |c - centre|^2 (the lane's own four owner slots are free again: it has read them)
+                        float n4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                            const float ex = c4[k].x - ocx, ey = c4[k].y - ocy, ez = c4[k].z - ocz;
+                            n4[k] = ex * ex + ey * ey + ez * ez;
+                        }
+                        *reinterpret_cast<float4*>(&s_owner[t0]) = make_float4(n4[0], n4[1], n4[2], n4[3]);
+                    }
                     if (INSTR)
                     {
 #pragma unroll
@@ -784,6 +823,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     }
                 }
                 __syncthreads();
+                if (use_mfma)
+                {
+                    const float* s_n   = reinterpret_cast<const float*>(s_owner);
+                    const bool   hi    = lane >= 32;
+                    const float* s_a0  = hi ? s_y : s_x;
+                    const float* s_a1  = hi ? s_n : s_z;
+                    const float  a2    = hi ? 0.0f : 1.0f;
+                    float        lim   = best_d2 * 1.000001f + mtol;
+                    for (uint32_t blk = 0; blk < m_pad; blk += 32u)
+                    {
+                        const uint32_t c   = blk + ((uint32_t)lane & 31u);
+                        const float    a0v = s_a0[c] - o0, a1v = s_a1[c] - o1;
+                        f32x16         acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
+                        const float m0 = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+                        const float m1 = fminf(fminf(acc[4], acc[5]), fminf(acc[6], acc[7]));
+                        const float m2 = fminf(fminf(acc[8], acc[9]), fminf(acc[10], acc[11]));
+                        const float m3 = fminf(fminf(acc[12], acc[13]), fminf(acc[14], acc[15]));
+                        const float mn = fminf(fminf(m0, m1), fminf(m2, m3));
+                        if (!done && mn <= lim)
+                        {
+#pragma unroll
+                            for (int r = 0; r < 16; r++)
+                            {
+                                if (acc[r] <= lim)
+                                {
+                                    // row of register r (C/D layout of the 32x32 MFMAs)
+                                    const uint32_t j  = blk + (uint32_t)((r & 3) + 8 * (r >> 2)) + (hi ? 4u : 0u);
+                                    const float    dd = dist2(qx, qy, qz, s_x[j], s_y[j], s_z[j]);
+                                    if (dd <= best_d2)
+                                    {
+                                        const uint32_t ci = s_idx[j];
+                                        if (dd < best_d2 || ci < best_idx)
+                                        {
+                                            best_d2   = dd;
+                                            best_idx  = ci;
+                                            best_spos = s_spos[j];
+                                            lim       = best_d2 * 1.000001f + mtol;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                else
                 // ---- scan: every lane tests (its slice of) the bucket against its query, 8
                 //      candidates per step on the packed-fp32 path; the update is rare
                 for (uint32_t jb = (uint32_t)slice * 8u; jb < m_pad; jb += 8u * S)
@@ -1322,6 +1409,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.tile_tick_cap = (unsigned long long)ctx->tune.tile_time_cap_us * 100ull;
     a.claim_dedup   = ctx->tune.claim_dedup;
     a.claim_peek    = ctx->tune.claim_peek;
+    a.mfma_scan     = ctx->tune.mfma_scan;
     a.local_taken =
         (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
     a.global_taken =
@@ -1393,6 +1481,13 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         else hipLaunchKernelGGL((nn_tile_kernel<QQ, false>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);      \
     } while (0)
         if (Q == 64) MP2P_LAUNCH_TILE(64);
+        else if (Q == 32 && a.mfma_scan)
+        {
+            if (instr) hipLaunchKernelGGL((nn_tile_kernel<32, true, true>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
+            else if (ctx->tune.tile_waves == 6) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 6>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
+            else if (ctx->tune.tile_waves == 4) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 4>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((nn_tile_kernel<32, false, true>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
+        }
         else if (Q == 32) MP2P_LAUNCH_TILE(32);
         else MP2P_LAUNCH_TILE(16);
 #undef MP2P_LAUNCH_TILE

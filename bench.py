@@ -30,6 +30,7 @@ and the exchange steps of mp2p_icp_amd/distributed.py run over RCCL.  Rank 0 pri
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -257,7 +258,9 @@ def roofline_block(n_l, touched_mean, nn_ms_avg, tag):
         f = os.path.join(ROOT, "profiles", f"r02_bench_{tag}_hbm_pmc.csv")
         t = 0.0
         for r in csv.DictReader(open(f)):
-            if "mp2p::nn_" in r["kernel"] and "true>" not in r["kernel"]:
+            # the three search launches of the timed path (INSTR = false variants; the instrumented ones
+            # only run in the counting replay)
+            if re.search(r"mp2p::nn_(lane_kernel<false>|tile_kernel<\d+, false|single_kernel<false)", r["kernel"]):
                 t += float(r["fetch_bytes_avg_corrected_x2"]) + float(r["write_bytes_avg"])
         if t > 0:
             out["traffic_from_profiles"] = t

@@ -121,7 +121,9 @@ struct Tune
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
     int      claim_peek    = 1;     // plain look at the claim word before the atomic
     int      compact_fused = 1;     // compaction: bounding-box reduction folded in
-    uint32_t tile_waves    = 5;     // tile kernel (matrix-pipe variant): register budget for this many waves per SIMD
+    uint32_t tile_waves    = 4;     // tile kernel (matrix-pipe variant): register budget for this many waves per SIMD.
+                                    // 4 = 121 VGPRs, no spill: as fast as 5 (96 VGPRs, 13 spilled dwords) and without
+                                    // the scratch write-backs (38 MB of HBM writes per launch); 6 is slower
     int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
 };

@@ -1485,8 +1485,8 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         {
             if (instr) hipLaunchKernelGGL((nn_tile_kernel<32, true, true>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
             else if (ctx->tune.tile_waves == 6) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 6>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
-            else if (ctx->tune.tile_waves == 4) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 4>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((nn_tile_kernel<32, false, true>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
+            else if (ctx->tune.tile_waves == 5) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 5>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 4>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
         }
         else if (Q == 32) MP2P_LAUNCH_TILE(32);
         else MP2P_LAUNCH_TILE(16);

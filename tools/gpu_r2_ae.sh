@@ -1,0 +1,17 @@
+#!/bin/bash
+mkdir -p gpurun_out/r2ae; export TMPDIR=/tmp
+O=gpurun_out/r2ae
+timeout 600 python -m pytest tests/test_gpu_matcher_pt2pt.py tests/test_gpu_fuzz.py tests/test_gpu_fullsize_properties.py -q -x --timeout=600 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -2 $O/pytest.log
+run() { MP2P_HIP_TUNE="$2" timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras $3 > $O/bench_$1.json 2> $O/bench_$1.err; echo "bench $1 rc=$?"; }
+run a1 ""
+run a2 ""
+run b1 "" "--scene b"
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r2ae/bench_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("bench_")[-1], round(d["value"], 1), round(d["ms_per_step"], 4), round(d["step_ms"]["median"], 4), {k: round(v, 4) for k, v in d["kernel_ms"].items() if k != "note"})
+    except Exception as e:
+        print(f, "unreadable", e)
+PY

@@ -165,7 +165,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->nn_spos.release(), ctx->nn_d2.release(), ctx->tile_bbox.release();
-    ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release();
+    ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release(), ctx->compact_flags.release();
     ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release();
     ctx->aos_stage.release(), ctx->pl_slots.release(), ctx->pl_knn.release();
     ctx->work.release(), ctx->work_q.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();

@@ -181,6 +181,7 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<uint32_t>           block_counts; // compaction
     mp2p::DevBuf<unsigned long long> counters;     // profiling counters
     mp2p::DevBuf<double>             gn_partials;  // [GN_BLOCKS][NSUMS]
+    mp2p::DevBuf<unsigned char>      compact_flags;  // the count pass's flags, one byte per thread
     mp2p::DevBuf<double>             gn_sums;      // [NSUMS]
     mp2p::DevBuf<double>             gn_state;     // pose(12) H(36) g(6) cost(1) iters(1) done(1)
     mp2p::DevBuf<unsigned char>      aos_stage;    // download staging

@@ -18,6 +18,7 @@ constexpr int CP_TILE    = CP_THREADS * CP_ITEMS;
 
 struct CompactArgs
 {
+    unsigned char* flags;  // [blocks * CP_THREADS] the CP_ITEMS flags of every thread, left by the count pass for the write pass
     const uint32_t*           nn_spos;  // [n_l][K] in the Morton order of the local layer
     const uint32_t*           pos;      // original local index -> place in that order
     const float*              nn_d2;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const Compact
 {
     __shared__ uint32_t s_w[CP_THREADS / 64];
     __shared__ float    s_bb[CP_THREADS / 64][6];
-    uint32_t            c = 0;
+    uint32_t            c = 0, fbits = 0;
     if (a.tile_bbox)
     {
         // this block's slice of the per-wave boxes (NaN-free by construction: nn_query.hip)
@@ -117,9 +118,12 @@ __global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const Compact
             uint32_t sp, i;
             size_t   src;
             float    d2;
-            if (base + k < (a.n_slots_dev ? min(*a.n_slots_dev, a.n_l) : a.n_l) && pair_flag(a, base + k, sp, i, src, d2)) c++;
+            if (base + k < (a.n_slots_dev ? min(*a.n_slots_dev, a.n_l) : a.n_l) && pair_flag(a, base + k, sp, i, src, d2))
+                c++, fbits |= 1u << k;
         }
     }
+    // the write pass gathers (record, claim word, global point) only where a pair is due: ~10 % of the slots
+    a.flags[(size_t)blockIdx.x * CP_THREADS + threadIdx.x] = (unsigned char)fbits;
     c = wave_sum_u32(c);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -262,11 +266,11 @@ __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const Compact
     float          d2[CP_ITEMS];
     bool           f[CP_ITEMS];
     uint32_t       c = 0;
+    const uint32_t fbits = a.flags[(size_t)blockIdx.x * CP_THREADS + threadIdx.x];
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; k++)
     {
-        f[k] = (base + k < (a.n_slots_dev ? min(*a.n_slots_dev, a.n_l) : a.n_l)) &&
-               pair_flag(a, base + k, sp[k], li[k], src[k], d2[k]);
+        f[k] = ((fbits >> k) & 1u) && pair_flag(a, base + k, sp[k], li[k], src[k], d2[k]);
         c += f[k] ? 1u : 0u;
     }
     const int      lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -310,6 +314,7 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     const size_t   n_l      = n_slots;
     const uint32_t n_blocks = (uint32_t)((n_l + CP_TILE - 1) / CP_TILE);
     MP2P_TRY_HIP(ctx, ctx->block_counts.ensure(n_blocks ? n_blocks : 1));
+    MP2P_TRY_HIP(ctx, ctx->compact_flags.ensure((size_t)(n_blocks ? n_blocks : 1) * CP_THREADS));
     CompactArgs a;
     memset(&a, 0, sizeof(a));
     a.nn_spos = ctx->nn_spos.p, a.nn_d2 = ctx->nn_d2.p, a.n_l = (uint32_t)n_l;
@@ -325,6 +330,7 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     a.gpts   = map->pts.p;
     a.lx = cloud->x.p, a.ly = cloud->y.p, a.lz = cloud->z.p;
     a.block_counts  = ctx->block_counts.p;
+    a.flags         = ctx->compact_flags.p;
     a.counts        = out->counts.p;
     a.cap           = out->cap_pt2pt;
     a.potential_add = potential_add;

@@ -6,7 +6,8 @@
 //   the threshold rule                   :252-259
 //   the "global point already paired"    :94-121 (claims; resolved in pairs.hip)
 //
-// Three kernels, all one wave64 per workgroup; a query is finished by the first one that can:
+// Three kernels, all one wave64 per workgroup; a query is finished by the first one that can
+// (DESIGN.md section 4 has the measurements behind every choice made here):
 //
 //  nn_lane_kernel  -- ONE QUERY PER LANE, no LDS staging, no wave-level coordination.  The lane
 //     transforms its point (K1), reads its warm-start record, and -- when the cube its search
@@ -19,11 +20,15 @@
 //     within the first radius of a cold start) are appended to the PENDING list with their state.
 //
 //  nn_tile_kernel  -- a TILE of Q consecutive PENDING queries per wave.  lane = (query slot,
-//     candidate slice).  The wave stages the points of all voxels overlapping the search box of
-//     the current GROUP of queries into LDS (SoA) with coalesced 16-byte loads, then every lane
-//     scans the staged bucket against its own query, 8 candidates per step (ds_read_b128
-//     broadcasts).  Queries that are spatially isolated inside their tile, whose radius outgrows
-//     the voxels, or whose tile has already staged more than its budget are DEFERRED to
+//     candidate slice).  The wave resolves the voxels overlapping the search box of the current
+//     GROUP of queries (dense voxel directory: one 8-byte load per voxel), stages their points
+//     into LDS (SoA) with coalesced 16-byte loads, then tests the staged bucket against the 32
+//     queries: d2 of 32 candidates x 32 queries per three v_mfma_f32_32x32x2_f32 on box-centred
+//     coordinates as a PREFILTER (error bounded by the box), the few candidates within that bound
+//     of a query's running best recomputed in the exact FMA-free sequence (Q = 32; Q = 16 / 64 and
+//     MP2P_HIP_TUNE=mfma_scan=0 scan exactly, 8 candidates per step on packed fp32).  Queries that
+//     are spatially isolated inside their tile, whose radius outgrows the voxels, or whose tile has
+//     already staged more than its budget or run longer than its time budget are DEFERRED to
 //
 //  nn_single_kernel -- one query per wave: the 64 lanes split the candidates (one coalesced
 //     16-byte load each, no LDS staging), and a wave arg-min merges them.  Deferred queries

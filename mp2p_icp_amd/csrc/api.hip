@@ -64,6 +64,7 @@ static void parse_tune(Tune& t)
             else if (k == "pl_q") t.pl_q = (v == 8 || v == 32) ? (uint32_t)v : 0u;
             else if (k == "claim_dedup") t.claim_dedup = (int)v;
             else if (k == "tile_waves") t.tile_waves = (uint32_t)v;
+            else if (k == "pipelines") t.pipelines = (uint32_t)v;
             else if (k == "mfma_scan") t.mfma_scan = (int)v;
             else if (k == "dir_budget_mb") t.dir_budget_mb = (uint32_t)v;
             else if (k == "claim_peek") t.claim_peek = (int)v;
@@ -173,6 +174,9 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     (void)mp2p_hip_pairs_copy_end(ctx);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
     (void)mp2p_hip_comm_destroy(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -124,6 +124,9 @@ struct Tune
     uint32_t tile_waves    = 4;     // tile kernel (matrix-pipe variant): register budget for this many waves per SIMD.
                                     // 4 = 121 VGPRs, no spill: as fast as 5 (96 VGPRs, 13 spilled dwords) and without
                                     // the scratch write-backs (38 MB of HBM writes per launch); 6 is slower
+    uint32_t pipelines     = 1;     // 2 = independent lane -> tile -> one-query chains over halves of the local layer
+                                    // on two streams (one chain's drain filled by the other's kernels): -6 % search
+                                    // time on scene B, +4 % on scene A
     int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
 };
@@ -213,6 +216,8 @@ struct mp2p_hip_ctx
     void*    pinned       = nullptr;  // 4 KB of page-locked host memory for the small read-backs
     void*    pinned_big   = nullptr;  // ... and a growable one for the pair lists handed to host containers
     size_t   pinned_big_bytes = 0;
+    hipStream_t stream2    = nullptr;    // second search pipeline (launch_nn_pt2pt)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t copy_ev     = nullptr;    // mp2p_hip_pairs_copy_pt2pt_begin: the index arrays have arrived
     void*      copy_locked = nullptr;    // ... the destination it page-locked
     bool       copy_open   = false;

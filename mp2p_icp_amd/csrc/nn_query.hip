@@ -100,6 +100,9 @@ struct NNArgs
     uint4*               work_q;
     uint32_t*            q_counters;
     uint32_t             n_seg, seg_waves, seg_cap, tiles_per_seg;
+    // one of several independent PIPELINES over the local layer (launch_nn_pt2pt): this launch serves the
+    // waves wave_base .. of the lane kernel = the segments seg_base .. seg_base + n_seg - 1
+    uint32_t             wave_base, seg_base;
     // the pending list comes in two classes, hard (list 0: radius above r_hard) and easy (list 2, stored
     // behind the hard entries at pend + list_cap): the tile kernel's grid serves the hard class FIRST.
     // Workgroups are dispatched in index order and a hard tile runs 5-8x as long as an easy one; started
@@ -369,7 +372,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     __shared__ unsigned long long s_claim[NN_CLAIM_SLOTS];
     const GridView& g    = a.g;
     const int       lane = threadIdx.x;
-    const uint32_t  qi   = blockIdx.x * 64u + (uint32_t)lane;
+    const uint32_t  wv   = a.wave_base + blockIdx.x;  // wave of the whole layer
+    const uint32_t  qi   = wv * 64u + (uint32_t)lane;
     const bool      valid = qi < a.n_l;
 
     float4 lp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     bz1 = wave_max_nn((visited && qz == qz) ? qz : -INFINITY);
         if (lane == 0)
         {
-            float* o = a.tile_bbox + (size_t)blockIdx.x * 6;
+            float* o = a.tile_bbox + (size_t)wv * 6;
             o[0] = bx0, o[1] = by0, o[2] = bz0, o[3] = bx1, o[4] = by1, o[5] = bz1;
         }
     }
@@ -566,10 +570,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const bool               hard  = pending && r > a.r_hard;
         const unsigned long long hmask = __ballot(hard), emask = pmask & ~hmask;
         if (hmask)
-            push_lanes(a, 0, blockIdx.x / a.seg_waves, hard, hmask, lane, qi, r, best_d2, best_idx, best_spos, qx, qy,
+            push_lanes(a, 0, wv / a.seg_waves, hard, hmask, lane, qi, r, best_d2, best_idx, best_spos, qx, qy,
                        qz);
         if (emask)
-            push_lanes(a, 2, blockIdx.x / a.seg_waves, pending && !hard, emask, lane, qi, r, best_d2, best_idx,
+            push_lanes(a, 2, wv / a.seg_waves, pending && !hard, emask, lane, qi, r, best_d2, best_idx,
                        best_spos, qx, qy, qz);
     }
 
@@ -636,6 +640,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     else
         seg = tl / a.tiles_per_seg, tk = tl - seg * a.tiles_per_seg;
     if (seg >= a.n_seg) return;
+    seg += a.seg_base;  // segment of the whole layer
     const uint32_t  n_pend = a.q_counters[((size_t)(cls ? 2 : 0) * NN_MAX_SEG + seg) * NN_CNT_STRIDE];
     if (tk * (uint32_t)Q >= n_pend) return;
     const unsigned long long tl0 = wall_clock64();
@@ -1087,7 +1092,7 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
         for (int k = 0; k < NN_MAX_SEG / 64; k++)
         {
             const uint32_t sg  = (uint32_t)(k * 64 + lane);
-            const uint32_t c   = sg < a.n_seg ? a.q_counters[((size_t)NN_MAX_SEG + sg) * NN_CNT_STRIDE] : 0u;
+            const uint32_t c   = sg < a.n_seg ? a.q_counters[((size_t)NN_MAX_SEG + a.seg_base + sg) * NN_CNT_STRIDE] : 0u;
             const uint32_t inc = wave_incl_scan(c, lane);
             s_segoff[sg]       = run + inc - c;
             run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -1109,7 +1114,7 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
             if (s_segoff[mid] <= k_item) lo = mid;
             else hi = mid - 1;
         }
-        const size_t   item = (size_t)lo * a.seg_cap + (k_item - s_segoff[lo]);
+        const size_t   item = (size_t)(a.seg_base + lo) * a.seg_cap + (k_item - s_segoff[lo]);
         const uint4    w    = a.work[item];
         const uint4    wq   = a.work_q[item];
         const uint32_t qi   = w.x;
@@ -1474,36 +1479,81 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (n_tiles)
     {
-        const bool     instr         = a.counters != nullptr;
-        const uint32_t single_blocks = (uint32_t)std::min<size_t>(n_l, 256u * 32u);
-        if (instr) hipLaunchKernelGGL(nn_lane_kernel<true>, dim3(n_waves), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(nn_lane_kernel<false>, dim3(n_waves), dim3(64), 0, ctx->stream, a);
-        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
-#define MP2P_LAUNCH_TILE(QQ)                                                                       \
-    do                                                                                             \
-    {                                                                                              \
-        if (instr) hipLaunchKernelGGL((nn_tile_kernel<QQ, true>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);  \
-        else hipLaunchKernelGGL((nn_tile_kernel<QQ, false>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);      \
-    } while (0)
-        if (Q == 64) MP2P_LAUNCH_TILE(64);
-        else if (Q == 32 && a.mfma_scan)
+        const bool instr = a.counters != nullptr;
+        // ---- PIPELINES.  lane -> tile -> one-query kernel is a strict chain, and both big kernels end with
+        //      a drain (the last round of tiles / queries runs on an emptying chip: 25-30 % of the tile
+        //      kernel's span).  The local layer is therefore cut into independent halves (disjoint segments,
+        //      records and list ranges; the claim words take atomics from both), each with its own chain on
+        //      its own stream: one chain's drain is filled by the other's kernels.  Joined before the
+        //      compaction.  Per-stage events (profiling 1), counters (2) and the timeline (4) keep one chain.
+        //      Measured (MP2P_HIP_TUNE=pipelines=2): scene B -6 % search time, scene A +4 % (two lane kernels, two
+        //      more launches and the fork / join events cost more than its shorter drains give back): off by
+        //      default.  Never on the legacy null stream (event record / wait on it crashed the runtime).
+        uint32_t P = (ctx->tune.pipelines >= 2 && n_seg >= 32 && (ctx->profiling == 0 || ctx->profiling == 3) &&
+                      ctx->stream != nullptr && ctx->stream != hipStreamLegacy) ? 2u : 1u;
+        if (P > 1)
         {
-            if (instr) hipLaunchKernelGGL((nn_tile_kernel<32, true, true>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
-            else if (ctx->tune.tile_waves == 6) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 6>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
-            else if (ctx->tune.tile_waves == 5) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 5>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 4>), dim3(n_tiles), dim3(64), 0, ctx->stream, a);
+            if (!ctx->stream2) MP2P_TRY_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            if (!ctx->ev_fork) MP2P_TRY_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            if (!ctx->ev_join) MP2P_TRY_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            MP2P_TRY_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         }
-        else if (Q == 32) MP2P_LAUNCH_TILE(32);
-        else MP2P_LAUNCH_TILE(16);
+        NNArgs     ap[2];
+        uint32_t   wn[2], tn[2], sbn[2];
+        hipStream_t st[2] = {ctx->stream, ctx->stream2};
+        for (uint32_t p = 0; p < P; p++)
+        {
+            const uint32_t s0 = (uint32_t)((unsigned long long)n_seg * p / P), s1 = (uint32_t)((unsigned long long)n_seg * (p + 1) / P);
+            const uint32_t w0 = s0 * seg_waves, w1 = std::min<uint32_t>(n_waves, s1 * seg_waves);
+            ap[p]           = a;
+            ap[p].seg_base  = s0, ap[p].n_seg = s1 - s0;
+            ap[p].wave_base = w0;
+            wn[p]           = w1 - w0;
+            tn[p]           = 2u * ((ap[p].n_seg + 7u) / 8u) * 8u * a.tiles_per_seg;
+            const uint32_t all = ctx->tune.single_blocks_per_cu ? 256u * ctx->tune.single_blocks_per_cu : 256u * 32u;
+            sbn[p]          = (uint32_t)std::min<size_t>((size_t)wn[p] * 64u, all / P);
+        }
+        for (uint32_t p = 0; p < P; p++)
+        {
+            if (instr) hipLaunchKernelGGL(nn_lane_kernel<true>, dim3(wn[p]), dim3(64), 0, st[p], ap[p]);
+            else hipLaunchKernelGGL(nn_lane_kernel<false>, dim3(wn[p]), dim3(64), 0, st[p], ap[p]);
+        }
+        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+#define MP2P_LAUNCH_TILE(QQ)                                                                                  \
+    do                                                                                                        \
+    {                                                                                                         \
+        if (instr) hipLaunchKernelGGL((nn_tile_kernel<QQ, true>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);   \
+        else hipLaunchKernelGGL((nn_tile_kernel<QQ, false>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);        \
+    } while (0)
+        for (uint32_t p = 0; p < P; p++)
+        {
+            if (Q == 64) MP2P_LAUNCH_TILE(64);
+            else if (Q == 32 && a.mfma_scan)
+            {
+                if (instr) hipLaunchKernelGGL((nn_tile_kernel<32, true, true>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
+                else if (ctx->tune.tile_waves == 6) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 6>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
+                else if (ctx->tune.tile_waves == 5) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 5>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
+                else hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 4>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
+            }
+            else if (Q == 32) MP2P_LAUNCH_TILE(32);
+            else MP2P_LAUNCH_TILE(16);
+        }
 #undef MP2P_LAUNCH_TILE
         if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         // deferred queries: the count lives on the device; a fixed grid strides over it
-        const uint32_t sb = ctx->tune.single_blocks_per_cu ? std::min<uint32_t>((uint32_t)n_l, 256u * ctx->tune.single_blocks_per_cu)
-                                                           : single_blocks;
-        if (instr) hipLaunchKernelGGL((nn_single_kernel<true, 1>), dim3(sb), dim3(64), 0, ctx->stream, a);
-        else if (ctx->tune.single_waves == 6) hipLaunchKernelGGL((nn_single_kernel<false, 6>), dim3(sb), dim3(64), 0, ctx->stream, a);
-        else if (ctx->tune.single_waves == 8) hipLaunchKernelGGL((nn_single_kernel<false, 8>), dim3(sb), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((nn_single_kernel<false, 1>), dim3(sb), dim3(64), 0, ctx->stream, a);
+        for (uint32_t p = 0; p < P; p++)
+        {
+            if (instr) hipLaunchKernelGGL((nn_single_kernel<true, 1>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
+            else if (ctx->tune.single_waves == 6) hipLaunchKernelGGL((nn_single_kernel<false, 6>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
+            else if (ctx->tune.single_waves == 8) hipLaunchKernelGGL((nn_single_kernel<false, 8>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
+            else hipLaunchKernelGGL((nn_single_kernel<false, 1>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
+        }
+        if (P > 1)
+        {
+            MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            MP2P_TRY_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
     }
     else if (ctx->prof_all())
     {

@@ -322,3 +322,28 @@ def test_max_local_points_visit_order(amd, oracle, K):
     o1, o2 = m2._visit_order(4000), m2._visit_order(4000)
     assert np.array_equal(o1, o2) and sorted(o1.tolist()) == list(range(2500))
     assert m2._visit_order(2500) is None
+
+
+@pytest.mark.parametrize("tune", ["pipelines=2", "mfma_scan=0", "tile_waves=5", "dir_budget_mb=0,claim_dedup=0,claim_peek=0"])
+def test_tune_knobs_do_not_change_the_lists(amd, oracle, tune, monkeypatch):
+    """MP2P_HIP_TUNE is read once per context: every setting is a measurement aid that must compute the
+    same lists (two search pipelines on two streams, exact scan instead of the matrix-pipe prefilter, another
+    register budget, no voxel directory / claim shortcuts).  A warm sequence of three poses."""
+    from mp2p_icp_amd import _lib, core, synthetic
+    d = synthetic.random_cloud_pair(40_000, 300_000, 123, outlier_frac=0.1)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    monkeypatch.setenv("MP2P_HIP_TUNE", tune)
+    ctx = amd.Context(0)
+    gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])
+    cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    pairs = core.DevicePairs(ctx, l.shape[0], 0)
+    prm = _lib.Pt2PtParams(0.8, 0.0, 1, 0, 0, 0.20, 0, 0.0, 0, 0.0, 0, 0.0, 0)
+    rng = np.random.default_rng(5)
+    pose = d["T_init"]
+    for _ in range(3):
+        want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.8, 0.0, tree=tree)
+        pairs.clear()
+        core.match_pt2pt(ctx, gmap, cloud, pose, prm, None, pairs)
+        _assert_same_pairs(pairs.download_pt2pt(), want)
+        pose = amd.se3.compose(pose, amd.se3.exp(np.concatenate([rng.normal(0, 0.02, 3), rng.normal(0, 0.004, 3)])))

@@ -180,7 +180,6 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
     (void)mp2p_hip_comm_destroy(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->pinned_big) (void)hipHostFree(ctx->pinned_big);
     if (ctx->q1_pairs) mp2p_hip_pairs_free(nullptr, ctx->q1_pairs);
     if (ctx->q1_cloud) mp2p_hip_cloud_free(nullptr, ctx->q1_cloud);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

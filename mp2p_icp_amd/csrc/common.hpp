@@ -214,8 +214,6 @@ struct mp2p_hip_ctx
     uint32_t last_n_tiles = 0;
     uint32_t last_q       = 64;
     void*    pinned       = nullptr;  // 4 KB of page-locked host memory for the small read-backs
-    void*    pinned_big   = nullptr;  // ... and a growable one for the pair lists handed to host containers
-    size_t   pinned_big_bytes = 0;
     hipStream_t stream2    = nullptr;    // second search pipeline (launch_nn_pt2pt)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t copy_ev     = nullptr;    // mp2p_hip_pairs_copy_pt2pt_begin: the index arrays have arrived

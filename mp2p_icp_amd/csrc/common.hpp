@@ -114,8 +114,9 @@ struct Tune
     uint32_t hard_radius_pct = 100; // pending queries with a radius above this % of a level-0 voxel are "hard":
                                     // their tiles are dispatched first (nn_query.hip)
     int      xcd_map       = 1;     // tile kernel: one segment of the pending list per XCD (L2 locality)
-    uint32_t single_waves  = 0;     // one-query-per-wave kernel: register budget for 6 or 8 waves per SIMD (0 = compiler's)
-    uint32_t single_blocks_per_cu = 0;  // ... and its grid, in workgroups per CU (0 = 32)
+    uint32_t single_waves  = 0;     // one-query-per-wave kernel: register budget for 4, 6 or 8 waves per SIMD (0 = 5: 96 VGPRs,
+                                    // no spill; 4 = the compiler's own 98 VGPRs: -3..-11 % slower; 6 / 8 spill)
+    uint32_t single_blocks_per_cu = 0;  // ... and its grid, in workgroups per CU (0 = 40: two resident rounds at 5 waves)
     uint32_t pl_q          = 0;     // point-to-plane search: queries per wave (0 = by layer size: 8 up to 400 k points, else 32)
     int      sync_spin     = 1;     // wait for the stream by polling hipStreamQuery (lower wake-up latency)
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic

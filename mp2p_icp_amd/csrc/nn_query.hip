@@ -1462,7 +1462,8 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     ctx->timeline_tiles = ctx->timeline_singles = 0;
     if (ctx->profiling == 4)
     {
-        const size_t single_blocks = std::min<size_t>(n_l, 256u * 32u);
+        // (upper bound of the one-query kernel's grid, see below)
+        const size_t single_blocks = 256u * (size_t)(ctx->tune.single_blocks_per_cu ? ctx->tune.single_blocks_per_cu : 40u);
         MP2P_TRY_HIP(ctx, ctx->timeline.ensure(2 * (n_tiles + single_blocks)));
         MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->timeline.p, 0, 2 * (n_tiles + single_blocks) * sizeof(unsigned long long),
                                          ctx->stream));
@@ -1511,7 +1512,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
             ap[p].wave_base = w0;
             wn[p]           = w1 - w0;
             tn[p]           = 2u * ((ap[p].n_seg + 7u) / 8u) * 8u * a.tiles_per_seg;
-            const uint32_t all = ctx->tune.single_blocks_per_cu ? 256u * ctx->tune.single_blocks_per_cu : 256u * 32u;
+            const uint32_t all = 256u * (ctx->tune.single_blocks_per_cu ? ctx->tune.single_blocks_per_cu : 40u);
             sbn[p]          = (uint32_t)std::min<size_t>((size_t)wn[p] * 64u, all / P);
         }
         for (uint32_t p = 0; p < P; p++)
@@ -1545,9 +1546,10 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         for (uint32_t p = 0; p < P; p++)
         {
             if (instr) hipLaunchKernelGGL((nn_single_kernel<true, 1>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
+            else if (ctx->tune.single_waves == 4) hipLaunchKernelGGL((nn_single_kernel<false, 1>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
             else if (ctx->tune.single_waves == 6) hipLaunchKernelGGL((nn_single_kernel<false, 6>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
             else if (ctx->tune.single_waves == 8) hipLaunchKernelGGL((nn_single_kernel<false, 8>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
-            else hipLaunchKernelGGL((nn_single_kernel<false, 1>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
+            else hipLaunchKernelGGL((nn_single_kernel<false, 5>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
         }
         if (P > 1)
         {

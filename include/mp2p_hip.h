@@ -568,6 +568,16 @@ typedef struct
      * finished without any search */
     double   ms_nn_lane;
     uint64_t nn_lane_searched, nn_lane_candidates, nn_lane_voxels, nn_lane_pending, nn_lane_skipped;
+    /* nn_wave_kernel (round 3; then nn_tiles = waves, nn_candidates_tested = points staged summed over
+     * waves, nn_cells_visited = voxels listed, nn_lane_pending = queries that needed a search):
+     * candidates tested summed over lanes / summed longest lane of every walk (what the waves waited
+     * for), voxel insertions, lanes that could not place a voxel, staging rounds, queries handed on for
+     * their cube's width, and 100 MHz ticks per phase summed over waves
+     * {prologue, voxel set, directory, staging, walks, records + claims} */
+    uint64_t nn_wave_path; /* 1: the last pt2pt search ran nn_wave_kernel */
+    uint64_t nn_wave_lane_tests, nn_wave_maxlane_tests, nn_wave_inserts, nn_wave_overflows, nn_wave_rounds;
+    uint64_t nn_wave_toobig;
+    uint64_t nn_wave_phase_ticks[6];
 } mp2p_hip_stats;
 /* ---- mp2p_icp::covariance (mp2p_icp/src/covariance.cpp:29-141, ICP.cpp:334-337):
  *      H = J^T J of the stacked error vector w.r.t. (x, y, z, yaw, pitch, roll), J by central

@@ -150,7 +150,11 @@ class Stats(C.Structure):
                 ("nn_single_max_passes", C.c_uint64), ("nn_single_max_cells", C.c_uint64),
                 ("ms_nn_lane", C.c_double), ("nn_lane_searched", C.c_uint64),
                 ("nn_lane_candidates", C.c_uint64), ("nn_lane_voxels", C.c_uint64),
-                ("nn_lane_pending", C.c_uint64), ("nn_lane_skipped", C.c_uint64)]
+                ("nn_lane_pending", C.c_uint64), ("nn_lane_skipped", C.c_uint64),
+                ("nn_wave_path", C.c_uint64), ("nn_wave_lane_tests", C.c_uint64),
+                ("nn_wave_maxlane_tests", C.c_uint64), ("nn_wave_inserts", C.c_uint64),
+                ("nn_wave_overflows", C.c_uint64), ("nn_wave_rounds", C.c_uint64),
+                ("nn_wave_toobig", C.c_uint64), ("nn_wave_phase_ticks", C.c_uint64 * 6)]
 
 
 _P = C.c_void_p

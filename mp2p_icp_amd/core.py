@@ -59,6 +59,7 @@ class Context:
         check(self._L.mp2p_hip_get_stats(self._h, C.byref(s)), self._h)
         d = {k: getattr(s, k) for k, _ in s._fields_}
         d["nn_tile_ticks_hist"] = list(s.nn_tile_ticks_hist)
+        d["nn_wave_phase_ticks"] = list(s.nn_wave_phase_ticks)
         return d
 
     def local_bbox_ptr(self):

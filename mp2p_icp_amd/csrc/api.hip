@@ -69,6 +69,7 @@ static void parse_tune(Tune& t)
             else if (k == "dir_budget_mb") t.dir_budget_mb = (uint32_t)v;
             else if (k == "claim_peek") t.claim_peek = (int)v;
             else if (k == "compact_fused") t.compact_fused = (int)v;
+            else if (k == "wave_kernel") t.wave_kernel = (int)v;
             else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
         }
         i = j + 1;
@@ -1035,6 +1036,10 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
             ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1];
             ctx->stats.nn_cells_visited = c[2], ctx->stats.nn_candidates_tested = c[3];
             ctx->stats.nn_unresolved_after_first_pass = c[4];
+            ctx->stats.nn_wave_lane_tests = c[NWC_LANE_TESTS], ctx->stats.nn_wave_maxlane_tests = c[NWC_MAXLANE];
+            ctx->stats.nn_wave_inserts = c[NWC_INSERTS], ctx->stats.nn_wave_overflows = c[NWC_OVF];
+            ctx->stats.nn_wave_rounds = c[NWC_ROUNDS], ctx->stats.nn_wave_toobig = c[NWC_TOOBIG];
+            for (int i = 0; i < 6; i++) ctx->stats.nn_wave_phase_ticks[i] = c[NWC_T_PRO + i];
             ctx->stats.nn_max_candidates_one_tile = c[5], ctx->stats.nn_max_passes_one_tile = c[6];
             std::vector<unsigned char> t(ctx->pending_map_n);
             MP2P_TRY_HIP(ctx, hipMemcpy(t.data(), ctx->pl_slots.p, t.size(), hipMemcpyDeviceToHost));
@@ -1042,6 +1047,7 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
             for (unsigned char b : t) k += b;
             ctx->stats.nn_points_staged = k;
         }
+        ctx->stats.nn_wave_path = (uint64_t)ctx->last_wave_path;
         ctx->pending_match = 0;
     }
     if (ctx->pending_gn)

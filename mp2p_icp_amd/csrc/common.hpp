@@ -130,6 +130,8 @@ struct Tune
                                     // time on scene B, +4 % on scene A
     int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
+    int      wave_kernel   = 1;     // point-to-point search, K = 1: nn_wave_kernel (per-lane balls over an LDS voxel set) instead
+                                    // of nn_lane_kernel + nn_tile_kernel (0 = the round-2 kernels)
 };
 
 // multi-GPU communicator of a context (comm.hip): RCCL, or caller-provided collectives
@@ -214,6 +216,7 @@ struct mp2p_hip_ctx
     mp2p::Comm                       comm;
     uint32_t last_n_tiles = 0;
     uint32_t last_q       = 64;
+    int      last_wave_path = 0;  // the last pt2pt search ran nn_wave_kernel
     void*    pinned       = nullptr;  // 4 KB of page-locked host memory for the small read-backs
     hipStream_t stream2    = nullptr;    // second search pipeline (launch_nn_pt2pt)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

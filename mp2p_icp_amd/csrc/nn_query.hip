@@ -1297,6 +1297,10 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
     }
 }
 
+}  // namespace mp2p
+#include "nn_wave.hip"  // nn_wave_kernel: prologue + search of round 3 (uses the helpers above)
+namespace mp2p
+{
 // resets the segment counters of the two query lists
 __global__ __launch_bounds__(NN_LISTS * NN_MAX_SEG) void nn_reset_kernel(uint32_t* q_counters)
 {
@@ -1464,21 +1468,42 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     {
         // (upper bound of the one-query kernel's grid, see below)
         const size_t single_blocks = 256u * (size_t)(ctx->tune.single_blocks_per_cu ? ctx->tune.single_blocks_per_cu : 40u);
-        MP2P_TRY_HIP(ctx, ctx->timeline.ensure(2 * (n_tiles + single_blocks)));
-        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->timeline.p, 0, 2 * (n_tiles + single_blocks) * sizeof(unsigned long long),
+        MP2P_TRY_HIP(ctx, ctx->timeline.ensure(2 * (std::max<size_t>(n_tiles, n_waves) + single_blocks)));
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->timeline.p, 0, 2 * (std::max<size_t>(n_tiles, n_waves) + single_blocks) * sizeof(unsigned long long),
                                          ctx->stream));
         a.timeline = ctx->timeline.p;
         ctx->timeline_tiles = n_tiles, ctx->timeline_singles = single_blocks;
     }
     ctx->pending_lane = 1;
     ctx->last_n_boxes = n_waves;
+    // round 3: one kernel for prologue + search (nn_wave.hip) when the map carries the level-0 occupancy
+    // bitmap it enumerates voxels from; an explicit tile size (queries_per_wave) asks for the tile kernels
+    const bool use_wave = ctx->tune.wave_kernel && prm->queries_per_wave == 0 && map->view.occ != nullptr &&
+                          map->view.occ_off[0] != OCC_NONE && ctx->tune.pipelines < 2;
+    ctx->last_wave_path = use_wave ? 1 : 0;
     // the list counters: cleared by the previous call's fused compaction, or here
     if (!ctx->q_counters_clean)
         hipLaunchKernelGGL(nn_reset_kernel, dim3(1), dim3(NN_LISTS * NN_MAX_SEG), 0, ctx->stream, a.q_counters);
     ctx->q_counters_clean = false;
     // ev[0]..ev[1] brackets exactly the search kernels (the roofline kernels of bench.py)
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    if (n_tiles)
+    if (n_tiles && use_wave)
+    {
+        const bool instr = a.counters != nullptr;
+        a.seg_base = 0, a.wave_base = 0;
+        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));  // no separate prologue
+        if (instr) hipLaunchKernelGGL(nn_wave_kernel<true>, dim3(n_waves), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(nn_wave_kernel<false>, dim3(n_waves), dim3(64), 0, ctx->stream, a);
+        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        const uint32_t sb = (uint32_t)std::min<size_t>((size_t)n_waves * 64u,
+                                                       256u * (ctx->tune.single_blocks_per_cu ? ctx->tune.single_blocks_per_cu : 40u));
+        if (instr) hipLaunchKernelGGL((nn_single_kernel<true, 1>), dim3(sb), dim3(64), 0, ctx->stream, a);
+        else if (ctx->tune.single_waves == 4) hipLaunchKernelGGL((nn_single_kernel<false, 1>), dim3(sb), dim3(64), 0, ctx->stream, a);
+        else if (ctx->tune.single_waves == 6) hipLaunchKernelGGL((nn_single_kernel<false, 6>), dim3(sb), dim3(64), 0, ctx->stream, a);
+        else if (ctx->tune.single_waves == 8) hipLaunchKernelGGL((nn_single_kernel<false, 8>), dim3(sb), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((nn_single_kernel<false, 5>), dim3(sb), dim3(64), 0, ctx->stream, a);
+    }
+    else if (n_tiles)
     {
         const bool instr = a.counters != nullptr;
         // ---- PIPELINES.  lane -> tile -> one-query kernel is a strict chain, and both big kernels end with

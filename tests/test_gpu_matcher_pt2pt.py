@@ -80,7 +80,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("n_g,n_l,thr,ang,seed,kw", CASES)
-@pytest.mark.parametrize("q", [64, 32, 16])
+@pytest.mark.parametrize("q", [0, 64, 32, 16])   # 0 = the default search (nn_wave_kernel), else the tile kernels
 def test_random_parity_vs_oracle(amd, oracle, n_g, n_l, thr, ang, seed, kw, q):
     from mp2p_icp_amd import synthetic
     d = synthetic.random_cloud_pair(n_l, n_g, seed, outlier_frac=0.1)
@@ -324,7 +324,8 @@ def test_max_local_points_visit_order(amd, oracle, K):
     assert m2._visit_order(2500) is None
 
 
-@pytest.mark.parametrize("tune", ["pipelines=2", "mfma_scan=0", "tile_waves=5", "dir_budget_mb=0,claim_dedup=0,claim_peek=0"])
+@pytest.mark.parametrize("tune", ["wave_kernel=0", "pipelines=2", "mfma_scan=0,wave_kernel=0", "tile_waves=5,wave_kernel=0",
+                                  "dir_budget_mb=0,claim_dedup=0,claim_peek=0", "dir_budget_mb=0,claim_dedup=0,claim_peek=0,wave_kernel=0"])
 def test_tune_knobs_do_not_change_the_lists(amd, oracle, tune, monkeypatch):
     """MP2P_HIP_TUNE is read once per context: every setting is a measurement aid that must compute the
     same lists (two search pipelines on two streams, exact scan instead of the matrix-pipe prefilter, another

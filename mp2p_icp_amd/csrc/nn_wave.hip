@@ -195,6 +195,7 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
     }
     bool deferred = false;
     const float hs = g.hf * (float)(1u << g.shift0);  // level-0 voxel edge
+    uint32_t dbg_nu = 0, dbg_rounds = 0, dbg_flags = 0;  // profiling level 4: packed into the timeline record
     uint32_t st_pass = 0, st_T = 0, st_tests = 0, st_maxlane = 0, st_ins = 0, st_ovf = 0, st_rounds = 0, st_listed = 0,
              st_toobig = 0, st_defer = 0;
     if (INSTR)
@@ -347,6 +348,8 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
                 }
         }
         __syncthreads();
+        dbg_nu = max(dbg_nu, n_u), dbg_rounds += (T + NW_CAP - 1) / NW_CAP;
+        dbg_flags |= (__ballot(part && ovf) ? 1u : 0u) | (__ballot(part && toobig) ? 2u : 0u);
         if (INSTR)
         {
             st_listed += n_u, st_T += T;
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
                 else if (L.z < base && L.z + L.w > base) s_owner[0] = e + 1u;
             }
             __syncthreads();
+            uint32_t e_first = 0, e_end = 0;  // the listed voxels that own slots of this round
             {
                 const uint4    o4 = *reinterpret_cast<const uint4*>(&s_owner[4 * lane]);
                 const uint32_t p0 = o4.x, p1 = max(p0, o4.y), p2 = max(p1, o4.z), p3 = max(p2, o4.w);
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
                 const uint32_t t0    = 4u * (uint32_t)lane;
                 uint32_t       src[4];
                 float4         c4[4];
+                uint32_t       last = 0u;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                 {
@@ -388,8 +393,11 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
                     {
                         const uint4 L = s_list[ow[k] - 1u];
                         src[k]        = L.y + (base + t0 + k - L.z);
+                        last          = ow[k];
                     }
                 }
+                e_first = (uint32_t)__builtin_amdgcn_readlane((int)ow[0], 0) - 1u;  // slot 0 always has an owner
+                e_end   = wave_max_u32(last);                                       // ids ascend with the slots
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                 {
@@ -418,10 +426,10 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
             uint32_t my_tests = 0;
             if (go)
             {
-                uint32_t e = 0, k = 0, kend = 0, sb = 0;
+                uint32_t e = e_first, k = 0, kend = 0, sb = 0;
                 for (;;)
                 {
-                    while (k >= kend && e < n_u)
+                    while (k >= kend && e < e_end)
                     {
                         const uint4    L  = s_list[e];
                         const uint32_t v  = L.x - 1u;
@@ -505,7 +513,13 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
               lb2_out >= 0.f ? lb2_out : fminf(best_d2, thr));
 
     if (a.timeline && lane == 0)
-        a.timeline[2 * (size_t)blockIdx.x] = tl0, a.timeline[2 * (size_t)blockIdx.x + 1] = wall_clock64();
+    {
+        // start tick in the low 40 bits; above: widest voxel list (8 bits), staging rounds (8), passes (4), flags
+        const unsigned long long info = (unsigned long long)min(dbg_nu, 255u) | ((unsigned long long)min(dbg_rounds, 255u) << 8) |
+                                        ((unsigned long long)min(st_pass, 15u) << 16) | ((unsigned long long)dbg_flags << 20);
+        a.timeline[2 * (size_t)blockIdx.x]     = (tl0 & 0xFFFFFFFFFFull) | (info << 40);
+        a.timeline[2 * (size_t)blockIdx.x + 1] = wall_clock64() & 0xFFFFFFFFFFull;
+    }
     if (INSTR)
     {
         const unsigned long long t_end = wall_clock64();

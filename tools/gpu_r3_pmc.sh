@@ -1,0 +1,33 @@
+#!/bin/bash
+# tools/gpu_r3_pmc.sh <tag> [timeline] [sq] [mem]: residency timeline and SQ / memory counters of the search kernels (nn_one.py chain poses)
+tag=$1; shift
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
+pass() { ( cd /tmp && timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $O/$1 -o p -- python $R/tools/nn_one.py chain 6 > $O/$1.log 2>&1; echo "$1 rc=$?" ); }
+for step in "$@"; do
+  case $step in
+    timeline) timeout 300 python tools/timeline_probe.py > $O/timeline.json 2> $O/timeline.err; echo "timeline rc=$?"; cat $O/timeline.json;;
+    sq) pass p1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY"
+        pass p2 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_WAIT_INST_LDS"
+        pass p3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_WAVES_EQ_64";;
+    mem) pass m1 "FETCH_SIZE"; pass m2 "WRITE_SIZE"; pass m3 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum";;
+    stats) ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o p -- python $R/tools/nn_one.py chain 6 > $O/ks.log 2>&1; echo "stats rc=$?" );;
+  esac
+done
+cd $R
+python - <<PY
+import csv, glob, collections
+for d in ("p1","p2","p3","m1","m2","m3"):
+    fs = glob.glob(f"gpurun_out/$tag/{d}/**/*counter_collection.csv", recursive=True)
+    if not fs: continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for r in csv.DictReader(open(fs[-1])):
+        k = r["Kernel_Name"][:44]
+        if "nn_" not in k or "reset" in k: continue
+        a = acc[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    for k, v in acc.items():
+        print(d, k, {c: round(t / n) for c, (n, t) in v.items()})
+for f in glob.glob(f"gpurun_out/$tag/ks/**/*kernel_stats.csv", recursive=True):
+    for i,l in enumerate(open(f)):
+        if i<14: print(l.strip()[:200])
+PY

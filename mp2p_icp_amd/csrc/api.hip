@@ -70,6 +70,7 @@ static void parse_tune(Tune& t)
             else if (k == "claim_peek") t.claim_peek = (int)v;
             else if (k == "compact_fused") t.compact_fused = (int)v;
             else if (k == "wave_kernel") t.wave_kernel = (int)v;
+            else if (k == "wave_waves") t.wave_waves = (uint32_t)v;
             else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
         }
         i = j + 1;

@@ -130,6 +130,7 @@ struct Tune
                                     // time on scene B, +4 % on scene A
     int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
+    uint32_t wave_waves    = 4;     // nn_wave_kernel: register budget for this many waves per SIMD (4, 5, 6)
     int      wave_kernel   = 1;     // point-to-point search, K = 1: nn_wave_kernel (per-lane balls over an LDS voxel set) instead
                                     // of nn_lane_kernel + nn_tile_kernel (0 = the round-2 kernels)
 };

@@ -1492,8 +1492,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         const bool instr = a.counters != nullptr;
         a.seg_base = 0, a.wave_base = 0;
         if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));  // no separate prologue
-        if (instr) hipLaunchKernelGGL(nn_wave_kernel<true>, dim3(n_waves), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(nn_wave_kernel<false>, dim3(n_waves), dim3(64), 0, ctx->stream, a);
+        if (instr) hipLaunchKernelGGL((nn_wave_kernel<true, 4>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
+        else if (ctx->tune.wave_waves == 5) hipLaunchKernelGGL((nn_wave_kernel<false, 5>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((nn_wave_kernel<false, 4>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
         if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         const uint32_t sb = (uint32_t)std::min<size_t>((size_t)n_waves * 64u,
                                                        256u * (ctx->tune.single_blocks_per_cu ? ctx->tune.single_blocks_per_cu : 40u));

@@ -5,32 +5,36 @@
 // Reference loop replaced: Matcher_Points_DistanceThreshold.cpp:214-265 (+ transform_local_to_global,
 // Matcher_Points_Base.cpp:183-249).
 //
-// Why another structure (DESIGN.md section 4 has the numbers): the tile kernel shared ONE box per 32
-// queries -- its candidates are the box's points, whatever each query's own radius -- and paid a
-// chain of ~6 dependent round trips per 32 queries.  On the bench chains 80 % of the queries have a
-// previous nearest neighbour 2..9 cm away while a few per tile are 0.3..1 m off: the box is sized by the
-// worst of them.  Here a wave owns 64 Morton-consecutive queries (one per lane) and
-//   A. every lane enumerates the OCCUPIED level-0 voxels its own ball [q, r] touches -- from the 4x4x4
-//      occupancy bricks (one 8-byte word per brick, <= 8 words per 4x4x4 sub-cube of the ball's cube) --
-//      and inserts them into a hash SET in LDS (ds_cmpst: duplicates of neighbouring queries collapse);
-//   B. the set's voxels are resolved through the directory (one 8-byte load per voxel, 4 per lane, all
-//      independent) and listed with their point ranges;
-//   C. the points of the listed voxels are staged into LDS with coalesced 16-byte loads;
-//   D. every lane walks the list, keeps the voxels its ball (shrinking with its running best) reaches,
-//      and tests their staged points in the exact FMA-free sequence.
+// Why another structure (DESIGN.md section 4 has the numbers): the tile kernel staged ONE box per 32
+// queries -- sized by the worst radius and the tile's extent -- and paid a chain of ~6 dependent round
+// trips per 32 queries.  On the bench chains 80 % of the queries have a previous nearest neighbour
+// 2..9 cm away while a few per tile are 0.3..1 m off.  Here a wave owns 64 Morton-consecutive queries
+// (one per lane); every step below is wave-uniform control flow:
+//   A. each lane's ball gives a cube of level-0 voxels; the wave looks at a WINDOW of up to 3 x 3 x 3
+//      occupancy bricks (4x4x4 voxels, one 8-byte word each, all words fetched by one load) around its
+//      first open query; per brick every lane ANDs the word with the mask of its own cube and a wave-wide OR
+//      gives the set of occupied voxels ANY lane needs -- the union of the cubes, not their bounding box;
+//   B. lane b resolves voxel b of each brick through the directory (one 8-byte load per voxel, all
+//      independent), the voxels holding points are listed and their counts prefixed;
+//   C. the listed points are staged into LDS (SoA) with coalesced 16-byte loads, 256 per round;
+//   D. every lane tests every staged point against its query in the exact FMA-free sequence, 8 per step
+//      on packed fp32 (the update is rare).
 // The radius of a warm query is the distance to its previous nearest neighbour (certain to conclude,
-// however small), so one pass finishes it.  Queries whose cube exceeds 8 voxels per axis, or whose radius
-// outgrows r_defer, go to nn_single_kernel (a whole wave per query) as before.
+// however small), so one pass finishes it.  Lanes whose cube does not fit the window wait for the next
+// pass (new window); queries whose cube exceeds 8 voxels per axis or whose radius outgrows r_defer, and
+// wide cubes that are alone in their wave, go to nn_single_kernel (a whole wave per query) as before.
 // Results are bit-identical to the other kernels' (same arg-min rule, same finality rule).
 #include "device_utils.hpp"
 
 namespace mp2p
 {
-constexpr int NW_HS       = 256;  // slots of the voxel set = capacity of the voxel list
-constexpr int NW_CAP      = 256;  // staged points per round
-constexpr int NW_MAXPROBE = 16;
-constexpr int NW_MAXPASS  = 4;
-constexpr uint32_t NW_MAXSPAN = 8;  // widest cube (level-0 voxels per axis) a lane enumerates
+constexpr int NW_NL      = 256;  // listed voxels per chunk
+constexpr int NW_CAP     = 256;  // staged points per round
+constexpr int NW_MAXPASS = 6;
+constexpr uint32_t NW_MAXSPAN = 8;  // widest cube (level-0 voxels per axis) the window can hold at any alignment
+constexpr uint32_t NW_MED_MIN = 8;  // cubes wider than 4 voxels stay in the wave only in this company
+constexpr uint32_t NW_WALK_MIN = 0xFFFFu;  // chunks of more listed voxels would be WALKED per lane instead of tested all-pairs: measured
+                                           // 3.5x slower at 24 (divergent refill loops + dependent LDS reads beat the 2x fewer tests): off
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t k)
 {
@@ -93,30 +97,58 @@ __device__ __forceinline__ unsigned long long cube_occ_mask(const GridView& g, u
 // counters of the instrumented variant (ctx->counters): 50.. = this kernel's own
 enum
 {
-    NWC_LANE_TESTS = 50,  // candidates tested, summed over lanes
-    NWC_MAXLANE    = 51,  // ... and what the waves waited for: the longest lane of each walk, in candidates
-    NWC_INSERTS    = 52,  // voxel insertions attempted (occupied voxels inside a ball)
-    NWC_OVF        = 53,  // lanes that could not place a voxel (set full) or sat too far from the wave's origin
+    NWC_LANE_TESTS = 50,  // distance tests (staged points x open lanes)
+    NWC_MAXLANE    = 51,  // staged points scanned, summed over waves (what a wave's scan costs)
+    NWC_INSERTS    = 52,  // bricks of all windows that held a needed voxel
+    NWC_OVF        = 53,  // lane-passes spent waiting for a window (cube outside the current one)
     NWC_ROUNDS     = 54,  // staging rounds
-    NWC_LISTED     = 55,  // voxels listed (sum over passes)
-    NWC_TOOBIG     = 56,  // queries handed on because their cube exceeds NW_MAXSPAN voxels per axis
+    NWC_LISTED     = 55,  // voxels listed
+    NWC_TOOBIG     = 56,  // queries handed on for their cube's width (too wide, or wide and alone)
     NWC_T_PRO      = 57,  // 100 MHz ticks per phase, summed over waves: prologue (loads, transform, warm start)
-    NWC_T_INS      = 58,  //   voxel enumeration + set insertion
+    NWC_T_INS      = 58,  //   window, brick words, masks
     NWC_T_DIR      = 59,  //   directory resolve + list
     NWC_T_STAGE    = 60,  //   staging
-    NWC_T_SCAN     = 61,  //   walks
+    NWC_T_SCAN     = 61,  //   distance tests
     NWC_T_EMIT     = 62,  //   hand-over + records + claims
 };
 
-template <bool INSTR>
-__global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t s_key[NW_HS];
-    __shared__ __attribute__((aligned(16))) uint4    s_list[NW_HS];  // {key, first sorted position, first staged slot, count}
-    __shared__ __attribute__((aligned(16))) float4   s_pts[NW_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t s_owner[NW_CAP];
-    static_assert(NN_CLAIM_SLOTS * sizeof(unsigned long long) <= NW_CAP * sizeof(float4), "claim table fits s_pts");
-    unsigned long long* s_claim = reinterpret_cast<unsigned long long*>(s_pts);
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo |= (uint32_t)dpp_i<DPP_ROW_ROR1>((int)lo), hi |= (uint32_t)dpp_i<DPP_ROW_ROR1>((int)hi);
+    lo |= (uint32_t)dpp_i<DPP_ROW_ROR2>((int)lo), hi |= (uint32_t)dpp_i<DPP_ROW_ROR2>((int)hi);
+    lo |= (uint32_t)dpp_i<DPP_ROW_ROR4>((int)lo), hi |= (uint32_t)dpp_i<DPP_ROW_ROR4>((int)hi);
+    lo |= (uint32_t)dpp_i<DPP_ROW_ROR8>((int)lo), hi |= (uint32_t)dpp_i<DPP_ROW_ROR8>((int)hi);
+    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lo, 0) | (uint32_t)__builtin_amdgcn_readlane((int)lo, 16) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)lo, 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, 48);
+    const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hi, 0) | (uint32_t)__builtin_amdgcn_readlane((int)hi, 16) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)hi, 32) | (uint32_t)__builtin_amdgcn_readlane((int)hi, 48);
+    return ((unsigned long long)h << 32) | l;
+}
+
+// 4-bit mask of the voxels 4b..4b+3 of brick b that lie in [c0, c1]; 0 when they do not overlap
+__device__ __forceinline__ uint32_t axis_mask_in(uint32_t b, uint32_t c0, uint32_t c1)
+{
+    const uint32_t lo = max(c0, b * 4u), hi = min(c1, b * 4u + 3u);
+    const uint32_t m  = ((2u << ((hi - b * 4u) & 3u)) - 1u) & ~((1u << ((lo - b * 4u) & 3u)) - 1u);
+    return lo <= hi ? m : 0u;
+}
+
+// WPE = waves per SIMD the register allocation aims at (MP2P_HIP_TUNE wave_waves)
+template <bool INSTR, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void nn_wave_kernel(const NNArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint2    s_list[NW_NL];  // listed voxels (all hold points): {first sorted position, first staged slot}
+    __shared__ __attribute__((aligned(16))) float    s_x[NW_CAP];
+    __shared__ __attribute__((aligned(16))) float    s_y[NW_CAP];
+    __shared__ __attribute__((aligned(16))) float    s_z[NW_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_idx[NW_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_spos[NW_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_owner[NW_CAP];  // staging: slot -> listed voxel; before: the voxel codes
+    static_assert(NW_NL == NW_CAP, "the voxel codes of a chunk live in s_owner");
+    static_assert(NN_CLAIM_SLOTS * sizeof(unsigned long long) <= 3 * NW_CAP * sizeof(float), "claim table fits s_x..s_z");
+    unsigned long long* s_claim = reinterpret_cast<unsigned long long*>(s_x);
+    uint32_t*           s_vox   = s_owner;
 
     const GridView& g    = a.g;
     const int       lane = threadIdx.x;
@@ -196,35 +228,27 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
     bool deferred = false;
     const float hs = g.hf * (float)(1u << g.shift0);  // level-0 voxel edge
     uint32_t dbg_nu = 0, dbg_rounds = 0, dbg_flags = 0;  // profiling level 4: packed into the timeline record
-    uint32_t st_pass = 0, st_T = 0, st_tests = 0, st_maxlane = 0, st_ins = 0, st_ovf = 0, st_rounds = 0, st_listed = 0,
-             st_toobig = 0, st_defer = 0;
-    if (INSTR)
+    uint32_t st_pass = 0, st_T = 0, st_tests = 0, st_bricks = 0, st_wait = 0, st_rounds = 0, st_listed = 0, st_toobig = 0,
+             st_defer = 0;
+    const bool clocks = INSTR || a.timeline != nullptr;  // uniform
+    unsigned long long t_pro = 0;
+    if (clocks)
     {
         const unsigned long long t = wall_clock64();
-        if (lane == 0) atomicAdd(&a.counters[NWC_T_PRO], t - tph);
-        tph = t;
+        t_pro = t - tph, tph = t;
     }
     const uint32_t n_search = (uint32_t)__popcll(__ballot(!done));
     const uint32_t n_skip   = (uint32_t)__popcll(__ballot(active && lb2_out >= 0.f));
+    const v2f      qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const uint32_t obx = g.occ_bx[0], oby = g.occ_by[0], obz = g.occ_bz[0];
+    const unsigned long long* occ0 = g.occ + g.occ_off[0];
 
     // ================= passes
     for (int pass = 0; pass < NW_MAXPASS; pass++)
     {
-        // a radius beyond r_defer leaves for the one-query-per-wave kernel (coarser levels, bricks)
-        {
-            const bool               wide  = !done && !deferred && r > a.r_defer;
-            const unsigned long long wmask = __ballot(wide);
-            if (wmask)
-            {
-                st_defer += push_lanes(a, 1, wv / a.seg_waves, wide, wmask, lane, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
-                if (wide) deferred = true;
-            }
-        }
-        const bool part = !done && !deferred;
-        if (__ballot(part) == 0ull) break;  // uniform
-        st_pass++;
-
         // ---- the lane's cube, in level-0 voxels, clipped to the layer's box ----------------------
+        bool     part = !done && !deferred;
         const float lox = fmaxf(qx - r, g.bbmin[0]), loy = fmaxf(qy - r, g.bbmin[1]), loz = fmaxf(qz - r, g.bbmin[2]);
         const float hix = fminf(qx + r, g.bbmax[0]), hiy = fminf(qy + r, g.bbmax[1]), hiz = fminf(qz + r, g.bbmax[2]);
         const bool  empty = !part || (lox > hix) || (loy > hiy) || (loz > hiz);  // nothing to visit at this radius
@@ -235,268 +259,448 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
             cy0 = cell_fine(loy, g.oy, g.inv_hf) >> g.shift0, cy1 = cell_fine(hiy, g.oy, g.inv_hf) >> g.shift0;
             cz0 = cell_fine(loz, g.oz, g.inv_hf) >> g.shift0, cz1 = cell_fine(hiz, g.oz, g.inv_hf) >> g.shift0;
         }
-        const bool toobig = !empty && ((cx1 - cx0) >= NW_MAXSPAN || (cy1 - cy0) >= NW_MAXSPAN || (cz1 - cz0) >= NW_MAXSPAN);
-        // voxels are keyed relative to the wave's lowest corner, 10 bits per axis: a lane too far from it
-        // (a Morton jump inside the wave) waits for a later pass
-        const bool     want = !empty && !toobig;
-        const uint32_t wx0 = wave_min_u32(want ? cx0 : 0xFFFFFFFFu), wy0 = wave_min_u32(want ? cy0 : 0xFFFFFFFFu),
-                       wz0 = wave_min_u32(want ? cz0 : 0xFFFFFFFFu);
-        const bool far = want && ((cx1 - wx0) > 1022u || (cy1 - wy0) > 1022u || (cz1 - wz0) > 1022u);
-        bool       ovf = far;  // this lane cannot conclude in this pass
-        const bool go  = want && !far;
-
-        // ---- A: the occupied voxels inside the ball go into the set ------------------------------
-        *reinterpret_cast<uint4*>(&s_key[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
-        const float prune  = r + 4.f * g.slack;
-        const float prune2 = prune * prune;
-        if (go)
+        // ---- who leaves for the one-query-per-wave kernel (coarser levels, bricks, a whole wave per query):
+        //      a radius beyond r_defer, a cube the window cannot hold, a wide cube without company ---------
         {
-            for (uint32_t sz = cz0; sz <= cz1; sz += 4u)
-                for (uint32_t sy = cy0; sy <= cy1; sy += 4u)
-                    for (uint32_t sx = cx0; sx <= cx1; sx += 4u)
+            const bool toobig = !empty && ((cx1 - cx0) >= NW_MAXSPAN || (cy1 - cy0) >= NW_MAXSPAN || (cz1 - cz0) >= NW_MAXSPAN);
+            const bool medium = !empty && !toobig && ((cx1 - cx0) >= 4u || (cy1 - cy0) >= 4u || (cz1 - cz0) >= 4u);
+            const uint32_t n_med = (uint32_t)__popcll(__ballot(medium));
+            const bool     leave = part && (r > a.r_defer || toobig || (medium && n_med < NW_MED_MIN));
+            const unsigned long long lmask = __ballot(leave);
+            if (lmask)
+            {
+                st_defer += push_lanes(a, 1, wv / a.seg_waves, leave, lmask, lane, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
+                if (leave) deferred = true, part = false;
+                if (INSTR) st_toobig += (uint32_t)__popcll(__ballot(leave && r <= a.r_defer));
+                dbg_flags |= 2u;
+            }
+        }
+        if (__ballot(part) == 0ull) break;  // uniform
+        st_pass++;
+        const bool want = part && !empty;
+        const unsigned long long wmask = __ballot(want);
+        bool go = false;  // this lane's cube lies inside the window of this pass
+        if (wmask)        // uniform
+        {
+            // ---- A: the window: up to 3 x 3 x 3 bricks holding the first open lane's cube, started at the
+            //      lowest brick any open lane needs where that still holds the first one ------------------
+            const int      seed = __ffsll((long long)wmask) - 1;
+            const uint32_t b0x = cx0 >> 2, b0y = cy0 >> 2, b0z = cz0 >> 2, b1x = cx1 >> 2, b1y = cy1 >> 2, b1z = cz1 >> 2;
+            const uint32_t s0x = (uint32_t)__builtin_amdgcn_readlane((int)b0x, seed), s1x = (uint32_t)__builtin_amdgcn_readlane((int)b1x, seed);
+            const uint32_t s0y = (uint32_t)__builtin_amdgcn_readlane((int)b0y, seed), s1y = (uint32_t)__builtin_amdgcn_readlane((int)b1y, seed);
+            const uint32_t s0z = (uint32_t)__builtin_amdgcn_readlane((int)b0z, seed), s1z = (uint32_t)__builtin_amdgcn_readlane((int)b1z, seed);
+            const uint32_t wx = min(max(wave_min_u32(want ? b0x : 0xFFFFFFFFu), s1x >= 2u ? s1x - 2u : 0u), s0x);
+            const uint32_t wy = min(max(wave_min_u32(want ? b0y : 0xFFFFFFFFu), s1y >= 2u ? s1y - 2u : 0u), s0y);
+            const uint32_t wz = min(max(wave_min_u32(want ? b0z : 0xFFFFFFFFu), s1z >= 2u ? s1z - 2u : 0u), s0z);
+            const uint32_t nbx = min(3u, max(wave_max_u32(want ? b1x : 0u), s1x) - wx + 1u);
+            const uint32_t nby = min(3u, max(wave_max_u32(want ? b1y : 0u), s1y) - wy + 1u);
+            const uint32_t nbz = min(3u, max(wave_max_u32(want ? b1z : 0u), s1z) - wz + 1u);
+            const uint32_t nbt = nbx * nby * nbz;  // <= 27
+            go = want && b0x >= wx && b1x < wx + nbx && b0y >= wy && b1y < wy + nby && b0z >= wz && b1z < wz + nbz;
+            // ---- a SPREAD wave (sparse far field: 64 Morton-consecutive queries metres apart, every one with
+            //      voxels of its own): some open lane lies outside the window.  Staging shares nothing there and
+            //      windows would take one pass per cluster -- every lane with a cube of at most 4 voxels per axis
+            //      searches it by itself instead (occupancy mask of its cube from <= 8 brick words, then voxel by
+            //      voxel: directory, points 4 loads in flight; nn_lane_kernel's own path).  Wider cubes keep to
+            //      the windows of the following passes. ----------------------------------------------------------
+            if (__ballot(want && !go))  // uniform
+            {
+                dbg_flags |= 1u;
+                const bool lite = want && (cx1 - cx0) < 4u && (cy1 - cy0) < 4u && (cz1 - cz0) < 4u;
+                if (INSTR) st_wait += (uint32_t)__popcll(__ballot(lite));
+                if (lite)
+                {
+                    unsigned long long m = cube_occ_mask(g, cx0, cy0, cz0, cx1, cy1, cz1);
+                    uint32_t           p = 0, pe = 0;
+                    for (;;)
                     {
-                        unsigned long long m = cube_occ_mask(g, sx, sy, sz, min(sx + 3u, cx1), min(sy + 3u, cy1), min(sz + 3u, cz1));
-                        while (m != 0ull)
+                        while (p >= pe && m != 0ull)
                         {
                             const uint32_t bit = (uint32_t)__ffsll((long long)m) - 1u;
                             m &= m - 1ull;
-                            const uint32_t cx = sx + (bit & 3u), cy = sy + ((bit >> 2) & 3u), cz = sz + (bit >> 4);
-                            const float    md2 = box_dist2(g.ox + (float)cx * hs, g.oy + (float)cy * hs, g.oz + (float)cz * hs, hs,
-                                                           qx, qy, qz);
-                            if (md2 <= fminf(prune2, voxel_limit(best_d2, g.slack)))
-                            {
-                                const uint32_t key  = 1u + (((cz - wz0) << 20) | ((cy - wy0) << 10) | (cx - wx0));
-                                uint32_t       slot = (key * 0x9E3779B1u) >> 24;  // log2(NW_HS) = 8 bits
-                                bool           ok   = false;
-                                for (int pr = 0; pr < NW_MAXPROBE; pr++)
-                                {
-                                    const uint32_t old = atomicCAS(&s_key[slot], 0u, key);
-                                    if (old == 0u || old == key)
-                                    {
-                                        ok = true;
-                                        break;
-                                    }
-                                    slot = (slot + 1u) & (uint32_t)(NW_HS - 1);
-                                }
-                                if (!ok) ovf = true;
-                                if (INSTR) st_ins++;
-                            }
+                            uint32_t s0 = 0, e0 = 0;
+                            if (voxel_range(g, 0u, cx0 + (bit & 3u), cy0 + ((bit >> 2) & 3u), cz0 + (bit >> 4), s0, e0, true)) p = s0, pe = e0;
                         }
+                        if (p >= pe) break;
+                        float4 c4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                        {
+                            c4[j] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
+                            if (p + j < pe) c4[j] = g.pts[p + j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                        {
+                            const float    d  = dist2(qx, qy, qz, c4[j].x, c4[j].y, c4[j].z);
+                            const uint32_t ci = __float_as_uint(c4[j].w);
+                            if (p + j < pe && (d < best_d2 || (d == best_d2 && ci < best_idx)))
+                                best_d2 = d, best_idx = ci, best_spos = p + j;
+                            if (INSTR && p + j < pe) a.touched[p + j] = 1, st_tests++;
+                        }
+                        p += 4u;
                     }
-        }
-        __syncthreads();
-        if (INSTR)
-        {
-            const unsigned long long t = wall_clock64();
-            t_ins += t - tph, tph = t;
-        }
-
-        // ---- B: resolve the set (4 slots per lane, loads independent), list the voxels that hold
-        //      points, prefix their point counts --------------------------------------------------
-        uint32_t n_u = 0, T = 0;
-        {
-            const uint4    k4    = *reinterpret_cast<const uint4*>(&s_key[4 * lane]);
-            const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
-            uint32_t       st[4] = {0u, 0u, 0u, 0u}, cn[4] = {0u, 0u, 0u, 0u};
-            const unsigned long long doff = g.dir_off[0];
-            if (doff != DIR_NONE)  // uniform
-            {
-                const uint32_t nx = g.occ_bx[0] * 4u, ny = g.occ_by[0] * 4u, nz = g.occ_bz[0] * 4u;
-                size_t         ix[4];
-                bool           in[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                {
-                    const uint32_t v  = kk[k] - 1u;
-                    const uint32_t cx = wx0 + (v & 1023u), cy = wy0 + ((v >> 10) & 1023u), cz = wz0 + (v >> 20);
-                    in[k] = kk[k] != 0u && cx < nx && cy < ny && cz < nz;
-                    ix[k] = in[k] ? ((size_t)cz * ny + cy) * nx + cx : 0;
+                    // its whole cube was examined
+                    if (is_final(r, rmax, best_d2, g.slack)) done = true;
+                    else r = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
                 }
-                uint2 e[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) e[k] = g.dir[doff + ix[k]];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (in[k] && e[k].y > e[k].x) st[k] = e[k].x, cn[k] = e[k].y - e[k].x;
-            }
-            else
-            {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (kk[k] != 0u)
-                    {
-                        const uint32_t v = kk[k] - 1u;
-                        uint32_t       s0 = 0, e0 = 0;
-                        if (voxel_range(g, 0u, wx0 + (v & 1023u), wy0 + ((v >> 10) & 1023u), wz0 + (v >> 20), s0, e0, true))
-                            st[k] = s0, cn[k] = e0 - s0;
-                    }
-            }
-            uint32_t used = 0, tot = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) used += cn[k] ? 1u : 0u, tot += cn[k];
-            const uint32_t iu = wave_incl_scan(used, lane), it = wave_incl_scan(tot, lane);
-            n_u = (uint32_t)__builtin_amdgcn_readlane((int)iu, 63);
-            T   = (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
-            uint32_t li = iu - used, off = it - tot;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (cn[k])
+                if (clocks)
                 {
-                    s_list[li] = make_uint4(kk[k], st[k], off, cn[k]);
-                    li++, off += cn[k];
+                    const unsigned long long t = wall_clock64();
+                    t_scan += t - tph, tph = t;
                 }
-        }
-        __syncthreads();
-        dbg_nu = max(dbg_nu, n_u), dbg_rounds += (T + NW_CAP - 1) / NW_CAP;
-        dbg_flags |= (__ballot(part && ovf) ? 1u : 0u) | (__ballot(part && toobig) ? 2u : 0u);
-        if (INSTR)
-        {
-            st_listed += n_u, st_T += T;
-            const unsigned long long t = wall_clock64();
-            t_dir += t - tph, tph = t;
-        }
-
-        // ---- C + D per round of NW_CAP staged points ---------------------------------------------
-        for (uint32_t base = 0; base < T; base += NW_CAP)
-        {
-            const uint32_t m = min((uint32_t)NW_CAP, T - base);
-            if (INSTR) st_rounds++;
-            // which listed voxel does a staged slot belong to: every voxel drops its id at its first slot of
-            // the round, a prefix-max carries it to the following slots (ids ascend with the offsets)
-            *reinterpret_cast<uint4*>(&s_owner[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
-            __syncthreads();
-            for (uint32_t e = (uint32_t)lane; e < n_u; e += 64u)
-            {
-                const uint4 L = s_list[e];
-                if (L.z >= base && L.z < base + NW_CAP) s_owner[L.z - base] = e + 1u;
-                else if (L.z < base && L.z + L.w > base) s_owner[0] = e + 1u;
-            }
-            __syncthreads();
-            uint32_t e_first = 0, e_end = 0;  // the listed voxels that own slots of this round
-            {
-                const uint4    o4 = *reinterpret_cast<const uint4*>(&s_owner[4 * lane]);
-                const uint32_t p0 = o4.x, p1 = max(p0, o4.y), p2 = max(p1, o4.z), p3 = max(p2, o4.w);
-                const uint32_t in = wave_incl_max(p3, lane);
-                uint32_t       ex = __shfl_up(in, 1, 64);
-                if (lane == 0) ex = 0u;
-                const uint32_t ow[4] = {max(ex, p0), max(ex, p1), max(ex, p2), max(ex, p3)};
-                const uint32_t t0    = 4u * (uint32_t)lane;
-                uint32_t       src[4];
-                float4         c4[4];
-                uint32_t       last = 0u;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                {
-                    src[k] = 0u;
-                    if (t0 + k < m)
-                    {
-                        const uint4 L = s_list[ow[k] - 1u];
-                        src[k]        = L.y + (base + t0 + k - L.z);
-                        last          = ow[k];
-                    }
-                }
-                e_first = (uint32_t)__builtin_amdgcn_readlane((int)ow[0], 0) - 1u;  // slot 0 always has an owner
-                e_end   = wave_max_u32(last);                                       // ids ascend with the slots
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                {
-                    c4[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
-                    if (t0 + k < m) c4[k] = g.pts[src[k]];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) s_pts[t0 + k] = c4[k];
-                if (INSTR)
-                {
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (t0 + k < m) a.touched[src[k]] = 1;
-                }
-            }
-            __syncthreads();
-            if (INSTR)
-            {
-                const unsigned long long t = wall_clock64();
-                t_stage += t - tph, tph = t;
+                go = go && !lite;  // the window of this pass serves the wider cubes inside it
             }
 
-            // ---- D: the lane's walk over the listed voxels: those its ball still reaches, their staged
-            //      points 4 at a time.  One flat loop (refill / work) so that lanes that skip a voxel do
-            //      not wait at every nesting level ---------------------------------------------------
-            uint32_t my_tests = 0;
+            // the window's occupancy words: lane k fetches brick k (x fastest)
+            unsigned long long word = 0ull;
+            if ((uint32_t)lane < nbt)
+            {
+                const uint32_t kz = (uint32_t)lane / (nbx * nby), kr = (uint32_t)lane - kz * nbx * nby;
+                const uint32_t ky = kr / nbx, kx = kr - ky * nbx;
+                const uint32_t Bx = wx + kx, By = wy + ky, Bz = wz + kz;
+                if (Bx < obx && By < oby && Bz < obz) word = occ0[((size_t)Bz * oby + By) * obx + Bx];
+            }
+            // the lane's cube as 4-bit masks per brick column of the window, spread over a brick's 64 voxels
+            // (kept packed -- 3 x 4 bits per axis -- and spread per brick: 2 registers instead of 18)
+            uint32_t ax = 0u, ay = 0u, az = 0u;
             if (go)
             {
-                uint32_t e = e_first, k = 0, kend = 0, sb = 0;
-                for (;;)
+#pragma unroll
+                for (int i = 0; i < 3; i++)
                 {
-                    while (k >= kend && e < e_end)
+                    ax |= axis_mask_in(wx + (uint32_t)i, cx0, cx1) << (4 * i);
+                    ay |= axis_mask_in(wy + (uint32_t)i, cy0, cy1) << (4 * i);
+                    az |= axis_mask_in(wz + (uint32_t)i, cz0, cz1) << (4 * i);
+                }
+            }
+            const uint32_t axy = ax | (ay << 12);  // 2 x 12 bits; az on its own
+            const uint32_t wlo = (uint32_t)word, whi = (uint32_t)(word >> 32);
+            // (the same conservative limit as the other kernels' voxel tests: radius + rounding slack, and the running best)
+            const float prune = r + 4.f * g.slack;
+            const float lim2  = fminf(prune * prune, voxel_limit(best_d2, g.slack));
+            const bool  refine = __ballot(go && r > hs) != 0ull;
+            if (clocks)
+            {
+                const unsigned long long t = wall_clock64();
+                t_ins += t - tph, tph = t;
+            }
+
+            // ---- bricks -> voxel list, in chunks of at most NW_NL voxels; each chunk is resolved, staged
+            //      and scanned before the next one is listed ------------------------------------------
+            uint32_t n_u = 0;
+            for (uint32_t k = 0; k <= nbt; k++)
+            {
+                if (k < nbt)
+                {
+                    const unsigned long long W = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)whi, (int)k) << 32) |
+                                                 (uint32_t)__builtin_amdgcn_readlane((int)wlo, (int)k);
+                    if (W == 0ull) continue;  // uniform: an empty brick
+                    const uint32_t kz = k / (nbx * nby), kr = k - kz * nbx * nby;
+                    const uint32_t ky = kr / nbx, kx = kr - ky * nbx;
+                    const unsigned long long sx = spread_x((axy >> (4u * kx)) & 15u);
+                    const unsigned long long sy = spread_y((axy >> (12u + 4u * ky)) & 15u);
+                    const unsigned long long sz = spread_z((az >> (4u * kz)) & 15u);
+                    unsigned long long N = W & sx & sy & sz;  // occupied voxels of this brick inside the lane's cube
+                    // a wide cube holds ~2-3x the points its ball reaches (a wall 0.9 m away: the cube cuts 1.8 x 1.8 m out
+                    // of it, the ball touches a 0.6 m disc): the voxels the BALL cannot reach are dropped, row by row
+                    // (x-interval of every (y, z) row from the per-axis squared distances).  Only when some lane's radius
+                    // exceeds a voxel: narrow cubes gain nothing
+                    if (refine)  // uniform
                     {
-                        const uint4    L  = s_list[e];
-                        const uint32_t v  = L.x - 1u;
-                        const uint32_t cx = wx0 + (v & 1023u), cy = wy0 + ((v >> 10) & 1023u), cz = wz0 + (v >> 20);
-                        e++;
-                        const float md2 = box_dist2(g.ox + (float)cx * hs, g.oy + (float)cy * hs, g.oz + (float)cz * hs, hs, qx, qy, qz);
-                        if (md2 <= fminf(prune2, voxel_limit(best_d2, g.slack)))
+                        unsigned long long keep = 0ull;
+                        if (N != 0ull)
                         {
-                            const uint32_t k0 = max(L.z, base), k1 = min(L.z + L.w, base + (uint32_t)NW_CAP);
-                            if (k0 < k1) k = k0 - base, kend = k1 - base, sb = L.y + (k0 - L.z) - k;  // sorted position of slot j = sb + j
+                            float ddx[4], ddy[4], ddz[4];
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                            {
+                                const float x0 = g.ox + (float)((wx + kx) * 4u + (uint32_t)i) * hs, y0 = g.oy + (float)((wy + ky) * 4u + (uint32_t)i) * hs,
+                                            z0 = g.oz + (float)((wz + kz) * 4u + (uint32_t)i) * hs;
+                                const float dx = fmaxf(0.f, fmaxf(x0 - qx, qx - (x0 + hs))), dy = fmaxf(0.f, fmaxf(y0 - qy, qy - (y0 + hs))),
+                                            dz = fmaxf(0.f, fmaxf(z0 - qz, qz - (z0 + hs)));
+                                ddx[i] = dx * dx, ddy[i] = dy * dy, ddz[i] = dz * dz;
+                            }
+#pragma unroll
+                            for (int zz = 0; zz < 4; zz++)
+#pragma unroll
+                                for (int yy = 0; yy < 4; yy++)
+                                {
+                                    // box_dist2's sum order: (dx2 + dy2) + dz2 <= lim2
+                                    uint32_t row = 0u;
+#pragma unroll
+                                    for (int xx = 0; xx < 4; xx++) row |= ((ddx[xx] + ddy[yy]) + ddz[zz] <= lim2) ? (1u << xx) : 0u;
+                                    keep |= (unsigned long long)row << (zz * 16 + yy * 4);
+                                }
+                        }
+                        N &= keep;
+                    }
+                    const unsigned long long U = wave_or_u64(N);  // voxels of this brick some lane needs
+                    if (U == 0ull) continue;  // uniform
+                    if (INSTR) st_bricks++;
+                    if ((U >> lane) & 1ull)
+                    {
+                        // voxel code: window-relative voxel coordinates, 4 bits each (bit = z * 16 + y * 4 + x)
+                        const uint32_t vx = kx * 4u + ((uint32_t)lane & 3u), vy = ky * 4u + (((uint32_t)lane >> 2) & 3u),
+                                       vz = kz * 4u + ((uint32_t)lane >> 4);
+                        s_vox[n_u + (uint32_t)__popcll(U & lane_lt)] = 1u | (vx << 4) | (vy << 8) | (vz << 12);
+                    }
+                    n_u += (uint32_t)__popcll(U);
+                    if (n_u <= (uint32_t)(NW_NL - 64) && k + 1u < nbt) continue;  // room for another brick
+                }
+                if (n_u == 0u) continue;
+                // ---- B: resolve the chunk (4 voxels per lane, loads independent), drop the voxels without
+                //      points (the bitmap said otherwise only for a stale map), prefix the counts --------
+                __syncthreads();
+                uint32_t T = 0, n_l = 0, omask = 0xFFFFFu;
+                bool     packed = true;
+                {
+                    const uint4 k4 = *reinterpret_cast<const uint4*>(&s_vox[4 * lane]);
+                    uint32_t    kk[4] = {k4.x, k4.y, k4.z, k4.w};
+                    uint32_t    st[4] = {0u, 0u, 0u, 0u}, cn[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (4u * (uint32_t)lane + (uint32_t)j >= n_u) kk[j] = 0u;  // stale codes of an earlier chunk
+                    const unsigned long long doff = g.dir_off[0];
+                    if (doff != DIR_NONE)  // uniform
+                    {
+                        const uint32_t nx = obx * 4u, ny = oby * 4u, nz = obz * 4u;
+                        size_t         ix[4];
+                        bool           in[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                        {
+                            const uint32_t cx = wx * 4u + ((kk[j] >> 4) & 15u), cy = wy * 4u + ((kk[j] >> 8) & 15u),
+                                           cz = wz * 4u + ((kk[j] >> 12) & 15u);
+                            in[j] = kk[j] != 0u && cx < nx && cy < ny && cz < nz;
+                            ix[j] = in[j] ? ((size_t)cz * ny + cy) * nx + cx : 0;
+                        }
+                        uint2 e[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) e[j] = g.dir[doff + ix[j]];
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (in[j] && e[j].y > e[j].x) st[j] = e[j].x, cn[j] = e[j].y - e[j].x;
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (kk[j] != 0u)
+                            {
+                                uint32_t s0 = 0, e0 = 0;
+                                if (voxel_range(g, 0u, wx * 4u + ((kk[j] >> 4) & 15u), wy * 4u + ((kk[j] >> 8) & 15u),
+                                                wz * 4u + ((kk[j] >> 12) & 15u), s0, e0, true))
+                                    st[j] = s0, cn[j] = e0 - s0;
+                            }
+                    }
+                    uint32_t used = 0, tot = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) used += cn[j] ? 1u : 0u, tot += cn[j];
+                    const uint32_t iu = wave_incl_scan(used, lane), it = wave_incl_scan(tot, lane);
+                    n_l = (uint32_t)__builtin_amdgcn_readlane((int)iu, 63);
+                    T   = (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+                    packed = T < (1u << 20);  // room for the voxel code above the offset (else: no walks)
+                    omask  = packed ? 0xFFFFFu : 0xFFFFFFFFu;
+                    uint32_t li = iu - used, off = it - tot;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (cn[j])
+                        {
+                            s_list[li] = make_uint2(st[j], packed ? (off | ((kk[j] >> 4) << 20)) : off);
+                            li++, off += cn[j];
+                        }
+                }
+                n_u = 0;
+                __syncthreads();
+                dbg_nu = max(dbg_nu, n_l), dbg_rounds += (T + NW_CAP - 1) / NW_CAP;
+                if (INSTR) st_listed += n_l, st_T += T;
+                if (clocks)
+                {
+                    const unsigned long long t = wall_clock64();
+                    t_dir += t - tph, tph = t;
+                }
+
+                // ---- C + D per round of NW_CAP staged points.  The loads of round n + 1 are issued before round n
+                //      is scanned (a chunk of a wide-radius wave takes up to 20+ rounds: their round trips were
+                //      most of its time).  Small chunks: every lane tests every staged point.  Chunks of more than
+                //      NW_WALK_MIN voxels (wide radii, or lanes that share little): every lane WALKS the voxels of
+                //      the round instead and tests only those its own ball reaches. ---------------------------
+                const bool walk = packed && n_l > NW_WALK_MIN;
+                uint32_t   src[4], e_first = 0, e_end = 0;
+                float4     c4[4];
+                // which listed voxel does a staged slot belong to: every voxel drops its id at its first slot of the
+                // round, a prefix-max carries it to the following slots (ids ascend with the offsets); then the loads
+                auto stage_issue = [&] __device__(uint32_t base) {
+                    const uint32_t m = min((uint32_t)NW_CAP, T - base);
+                    *reinterpret_cast<uint4*>(&s_owner[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+                    __syncthreads();
+                    for (uint32_t e = (uint32_t)lane; e < n_l; e += 64u)
+                    {
+                        const uint32_t off = s_list[e].y & omask, nxt = e + 1u < n_l ? (s_list[e + 1u].y & omask) : T;  // its points: [off, nxt)
+                        if (off >= base && off < base + NW_CAP) s_owner[off - base] = e + 1u;
+                        else if (off < base && nxt > base) s_owner[0] = e + 1u;
+                    }
+                    __syncthreads();
+                    const uint4    o4 = *reinterpret_cast<const uint4*>(&s_owner[4 * lane]);
+                    const uint32_t p0 = o4.x, p1 = max(p0, o4.y), p2 = max(p1, o4.z), p3 = max(p2, o4.w);
+                    const uint32_t in = wave_incl_max(p3, lane);
+                    uint32_t       ex = __shfl_up(in, 1, 64);
+                    if (lane == 0) ex = 0u;
+                    const uint32_t ow[4] = {max(ex, p0), max(ex, p1), max(ex, p2), max(ex, p3)};
+                    const uint32_t t0    = 4u * (uint32_t)lane;
+                    uint32_t       last  = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                    {
+                        src[j] = NONE_U32;
+                        if (t0 + j < m)
+                        {
+                            const uint2 L = s_list[ow[j] - 1u];
+                            src[j]        = L.x + (base + t0 + j - (L.y & omask));
+                            last          = ow[j];
                         }
                     }
-                    if (k >= kend) break;
-                    float4 c4[4];
+                    e_first = (uint32_t)__builtin_amdgcn_readlane((int)ow[0], 0) - 1u;  // slot 0 always has an owner
+                    e_end   = wave_max_u32(last);                                       // ids ascend with the slots
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                     {
                         c4[j] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
-                        if (k + j < kend) c4[j] = s_pts[k + j];
+                        if (t0 + j < m) c4[j] = g.pts[src[j]];
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
+                };
+                if (T) stage_issue(0u);
+                for (uint32_t base = 0; base < T; base += NW_CAP)
+                {
+                    const uint32_t m = min((uint32_t)NW_CAP, T - base);
+                    if (INSTR) st_rounds++;
+                    const uint32_t ef = e_first, ee = e_end;  // voxels owning slots of THIS round
                     {
-                        const float    d  = dist2(qx, qy, qz, c4[j].x, c4[j].y, c4[j].z);
-                        const uint32_t ci = __float_as_uint(c4[j].w);
-                        if (k + j < kend && (d < best_d2 || (d == best_d2 && ci < best_idx)))
-                            best_d2 = d, best_idx = ci, best_spos = sb + k + j;
-                        if (INSTR && k + j < kend) my_tests++;
+                        const uint32_t t0 = 4u * (uint32_t)lane;
+                        *reinterpret_cast<float4*>(&s_x[t0]) = make_float4(c4[0].x, c4[1].x, c4[2].x, c4[3].x);
+                        *reinterpret_cast<float4*>(&s_y[t0]) = make_float4(c4[0].y, c4[1].y, c4[2].y, c4[3].y);
+                        *reinterpret_cast<float4*>(&s_z[t0]) = make_float4(c4[0].z, c4[1].z, c4[2].z, c4[3].z);
+                        *reinterpret_cast<uint4*>(&s_idx[t0]) = make_uint4(__float_as_uint(c4[0].w), __float_as_uint(c4[1].w),
+                                                                           __float_as_uint(c4[2].w), __float_as_uint(c4[3].w));
+                        *reinterpret_cast<uint4*>(&s_spos[t0]) = make_uint4(src[0], src[1], src[2], src[3]);
+                        if (INSTR)
+                        {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (t0 + j < m) a.touched[src[j]] = 1;
+                        }
                     }
-                    k += 4u;
+                    __syncthreads();
+                    if (base + NW_CAP < T) stage_issue(base + NW_CAP);  // in flight while this round is scanned
+                    if (clocks)
+                    {
+                        const unsigned long long t = wall_clock64();
+                        t_stage += t - tph, tph = t;
+                    }
+                    if (walk)
+                    {
+                        // ---- D (walk): the voxels of this round the lane's ball still reaches, their staged points 4 at
+                        //      a time; one flat loop (refill / work) so that lanes skipping a voxel do not wait at
+                        //      every nesting level --------------------------------------------------------------
+                        if (go)
+                        {
+                            const float prune = r + 4.f * g.slack, prune2 = prune * prune;
+                            uint32_t    e = ef, k = 0, kend = 0;
+                            for (;;)
+                            {
+                                while (k >= kend && e < ee)
+                                {
+                                    const uint2    L    = s_list[e];
+                                    const uint32_t off  = L.y & omask, nxt = e + 1u < n_l ? (s_list[e + 1u].y & omask) : T;
+                                    const uint32_t code = L.y >> 20;
+                                    const uint32_t cx = wx * 4u + (code & 15u), cy = wy * 4u + ((code >> 4) & 15u), cz = wz * 4u + (code >> 8);
+                                    e++;
+                                    if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1 || cz < cz0 || cz > cz1) continue;  // outside the lane's cube
+                                    const float md2 = box_dist2(g.ox + (float)cx * hs, g.oy + (float)cy * hs, g.oz + (float)cz * hs, hs, qx, qy, qz);
+                                    if (md2 <= fminf(prune2, voxel_limit(best_d2, g.slack)))
+                                    {
+                                        const uint32_t k0 = max(off, base), k1 = min(nxt, base + (uint32_t)NW_CAP);
+                                        if (k0 < k1) k = k0 - base, kend = k1 - base;
+                                    }
+                                }
+                                if (k >= kend) break;
+#pragma unroll
+                                for (int j = 0; j < 4; j++)
+                                {
+                                    if (k + j < kend)
+                                    {
+                                        const float d = dist2(qx, qy, qz, s_x[k + j], s_y[k + j], s_z[k + j]);
+                                        if (d <= best_d2)
+                                        {
+                                            const uint32_t ci = s_idx[k + j];
+                                            if (d < best_d2 || ci < best_idx) best_d2 = d, best_idx = ci, best_spos = s_spos[k + j];
+                                        }
+                                        if (INSTR) st_tests++;
+                                    }
+                                }
+                                k += 4u;
+                            }
+                        }
+                    }
+                    else
+                    {
+                        // ---- D (all pairs): every lane tests every staged point, 8 per step on the packed-fp32 path
+                        //      (same roundings as dist2()); the update is rare.  Every staged point is a map point,
+                        //      so open lanes outside the window collect upper bounds too -------------------------
+                        const uint32_t m_pad = (m + 7u) & ~7u;
+                        for (uint32_t jb = 0; jb < m_pad; jb += 8u)
+                        {
+                            const float4 xa = *reinterpret_cast<const float4*>(&s_x[jb]);
+                            const float4 xb = *reinterpret_cast<const float4*>(&s_x[jb + 4]);
+                            const float4 ya = *reinterpret_cast<const float4*>(&s_y[jb]);
+                            const float4 yb = *reinterpret_cast<const float4*>(&s_y[jb + 4]);
+                            const float4 za = *reinterpret_cast<const float4*>(&s_z[jb]);
+                            const float4 zb = *reinterpret_cast<const float4*>(&s_z[jb + 4]);
+                            const v2f d01 = dist2_pk(qx2, qy2, qz2, v2f{xa.x, xa.y}, v2f{ya.x, ya.y}, v2f{za.x, za.y});
+                            const v2f d23 = dist2_pk(qx2, qy2, qz2, v2f{xa.z, xa.w}, v2f{ya.z, ya.w}, v2f{za.z, za.w});
+                            const v2f d45 = dist2_pk(qx2, qy2, qz2, v2f{xb.x, xb.y}, v2f{yb.x, yb.y}, v2f{zb.x, zb.y});
+                            const v2f d67 = dist2_pk(qx2, qy2, qz2, v2f{xb.z, xb.w}, v2f{yb.z, yb.w}, v2f{zb.z, zb.w});
+                            const float d[8] = {d01.x, d01.y, d23.x, d23.y, d45.x, d45.y, d67.x, d67.y};
+                            const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])),
+                                                   fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+                            if (part && mn <= best_d2)
+                            {
+#pragma unroll
+                                for (int j = 0; j < 8; j++)
+                                {
+                                    if (d[j] <= best_d2)
+                                    {
+                                        const uint32_t ci = s_idx[jb + j];
+                                        if (d[j] < best_d2 || ci < best_idx)
+                                        {
+                                            best_d2   = d[j];
+                                            best_idx  = ci;
+                                            best_spos = s_spos[jb + j];
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        if (INSTR) st_tests += m * (uint32_t)__popcll(__ballot(part));
+                    }
+                    __syncthreads();  // the next round overwrites the staged points
+                    if (clocks)
+                    {
+                        const unsigned long long t = wall_clock64();
+                        t_scan += t - tph, tph = t;
+                    }
                 }
             }
-            __syncthreads();  // the next round overwrites the staged points
-            if (INSTR)
-            {
-                st_tests += my_tests;
-                st_maxlane += wave_max_u32(my_tests);
-                const unsigned long long t = wall_clock64();
-                t_scan += t - tph, tph = t;
-            }
         }
-
-        // ---- conclude, or grow ---------------------------------------------------------------------
-        if (part)
+        // ---- conclude, or grow: lanes whose whole cube was inside the window (or empty) --------------
+        if (part && (go || empty))
         {
-            if (toobig)
-            {
-                if (INSTR) st_toobig++;
-            }
-            else if (ovf)
-            {
-                if (INSTR) st_ovf++;
-            }
-            else if (is_final(r, rmax, best_d2, g.slack)) done = true;
+            if (is_final(r, rmax, best_d2, g.slack)) done = true;
             else r = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
         }
-        // a cube too wide for a lane: the one-query-per-wave kernel enumerates bricks at a coarser level
-        {
-            const unsigned long long bmask = __ballot(part && toobig);
-            if (bmask)
-            {
-                st_defer += push_lanes(a, 1, wv / a.seg_waves, part && toobig, bmask, lane, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
-                if (part && toobig) deferred = true;
-            }
-        }
     }
-    // whatever is still open (set overflow, many growth steps) is handed on with its state
+    // whatever is still open (many windows, many growth steps) is handed on with its state
     {
         const bool               left  = !done && !deferred;
         const unsigned long long lmask = __ballot(left);
@@ -514,17 +718,19 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
 
     if (a.timeline && lane == 0)
     {
-        // start tick in the low 40 bits; above: widest voxel list (8 bits), staging rounds (8), passes (4), flags
+        // 8 words per wave: start tick (low 40 bits; above: widest voxel list (8 bits), staging rounds (8), passes (4),
+        // flags), end tick, ticks of {prologue, window, directory, staging, tests, records + claims}
         const unsigned long long info = (unsigned long long)min(dbg_nu, 255u) | ((unsigned long long)min(dbg_rounds, 255u) << 8) |
                                         ((unsigned long long)min(st_pass, 15u) << 16) | ((unsigned long long)dbg_flags << 20);
-        a.timeline[2 * (size_t)blockIdx.x]     = (tl0 & 0xFFFFFFFFFFull) | (info << 40);
-        a.timeline[2 * (size_t)blockIdx.x + 1] = wall_clock64() & 0xFFFFFFFFFFull;
+        const unsigned long long t_end = wall_clock64();
+        unsigned long long* o = a.timeline + 8 * (size_t)blockIdx.x;
+        o[0] = (tl0 & 0xFFFFFFFFFFull) | (info << 40), o[1] = t_end & 0xFFFFFFFFFFull;
+        o[2] = t_pro, o[3] = t_ins, o[4] = t_dir, o[5] = t_stage, o[6] = t_scan, o[7] = t_end - tph;
     }
     if (INSTR)
     {
         const unsigned long long t_end = wall_clock64();
-        const uint32_t tests = wave_sum_u32(st_tests), ins = wave_sum_u32(st_ins), ovfs = wave_sum_u32(st_ovf),
-                       big = wave_sum_u32(st_toobig);
+        const uint32_t waits = st_wait;
         if (lane == 0)
         {
             atomicAdd(&a.counters[0], 1ull);
@@ -543,13 +749,14 @@ __global__ __launch_bounds__(64) void nn_wave_kernel(const NNArgs a)
             atomicAdd(&a.counters[16 + b], 1ull);
             atomicAdd(&a.counters[47], (unsigned long long)n_search);
             atomicAdd(&a.counters[48], (unsigned long long)n_skip);
-            atomicAdd(&a.counters[NWC_LANE_TESTS], (unsigned long long)tests);
-            atomicAdd(&a.counters[NWC_MAXLANE], (unsigned long long)st_maxlane);
-            atomicAdd(&a.counters[NWC_INSERTS], (unsigned long long)ins);
-            atomicAdd(&a.counters[NWC_OVF], (unsigned long long)ovfs);
+            atomicAdd(&a.counters[NWC_LANE_TESTS], (unsigned long long)st_tests);
+            atomicAdd(&a.counters[NWC_MAXLANE], (unsigned long long)st_T);
+            atomicAdd(&a.counters[NWC_INSERTS], (unsigned long long)st_bricks);
+            atomicAdd(&a.counters[NWC_OVF], (unsigned long long)waits);
             atomicAdd(&a.counters[NWC_ROUNDS], (unsigned long long)st_rounds);
             atomicAdd(&a.counters[NWC_LISTED], (unsigned long long)st_listed);
-            atomicAdd(&a.counters[NWC_TOOBIG], (unsigned long long)big);
+            atomicAdd(&a.counters[NWC_TOOBIG], (unsigned long long)st_toobig);
+            atomicAdd(&a.counters[NWC_T_PRO], t_pro);
             atomicAdd(&a.counters[NWC_T_INS], t_ins);
             atomicAdd(&a.counters[NWC_T_DIR], t_dir);
             atomicAdd(&a.counters[NWC_T_STAGE], t_stage);

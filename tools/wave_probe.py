@@ -14,6 +14,7 @@ import mp2p_icp_amd as amd  # noqa: E402
 from mp2p_icp_amd import _lib, core  # noqa: E402
 
 scene = sys.argv[1] if len(sys.argv) > 1 else "a"
+only = sys.argv[2] if len(sys.argv) > 2 else ""
 d = bench.build_inputs(1_000_000, 10_000_000, 1, 0, 1, scene)
 ctx = amd.Context(0)
 g, l = d["glob"], d["local"]
@@ -25,6 +26,8 @@ chain = amd.se3.compose(d["T_gt"], amd.se3.exp(np.array([0.3, -0.3, 0.05, 0.0, 0
 chain_prev = amd.se3.compose(chain, amd.se3.exp(np.array([0.004, 0.002, 0.0, 0.0, 0.0, 0.001])))
 M40 = np.uint64((1 << 40) - 1)
 for name, warm, pose in (("chain", chain_prev, chain), ("init_after_gt", d["T_gt"], d["T_init"])):
+    if only and name != only:
+        continue
     ctx.set_profiling(0)
     pairs.clear()
     core.match_pt2pt(ctx, gmap, cloud, warm, prm, None, pairs)
@@ -35,7 +38,8 @@ for name, warm, pose in (("chain", chain_prev, chain), ("init_after_gt", d["T_gt
     tiles, singles = core.timeline(ctx)
     ctx.set_profiling(0)
     n_w = (l.shape[0] + 63) // 64
-    rec = tiles[:n_w]
+    rec = tiles.reshape(-1)[:8 * n_w].reshape(n_w, 8)
+    phases = rec[:, 2:8].astype(np.float64) / 100.0  # us: prologue, window, directory, staging, tests, emit
     start, end = (rec[:, 0] & M40).astype(np.int64), (rec[:, 1] & M40).astype(np.int64)
     info = (rec[:, 0] >> np.uint64(40)).astype(np.int64)
     nu, rounds, passes, flags = info & 255, (info >> 8) & 255, (info >> 16) & 15, (info >> 20) & 3
@@ -53,6 +57,11 @@ for name, warm, pose in (("chain", chain_prev, chain), ("init_after_gt", d["T_gt
                 rows.append((f"[{a},{b})", int(m.sum()), round(float(dur[m].mean()), 1), round(float(dur[m].sum() / 1e3), 1)))
         by[lab] = rows
     out["by(count, mean_us, total_ms)"] = by
+    names = ("prologue", "window", "directory", "staging", "tests", "emit")
+    out["phase_us_mean"] = {n: round(float(phases[:, i].mean()), 2) for i, n in enumerate(names)}
+    light = (nu < 16) & (rounds <= 1) & (passes <= 1)
+    out["phase_us_mean_light_waves"] = {n: round(float(phases[light, i].mean()), 2) for i, n in enumerate(names)}
+    out["light_waves"] = [int(light.sum()), round(float(dur[light].mean()), 2)]
     out["flags(ovf,toobig) waves"] = [int((flags & 1).astype(bool).sum()), int((flags & 2).astype(bool).sum())]
     top = np.argsort(-dur)[:15]
     out["slowest(wave, us, nu, rounds, passes, flags)"] = [(int(i), round(float(dur[i]), 1), int(nu[i]), int(rounds[i]), int(passes[i]), int(flags[i])) for i in top]

@@ -70,7 +70,8 @@ static void parse_tune(Tune& t)
             else if (k == "claim_peek") t.claim_peek = (int)v;
             else if (k == "compact_fused") t.compact_fused = (int)v;
             else if (k == "wave_kernel") t.wave_kernel = (int)v;
-            else if (k == "wave_waves") t.wave_waves = (uint32_t)v;
+            else if (k == "predict") t.predict = (int)v;
+            else if (k == "wave_mfma") t.wave_mfma = (int)v;
             else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
         }
         i = j + 1;
@@ -173,6 +174,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->aos_stage.release(), ctx->pl_slots.release(), ctx->pl_knn.release();
     ctx->work.release(), ctx->work_q.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();
     ctx->pend.release(), ctx->pend_q.release(), ctx->q_counters.release(), ctx->nn_rec.release();
+    ctx->pred_buf[0].release(), ctx->pred_buf[1].release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     (void)mp2p_hip_pairs_copy_end(ctx);

@@ -130,7 +130,9 @@ struct Tune
                                     // time on scene B, +4 % on scene A
     int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
-    uint32_t wave_waves    = 4;     // nn_wave_kernel: register budget for this many waves per SIMD (4, 5, 6)
+    int      wave_mfma     = 0;     // nn_wave_kernel: distance tests on the matrix pipe as a prefilter (measured: no gain there)
+    int      predict       = 1;     // wave path: queries predicted to be far are served by the one-query kernel on a second
+                                    // stream from the start of the call (0 = only after nn_wave_kernel)
     int      wave_kernel   = 1;     // point-to-point search, K = 1: nn_wave_kernel (per-lane balls over an LDS voxel set) instead
                                     // of nn_lane_kernel + nn_tile_kernel (0 = the round-2 kernels)
 };
@@ -218,6 +220,11 @@ struct mp2p_hip_ctx
     uint32_t last_n_tiles = 0;
     uint32_t last_q       = 64;
     int      last_wave_path = 0;  // the last pt2pt search ran nn_wave_kernel
+    // prediction lists of the wave path (nn_query.hip, NNArgs::pred / next): ping-pong
+    mp2p::DevBuf<uint32_t> pred_buf[2];
+    int      pred_cur = 0;        // pred_buf[pred_cur] / list 3 + pred_cur is served by the next call
+    bool     pred_valid = false;  // ... and holds what the previous call predicted
+    int      nn_zero_list = -1;   // the list the last search consumed (the fused compaction re-zeroes its counters)
     void*    pinned       = nullptr;  // 4 KB of page-locked host memory for the small read-backs
     hipStream_t stream2    = nullptr;    // second search pipeline (launch_nn_pt2pt)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

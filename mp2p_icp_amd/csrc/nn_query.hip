@@ -58,6 +58,7 @@ constexpr int NN_COOP_MAX = 4;    // groups of up to this many queries are defer
 constexpr int NN_CLAIM_SLOTS = 128;  // in-wave claim table (LDS)
 constexpr int NN_MAX_SEG     = 256;  // segments of a query list
 constexpr int NN_LISTS       = 3;    // 0 = pending/hard, 1 = deferred, 2 = pending/easy
+constexpr int NN_ALL_LISTS   = 5;    // + 3, 4 = the two PREDICTION lists of nn_wave.hip's flow (ping-pong)
 constexpr int NN_CNT_STRIDE  = 32;   // uint32 words between two segment counters (128 bytes)
 
 struct NNArgs
@@ -120,6 +121,15 @@ struct NNArgs
     // kernels ([n_tiles] then [single blocks]); the plain kernels only pay a uniform null test
     unsigned long long*  timeline;
     uint32_t             timeline_single_base;
+    // ---- prediction (round 3): a query the one-query-per-wave kernel had to finish is far from the map and stays
+    //      so for many ICP iterations.  Whoever finishes such a query appends its index to the NEXT list (and sets
+    //      bit 1 of the record's flag word); in the following call the list is served by nn_single_kernel<PRED> on a
+    //      second stream FROM THE START, next to nn_wave_kernel (whose lanes skip the flagged queries), instead of
+    //      after it.  Lists 3 / 4 of q_counters, same segments as the others; entries = sorted local index.
+    uint32_t*            pred;       // the list served now (null: none)
+    uint32_t*            next;       // the list being written (null: prediction off)
+    int                  pred_list, next_list;  // their indices in q_counters
+    float                again_d;    // a found distance beyond this predicts another hand-over
 };
 
 // ---- geometry of one search pass (all values wave-uniform) -----------------------------------
@@ -1073,7 +1083,7 @@ constexpr int NN_VLIST = 1024;  // occupied voxels listed per round (LDS)
 // W = waves per SIMD the register allocation aims at (__launch_bounds__' second argument; 1 = the
 // compiler's own choice, 96-98 VGPRs = 5 waves): the kernel is a chain of dependent loads per query, so
 // queries in flight per CU is what it is bound by (measured variants: MP2P_HIP_TUNE single_waves)
-template <bool INSTR, int W>
+template <bool INSTR, int W, bool PRED = false>
 __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
 {
     __shared__ uint32_t s_cstart[64];
@@ -1092,7 +1102,7 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
         for (int k = 0; k < NN_MAX_SEG / 64; k++)
         {
             const uint32_t sg  = (uint32_t)(k * 64 + lane);
-            const uint32_t c   = sg < a.n_seg ? a.q_counters[((size_t)NN_MAX_SEG + a.seg_base + sg) * NN_CNT_STRIDE] : 0u;
+            const uint32_t c   = sg < a.n_seg ? a.q_counters[((size_t)(PRED ? a.pred_list : 1) * NN_MAX_SEG + a.seg_base + sg) * NN_CNT_STRIDE] : 0u;
             const uint32_t inc = wave_incl_scan(c, lane);
             s_segoff[sg]       = run + inc - c;
             run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -1115,22 +1125,68 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
             else hi = mid - 1;
         }
         const size_t   item = (size_t)(a.seg_base + lo) * a.seg_cap + (k_item - s_segoff[lo]);
-        const uint4    w    = a.work[item];
-        const uint4    wq   = a.work_q[item];
-        const uint32_t qi   = w.x;
-        const uint32_t orig = __float_as_uint(a.lpts[qi].w);  // used by the claim at the end only
-        const float    qx = __uint_as_float(wq.x), qy = __uint_as_float(wq.y), qz = __uint_as_float(wq.z);
-        const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));
-        const float thr    = fadd(a.maxDistSq, fmul(a.angSq, normSq));
-        const float rmax   = sqrtf(thr) * 1.002f + g.slack;
-        float       r      = __uint_as_float(w.y);
-        // wave-uniform running best (carried over from the tile kernel)
-        float    best_d2  = __uint_as_float(w.z);
-        uint32_t best_idx = w.w, best_spos = wq.w;
+        uint32_t qi, orig, best_idx, best_spos;
+        float    qx, qy, qz, thr, rmax, r, best_d2;
+        bool     search = true, active = true;
+        float    lb2_skip = -1.f;
+        if (PRED)
+        {
+            // a predicted query: only its index is known -- the whole prologue of nn_wave_kernel for ONE query
+            // (every lane computes the same values from the same addresses)
+            qi = a.pred[item];
+            const float4 lp = a.lpts[qi];
+            const uint4  h  = a.rec[qi];
+            orig = __float_as_uint(lp.w);
+            bool visited = true;
+            if (a.rank) visited = a.rank[orig] != NONE_U32;
+            compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
+            const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));
+            thr  = fadd(a.maxDistSq, fmul(a.angSq, normSq));
+            rmax = sqrtf(thr) * 1.002f + g.slack;
+            active = visited && (normSq < INFINITY);
+            if (active && a.local_taken && a.local_taken[orig]) active = false;  // :218-220
+            r = fminf(a.r0, rmax), best_d2 = INFINITY, best_idx = NONE_U32, best_spos = NONE_U32;
+            search = active;
+            if (active)
+            {
+                float ox, oy, oz;
+                compose_point_f(a.prev_pose, lp.x, lp.y, lp.z, ox, oy, oz);
+                const float disp = sqrtf(dist2(qx, qy, qz, ox, oy, oz));
+                float       lb   = sqrtf(__uint_as_float(h.z)) * 0.99999f - disp * 1.00001f - 4.f * g.slack;
+                if (!(lb > 0.f)) lb = 0.f;
+                float hr = 0.f;
+                if (h.x < g.n)
+                {
+                    const float4 hp = g.pts[h.x];
+                    const float  hd = dist2(qx, qy, qz, hp.x, hp.y, hp.z);
+                    if (hd < INFINITY) best_d2 = hd, best_idx = __float_as_uint(hp.w), best_spos = h.x, hr = sqrtf(hd) * (1.0f + 1.0f / 512.0f) + 4.f * g.slack;
+                }
+                if (lb * 0.999f > sqrtf(thr)) search = false, lb2_skip = (lb * 0.9999f) * (lb * 0.9999f);
+                else
+                {
+                    const float cap = fmaxf(2.0f * lb, r);
+                    r = fminf(hr > 0.f ? fminf(hr, cap) : cap, rmax);
+                }
+            }
+        }
+        else
+        {
+            const uint4 w  = a.work[item];
+            const uint4 wq = a.work_q[item];
+            qi   = w.x;
+            orig = __float_as_uint(a.lpts[qi].w);  // used by the claim at the end only
+            qx = __uint_as_float(wq.x), qy = __uint_as_float(wq.y), qz = __uint_as_float(wq.z);
+            const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));
+            thr  = fadd(a.maxDistSq, fmul(a.angSq, normSq));
+            rmax = sqrtf(thr) * 1.002f + g.slack;
+            r    = __uint_as_float(w.y);
+            // wave-uniform running best (carried over from the kernel that handed the query on)
+            best_d2 = __uint_as_float(w.z), best_idx = w.w, best_spos = wq.w;
+        }
         uint32_t st_pass = 0, st_cand = 0, st_cells = 0;
         const long long t_start = INSTR ? (long long)wall_clock64() : 0;
 
-        for (;;)
+        for (; search;)
         {
             st_pass++;
             const float prune  = r + 4.f * g.slack;
@@ -1269,12 +1325,20 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
         }
         if (lane == 0)
         {
-            bool acc = best_idx != NONE_U32 && best_d2 < thr;                    // :259
+            bool acc = active && best_idx != NONE_U32 && best_d2 < thr;         // :259
             if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;  // :98-101
-            a.rec[qi] = make_uint4(best_spos, __float_as_uint(best_d2), __float_as_uint(fminf(best_d2, thr)),
-                                   acc ? 1u : 0u);
+            // will the next call hand this query on again?  (its neighbour is as far then as now)
+            const bool again = a.next != nullptr && active && !(sqrtf(best_d2) <= a.again_d);
+            const float lb2 = !active ? 0.f : (lb2_skip >= 0.f ? lb2_skip : fminf(best_d2, thr));
+            a.rec[qi] = make_uint4(best_spos, __float_as_uint(best_d2), __float_as_uint(lb2), (acc ? 1u : 0u) | (again ? 2u : 0u));
             if (acc && a.claims)
                 claim_global(a, best_spos, (uint32_t)(a.local_offset + (a.rank ? a.rank[orig] : orig)));
+            if (again)
+            {
+                const uint32_t seg  = (qi >> 6) / a.seg_waves;
+                const uint32_t slot = atomicAdd(a.q_counters + ((size_t)a.next_list * NN_MAX_SEG + seg) * NN_CNT_STRIDE, 1u);
+                a.next[(size_t)seg * a.seg_cap + slot] = qi;
+            }
         }
         if (INSTR && lane == 0)
         {
@@ -1302,9 +1366,9 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
 namespace mp2p
 {
 // resets the segment counters of the two query lists
-__global__ __launch_bounds__(NN_LISTS * NN_MAX_SEG) void nn_reset_kernel(uint32_t* q_counters)
+__global__ __launch_bounds__(NN_MAX_SEG) void nn_reset_kernel(uint32_t* q_counters)
 {
-    q_counters[(size_t)threadIdx.x * NN_CNT_STRIDE] = 0u;
+    q_counters[((size_t)blockIdx.x * NN_MAX_SEG + threadIdx.x) * NN_CNT_STRIDE] = 0u;  // one block per list
 }
 
 // the [n_l][1] result arrays the other matchers' kernels read, from the packed records
@@ -1314,7 +1378,7 @@ __global__ __launch_bounds__(256) void nn_unpack_rec_kernel(const uint4* __restr
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4 r = rec[i];
-    spos[i] = r.w ? r.x : NONE_U32;
+    spos[i] = (r.w & 1u) ? r.x : NONE_U32;
     d2[i]   = __uint_as_float(r.y);
 }
 int launch_unpack_rec(mp2p_hip_ctx* ctx, size_t n_l)
@@ -1389,9 +1453,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     MP2P_TRY_HIP(ctx, ctx->work_q.ensure(list_cap));
     MP2P_TRY_HIP(ctx, ctx->pend.ensure(2 * list_cap));  // hard class, then easy class
     MP2P_TRY_HIP(ctx, ctx->pend_q.ensure(2 * list_cap));
-    if (ctx->q_counters.n < (size_t)NN_LISTS * NN_MAX_SEG * NN_CNT_STRIDE)
+    if (ctx->q_counters.n < (size_t)NN_ALL_LISTS * NN_MAX_SEG * NN_CNT_STRIDE)
     {
-        MP2P_TRY_HIP(ctx, ctx->q_counters.ensure((size_t)NN_LISTS * NN_MAX_SEG * NN_CNT_STRIDE));
+        MP2P_TRY_HIP(ctx, ctx->q_counters.ensure((size_t)NN_ALL_LISTS * NN_MAX_SEG * NN_CNT_STRIDE));
         ctx->q_counters_clean = false;
     }
     ctx->last_q       = Q;
@@ -1481,28 +1545,67 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     const bool use_wave = ctx->tune.wave_kernel && prm->queries_per_wave == 0 && map->view.occ != nullptr &&
                           map->view.occ_off[0] != OCC_NONE && ctx->tune.pipelines < 2;
     ctx->last_wave_path = use_wave ? 1 : 0;
-    // the list counters: cleared by the previous call's fused compaction, or here
-    if (!ctx->q_counters_clean)
-        hipLaunchKernelGGL(nn_reset_kernel, dim3(1), dim3(NN_LISTS * NN_MAX_SEG), 0, ctx->stream, a.q_counters);
+    // ---- prediction (NNArgs::pred / next): only on the wave path, with plain timing (levels 0 / 3), on a real stream
+    const bool predict = use_wave && ctx->tune.predict && (ctx->profiling == 0 || ctx->profiling == 3) && ctx->stream != nullptr &&
+                         ctx->stream != hipStreamLegacy;
+    // the list counters: cleared by the previous call's fused compaction, or here (then any prediction is gone too)
+    if (!ctx->q_counters_clean || (ctx->pred_valid && !(predict && a.use_hint)))
+    {
+        hipLaunchKernelGGL(nn_reset_kernel, dim3(NN_ALL_LISTS), dim3(NN_MAX_SEG), 0, ctx->stream, a.q_counters);
+        ctx->pred_valid = false;
+    }
     ctx->q_counters_clean = false;
+    a.pred = a.next = nullptr, a.pred_list = a.next_list = 0, ctx->nn_zero_list = -1;
+    if (predict)
+    {
+        const int cur = ctx->pred_cur;
+        MP2P_TRY_HIP(ctx, ctx->pred_buf[0].ensure(list_cap));
+        MP2P_TRY_HIP(ctx, ctx->pred_buf[1].ensure(list_cap));
+        a.next = ctx->pred_buf[1 - cur].p, a.next_list = 3 + (1 - cur);
+        if (ctx->pred_valid) a.pred = ctx->pred_buf[cur].p, a.pred_list = 3 + cur;
+        // a neighbour farther than this is handed on by nn_wave_kernel (radius beyond r_defer, or a cube of 9+ voxels)
+        a.again_d = fminf(a.r_defer, 3.4f * cell0) * 0.99f;
+        ctx->nn_zero_list = 3 + cur;  // consumed by this call; the next call writes it
+        ctx->pred_cur = 1 - cur, ctx->pred_valid = true;
+    }
     // ev[0]..ev[1] brackets exactly the search kernels (the roofline kernels of bench.py)
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (n_tiles && use_wave)
     {
         const bool instr = a.counters != nullptr;
         a.seg_base = 0, a.wave_base = 0;
-        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));  // no separate prologue
-        if (instr) hipLaunchKernelGGL((nn_wave_kernel<true, 4>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
-        else if (ctx->tune.wave_waves == 5) hipLaunchKernelGGL((nn_wave_kernel<false, 5>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((nn_wave_kernel<false, 4>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
-        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         const uint32_t sb = (uint32_t)std::min<size_t>((size_t)n_waves * 64u,
                                                        256u * (ctx->tune.single_blocks_per_cu ? ctx->tune.single_blocks_per_cu : 40u));
+        if (a.pred)
+        {  // the predicted queries: from the start, on the second stream
+            if (!ctx->stream2)
+            {
+                // a HIGH-priority stream: its own hardware queue (two plain streams may share one -- then the two
+                // kernels run back to back), and the far queries are the critical path anyway
+                int least = 0, greatest = 0;
+                MP2P_TRY_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                MP2P_TRY_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest));
+            }
+            if (!ctx->ev_fork) MP2P_TRY_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            if (!ctx->ev_join) MP2P_TRY_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            MP2P_TRY_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            hipLaunchKernelGGL((nn_single_kernel<false, 1, true>), dim3(sb), dim3(64), 0, ctx->stream2, a);  // 4 waves per SIMD: 5 spill here
+            MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+        }
+        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));  // no separate prologue
+        // (the matrix-pipe prefilter buys nothing here -- the rounds wait for their staging loads, not for the tests:
+        //  0.246 vs 0.253 ms -- so the exact packed scan is the default; MP2P_HIP_TUNE wave_mfma=1 for the other)
+        if (instr) hipLaunchKernelGGL((nn_wave_kernel<true, 4, false>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
+        else if (ctx->tune.wave_mfma) hipLaunchKernelGGL((nn_wave_kernel<false, 4, true>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((nn_wave_kernel<false, 4, false>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
+        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         if (instr) hipLaunchKernelGGL((nn_single_kernel<true, 1>), dim3(sb), dim3(64), 0, ctx->stream, a);
         else if (ctx->tune.single_waves == 4) hipLaunchKernelGGL((nn_single_kernel<false, 1>), dim3(sb), dim3(64), 0, ctx->stream, a);
         else if (ctx->tune.single_waves == 6) hipLaunchKernelGGL((nn_single_kernel<false, 6>), dim3(sb), dim3(64), 0, ctx->stream, a);
         else if (ctx->tune.single_waves == 8) hipLaunchKernelGGL((nn_single_kernel<false, 8>), dim3(sb), dim3(64), 0, ctx->stream, a);
         else hipLaunchKernelGGL((nn_single_kernel<false, 5>), dim3(sb), dim3(64), 0, ctx->stream, a);
+        if (a.pred) MP2P_TRY_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     else if (n_tiles)
     {

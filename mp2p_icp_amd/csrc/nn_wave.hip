@@ -10,7 +10,7 @@
 // trips per 32 queries.  On the bench chains 80 % of the queries have a previous nearest neighbour
 // 2..9 cm away while a few per tile are 0.3..1 m off.  Here a wave owns 64 Morton-consecutive queries
 // (one per lane); every step below is wave-uniform control flow:
-//   A. each lane's ball gives a cube of level-0 voxels; the wave looks at a WINDOW of up to 3 x 3 x 3
+//   A. each lane's ball gives a cube of level-0 voxels; the wave looks at a WINDOW of up to 4 x 4 x 4
 //      occupancy bricks (4x4x4 voxels, one 8-byte word each, all words fetched by one load) around its
 //      first open query; per brick every lane ANDs the word with the mask of its own cube and a wave-wide OR
 //      gives the set of occupied voxels ANY lane needs -- the union of the cubes, not their bounding box;
@@ -31,10 +31,9 @@ namespace mp2p
 constexpr int NW_NL      = 256;  // listed voxels per chunk
 constexpr int NW_CAP     = 256;  // staged points per round
 constexpr int NW_MAXPASS = 6;
+constexpr uint32_t NW_WIN = 4;     // window: at most this many bricks per axis
 constexpr uint32_t NW_MAXSPAN = 8;  // widest cube (level-0 voxels per axis) the window can hold at any alignment
 constexpr uint32_t NW_MED_MIN = 8;  // cubes wider than 4 voxels stay in the wave only in this company
-constexpr uint32_t NW_WALK_MIN = 0xFFFFu;  // chunks of more listed voxels would be WALKED per lane instead of tested all-pairs: measured
-                                           // 3.5x slower at 24 (divergent refill loops + dependent LDS reads beat the 2x fewer tests): off
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t k)
 {
@@ -126,6 +125,14 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
     return ((unsigned long long)h << 32) | l;
 }
 
+// bit b of an 8-bit value -> the nibble at bit 4b (all four bits)
+__device__ __forceinline__ uint32_t nibble_spread8(uint32_t x)
+{
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x * 0xFu;
+}
 // 4-bit mask of the voxels 4b..4b+3 of brick b that lie in [c0, c1]; 0 when they do not overlap
 __device__ __forceinline__ uint32_t axis_mask_in(uint32_t b, uint32_t c0, uint32_t c1)
 {
@@ -135,7 +142,7 @@ __device__ __forceinline__ uint32_t axis_mask_in(uint32_t b, uint32_t c0, uint32
 }
 
 // WPE = waves per SIMD the register allocation aims at (MP2P_HIP_TUNE wave_waves)
-template <bool INSTR, int WPE>
+template <bool INSTR, int WPE, bool MF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void nn_wave_kernel(const NNArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint2    s_list[NW_NL];  // listed voxels (all hold points): {first sorted position, first staged slot}
@@ -226,6 +233,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         }
     }
     bool deferred = false;
+    // a query the previous call predicted to be far: nn_single_kernel<PRED> serves it on the other stream (NNArgs::pred)
+    if (a.pred != nullptr && valid && (h.w & 2u)) done = true, deferred = true;
     const float hs = g.hf * (float)(1u << g.shift0);  // level-0 voxel edge
     uint32_t dbg_nu = 0, dbg_rounds = 0, dbg_flags = 0;  // profiling level 4: packed into the timeline record
     uint32_t st_pass = 0, st_T = 0, st_tests = 0, st_bricks = 0, st_wait = 0, st_rounds = 0, st_listed = 0, st_toobig = 0,
@@ -289,13 +298,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             const uint32_t s0x = (uint32_t)__builtin_amdgcn_readlane((int)b0x, seed), s1x = (uint32_t)__builtin_amdgcn_readlane((int)b1x, seed);
             const uint32_t s0y = (uint32_t)__builtin_amdgcn_readlane((int)b0y, seed), s1y = (uint32_t)__builtin_amdgcn_readlane((int)b1y, seed);
             const uint32_t s0z = (uint32_t)__builtin_amdgcn_readlane((int)b0z, seed), s1z = (uint32_t)__builtin_amdgcn_readlane((int)b1z, seed);
-            const uint32_t wx = min(max(wave_min_u32(want ? b0x : 0xFFFFFFFFu), s1x >= 2u ? s1x - 2u : 0u), s0x);
-            const uint32_t wy = min(max(wave_min_u32(want ? b0y : 0xFFFFFFFFu), s1y >= 2u ? s1y - 2u : 0u), s0y);
-            const uint32_t wz = min(max(wave_min_u32(want ? b0z : 0xFFFFFFFFu), s1z >= 2u ? s1z - 2u : 0u), s0z);
-            const uint32_t nbx = min(3u, max(wave_max_u32(want ? b1x : 0u), s1x) - wx + 1u);
-            const uint32_t nby = min(3u, max(wave_max_u32(want ? b1y : 0u), s1y) - wy + 1u);
-            const uint32_t nbz = min(3u, max(wave_max_u32(want ? b1z : 0u), s1z) - wz + 1u);
-            const uint32_t nbt = nbx * nby * nbz;  // <= 27
+            constexpr uint32_t NB = NW_WIN;  // bricks per axis at most (NB^3 <= 64: one occupancy word per lane)
+            const uint32_t wx = min(max(wave_min_u32(want ? b0x : 0xFFFFFFFFu), s1x >= NB - 1u ? s1x - (NB - 1u) : 0u), s0x);
+            const uint32_t wy = min(max(wave_min_u32(want ? b0y : 0xFFFFFFFFu), s1y >= NB - 1u ? s1y - (NB - 1u) : 0u), s0y);
+            const uint32_t wz = min(max(wave_min_u32(want ? b0z : 0xFFFFFFFFu), s1z >= NB - 1u ? s1z - (NB - 1u) : 0u), s0z);
+            const uint32_t nbx = min(NB, max(wave_max_u32(want ? b1x : 0u), s1x) - wx + 1u);
+            const uint32_t nby = min(NB, max(wave_max_u32(want ? b1y : 0u), s1y) - wy + 1u);
+            const uint32_t nbz = min(NB, max(wave_max_u32(want ? b1z : 0u), s1z) - wz + 1u);
+            const uint32_t nbt = nbx * nby * nbz;  // <= 64
             go = want && b0x >= wx && b1x < wx + nbx && b0y >= wy && b1y < wy + nby && b0z >= wz && b1z < wz + nbz;
             // ---- a SPREAD wave (sparse far field: 64 Morton-consecutive queries metres apart, every one with
             //      voxels of its own): some open lane lies outside the window.  Staging shares nothing there and
@@ -362,24 +372,57 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 if (Bx < obx && By < oby && Bz < obz) word = occ0[((size_t)Bz * oby + By) * obx + Bx];
             }
             // the lane's cube as 4-bit masks per brick column of the window, spread over a brick's 64 voxels
-            // (kept packed -- 3 x 4 bits per axis -- and spread per brick: 2 registers instead of 18)
+            // (kept packed -- 4 bits per brick column and axis -- and spread per brick: 2 registers instead of 24)
             uint32_t ax = 0u, ay = 0u, az = 0u;
             if (go)
             {
 #pragma unroll
-                for (int i = 0; i < 3; i++)
+                for (int i = 0; i < (int)NB; i++)
                 {
                     ax |= axis_mask_in(wx + (uint32_t)i, cx0, cx1) << (4 * i);
                     ay |= axis_mask_in(wy + (uint32_t)i, cy0, cy1) << (4 * i);
                     az |= axis_mask_in(wz + (uint32_t)i, cz0, cz1) << (4 * i);
                 }
             }
-            const uint32_t axy = ax | (ay << 12);  // 2 x 12 bits; az on its own
+            const uint32_t axy = ax | (ay << 16);  // 2 x 16 bits; az on its own
             const uint32_t wlo = (uint32_t)word, whi = (uint32_t)(word >> 32);
             // (the same conservative limit as the other kernels' voxel tests: radius + rounding slack, and the running best)
             const float prune = r + 4.f * g.slack;
             const float lim2  = fminf(prune * prune, voxel_limit(best_d2, g.slack));
             const bool  refine = __ballot(go && r > hs) != 0ull;
+            // ---- matrix-pipe prefilter (MP2P_HIP_TUNE mfma_scan, default on): d2 of 32 staged points x 32 queries by
+            //      three v_mfma_f32_32x32x2_f32 on coordinates centred on the box of the window's open cubes,
+            //        S = -2 c'.q' + |c'|^2 + |q'|^2,  A = [c'x c'y | c'z |c'|^2 | 1 0],  B = [-2q'x -2q'y | -2q'z 1 | |q'|^2 0]
+            //      (rows = points, columns = queries; lane l holds column l & 31 and 16 of the 32 rows), exactly as
+            //      nn_tile_kernel's: |S - exact d2| <= mtol for every query in the box and every point in the box grown
+            //      by one voxel (tests/test_prefilter_bound.py), so a point with S > best + mtol cannot beat or tie the
+            //      best; the others are recomputed in the exact FMA-free sequence.  The wave's 64 queries are two
+            //      such tiles: in tile t the lanes of half t work for their own query, the other half for its partner's
+            //      (lane ^ 32) -- a FOREIGN running best that is merged back after the chunk.
+            const bool  hb = lane >= 32;
+            float       ocx = 0.f, ocy = 0.f, ocz = 0.f, mtol = 0.f;
+            float       bq0[2] = {0.f, 0.f}, bq1[2] = {0.f, 0.f}, bq2[2] = {0.f, 0.f};  // B operands of the two tiles
+            float       fqx = 0.f, fqy = 0.f, fqz = 0.f;                                  // the partner's query
+            bool        fgo = false;
+            if (MF)
+            {
+                const float blx = wave_min_nn(go ? qx - r : INFINITY), bly = wave_min_nn(go ? qy - r : INFINITY), blz = wave_min_nn(go ? qz - r : INFINITY);
+                const float bhx = wave_max_nn(go ? qx + r : -INFINITY), bhy = wave_max_nn(go ? qy + r : -INFINITY), bhz = wave_max_nn(go ? qz + r : -INFINITY);
+                ocx = 0.5f * (blx + bhx), ocy = 0.5f * (bly + bhy), ocz = 0.5f * (blz + bhz);
+                const float hx = 0.5f * (bhx - blx) + hs, hy = 0.5f * (bhy - bly) + hs, hz = 0.5f * (bhz - blz) + hs;
+                mtol = (hx * hx + hy * hy + hz * hz) * (1.0f / 32768.0f);
+                fqx = __shfl_xor(qx, 32, 64), fqy = __shfl_xor(qy, 32, 64), fqz = __shfl_xor(qz, 32, 64);
+                fgo = __shfl_xor(go ? 1 : 0, 32, 64) != 0;
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+                {
+                    const bool  own = hb == (t == 1);  // this lane's own query sits in tile t
+                    const float cx = (own ? qx : fqx) - ocx, cy = (own ? qy : fqy) - ocy, cz = (own ? qz : fqz) - ocz;
+                    bq0[t] = -2.0f * (hb ? cy : cx);
+                    bq1[t] = hb ? 1.0f : -2.0f * cz;
+                    bq2[t] = hb ? 0.0f : (cx * cx + cy * cy + cz * cz);
+                }
+            }
             if (clocks)
             {
                 const unsigned long long t = wall_clock64();
@@ -399,7 +442,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     const uint32_t kz = k / (nbx * nby), kr = k - kz * nbx * nby;
                     const uint32_t ky = kr / nbx, kx = kr - ky * nbx;
                     const unsigned long long sx = spread_x((axy >> (4u * kx)) & 15u);
-                    const unsigned long long sy = spread_y((axy >> (12u + 4u * ky)) & 15u);
+                    const unsigned long long sy = spread_y((axy >> (16u + 4u * ky)) & 15u);
                     const unsigned long long sz = spread_z((az >> (4u * kz)) & 15u);
                     unsigned long long N = W & sx & sy & sz;  // occupied voxels of this brick inside the lane's cube
                     // a wide cube holds ~2-3x the points its ball reaches (a wall 0.9 m away: the cube cuts 1.8 x 1.8 m out
@@ -411,27 +454,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                         unsigned long long keep = 0ull;
                         if (N != 0ull)
                         {
-                            float ddx[4], ddy[4], ddz[4];
+                            // the brick's x-extent as ONE slab (its nearest face), the 4 y- and 4 z-slabs exactly: a (y, z)
+                            // row is kept when the ball reaches it at all (the per-voxel x test costs 4x the instructions
+                            // and the all-pairs scan it saves is cheaper than that)
+                            const float bx0 = g.ox + (float)((wx + kx) * 4u) * hs;
+                            const float dxb = fmaxf(0.f, fmaxf(bx0 - qx, qx - (bx0 + 4.f * hs)));
+                            const float lim_yz = lim2 - dxb * dxb * 0.999999f;
+                            float ddy[4], ddz[4];
 #pragma unroll
                             for (int i = 0; i < 4; i++)
                             {
-                                const float x0 = g.ox + (float)((wx + kx) * 4u + (uint32_t)i) * hs, y0 = g.oy + (float)((wy + ky) * 4u + (uint32_t)i) * hs,
-                                            z0 = g.oz + (float)((wz + kz) * 4u + (uint32_t)i) * hs;
-                                const float dx = fmaxf(0.f, fmaxf(x0 - qx, qx - (x0 + hs))), dy = fmaxf(0.f, fmaxf(y0 - qy, qy - (y0 + hs))),
-                                            dz = fmaxf(0.f, fmaxf(z0 - qz, qz - (z0 + hs)));
-                                ddx[i] = dx * dx, ddy[i] = dy * dy, ddz[i] = dz * dz;
+                                const float y0 = g.oy + (float)((wy + ky) * 4u + (uint32_t)i) * hs, z0 = g.oz + (float)((wz + kz) * 4u + (uint32_t)i) * hs;
+                                const float dy = fmaxf(0.f, fmaxf(y0 - qy, qy - (y0 + hs))), dz = fmaxf(0.f, fmaxf(z0 - qz, qz - (z0 + hs)));
+                                ddy[i] = dy * dy, ddz[i] = dz * dz;
                             }
+                            uint32_t rows = 0u;  // bit zz * 4 + yy
 #pragma unroll
                             for (int zz = 0; zz < 4; zz++)
 #pragma unroll
-                                for (int yy = 0; yy < 4; yy++)
-                                {
-                                    // box_dist2's sum order: (dx2 + dy2) + dz2 <= lim2
-                                    uint32_t row = 0u;
-#pragma unroll
-                                    for (int xx = 0; xx < 4; xx++) row |= ((ddx[xx] + ddy[yy]) + ddz[zz] <= lim2) ? (1u << xx) : 0u;
-                                    keep |= (unsigned long long)row << (zz * 16 + yy * 4);
-                                }
+                                for (int yy = 0; yy < 4; yy++) rows |= (ddy[yy] + ddz[zz] <= lim_yz) ? (1u << (zz * 4 + yy)) : 0u;
+                            // 16 row bits -> 64 voxel bits (every row bit times 0xF at bit 4 * row)
+                            const uint32_t r_lo = rows & 0xFFu, r_hi = rows >> 8;
+                            const uint32_t e_lo = nibble_spread8(r_lo), e_hi = nibble_spread8(r_hi);
+                            keep = ((unsigned long long)e_hi << 32) | e_lo;
                         }
                         N &= keep;
                     }
@@ -452,8 +497,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 // ---- B: resolve the chunk (4 voxels per lane, loads independent), drop the voxels without
                 //      points (the bitmap said otherwise only for a stale map), prefix the counts --------
                 __syncthreads();
-                uint32_t T = 0, n_l = 0, omask = 0xFFFFFu;
-                bool     packed = true;
+                uint32_t T = 0, n_l = 0;
                 {
                     const uint4 k4 = *reinterpret_cast<const uint4*>(&s_vox[4 * lane]);
                     uint32_t    kk[4] = {k4.x, k4.y, k4.z, k4.w};
@@ -500,19 +544,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     const uint32_t iu = wave_incl_scan(used, lane), it = wave_incl_scan(tot, lane);
                     n_l = (uint32_t)__builtin_amdgcn_readlane((int)iu, 63);
                     T   = (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
-                    packed = T < (1u << 20);  // room for the voxel code above the offset (else: no walks)
-                    omask  = packed ? 0xFFFFFu : 0xFFFFFFFFu;
                     uint32_t li = iu - used, off = it - tot;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         if (cn[j])
                         {
-                            s_list[li] = make_uint2(st[j], packed ? (off | ((kk[j] >> 4) << 20)) : off);
+                            s_list[li] = make_uint2(st[j], off);
                             li++, off += cn[j];
                         }
                 }
                 n_u = 0;
                 __syncthreads();
+                // a wave with much to scan (wide radii) is on the kernel's critical path -- the other ~4 000 resident
+                // waves finish in a tenth of its time: it takes the SIMD's issue slots first from here on
+                if (T > 2u * NW_CAP) __builtin_amdgcn_s_setprio(3);
                 dbg_nu = max(dbg_nu, n_l), dbg_rounds += (T + NW_CAP - 1) / NW_CAP;
                 if (INSTR) st_listed += n_l, st_T += T;
                 if (clocks)
@@ -523,11 +568,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
                 // ---- C + D per round of NW_CAP staged points.  The loads of round n + 1 are issued before round n
                 //      is scanned (a chunk of a wide-radius wave takes up to 20+ rounds: their round trips were
-                //      most of its time).  Small chunks: every lane tests every staged point.  Chunks of more than
-                //      NW_WALK_MIN voxels (wide radii, or lanes that share little): every lane WALKS the voxels of
-                //      the round instead and tests only those its own ball reaches. ---------------------------
-                const bool walk = packed && n_l > NW_WALK_MIN;
-                uint32_t   src[4], e_first = 0, e_end = 0;
+                //      most of its time).  Every lane tests every staged point: per-lane WALKS over the round's voxels
+                //      (only those the lane's ball reaches: half the tests) were measured 3.5x slower -- divergent refill
+                //      loops and dependent LDS reads (commit "wave kernel v2"). ---------------------------------
+                uint32_t   src[4];
                 float4     c4[4];
                 // which listed voxel does a staged slot belong to: every voxel drops its id at its first slot of the
                 // round, a prefix-max carries it to the following slots (ids ascend with the offsets); then the loads
@@ -537,7 +581,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     __syncthreads();
                     for (uint32_t e = (uint32_t)lane; e < n_l; e += 64u)
                     {
-                        const uint32_t off = s_list[e].y & omask, nxt = e + 1u < n_l ? (s_list[e + 1u].y & omask) : T;  // its points: [off, nxt)
+                        const uint32_t off = s_list[e].y, nxt = e + 1u < n_l ? s_list[e + 1u].y : T;  // its points: [off, nxt)
                         if (off >= base && off < base + NW_CAP) s_owner[off - base] = e + 1u;
                         else if (off < base && nxt > base) s_owner[0] = e + 1u;
                     }
@@ -549,7 +593,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     if (lane == 0) ex = 0u;
                     const uint32_t ow[4] = {max(ex, p0), max(ex, p1), max(ex, p2), max(ex, p3)};
                     const uint32_t t0    = 4u * (uint32_t)lane;
-                    uint32_t       last  = 0u;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                     {
@@ -557,12 +600,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                         if (t0 + j < m)
                         {
                             const uint2 L = s_list[ow[j] - 1u];
-                            src[j]        = L.x + (base + t0 + j - (L.y & omask));
-                            last          = ow[j];
+                            src[j]        = L.x + (base + t0 + j - L.y);
                         }
                     }
-                    e_first = (uint32_t)__builtin_amdgcn_readlane((int)ow[0], 0) - 1u;  // slot 0 always has an owner
-                    e_end   = wave_max_u32(last);                                       // ids ascend with the slots
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                     {
@@ -571,11 +611,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     }
                 };
                 if (T) stage_issue(0u);
+                // the partner's running best (the query this lane works for in the other tile)
+                float    fb_d2 = INFINITY;
+                uint32_t fb_idx = NONE_U32, fb_spos = NONE_U32;
+                if (MF) fb_d2 = __shfl_xor(best_d2, 32, 64), fb_idx = __shfl_xor(best_idx, 32, 64), fb_spos = __shfl_xor(best_spos, 32, 64);
                 for (uint32_t base = 0; base < T; base += NW_CAP)
                 {
                     const uint32_t m = min((uint32_t)NW_CAP, T - base);
                     if (INSTR) st_rounds++;
-                    const uint32_t ef = e_first, ee = e_end;  // voxels owning slots of THIS round
                     {
                         const uint32_t t0 = 4u * (uint32_t)lane;
                         *reinterpret_cast<float4*>(&s_x[t0]) = make_float4(c4[0].x, c4[1].x, c4[2].x, c4[3].x);
@@ -598,50 +641,59 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                         const unsigned long long t = wall_clock64();
                         t_stage += t - tph, tph = t;
                     }
-                    if (walk)
+                    if (MF)
                     {
-                        // ---- D (walk): the voxels of this round the lane's ball still reaches, their staged points 4 at
-                        //      a time; one flat loop (refill / work) so that lanes skipping a voxel do not wait at
-                        //      every nesting level --------------------------------------------------------------
-                        if (go)
+                        // ---- D (matrix pipe): 32 staged points x 2 tiles of 32 queries per step ------------------
+                        const uint32_t m_pad = (m + 31u) & ~31u;  // slots beyond m hold x = inf: S = inf or NaN, never <= lim
+                        for (uint32_t blk = 0; blk < m_pad; blk += 32u)
                         {
-                            const float prune = r + 4.f * g.slack, prune2 = prune * prune;
-                            uint32_t    e = ef, k = 0, kend = 0;
-                            for (;;)
-                            {
-                                while (k >= kend && e < ee)
-                                {
-                                    const uint2    L    = s_list[e];
-                                    const uint32_t off  = L.y & omask, nxt = e + 1u < n_l ? (s_list[e + 1u].y & omask) : T;
-                                    const uint32_t code = L.y >> 20;
-                                    const uint32_t cx = wx * 4u + (code & 15u), cy = wy * 4u + ((code >> 4) & 15u), cz = wz * 4u + (code >> 8);
-                                    e++;
-                                    if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1 || cz < cz0 || cz > cz1) continue;  // outside the lane's cube
-                                    const float md2 = box_dist2(g.ox + (float)cx * hs, g.oy + (float)cy * hs, g.oz + (float)cz * hs, hs, qx, qy, qz);
-                                    if (md2 <= fminf(prune2, voxel_limit(best_d2, g.slack)))
-                                    {
-                                        const uint32_t k0 = max(off, base), k1 = min(nxt, base + (uint32_t)NW_CAP);
-                                        if (k0 < k1) k = k0 - base, kend = k1 - base;
-                                    }
-                                }
-                                if (k >= kend) break;
+                            const uint32_t c  = blk + ((uint32_t)lane & 31u);
+                            const float    px = s_x[c], py = s_y[c], pz = s_z[c];
+                            const float    ex = px - ocx, ey = py - ocy, ez = pz - ocz;
+                            const float    a0v = hb ? ey : ex;
+                            const float    a1v = hb ? (ex * ex + ey * ey + ez * ez) : ez;
+                            const float    a2v = hb ? 0.0f : 1.0f;
 #pragma unroll
-                                for (int j = 0; j < 4; j++)
+                            for (int t = 0; t < 2; t++)
+                            {
+                                const bool own = hb == (t == 1);
+                                f32x16     acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, bq0[t], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, bq1[t], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2v, bq2[t], acc, 0, 0, 0);
+                                const float m0 = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+                                const float m1 = fminf(fminf(acc[4], acc[5]), fminf(acc[6], acc[7]));
+                                const float m2 = fminf(fminf(acc[8], acc[9]), fminf(acc[10], acc[11]));
+                                const float m3 = fminf(fminf(acc[12], acc[13]), fminf(acc[14], acc[15]));
+                                const float mn = fminf(fminf(m0, m1), fminf(m2, m3));
+                                // the query this lane works for in tile t, and its running best
+                                const float tqx = own ? qx : fqx, tqy = own ? qy : fqy, tqz = own ? qz : fqz;
+                                float       bd  = own ? best_d2 : fb_d2;
+                                uint32_t    bi = own ? best_idx : fb_idx, bs = own ? best_spos : fb_spos;
+                                float       lim = bd * 1.000001f + mtol;
+                                if ((own ? go : fgo) && mn <= lim)
                                 {
-                                    if (k + j < kend)
+#pragma unroll
+                                    for (int rr = 0; rr < 16; rr++)
                                     {
-                                        const float d = dist2(qx, qy, qz, s_x[k + j], s_y[k + j], s_z[k + j]);
-                                        if (d <= best_d2)
+                                        if (acc[rr] <= lim)
                                         {
-                                            const uint32_t ci = s_idx[k + j];
-                                            if (d < best_d2 || ci < best_idx) best_d2 = d, best_idx = ci, best_spos = s_spos[k + j];
+                                            // row of register rr (C/D layout of the 32x32 MFMAs)
+                                            const uint32_t j  = blk + (uint32_t)((rr & 3) + 8 * (rr >> 2)) + (hb ? 4u : 0u);
+                                            const float    dd = dist2(tqx, tqy, tqz, s_x[j], s_y[j], s_z[j]);
+                                            if (dd <= bd)
+                                            {
+                                                const uint32_t ci = s_idx[j];
+                                                if (dd < bd || ci < bi) bd = dd, bi = ci, bs = s_spos[j], lim = bd * 1.000001f + mtol;
+                                            }
                                         }
-                                        if (INSTR) st_tests++;
                                     }
+                                    if (own) best_d2 = bd, best_idx = bi, best_spos = bs;
+                                    else fb_d2 = bd, fb_idx = bi, fb_spos = bs;
                                 }
-                                k += 4u;
                             }
                         }
+                        if (INSTR) st_tests += m * (uint32_t)__popcll(__ballot(go));
                     }
                     else
                     {
@@ -690,6 +742,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                         const unsigned long long t = wall_clock64();
                         t_scan += t - tph, tph = t;
                     }
+                }
+                if (MF)
+                {  // what the partner found for this lane's query
+                    const float    od = __shfl_xor(fb_d2, 32, 64);
+                    const uint32_t oi = __shfl_xor(fb_idx, 32, 64), os = __shfl_xor(fb_spos, 32, 64);
+                    if (od < best_d2 || (od == best_d2 && oi < best_idx)) best_d2 = od, best_idx = oi, best_spos = os;
                 }
             }
         }

@@ -31,6 +31,7 @@ struct CompactArgs
     float*                    block_bbox;    // [n_blocks][6]
     float*                    local_bbox_out;
     uint32_t*                 q_counters;    // the search's query-list counters, re-zeroed for the next call
+    int                       zero_list;     // ... and the prediction list the search has just consumed (-1: none)
     uint32_t                  n_l;      // number of SLOTS = visited local points x K, in visiting order
     uint32_t                  K;        // pairingsPerPoint
     const uint32_t*           order;    // visit position -> original local index (null: identity)
@@ -77,7 +78,7 @@ __device__ __forceinline__ bool pair_flag(const CompactArgs& a, uint32_t t, uint
     if (a.rec)
     {
         const uint4 q = a.rec[src];
-        spos = q.w ? q.x : NONE_U32, d2 = __uint_as_float(q.y);
+        spos = (q.w & 1u) ? q.x : NONE_U32, d2 = __uint_as_float(q.y);  // bit 1: nn_query.hip's prediction flag
     }
     else
     {
@@ -254,6 +255,8 @@ __global__ __launch_bounds__(1024) void compact_scan_bbox_kernel(const CompactAr
         a.counts[7] = overlap ? 1ull : 0ull;
     }
     if (a.q_counters && threadIdx.x < NN_LISTS * NN_MAX_SEG) a.q_counters[(size_t)threadIdx.x * NN_CNT_STRIDE] = 0u;
+    if (a.q_counters && a.zero_list >= 0 && threadIdx.x < NN_MAX_SEG)
+        a.q_counters[((size_t)a.zero_list * NN_MAX_SEG + threadIdx.x) * NN_CNT_STRIDE] = 0u;
 }
 
 __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const CompactArgs a)
@@ -317,6 +320,7 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     MP2P_TRY_HIP(ctx, ctx->compact_flags.ensure((size_t)(n_blocks ? n_blocks : 1) * CP_THREADS));
     CompactArgs a;
     memset(&a, 0, sizeof(a));
+    a.zero_list = -1;
     a.nn_spos = ctx->nn_spos.p, a.nn_d2 = ctx->nn_d2.p, a.n_l = (uint32_t)n_l;
     a.rec = from_rec ? ctx->nn_rec.p : nullptr;
     a.K = K, a.order = order, a.n_slots_dev = n_slots_dev, a.always_mark = always_mark ? 1 : 0;
@@ -346,7 +350,7 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
         MP2P_TRY_HIP(ctx, ctx->block_bbox.ensure((size_t)n_blocks * 6));
         a.tile_bbox = ctx->tile_bbox.p, a.n_tile_boxes = ctx->last_n_boxes;
         a.block_bbox = ctx->block_bbox.p, a.local_bbox_out = ctx->local_bbox.p;
-        a.q_counters = ctx->q_counters.p;
+        a.q_counters = ctx->q_counters.p, a.zero_list = ctx->nn_zero_list;
     }
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (n_blocks)
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256) void claims_export_kernel(const uint32_t* __re
         if (rec)
         {
             const uint4 q = rec[pos[i]];
-            spos          = q.w ? q.x : NONE_U32;
+            spos          = (q.w & 1u) ? q.x : NONE_U32;
         }
         else
             spos = nn_spos[(size_t)pos[i] * K + k];

@@ -324,7 +324,7 @@ def test_max_local_points_visit_order(amd, oracle, K):
     assert m2._visit_order(2500) is None
 
 
-@pytest.mark.parametrize("tune", ["wave_kernel=0", "pipelines=2", "mfma_scan=0,wave_kernel=0", "tile_waves=5,wave_kernel=0",
+@pytest.mark.parametrize("tune", ["wave_kernel=0", "predict=0", "wave_mfma=1", "pipelines=2", "mfma_scan=0,wave_kernel=0", "tile_waves=5,wave_kernel=0",
                                   "dir_budget_mb=0,claim_dedup=0,claim_peek=0", "dir_budget_mb=0,claim_dedup=0,claim_peek=0,wave_kernel=0"])
 def test_tune_knobs_do_not_change_the_lists(amd, oracle, tune, monkeypatch):
     """MP2P_HIP_TUNE is read once per context: every setting is a measurement aid that must compute the

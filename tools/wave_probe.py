@@ -62,6 +62,8 @@ for name, warm, pose in (("chain", chain_prev, chain), ("init_after_gt", d["T_gt
     light = (nu < 16) & (rounds <= 1) & (passes <= 1)
     out["phase_us_mean_light_waves"] = {n: round(float(phases[light, i].mean()), 2) for i, n in enumerate(names)}
     out["light_waves"] = [int(light.sum()), round(float(dur[light].mean()), 2)]
+    heavy = dur >= np.percentile(dur, 99)
+    out["phase_us_mean_slowest_1pct"] = {n: round(float(phases[heavy, i].mean()), 2) for i, n in enumerate(names)}
     out["flags(ovf,toobig) waves"] = [int((flags & 1).astype(bool).sum()), int((flags & 2).astype(bool).sum())]
     top = np.argsort(-dur)[:15]
     out["slowest(wave, us, nu, rounds, passes, flags)"] = [(int(i), round(float(dur[i]), 1), int(nu[i]), int(rounds[i]), int(passes[i]), int(flags[i])) for i in top]

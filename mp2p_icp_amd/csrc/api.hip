@@ -72,6 +72,7 @@ static void parse_tune(Tune& t)
             else if (k == "wave_kernel") t.wave_kernel = (int)v;
             else if (k == "predict") t.predict = (int)v;
             else if (k == "wave_mfma") t.wave_mfma = (int)v;
+            else if (k == "wave_levels") t.wave_levels = (uint32_t)v;
             else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
         }
         i = j + 1;

@@ -130,11 +130,16 @@ struct Tune
                                     // time on scene B, +4 % on scene A
     int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
+    uint32_t wave_levels   = 0;     // nn_wave_kernel: coarsest grid level of its wide-radius groups (measured worse above 0)
     int      wave_mfma     = 0;     // nn_wave_kernel: distance tests on the matrix pipe as a prefilter (measured: no gain there)
-    int      predict       = 1;     // wave path: queries predicted to be far are served by the one-query kernel on a second
-                                    // stream from the start of the call (0 = only after nn_wave_kernel)
-    int      wave_kernel   = 1;     // point-to-point search, K = 1: nn_wave_kernel (per-lane balls over an LDS voxel set) instead
-                                    // of nn_lane_kernel + nn_tile_kernel (0 = the round-2 kernels)
+    int      predict       = 0;     // wave path: queries predicted to be far served by the one-query kernel on a second stream
+                                    // from the start of the call.  Measured: no gain (each kernel alone fills the register
+                                    // file; run together both stretch: 216 + 106 us apart, 305 || 170 us together): off
+    int      wave_kernel   = 0;     // point-to-point search, K = 1: nn_wave_kernel (64 queries per wave, union of the lanes' cubes
+                                    // staged once, all-pairs scan) instead of nn_lane_kernel + nn_tile_kernel.  Its bulk is 3x
+                                    // faster (65 vs 186 us of lane + tile on scene A) but the waves of wide-radius queries
+                                    // (far-field walls 0.9 m off) take 150-230 us and set the kernel's span: 0.230 vs 0.186 ms
+                                    // (scene A), 0.429 vs 0.389 ms (scene B) -> the round-2 kernels stay the default
 };
 
 // multi-GPU communicator of a context (comm.hip): RCCL, or caller-provided collectives

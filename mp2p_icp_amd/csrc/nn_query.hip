@@ -130,6 +130,7 @@ struct NNArgs
     uint32_t*            next;       // the list being written (null: prediction off)
     int                  pred_list, next_list;  // their indices in q_counters
     float                again_d;    // a found distance beyond this predicts another hand-over
+    uint32_t             wave_lev_max;  // nn_wave_kernel: coarsest level its wide groups may use
 };
 
 // ---- geometry of one search pass (all values wave-uniform) -----------------------------------
@@ -1508,6 +1509,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.list_cap = (uint32_t)list_cap;
     a.r_hard   = cell0 * 0.01f * (float)ctx->tune.hard_radius_pct;
     a.xcd_map  = ctx->tune.xcd_map;
+    a.wave_lev_max = ctx->tune.wave_levels;
     const uint32_t n_tiles = 2u * ((n_seg + 7u) / 8u) * 8u * a.tiles_per_seg;  // worst case for each class: every query in it
     ctx->last_n_tiles = n_tiles;
     for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->hint_pose[i];

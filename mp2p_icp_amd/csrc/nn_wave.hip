@@ -21,8 +21,9 @@
 //      on packed fp32 (the update is rare).
 // The radius of a warm query is the distance to its previous nearest neighbour (certain to conclude,
 // however small), so one pass finishes it.  Lanes whose cube does not fit the window wait for the next
-// pass (new window); queries whose cube exceeds 8 voxels per axis or whose radius outgrows r_defer, and
-// wide cubes that are alone in their wave, go to nn_single_kernel (a whole wave per query) as before.
+// pass (new window); queries whose cube exceeds 8 voxels per axis or whose radius outgrows r_defer go to
+// nn_single_kernel (a whole wave per query) as before.  Radii above one voxel are served in groups of 16 queries
+// (16 queries x 4 slices of the staged points) after the narrow ones.
 // Results are bit-identical to the other kernels' (same arg-min rule, same finality rule).
 #include "device_utils.hpp"
 
@@ -30,10 +31,9 @@ namespace mp2p
 {
 constexpr int NW_NL      = 256;  // listed voxels per chunk
 constexpr int NW_CAP     = 256;  // staged points per round
-constexpr int NW_MAXPASS = 6;
+constexpr int NW_MAXPASS = 10;  // (a wave of 64 wide cubes takes 4 group passes)
 constexpr uint32_t NW_WIN = 4;     // window: at most this many bricks per axis
 constexpr uint32_t NW_MAXSPAN = 8;  // widest cube (level-0 voxels per axis) the window can hold at any alignment
-constexpr uint32_t NW_MED_MIN = 8;  // cubes wider than 4 voxels stay in the wave only in this company
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t k)
 {
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[NW_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t s_spos[NW_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t s_owner[NW_CAP];  // staging: slot -> listed voxel; before: the voxel codes
+    __shared__ uint32_t s_grp[16];  // group pass: the lanes of the group's members
     static_assert(NW_NL == NW_CAP, "the voxel codes of a chunk live in s_owner");
     static_assert(NN_CLAIM_SLOTS * sizeof(unsigned long long) <= 3 * NW_CAP * sizeof(float), "claim table fits s_x..s_z");
     unsigned long long* s_claim = reinterpret_cast<unsigned long long*>(s_x);
@@ -250,31 +251,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     const uint32_t n_skip   = (uint32_t)__popcll(__ballot(active && lb2_out >= 0.f));
     const v2f      qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const uint32_t obx = g.occ_bx[0], oby = g.occ_by[0], obz = g.occ_bz[0];
-    const unsigned long long* occ0 = g.occ + g.occ_off[0];
+    // the coarsest level a pass may use: it needs an occupancy bitmap (levels are built finest first)
+    // (MP2P_HIP_TUNE wave_levels, default 0 = level 0 only: coarser voxels for the wide groups were measured WORSE --
+    //  scene A 0.230 -> 0.315 ms, scene B 0.429 -> 0.794 ms: twice the staged points, the rounds wait for their loads)
+    uint32_t lev_max = 0;
+    while (lev_max + 1u < g.n_levels && lev_max < a.wave_lev_max && g.occ_off[lev_max + 1u] != OCC_NONE) lev_max++;
+    const float hs0   = hs;
+    // a cube of this half-width spans <= 8 voxels of level 0 (any alignment fits the 4-brick window), <= 5 of a coarser one
+    const float r_fit = (lev_max == 0u ? 3.4f : 1.7f * (float)(1u << lev_max)) * hs0;
 
     // ================= passes
     for (int pass = 0; pass < NW_MAXPASS; pass++)
     {
-        // ---- the lane's cube, in level-0 voxels, clipped to the layer's box ----------------------
-        bool     part = !done && !deferred;
+        bool        part = !done && !deferred;
         const float lox = fmaxf(qx - r, g.bbmin[0]), loy = fmaxf(qy - r, g.bbmin[1]), loz = fmaxf(qz - r, g.bbmin[2]);
         const float hix = fminf(qx + r, g.bbmax[0]), hiy = fminf(qy + r, g.bbmax[1]), hiz = fminf(qz + r, g.bbmax[2]);
         const bool  empty = !part || (lox > hix) || (loy > hiy) || (loz > hiz);  // nothing to visit at this radius
-        uint32_t cx0 = 0, cy0 = 0, cz0 = 0, cx1 = 0, cy1 = 0, cz1 = 0;
-        if (!empty)
+        // ---- who leaves for the one-query-per-wave kernel (a whole wave per query): a radius beyond r_defer, or
+        //      one whose cube no usable level holds in a window ---------------------------------------------
         {
-            cx0 = cell_fine(lox, g.ox, g.inv_hf) >> g.shift0, cx1 = cell_fine(hix, g.ox, g.inv_hf) >> g.shift0;
-            cy0 = cell_fine(loy, g.oy, g.inv_hf) >> g.shift0, cy1 = cell_fine(hiy, g.oy, g.inv_hf) >> g.shift0;
-            cz0 = cell_fine(loz, g.oz, g.inv_hf) >> g.shift0, cz1 = cell_fine(hiz, g.oz, g.inv_hf) >> g.shift0;
-        }
-        // ---- who leaves for the one-query-per-wave kernel (coarser levels, bricks, a whole wave per query):
-        //      a radius beyond r_defer, a cube the window cannot hold, a wide cube without company ---------
-        {
-            const bool toobig = !empty && ((cx1 - cx0) >= NW_MAXSPAN || (cy1 - cy0) >= NW_MAXSPAN || (cz1 - cz0) >= NW_MAXSPAN);
-            const bool medium = !empty && !toobig && ((cx1 - cx0) >= 4u || (cy1 - cy0) >= 4u || (cz1 - cz0) >= 4u);
-            const uint32_t n_med = (uint32_t)__popcll(__ballot(medium));
-            const bool     leave = part && (r > a.r_defer || toobig || (medium && n_med < NW_MED_MIN));
+            const bool leave = part && !empty && (r > a.r_defer || r > r_fit);
             const unsigned long long lmask = __ballot(leave);
             if (lmask)
             {
@@ -286,7 +282,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         }
         if (__ballot(part) == 0ull) break;  // uniform
         st_pass++;
-        const bool want = part && !empty;
+        // ---- the kind of pass.  NARROW cubes (radius up to one level-0 voxel: a few dozen points each, shared by
+        //      the neighbours) are served 64 at a time at level 0, every lane testing every staged point.  WIDE
+        //      cubes hold hundreds of points per query and the union over 64 queries thousands -- all of which
+        //      every lane would test: they are served in GROUPS of 16 Morton-adjacent queries (a quarter of the
+        //      union), the 64 lanes being 16 queries x 4 slices of the staged points, and at the LEVEL whose voxels
+        //      their radius spans in <= 5 (a 0.9 m ball is 8 level-0 voxels wide -- a 64-brick window and hundreds
+        //      of directory entries -- but 4 of level 1).  Narrow ones first. ------------------------------------
+        const bool               wide  = part && !empty && r > hs0;
+        const unsigned long long nmask = __ballot(part && !empty && !wide);
+        const bool               grp   = nmask == 0ull;  // uniform: only wide cubes are left
+        bool                     want  = part && !empty && (grp || !wide);
+        if (grp) want = want && (uint32_t)__popcll(__ballot(want) & lane_lt) < 16u;  // the first 16 of them
+        uint32_t lev = 0;
+        if (grp)
+        {
+            const float rg = wave_max_pos(want ? r : 0.f);
+            while (lev < lev_max && rg > 1.7f * hs0 * (float)(1u << lev)) lev++;
+        }
+        const uint32_t sh  = g.shift0 + lev;
+        const float    hs  = hs0 * (float)(1u << lev);  // voxel edge of this pass (shadows the level-0 edge)
+        const uint32_t obx = g.occ_bx[lev], oby = g.occ_by[lev], obz = g.occ_bz[lev];
+        const unsigned long long* occ0 = g.occ + g.occ_off[lev];
+        // ---- the lane's cube, in voxels of that level, clipped to the layer's box ----------------------
+        uint32_t cx0 = 0, cy0 = 0, cz0 = 0, cx1 = 0, cy1 = 0, cz1 = 0;
+        if (want)
+        {
+            cx0 = cell_fine(lox, g.ox, g.inv_hf) >> sh, cx1 = cell_fine(hix, g.ox, g.inv_hf) >> sh;
+            cy0 = cell_fine(loy, g.oy, g.inv_hf) >> sh, cy1 = cell_fine(hiy, g.oy, g.inv_hf) >> sh;
+            cz0 = cell_fine(loz, g.oz, g.inv_hf) >> sh, cz1 = cell_fine(hiz, g.oz, g.inv_hf) >> sh;
+            // (r <= 1.7 voxels of the level -> at most 5 voxels per axis; a clipped or oddly aligned one is cut off
+            //  by the window test below and waits / leaves like any lane outside the window)
+        }
         const unsigned long long wmask = __ballot(want);
         bool go = false;  // this lane's cube lies inside the window of this pass
         if (wmask)        // uniform
@@ -313,7 +340,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             //      searches it by itself instead (occupancy mask of its cube from <= 8 brick words, then voxel by
             //      voxel: directory, points 4 loads in flight; nn_lane_kernel's own path).  Wider cubes keep to
             //      the windows of the following passes. ----------------------------------------------------------
-            if (__ballot(want && !go))  // uniform
+            if (!grp && __ballot(want && !go))  // uniform
             {
                 dbg_flags |= 1u;
                 const bool lite = want && (cx1 - cx0) < 4u && (cy1 - cy0) < 4u && (cz1 - cz0) < 4u;
@@ -389,7 +416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             // (the same conservative limit as the other kernels' voxel tests: radius + rounding slack, and the running best)
             const float prune = r + 4.f * g.slack;
             const float lim2  = fminf(prune * prune, voxel_limit(best_d2, g.slack));
-            const bool  refine = __ballot(go && r > hs) != 0ull;
+            const bool  refine = __ballot(go && r > hs0) != 0ull;
             // ---- matrix-pipe prefilter (MP2P_HIP_TUNE mfma_scan, default on): d2 of 32 staged points x 32 queries by
             //      three v_mfma_f32_32x32x2_f32 on coordinates centred on the box of the window's open cubes,
             //        S = -2 c'.q' + |c'|^2 + |q'|^2,  A = [c'x c'y | c'z |c'|^2 | 1 0],  B = [-2q'x -2q'y | -2q'z 1 | |q'|^2 0]
@@ -505,7 +532,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         if (4u * (uint32_t)lane + (uint32_t)j >= n_u) kk[j] = 0u;  // stale codes of an earlier chunk
-                    const unsigned long long doff = g.dir_off[0];
+                    const unsigned long long doff = g.dir_off[lev];
                     if (doff != DIR_NONE)  // uniform
                     {
                         const uint32_t nx = obx * 4u, ny = oby * 4u, nz = obz * 4u;
@@ -533,7 +560,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                             if (kk[j] != 0u)
                             {
                                 uint32_t s0 = 0, e0 = 0;
-                                if (voxel_range(g, 0u, wx * 4u + ((kk[j] >> 4) & 15u), wy * 4u + ((kk[j] >> 8) & 15u),
+                                if (voxel_range(g, lev, wx * 4u + ((kk[j] >> 4) & 15u), wy * 4u + ((kk[j] >> 8) & 15u),
                                                 wz * 4u + ((kk[j] >> 12) & 15u), s0, e0, true))
                                     st[j] = s0, cn[j] = e0 - s0;
                             }
@@ -611,6 +638,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     }
                 };
                 if (T) stage_issue(0u);
+                // group pass: lane l works for the (l & 15)-th member of the group on slice l >> 4 of the staged points
+                float    gqx = qx, gqy = qy, gqz = qz, gb_d2 = best_d2;
+                uint32_t gb_idx = best_idx, gb_spos = best_spos;
+                bool     gok = false;
+                if (grp)
+                {
+                    const unsigned long long gomask = __ballot(go);
+                    const uint32_t           rank   = (uint32_t)__popcll(gomask & lane_lt);
+                    if (go) s_grp[rank] = (uint32_t)lane;
+                    __syncthreads();
+                    const uint32_t mem = ((uint32_t)lane & 15u) < (uint32_t)__popcll(gomask) ? s_grp[lane & 15] : 0u;
+                    gok  = ((uint32_t)lane & 15u) < (uint32_t)__popcll(gomask);
+                    gqx = __shfl(qx, (int)mem, 64), gqy = __shfl(qy, (int)mem, 64), gqz = __shfl(qz, (int)mem, 64);
+                    gb_d2 = __shfl(best_d2, (int)mem, 64), gb_idx = __shfl(best_idx, (int)mem, 64), gb_spos = __shfl(best_spos, (int)mem, 64);
+                }
                 // the partner's running best (the query this lane works for in the other tile)
                 float    fb_d2 = INFINITY;
                 uint32_t fb_idx = NONE_U32, fb_spos = NONE_U32;
@@ -641,7 +683,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                         const unsigned long long t = wall_clock64();
                         t_stage += t - tph, tph = t;
                     }
-                    if (MF)
+                    if (grp)  // uniform
+                    {
+                        // ---- D (groups): 16 queries x 4 slices; the lane tests the 8-point blocks of its slice ----
+                        const v2f      gx2 = {gqx, gqx}, gy2 = {gqy, gqy}, gz2 = {gqz, gqz};
+                        const uint32_t m_pad = (m + 7u) & ~7u;
+                        for (uint32_t jb = ((uint32_t)lane >> 4) * 8u; jb < m_pad; jb += 32u)
+                        {
+                            const float4 xa = *reinterpret_cast<const float4*>(&s_x[jb]);
+                            const float4 xb = *reinterpret_cast<const float4*>(&s_x[jb + 4]);
+                            const float4 ya = *reinterpret_cast<const float4*>(&s_y[jb]);
+                            const float4 yb = *reinterpret_cast<const float4*>(&s_y[jb + 4]);
+                            const float4 za = *reinterpret_cast<const float4*>(&s_z[jb]);
+                            const float4 zb = *reinterpret_cast<const float4*>(&s_z[jb + 4]);
+                            const v2f d01 = dist2_pk(gx2, gy2, gz2, v2f{xa.x, xa.y}, v2f{ya.x, ya.y}, v2f{za.x, za.y});
+                            const v2f d23 = dist2_pk(gx2, gy2, gz2, v2f{xa.z, xa.w}, v2f{ya.z, ya.w}, v2f{za.z, za.w});
+                            const v2f d45 = dist2_pk(gx2, gy2, gz2, v2f{xb.x, xb.y}, v2f{yb.x, yb.y}, v2f{zb.x, zb.y});
+                            const v2f d67 = dist2_pk(gx2, gy2, gz2, v2f{xb.z, xb.w}, v2f{yb.z, yb.w}, v2f{zb.z, zb.w});
+                            const float d[8] = {d01.x, d01.y, d23.x, d23.y, d45.x, d45.y, d67.x, d67.y};
+                            const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])),
+                                                   fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+                            if (gok && mn <= gb_d2)
+                            {
+#pragma unroll
+                                for (int j = 0; j < 8; j++)
+                                {
+                                    if (d[j] <= gb_d2)
+                                    {
+                                        const uint32_t ci = s_idx[jb + j];
+                                        if (d[j] < gb_d2 || ci < gb_idx) gb_d2 = d[j], gb_idx = ci, gb_spos = s_spos[jb + j];
+                                    }
+                                }
+                            }
+                        }
+                        if (INSTR) st_tests += m * 16u;
+                    }
+                    else if (MF)
                     {
                         // ---- D (matrix pipe): 32 staged points x 2 tiles of 32 queries per step ------------------
                         const uint32_t m_pad = (m + 31u) & ~31u;  // slots beyond m hold x = inf: S = inf or NaN, never <= lim
@@ -743,7 +820,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                         t_scan += t - tph, tph = t;
                     }
                 }
-                if (MF)
+                if (grp)
+                {
+                    // the 4 slices of every member, then back to the member's own lane
+#pragma unroll
+                    for (int off = 16; off < 64; off <<= 1)
+                    {
+                        const float    od = __shfl_xor(gb_d2, off, 64);
+                        const uint32_t oi = __shfl_xor(gb_idx, off, 64), os = __shfl_xor(gb_spos, off, 64);
+                        if (od < gb_d2 || (od == gb_d2 && oi < gb_idx)) gb_d2 = od, gb_idx = oi, gb_spos = os;
+                    }
+                    const uint32_t rank = (uint32_t)__popcll(__ballot(go) & lane_lt);  // this member's workers: lanes rank, rank + 16, ..
+                    const float    md = __shfl(gb_d2, (int)rank, 64);
+                    const uint32_t mi = __shfl(gb_idx, (int)rank, 64), ms = __shfl(gb_spos, (int)rank, 64);
+                    if (go && (md < best_d2 || (md == best_d2 && mi < best_idx))) best_d2 = md, best_idx = mi, best_spos = ms;
+                }
+                else if (MF)
                 {  // what the partner found for this lane's query
                     const float    od = __shfl_xor(fb_d2, 32, 64);
                     const uint32_t oi = __shfl_xor(fb_idx, 32, 64), os = __shfl_xor(fb_spos, 32, 64);

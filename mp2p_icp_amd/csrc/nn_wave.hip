@@ -178,17 +178,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
     float qx, qy, qz;
     compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
-    {
-        const float bx0 = wave_min_nn((visited && qx == qx) ? qx : INFINITY), by0 = wave_min_nn((visited && qy == qy) ? qy : INFINITY),
-                    bz0 = wave_min_nn((visited && qz == qz) ? qz : INFINITY);
-        const float bx1 = wave_max_nn((visited && qx == qx) ? qx : -INFINITY), by1 = wave_max_nn((visited && qy == qy) ? qy : -INFINITY),
-                    bz1 = wave_max_nn((visited && qz == qz) ? qz : -INFINITY);
-        if (lane == 0)
-        {
-            float* o = a.tile_bbox + (size_t)wv * 6;
-            o[0] = bx0, o[1] = by0, o[2] = bz0, o[3] = bx1, o[4] = by1, o[5] = bz1;
-        }
-    }
+    // (stored at the very end: a store in flight holds up every later wait for a load -- vmcnt counts both)
+    const float wbx0 = wave_min_nn((visited && qx == qx) ? qx : INFINITY), wby0 = wave_min_nn((visited && qy == qy) ? qy : INFINITY),
+                wbz0 = wave_min_nn((visited && qz == qz) ? qz : INFINITY);
+    const float wbx1 = wave_max_nn((visited && qx == qx) ? qx : -INFINITY), wby1 = wave_max_nn((visited && qy == qy) ? qy : -INFINITY),
+                wbz1 = wave_max_nn((visited && qz == qz) ? qz : -INFINITY);
     const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));
     const float thr    = fadd(a.maxDistSq, fmul(a.angSq, normSq));
     const float rmax   = sqrtf(thr) * 1.002f + g.slack;
@@ -862,6 +856,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     }
 
     // ================= records + claims (Morton order of the local layer)
+    if (lane == 0)
+    {
+        float* o = a.tile_bbox + (size_t)wv * 6;
+        o[0] = wbx0, o[1] = wby0, o[2] = wbz0, o[3] = wbx1, o[4] = wby1, o[5] = wbz1;
+    }
     __syncthreads();  // the claim table lives in the staging area
     emit_wave(a, s_claim, lane, valid && !deferred, qi, orig, active, thr, best_d2, best_idx, best_spos,
               lb2_out >= 0.f ? lb2_out : fminf(best_d2, thr));

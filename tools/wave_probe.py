@@ -18,6 +18,8 @@ only = sys.argv[2] if len(sys.argv) > 2 else ""
 d = bench.build_inputs(1_000_000, 10_000_000, 1, 0, 1, scene)
 ctx = amd.Context(0)
 g, l = d["glob"], d["local"]
+if os.environ.get("PROBE_NL"):
+    l = np.ascontiguousarray(l[: int(os.environ["PROBE_NL"])])  # a prefix (scan order: one sector): few waves, no contention
 gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])
 cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
 pairs = core.DevicePairs(ctx, l.shape[0], 0)

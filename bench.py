@@ -19,9 +19,11 @@ The default line (no --config) carries, next to the contract's fields:
   step_ms        min / median / max of the K timed steps; `stability` = 200 more chained steps
   host_boundary  the same step through HOST containers, i.e. through the reference-side adapter's code
                  (adapter/mp2p_hip_host.hpp): fresh MatchState, pairs into a host vector, marks, solver
-  scene_b        the same metric on the SURVEY.md 8d scene (map = union of consecutive scans, voxel-
-                 thinned; scan and map densities match and the chain converges); `value` stays on
-                 scene A (scan vs surface-sampled map) for continuity with round 1
+  scene_a        the same metric on round 1's scene (scan vs a map sampled uniformly on the surfaces).  `value`,
+                 `roofline` and `cpu_baseline` are on the scene SURVEY.md 8d specifies (--scene b: the map is the
+                 voxel-thinned union of consecutive scans)
+  converging     a third pose chain on the headline scene that reaches millimetre steps (point-to-plane matcher +
+                 Gauss-Newton): the regime a converged registration spends most iterations in
 N > 1 is launched by torch.distributed.run (one rank per GPU); the local layer is sharded
 (weak scaling: every rank holds its own 1 M-point slice of an N x 1 M-point local layer; the block
 `strong_scaling` times ONE 1 M-point scan split N ways), the 10 M-point global layer is replicated,
@@ -252,6 +254,65 @@ def instrumented(rig, n_steps, rank, tag):
     return rows, final_err
 
 
+def converging_block(rig, args):
+    """A chain that CONVERGES: point-to-plane matcher (knn 5, 0.4 m) + Gauss-Newton from the perturbed
+    guess until the step is below a millimetre, then the headline pair (pt2pt matcher + GN) for 10 more steps from
+    there -- the millimetre-step regime a converged registration spends most of its iterations in."""
+    import torch
+    from mp2p_icp_amd import _lib, core
+    amd, d, ctx = rig.amd, rig.d, rig.ctx
+    pl = _lib.Pt2PlParams()
+    pl.distanceThreshold, pl.searchRadius, pl.knn, pl.minimumPlanePoints, pl.planeEigenThreshold = 0.4, 0.4, 5, 5, 0.05
+    pl.bounding_box_intersection_check_epsilon = 0.20
+    pairs_pl = core.DevicePairs(ctx, 0, rig.n_l)
+    pose, errs, ms_pl = d["T_init"].copy(), [], []
+
+    def err(p):
+        e = amd.se3.log(amd.se3.inverse_compose(p, d["T_gt"]))
+        return float(np.linalg.norm(e[:3])), float(np.linalg.norm(e[3:]))
+
+    for it in range(25):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pairs_pl.clear()
+        core.match_pt2pl(ctx, rig.gmap, rig.cloud, pose, pl, None, pairs_pl)
+        new = np.array(core.gn_solve(ctx, pairs_pl, pose, rig.gnp).pose)
+        ms_pl.append((time.perf_counter() - t0) * 1e3)
+        step = amd.se3.log(amd.se3.inverse_compose(pose, new))
+        pose = new
+        errs.append(err(pose))
+        if np.linalg.norm(step[:3]) < 1e-3 and np.linalg.norm(step[3:]) < 1e-4:
+            break
+    n_pl = len(errs)
+    # the headline pair from the converged pose: 3 untimed steps (the warm start settles), 10 timed
+    rig.state = {"pose": pose.copy(), "s": 1}  # s != 0 (mod CYCLE): no restart
+    for _ in range(3):
+        rig.one_step(); rig.state["s"] = 1
+    rig.ctx.set_profiling(3)
+    ts, nn = [], []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        rig.one_step(); rig.state["s"] = 1
+        ts.append((time.perf_counter() - t0) * 1e3)
+        nn.append(rig.ctx.stats()["ms_nn"])
+    rig.ctx.set_profiling(2)
+    rig.reg.match(rig.state["pose"])
+    st = rig.ctx.stats()
+    rig.ctx.set_profiling(0)
+    e_end = err(rig.state["pose"])
+    return {"plane_chain": {"iterations": n_pl, "trans_err_m": [round(e[0], 5) for e in errs], "rot_err_rad": [round(e[1], 6) for e in errs],
+                            "ms_per_iteration_median": float(np.median(ms_pl[1:])) if n_pl > 1 else float(ms_pl[0])},
+            "final_pose_error": {"trans_m": errs[-1][0], "rot_rad": errs[-1][1]},
+            "pt2pt_at_the_converged_pose": {"ms_per_step_median": float(np.median(ts)), "iterations_per_s": 1e3 / float(np.median(ts)),
+                                            "nn_search_ms": float(np.median(nn)), "pose_error_after": {"trans_m": e_end[0], "rot_rad": e_end[1]},
+                                            "finished_without_search_frac": st["nn_lane_skipped"] / rig.n_l,
+                                            "deferred_to_one_query_kernel_frac": st["nn_single_queries"] / rig.n_l,
+                                            "staged_points_per_tile": st["nn_candidates_tested"] / max(1, st["nn_tiles"])},
+            "note": "point-to-plane ICP converges where the point-to-point chain of `value` slides along the street; "
+                    "the warm start of the point matcher can only skip a query whose nearest neighbour lies beyond the "
+                    "threshold AND whose step is below ~2 mm (the stored lower bound is capped at the threshold)"}
+
+
 def stats_ms(xs):
     a = np.asarray(xs, dtype=np.float64) * 1e3
     return {"min": float(a.min()), "median": float(np.median(a)), "max": float(a.max())}
@@ -272,12 +333,12 @@ def roofline_block(n_l, touched_mean, nn_ms_avg, tag):
     # from profiles/, not a measurement of this run
     try:
         import csv
-        f = os.path.join(ROOT, "profiles", f"r02_bench_{tag}_hbm_pmc.csv")
+        f = os.path.join(ROOT, "profiles", f"r03_bench_{tag}_hbm_pmc.csv")
         t = 0.0
         for r in csv.DictReader(open(f)):
             # the three search launches of the timed path (INSTR = false variants; the instrumented ones
             # only run in the counting replay)
-            if re.search(r"mp2p::nn_(lane_kernel<false>|tile_kernel<\d+, false|single_kernel<false)", r["kernel"]):
+            if re.search(r"mp2p::nn_(lane_kernel<false>|tile_kernel<\d+, false|single_kernel<false|wave_kernel<false)", r["kernel"]):
                 t += float(r["fetch_bytes_avg_corrected_x2"]) + float(r["write_bytes_avg"])
         if t > 0:
             out["traffic_from_profiles"] = t
@@ -458,7 +519,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--config", choices=["c2", "c3", "c5"], default=None,
                     help="another BASELINE config as a bench line of its own (1 GPU)")
-    ap.add_argument("--scene", choices=["a", "b"], default="a", help="scene of `value` (see the module docstring)")
+    ap.add_argument("--scene", choices=["a", "b"], default="b", help="scene of `value` (see the module docstring)")
     ap.add_argument("--q", type=int, default=0, help="queries per wave (tuning)")
     ap.add_argument("--r0", type=float, default=0.0, help="initial radius in cells (tuning)")
     ap.add_argument("--grp", type=float, default=0.0, help="group radius factor (tuning)")
@@ -644,6 +705,11 @@ def main():
                             "p95": float(np.percentile(a, 95)), "max": float(a.max()),
                             "note": "no hipEvents in this loop; chain position 0 (the restart from the perturbed guess, "
                                     "stale warm start) is the slow step of every cycle"}
+        # ---- a chain that converges -------------------------------------------------------------------------
+        try:
+            out["converging"] = converging_block(rig, args)
+        except Exception as ex:
+            out["converging"] = {"error": repr(ex)}
         # ---- the boundary through host containers ------------------------------------------------------
         try:
             out["host_boundary"] = host_boundary(args, d, ms_per_step)

@@ -72,6 +72,7 @@ static void parse_tune(Tune& t)
             else if (k == "wave_kernel") t.wave_kernel = (int)v;
             else if (k == "predict") t.predict = (int)v;
             else if (k == "wave_mfma") t.wave_mfma = (int)v;
+            else if (k == "pl_warm") t.pl_warm = (int)v;
             else if (k == "wave_levels") t.wave_levels = (uint32_t)v;
             else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
         }
@@ -175,7 +176,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->aos_stage.release(), ctx->pl_slots.release(), ctx->pl_knn.release();
     ctx->work.release(), ctx->work_q.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();
     ctx->pend.release(), ctx->pend_q.release(), ctx->q_counters.release(), ctx->nn_rec.release();
-    ctx->pred_buf[0].release(), ctx->pred_buf[1].release();
+    ctx->pred_buf[0].release(), ctx->pred_buf[1].release(), ctx->pl_kth.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     (void)mp2p_hip_pairs_copy_end(ctx);
@@ -235,6 +236,7 @@ void mp2p_hip_map_free(mp2p_hip_ctx* ctx, mp2p_hip_map* map)
 {
     if (!map) return;
     if (ctx && ctx->hint_map == map) ctx->hint_map = nullptr;
+    if (ctx && ctx->pl_hint_map == map) ctx->pl_hint_map = nullptr;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     map->pts.release(), map->table.release(), map->claims.release();
     delete map;
@@ -284,6 +286,7 @@ void mp2p_hip_cloud_free(mp2p_hip_ctx* ctx, mp2p_hip_cloud* c)
 {
     if (!c) return;
     if (ctx && ctx->hint_cloud == c) ctx->hint_cloud = nullptr;
+    if (ctx && ctx->pl_hint_cloud == c) ctx->pl_hint_cloud = nullptr;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     c->sorted.release(), c->x.release(), c->y.release(), c->z.release();
     c->order.release(), c->rank.release(), c->pos.release();

@@ -131,6 +131,7 @@ struct Tune
     int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
     uint32_t wave_levels   = 0;     // nn_wave_kernel: coarsest grid level of its wide-radius groups (measured worse above 0)
+    int      pl_warm       = 1;     // point-to-plane search: start radius from the previous call's k-th distance (0 = full radius)
     int      wave_mfma     = 0;     // nn_wave_kernel: distance tests on the matrix pipe as a prefilter (measured: no gain there)
     int      predict       = 0;     // wave path: queries predicted to be far served by the one-query kernel on a second stream
                                     // from the start of the call.  Measured: no gain (each kernel alone fills the register
@@ -201,6 +202,13 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<unsigned char>      aos_stage;    // download staging
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
     mp2p::DevBuf<uint32_t>           pl_knn;       // pt2pl neighbour lists [n_local][K] (search -> fit kernel)
+    mp2p::DevBuf<float>              pl_kth;       // pt2pl warm start: d2 of every query's k-th neighbour at the previous call
+    const void*                      pl_hint_map = nullptr;    //   ... and what that call was made on
+    const void*                      pl_hint_cloud = nullptr;
+    size_t                           pl_hint_n = 0;
+    uint32_t                         pl_hint_knn = 0;
+    double                           pl_hint_rad = 0.0;
+    double                           pl_hint_pose[12] = {};
     mp2p::DevBuf<unsigned long long> timeline;     // profiling level 4: {start, end} ticks per workgroup
     size_t                           timeline_tiles = 0, timeline_singles = 0;
     mp2p::DevBuf<unsigned char>      horn_flags;   // Horn: scale-outlier flag per point pairing

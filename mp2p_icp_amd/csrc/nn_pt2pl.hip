@@ -40,6 +40,15 @@ struct PlArgs
     unsigned char*       out_flag;  // [n_l] by original local index
     double*              out_rec;   // [n_l][7] plane(4) + centroid(3)
     float*               tile_bbox;
+    // warm start (round 3): the matcher is called on the same map and cloud with a slowly changing pose.  Every
+    // one of a query's previous k neighbours is still a map point and at most (its old distance + the query's
+    // displacement) away, so the previous k-th distance + the displacement is a radius CERTAIN to hold k points
+    // again: the search starts there (typically 0.1 m) instead of at the full search radius (0.4 m: 8..30 x the
+    // points).  kth_io[n_l] in the Morton order of the local layer: d2 of the knn-th neighbour (inf: fewer in reach)
+    float*               kth_io;
+    int                  use_hint;
+    PoseRt               prev_pose;
+    float                grp_min;   // smallest group extent [m]: tight radii must not split a tile into many passes
 };
 
 // cyclic Jacobi, identical operation order to sym_eig_jacobi(3, ...) of the oracle
@@ -125,7 +134,7 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                                            unsigned long long* dbg, uint32_t* s_hit, float4* s_cand,
                                            uint32_t* s_spos, uint32_t* s_cstart,
                                            uint32_t* s_coff, float (&kd2)[K], uint32_t (&kidx)[K],
-                                           uint32_t (&kspos)[K])
+                                           uint32_t (&kspos)[K], float grp_min = 0.f)
 {
     float r    = fminf(r0, rmax);
     bool  done = !active;
@@ -145,9 +154,9 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
         const int   seed = __ffsll((long long)pend) - 1;
         const float sx = readlane_f(qx, seed), sy = readlane_f(qy, seed), sz = readlane_f(qz, seed);
         const float sr = readlane_f(r, seed);
-        const float G  = grp_factor * sr;
+        const float G  = fmaxf(grp_factor * sr, grp_min);
         const bool  grp = !done && fabsf(qx - sx) <= G && fabsf(qy - sy) <= G && fabsf(qz - sz) <= G &&
-                         r <= 2.0f * sr;
+                         r <= fmaxf(2.0f * sr, 0.5f * grp_min);
         float lox = wave_min_nn(grp ? qx - r : INFINITY), loy = wave_min_nn(grp ? qy - r : INFINITY),
               loz = wave_min_nn(grp ? qz - r : INFINITY);
         float hix = wave_max_nn(grp ? qx + r : -INFINITY), hiy = wave_max_nn(grp ? qy + r : -INFINITY),
@@ -426,8 +435,9 @@ constexpr int PL_Q = 32;  // queries per wave (2 candidate slices)
 // Q = 32 for large local layers (a staged bucket serves 32 queries); Q = 8 when the layer is too small
 // to fill the chip with 32-query tiles (a KITTI scan of 120 k points = 3 750 tiles for 5 120 wave
 // slots: the kernel then lasts as long as its slowest tile; 8-query tiles cut that tile's work 4x).
+// (register budget: the occupancy the kernel had before the warm start: 5 / 4 / 3 / 2 waves per SIMD for K = 5 / 8 / 12 / 16)
 template <int K, int Q>
-__global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 5 ? 5 : (K <= 8 ? 4 : (K <= 12 ? 3 : 2)), 8))) void pt2pl_tile_kernel(const PlArgs a)
 {
     __shared__ float4   s_cand[PL_CAP];
     __shared__ uint32_t s_spos[PL_CAP];
@@ -445,12 +455,25 @@ __global__ __launch_bounds__(64) void pt2pl_tile_kernel(const PlArgs a)
     bool        active = visited && (fin - fin == 0.0f);
     if (active && a.local_taken && a.local_taken[orig]) active = false;  // Matcher_Point2Plane.cpp:83-85
 
+    const uint32_t qi = blockIdx.x * Q + (uint32_t)(lane % Q);  // place in the sorted copy
+    float          r0 = a.r0;
+    if (a.use_hint && active)
+    {
+        const float4 lp = a.lpts[qi];
+        float        ox, oy, oz;
+        compose_point_f(a.prev_pose, lp.x, lp.y, lp.z, ox, oy, oz);
+        const float disp = sqrtf(dist2(qx, qy, qz, ox, oy, oz));
+        const float kp   = a.kth_io[qi];
+        if (kp < INFINITY) r0 = sqrtf(kp) * (1.0f + 1.0f / 512.0f) + disp * 1.00001f + 4.f * g.slack;  // NaN / inf: the full radius
+    }
     float    kd2[K];
     uint32_t kidx[K], kspos[K];
-    knn_search<K, false, Q>(g, lane, qx, qy, qz, active, a.radSq, a.rad * 1.002f + g.slack, a.r0, a.knn,
-                            a.grp_factor, a.cell_budget, a.dbg, s_hit, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos);
+    knn_search<K, false, Q>(g, lane, qx, qy, qz, active, a.radSq, a.rad * 1.002f + g.slack, r0, a.knn,
+                            a.grp_factor, a.cell_budget, a.dbg, s_hit, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos,
+                            a.grp_min);
     // the neighbour list (sorted positions, ascending (d2, idx); NONE beyond its end) for the fit kernel
     if (!valid || lane >= Q) return;
+    if (a.kth_io) a.kth_io[qi] = active ? kth_d2(kd2, a.knn) : INFINITY;
     uint32_t* o = a.out_knn + (size_t)orig * K;
 #pragma unroll
     for (int j = 0; j < K; j++) o[j] = (active && kidx[j] != NONE_U32) ? kspos[j] : NONE_U32;
@@ -706,6 +729,16 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     a.rank     = cloud->n_visit ? cloud->rank.p : nullptr;
     a.out_flag = flag, a.out_rec = rec, a.tile_bbox = ctx->tile_bbox.p;
     a.out_knn  = ctx->pl_knn.p;
+    // warm start: same map, cloud, neighbour count and radius as the previous call of this matcher on this context
+    MP2P_TRY_HIP(ctx, ctx->pl_kth.ensure(n_l ? n_l : 1));
+    a.kth_io   = ctx->pl_kth.p;
+    a.use_hint = (ctx->pl_hint_map == map && ctx->pl_hint_cloud == cloud && ctx->pl_hint_n == n_l && ctx->pl_hint_knn == prm->knn &&
+                  ctx->pl_hint_rad == prm->searchRadius && ctx->tune.pl_warm) ? 1 : 0;
+    for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->pl_hint_pose[i];
+    for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->pl_hint_pose[9 + i];
+    ctx->pl_hint_map = map, ctx->pl_hint_cloud = cloud, ctx->pl_hint_n = n_l, ctx->pl_hint_knn = prm->knn, ctx->pl_hint_rad = prm->searchRadius;
+    for (int i = 0; i < 12; i++) ctx->pl_hint_pose[i] = pose[i];
+    a.grp_min = 2.0f * cell0;
     a.dbg = nullptr;
     if (ctx->profiling == 2)
     {

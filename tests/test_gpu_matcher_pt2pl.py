@@ -170,3 +170,37 @@ def test_pt2pl_max_local_points_visit_order(amd, oracle):
     assert m.match(pcG, pcL, d["T_gt"], amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
     _check(pairs, want, widx)
     assert pairs.potential_pairings == pot == l.shape[0]  # :54: pcLocal.size(), not the visited subset
+
+
+@pytest.mark.parametrize("knn,radius", [(5, 0.4), (8, 0.6), (16, 0.8)])
+def test_warm_start_pose_sequence(amd, oracle, knn, radius):
+    """the search's warm start (start radius = previous k-th distance + displacement): a sequence of poses on ONE
+    context / map / cloud -- small steps, a jump, a return -- every call equal to the oracle's cold result; and
+    MP2P_HIP_TUNE pl_warm=0 (own context) gives the same lists"""
+    from mp2p_icp_amd import _lib, core, synthetic
+    d = synthetic.make_pair(6000, 60000, 177 + knn)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    rng = np.random.default_rng(knn)
+    poses = [d["T_init"]]
+    for k in range(5):
+        step = np.concatenate([rng.normal(0, 0.01, 3), rng.normal(0, 0.002, 3)]) * (30.0 if k == 2 else 1.0)  # k = 2: a jump
+        poses.append(amd.se3.compose(poses[-1], amd.se3.exp(step)))
+    poses.append(d["T_init"])  # and back
+    ctx = amd.Context(0)
+    gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])
+    cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    pairs = core.DevicePairs(ctx, 0, l.shape[0])
+    prm = _lib.Pt2PlParams()
+    prm.distanceThreshold, prm.searchRadius, prm.knn, prm.minimumPlanePoints, prm.planeEigenThreshold = 0.25, radius, knn, 5, 0.05
+    prm.bounding_box_intersection_check_epsilon = 0.20
+    for pose in poses:
+        want, widx, pot = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.25, radius, knn, 5, 0.05, tree=tree)
+        pairs.clear()
+        core.match_pt2pl(ctx, gmap, cloud, pose, prm, None, pairs)
+        got, gidx = pairs.download_pt2pl()
+        assert len(got) == len(want), (len(got), len(want))
+        assert np.array_equal(gidx, widx)
+        if len(got):
+            assert np.allclose(got["plane"], want["plane"], rtol=0, atol=1e-9)
+            assert np.allclose(got["centroid"], want["centroid"], rtol=0, atol=1e-9)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MP2P_HIP_ABI_VERSION 2
+#define MP2P_HIP_ABI_VERSION 3
 
 enum
 {
@@ -545,6 +545,14 @@ int mp2p_hip_comm_allreduce_f64(mp2p_hip_ctx* ctx, void* dev_buf, size_t n, int 
 int mp2p_hip_step_sharded(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
                           const double pose[12], const mp2p_hip_pt2pt_params* prm, const mp2p_hip_gn_params* gn,
                           mp2p_hip_pairs* pairs, mp2p_hip_gn_result* out, int32_t* redone);
+
+/* the same for Matcher_Point2Plane + Solver_GaussNewton (BASELINE config C3 sharded): every local point is paired on its
+ * own (no uniqueness filter, Matcher_Point2Plane.cpp:87-90), so the shards exchange only the layer's bounding box
+ * (:59-66; one all-reduce MAX of 8 doubles) and, per inner Gauss-Newton iteration, the 48 sums.  local_index_offset =
+ * whole-layer index of this shard's first local point.  Without a communicator: matcher + solver in one call. */
+int mp2p_hip_step_sharded_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                                const double pose[12], const mp2p_hip_pt2pl_params* prm, uint64_t local_index_offset,
+                                const mp2p_hip_gn_params* gn, mp2p_hip_pairs* pairs, mp2p_hip_gn_result* out);
 
 /* ---- instrumentation ------------------------------------------------------------------ */
 typedef struct

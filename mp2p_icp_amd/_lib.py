@@ -259,6 +259,8 @@ SIGNATURES = {
     "mp2p_hip_comm_allreduce_f64": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
     "mp2p_hip_step_sharded": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PtParams), C.POINTER(GNParams), _P,
                                         C.POINTER(GNResult), C.POINTER(C.c_int32)]),
+    "mp2p_hip_step_sharded_pt2pl": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PlParams), C.c_uint64, C.POINTER(GNParams), _P,
+                                              C.POINTER(GNResult)]),
     "mp2p_hip_set_profiling": (C.c_int, [_P, C.c_int]),
     "mp2p_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "mp2p_hip_get_timeline": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t),
@@ -307,7 +309,7 @@ def load():
         fn = getattr(L, name)  # AttributeError = symbol missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if L.mp2p_hip_abi_version() != 2:
+    if L.mp2p_hip_abi_version() != 3:
         raise ImportError("libmp2p_hip.so ABI version mismatch")
     _lib = L
     return L

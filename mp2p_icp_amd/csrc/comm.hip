@@ -138,8 +138,12 @@ static int sharded_match(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     return mp2p_hip_match_pt2pt_phase2(ctx, map, cloud, prm, nullptr, out);
 }
 
+constexpr size_t COMM_PINNED_EXCH = 3072;  // where the 64 exchanged bytes land in the context's pinned page (gn_end uses [0, 512))
+
+// also_exch: the all-reduced exchange block travels to the host together with the pose read-back that ends the
+// step (one wait instead of two)
 static int sharded_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose[12],
-                         const mp2p_hip_gn_params* gn, mp2p_hip_gn_result* res)
+                         const mp2p_hip_gn_params* gn, mp2p_hip_gn_result* res, bool also_exch = false)
 {
     if (ctx->comm.nranks <= 1) return mp2p_hip_gn_solve(ctx, pairs, pose, gn, res);
     int rc = mp2p_hip_gn_begin(ctx, pairs, pose, gn);
@@ -150,7 +154,27 @@ static int sharded_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const d
         if ((rc = comm_allreduce_f64(ctx, (double*)mp2p_hip_gn_sums_ptr(ctx), MP2P_HIP_GN_NSUMS, 0))) return rc;
         if ((rc = mp2p_hip_gn_step(ctx))) return rc;  // every rank solves the same 6x6: no broadcast
     }
-    return mp2p_hip_gn_end(ctx, res);
+    if (also_exch)
+    {
+        if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync((char*)ctx->pinned + COMM_PINNED_EXCH, ctx->exch.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return mp2p_hip_gn_end(ctx, res);  // the pose read-back: its wait covers the copy above
+}
+
+// {-min xyz, max xyz} of ctx->local_bbox <-> the first six doubles of ctx->exch (MAX-reducible)
+__global__ void bbox_to_exch_kernel(const float* __restrict__ bb, double* __restrict__ exch)
+{
+    const int d = threadIdx.x;
+    if (d < 3) exch[d] = -(double)bb[d];
+    else if (d < 6) exch[d] = (double)bb[d];
+    else if (d < 8) exch[d] = 0.0;
+}
+__global__ void exch_to_bbox_kernel(const double* __restrict__ exch, float* __restrict__ bb)
+{
+    const int d = threadIdx.x;
+    if (d < 3) bb[d] = (float)(-exch[d]);
+    else if (d < 6) bb[d] = (float)exch[d];
 }
 }  // namespace mp2p
 
@@ -241,19 +265,58 @@ int mp2p_hip_step_sharded(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p
         // between the matcher's phases); second attempt: the exact length
         rc = sharded_match(ctx, map, cloud, pose, prm, pairs, attempt == 0 ? c.cap_guess : 0, &cap);
         if (rc) return rc;
-        rc = sharded_solve(ctx, pairs, pose, gn, out);  // ends with the pose read-back: the stream is idle now
+        // ends with the pose read-back; the true longest list of this iteration (all-reduced MAX in exch[6]) rides along
+        rc = sharded_solve(ctx, pairs, pose, gn, out, claims);
         if (rc) return rc;
         if (!claims) return MP2P_HIP_OK;
-        // the true longest list of this iteration (all-reduced MAX in exch[6])
-        if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
-        MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->exch.p, 64, hipMemcpyDeviceToHost, ctx->stream));
-        MP2P_TRY_HIP(ctx, stream_wait(ctx));
-        const double n_max = ((const double*)ctx->pinned)[6];
+        const double n_max = ((const double*)((const char*)ctx->pinned + COMM_PINNED_EXCH))[6];
         c.cap_guess        = round_cap(n_max * 1.25 + 1024.0);
         if ((double)cap >= n_max) return MP2P_HIP_OK;
         if (redone) *redone = 1;  // rare: the lists did not fit the predicted length
     }
     return set_err(ctx, MP2P_HIP_ERR_HIP, "sharded step: record lists did not fit twice");
+}
+
+int mp2p_hip_step_sharded_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
+                                const double pose[12], const mp2p_hip_pt2pl_params* prm, uint64_t local_index_offset,
+                                const mp2p_hip_gn_params* gn, mp2p_hip_pairs* pairs, mp2p_hip_gn_result* out)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, map && cloud && pose && prm && gn && pairs && out, "null argument");
+    MP2P_REQUIRE(ctx, map->ctx == ctx && cloud->ctx == ctx && pairs->ctx == ctx, "handle belongs to another context");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = mp2p_hip_pairs_clear(ctx, pairs);
+    if (rc) return rc;
+    Comm& c = ctx->comm;
+    if (c.nranks <= 1)
+    {  // one rank: the plain matcher + solver in one boundary call
+        if ((rc = mp2p_hip_match_pt2pl(ctx, map, cloud, pose, prm, nullptr, pairs))) return rc;
+        return mp2p_hip_gn_solve(ctx, pairs, pose, gn, out);
+    }
+    // Matcher_Point2Plane pairs every local point on its own (no global uniqueness, Matcher_Point2Plane.cpp:87-90):
+    // the only thing the shards share before the solver is the layer's bounding box (:59-66)
+    if (cloud->n && map->n)
+    {
+        if ((rc = launch_match_pt2pl(ctx, map, cloud, pose, prm, nullptr, pairs, 1, local_index_offset))) return rc;
+    }
+    else
+    {  // an empty shard: a box that loses every MAX
+        MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
+        const float e[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(ctx->local_bbox.p, e, sizeof(e), hipMemcpyHostToDevice, ctx->stream));
+        MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `e` is a stack temporary
+    }
+    MP2P_TRY_HIP(ctx, ctx->exch.ensure(8));
+    hipLaunchKernelGGL(bbox_to_exch_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->local_bbox.p, ctx->exch.p);
+    if ((rc = comm_allreduce_f64(ctx, ctx->exch.p, 8, 1))) return rc;
+    hipLaunchKernelGGL(exch_to_bbox_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->exch.p, ctx->local_bbox.p);
+    if (cloud->n && map->n)
+    {
+        if ((rc = launch_match_pt2pl(ctx, map, cloud, pose, prm, nullptr, pairs, 2, local_index_offset))) return rc;
+    }
+    else if ((rc = launch_add_potential(ctx, pairs, (unsigned long long)cloud->n))) return rc;  // :54 before the early-out
+    // per inner iteration: accumulate ; all-reduce SUM of the 48 sums ; every rank takes the same step
+    return sharded_solve(ctx, pairs, pose, gn, out);
 }
 
 }  // extern "C"

@@ -694,9 +694,12 @@ static void launch_k(const PlArgs& a, uint32_t q, const mp2p_hip_cloud* cloud, h
                        cloud->z.p);
 }
 
+// phase: 0 = the whole matcher; 1 = search + plane fit + the shard's bounding box (left in ctx->local_bbox);
+// 2 = the compaction (a sharded caller all-reduces the box in between: mp2p_hip_step_sharded_pt2pl).
+// local_offset: whole-layer index of this shard's first local point (Pairings carry whole-layer indices)
 int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_cloud* cloud,
                        const double pose[12], const mp2p_hip_pt2pl_params* prm,
-                       mp2p_hip_mstate* ms, mp2p_hip_pairs* out)
+                       mp2p_hip_mstate* ms, mp2p_hip_pairs* out, int phase = 0, unsigned long long local_offset = 0)
 {
     const size_t   n_l     = cloud->n;
     // tile size: see pt2pl_tile_kernel (MP2P_HIP_TUNE pl_q = 8 / 32 forces one)
@@ -736,8 +739,11 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
                   ctx->pl_hint_rad == prm->searchRadius && ctx->tune.pl_warm) ? 1 : 0;
     for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->pl_hint_pose[i];
     for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->pl_hint_pose[9 + i];
-    ctx->pl_hint_map = map, ctx->pl_hint_cloud = cloud, ctx->pl_hint_n = n_l, ctx->pl_hint_knn = prm->knn, ctx->pl_hint_rad = prm->searchRadius;
-    for (int i = 0; i < 12; i++) ctx->pl_hint_pose[i] = pose[i];
+    if (phase != 2)
+    {
+        ctx->pl_hint_map = map, ctx->pl_hint_cloud = cloud, ctx->pl_hint_n = n_l, ctx->pl_hint_knn = prm->knn, ctx->pl_hint_rad = prm->searchRadius;
+        for (int i = 0; i < 12; i++) ctx->pl_hint_pose[i] = pose[i];
+    }
     a.grp_min = 2.0f * cell0;
     a.dbg = nullptr;
     if (ctx->profiling == 2)
@@ -748,6 +754,8 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     }
 
     ctx->pending_lane = 0;
+    if (phase != 2)
+    {
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (Kcap == 5) launch_k<5>(a, Q, cloud, ctx->stream);
     else if (Kcap == 8) launch_k<8>(a, Q, cloud, ctx->stream);
@@ -759,6 +767,12 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
         const int rc = launch_bbox_reduce(ctx, n_tiles);
         if (rc) return rc;
     }
+    }
+    if (phase == 1)
+    {
+        MP2P_TRY_HIP(ctx, hipGetLastError());
+        return MP2P_HIP_OK;
+    }
 
     const size_t   n_slots  = cloud->n_visit ? cloud->n_visit : n_l;
     const uint32_t n_blocks = (uint32_t)((n_slots + PC_TILE - 1) / PC_TILE);
@@ -766,6 +780,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     PlCompactArgs c;
     memset(&c, 0, sizeof(c));
     c.flag = flag, c.rec = rec, c.n_l = (uint32_t)n_slots, c.local_bbox = ctx->local_bbox.p;
+    c.local_offset = local_offset;
     c.order = cloud->n_visit ? cloud->order.p : nullptr;
     for (int d = 0; d < 3; d++) c.gbb[d] = map->view.bbmin[d], c.gbb[3 + d] = map->view.bbmax[d];
     c.margin = (float)(prm->distanceThreshold + prm->bounding_box_intersection_check_epsilon);

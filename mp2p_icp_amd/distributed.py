@@ -137,15 +137,35 @@ class HipBackend:
         from . import _lib
         torch = self.torch
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        # The decision is COLLECTIVE: a rank that falls back on its own would call torch.distributed
+        # collectives while the others sit in ncclCommInitRank / mp2p_hip_step_sharded -- a deadlock.  Rank 0
+        # broadcasts a status byte with the id; after the init every rank contributes a success flag to an
+        # all-reduce MIN; the native route is taken only if every rank made it, otherwise every rank destroys
+        # what it created and all fall back together.
         buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        ok0 = 1
         if rank == 0:
-            _lib.check(self.ctx._L.mp2p_hip_comm_get_unique_id(buf))
+            try:
+                _lib.check(self.ctx._L.mp2p_hip_comm_get_unique_id(buf))
+            except Exception:
+                ok0 = 0
         dev = self.dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+        t = torch.tensor([ok0] + list(buf), dtype=torch.uint8, device=dev)
         dist.broadcast(t, src=0, group=group)
         raw = bytes(t.cpu().tolist())
-        idb = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(raw)
-        _lib.check(self.ctx._L.mp2p_hip_comm_init(self.ctx.handle, idb, rank, world), self.ctx.handle)
+        ok = raw[0] == 1
+        if ok:
+            idb = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(raw[1:])
+            try:
+                _lib.check(self.ctx._L.mp2p_hip_comm_init(self.ctx.handle, idb, rank, world), self.ctx.handle)
+            except Exception:
+                ok = False
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            if ok:
+                self.ctx._L.mp2p_hip_comm_destroy(self.ctx.handle)
+            raise RuntimeError("the native communicator could not be created on every rank")
         self.native = True
 
     def step_native(self, pose):
@@ -163,6 +183,34 @@ class HipBackend:
     @property
     def max_inner(self):
         return int(self.gn_prm.maxInnerLoopIterations)
+
+
+class HipPlaneBackend(HipBackend):
+    """This rank's shard for Matcher_Point2Plane + Gauss-Newton (BASELINE config C3 sharded).  The matcher pairs every
+    local point on its own, so the shards exchange only the layer's bounding box and the normal-equation sums -- both
+    inside libmp2p_hip (mp2p_hip_step_sharded_pt2pl): this backend offers the native route only."""
+
+    def __init__(self, ctx, gmap, cloud, pt2pl_params, gn_params, pairs, local_index_offset=0):
+        HipBackend.__init__(self, ctx, gmap, cloud, pt2pl_params, gn_params, pairs)
+        self.uses_claims = False
+        self.offset = int(local_index_offset)
+
+    def step_native(self, pose):
+        import ctypes as C
+        from . import _lib
+        T = np.ascontiguousarray(pose, dtype=np.float64)
+        res = _lib.GNResult()
+        _lib.check(self.ctx._L.mp2p_hip_step_sharded_pt2pl(self.ctx.handle, self.gmap.handle, self.cloud.handle,
+                                                           T.ctypes.data_as(C.POINTER(C.c_double)), C.byref(self.prm),
+                                                           self.offset, C.byref(self.gn_prm), self.pairs.handle,
+                                                           C.byref(res)), self.ctx.handle)
+        return np.array(res.pose), int(res.iterations)
+
+    def phase1(self, pose):
+        raise RuntimeError("HipPlaneBackend runs inside libmp2p_hip only (mp2p_hip_comm_init / one rank)")
+
+    def n_pairs(self):
+        return self.pairs.counts()[1]
 
 
 class ShardedRegistration:

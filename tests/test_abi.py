@@ -29,7 +29,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in mp2p_hip.h but not exported"
     # the ctypes table covers exactly the header
     assert sorted(_lib.SIGNATURES) == declared
-    assert L.mp2p_hip_abi_version() == 2
+    assert L.mp2p_hip_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

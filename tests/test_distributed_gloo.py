@@ -289,3 +289,132 @@ def test_batch_registration_gloo_world2():
         p.join(timeout=60)
     for rank, ok, msg in res:
         assert ok, f"rank {rank}: {msg}"
+
+
+class OraclePlaneBackend:
+    """Matcher_Point2Plane + Gauss-Newton of ONE shard on the CPU oracle behind HipBackend's protocol: no claims
+    (Matcher_Point2Plane.cpp:87-90), the exchange block carries the bounding box only; `sums` = this shard's H (36)
+    and g (6) at the current iterate (linear in the pairings, so their SUM over the ranks is the whole layer's)."""
+
+    def __init__(self, orc, torch, g, l_shard, offset, gn_iters):
+        self.o, self.torch = orc, torch
+        self.g, self.l, self.offset = g, l_shard, offset
+        self.tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
+        self.exch = torch.zeros(8, dtype=torch.float64)
+        self.bbox = np.zeros(6, np.float32)
+        self.sums = torch.zeros(48, dtype=torch.float64)
+        self.uses_claims = False
+        self.max_inner = gn_iters
+        self.pairs = self.idx = None
+
+    def phase1(self, pose):
+        o, l = self.o, self.l
+        _, _, _, bmin, bmax = o.transform_local_to_global(l[:, 0], l[:, 1], l[:, 2], pose)
+        self.bbox[:3], self.bbox[3:] = bmin, bmax
+        self.pairs, idx, _ = o.match_pt2pl(self.g[:, 0], self.g[:, 1], self.g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose,
+                                           0.5, 1.0, 5, 5, 0.05, tree=self.tree)
+        self.idx = idx.astype(np.int64) + self.offset  # whole-layer indices
+
+    def exchange_pack(self):
+        self.exch[:3] = self.torch.from_numpy(-self.bbox[:3].astype(np.float64))
+        self.exch[3:6] = self.torch.from_numpy(self.bbox[3:].astype(np.float64))
+        self.exch[6] = self.exch[7] = 0.0
+        return self.exch, self.torch.zeros(0, dtype=self.torch.int64)
+
+    def exchange_unpack(self, gathered):
+        assert gathered is None
+        e = self.exch.numpy()
+        self.bbox[:3], self.bbox[3:] = (-e[:3]).astype(np.float32), e[3:6].astype(np.float32)
+
+    def phase2(self):
+        gmin, gmax = self.g.min(0), self.g.max(0)
+        eps = np.float32(0.5 + 0.2)
+        if not all(self.bbox[d] - eps <= gmax[d] and self.bbox[3 + d] + eps >= gmin[d] for d in range(3)):
+            self.pairs, self.idx = self.pairs[:0], self.idx[:0]  # the LAYER's box misses the map: nothing is paired
+
+    def gn_begin(self, pose):
+        self.pose, self.it, self.done = np.array(pose, dtype=np.float64), 0, False
+
+    def gn_accumulate(self):
+        s = np.zeros(48)
+        if not self.done and len(self.pairs):
+            _, _, H, g = self.o.optimal_tf_gauss_newton(None, self.pairs, None, self.pose, self.o.make_gn_params(1))
+            s[:36], s[36:42] = H.reshape(-1), g
+        self.sums.copy_(self.torch.from_numpy(s))
+
+    def gn_step(self):
+        if self.done:
+            return
+        s = self.sums.numpy()
+        self.it += 1
+        if not s[:36].any():  # no pairings anywhere: the pose stays
+            self.done = True
+            return
+        delta = -np.linalg.solve(s[:36].reshape(6, 6), s[36:42])
+        self.pose = self.o.pose_compose(self.pose, self.o.se3_exp(delta))
+        self.done = bool(np.linalg.norm(delta) < 1e-7)
+
+    def gn_end(self):
+        return self.pose, self.it
+
+
+def _plane_worker(rank, world, port, q):
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import oracle as orc
+        from mp2p_icp_amd import synthetic
+        from mp2p_icp_amd.distributed import ShardedRegistration, shard_range
+
+        d = synthetic.make_pair(1500, 300000, 9)
+        g, l = d["glob"], d["local"]
+        b, e = shard_range(l.shape[0], rank, world)
+        be = OraclePlaneBackend(orc, torch, g, l[b:e], b, 3)
+        reg = ShardedRegistration(be, dist)
+        pose, lists = d["T_init"].copy(), []
+        for it in range(3):
+            new_pose, _ = reg.step(pose)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (be.pairs, be.idx))
+            lists.append((np.concatenate([x[0] for x in gathered]), np.concatenate([x[1] for x in gathered])))
+            pose = new_pose
+        tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
+        pose_o, ok, msg = d["T_init"].copy(), True, ""
+        for it in range(3):
+            want, widx, _ = orc.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose_o, 0.5, 1.0, 5, 5, 0.05, tree=tree)
+            got, gidx = lists[it]
+            if not (len(want) > 100 and len(got) == len(want) and np.array_equal(gidx, widx) and np.allclose(got["plane"], want["plane"], rtol=0, atol=1e-12)):
+                ok, msg = False, f"plane pairings differ at iteration {it}: {len(got)} vs {len(want)}"
+                break
+            pose_o, *_ = orc.optimal_tf_gauss_newton(None, want, None, pose_o, orc.make_gn_params(3))
+        if ok:
+            dt, dr = orc.pose_err_split(pose, pose_o)
+            if not (dt < 1e-8 and dr < 1e-8):
+                ok, msg = False, f"pose differs: {dt} {dr}"
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok, msg))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc() + str(ex)))
+
+
+@pytest.mark.timeout(300)
+def test_sharded_plane_registration_gloo_world2():
+    """BASELINE config C3 sharded (Matcher_Point2Plane + Gauss-Newton): the exchange steps of ShardedRegistration
+    without claims -- one MAX all-reduce (bounding box), one SUM all-reduce per inner iteration -- over gloo"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plane_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(WORLD)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"

@@ -202,3 +202,89 @@ def test_sharded_step_through_hooks(oracle, world, allow_global):
     else:
         assert ex.calls["allgather"] >= len(seq) and n_redone >= 1
     assert ex.calls["allreduce"] >= len(seq) * 4  # box + three Gauss-Newton sums per step
+
+
+def _step_sharded_pt2pl(ctx, gmap, cloud, pose, prm, offset, gnp, pairs):
+    from mp2p_icp_amd import _lib
+    T = np.ascontiguousarray(pose, dtype=np.float64)
+    res = _lib.GNResult()
+    _lib.check(ctx._L.mp2p_hip_step_sharded_pt2pl(ctx.handle, gmap.handle, cloud.handle, T.ctypes.data_as(C.POINTER(C.c_double)),
+                                                  C.byref(prm), offset, C.byref(gnp), pairs.handle, C.byref(res)), ctx.handle)
+    return np.array(res.pose)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_pt2pl_step_through_hooks(oracle, world):
+    """mp2p_hip_step_sharded_pt2pl (Matcher_Point2Plane + Gauss-Newton, BASELINE config C3 sharded): a chain of three
+    iterations on `world` in-process ranks (world = 1: no communicator) against the UNSHARDED oracle chain -- the
+    shards' pair lists concatenated in rank order are the oracle's (whole-layer local indices, planes 1e-9), every rank
+    ends every iteration with the same pose bit for bit, the pose within 1e-5 of the oracle's"""
+    import torch
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import _lib, core, synthetic
+    from mp2p_icp_amd.distributed import shard_range
+    d = synthetic.make_pair(30_000, 200_000, 33)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(*_xyz(g))
+    dev = torch.device("cuda", 0)
+    ex = _Exchange(world, torch, dev)
+    n_it = 3
+    out = [None] * world
+    keep = []
+
+    def prms():
+        pl = _lib.Pt2PlParams()
+        pl.distanceThreshold, pl.searchRadius, pl.knn, pl.minimumPlanePoints, pl.planeEigenThreshold = 0.3, 0.5, 5, 5, 0.05
+        pl.bounding_box_intersection_check_epsilon = 0.20
+        gn = _lib.GNParams()
+        gn.maxInnerLoopIterations, gn.minDelta, gn.maxCost = 3, 1e-7, 0.0
+        gn.kernel, gn.kernelParam, gn.w_pt2pt, gn.w_pt2pl = _lib.KERNEL_GEMANMCCLURE, 0.15, 1.0, 1.0
+        return pl, gn
+
+    def run(rank):
+        try:
+            ctx = amd.Context(0)
+            b, e = shard_range(l.shape[0], rank, world)
+            gmap, cloud = core.GlobalMap(ctx, *_xyz(g)), core.LocalCloud(ctx, *_xyz(l[b:e]))
+            pairs = core.DevicePairs(ctx, 0, e - b)
+            pl, gn = prms()
+            if world > 1:
+                ar, ag = ex.hooks(rank)
+                keep.append((ar, ag))
+                _lib.check(ctx._L.mp2p_hip_comm_init_hooks(ctx.handle, rank, world, ar, ag, None), ctx.handle)
+            res, pose = [], d["T_init"].copy()
+            for _ in range(n_it):
+                start = pose.copy()
+                pose = _step_sharded_pt2pl(ctx, gmap, cloud, pose, pl, b, gn, pairs)
+                rec, idx = pairs.download_pt2pl()
+                res.append((start, rec, idx, pose.copy(), pairs.counts()[2]))
+            out[rank] = res
+        except Exception as exn:  # pragma: no cover
+            ex.bar.abort()
+            out[rank] = exn
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+        assert out[r] is not None
+    oprm = oracle.make_gn_params(3, kernel=oracle.KERNEL_GEMANMCCLURE, kernelParam=0.15)
+    for k in range(n_it):
+        start = out[0][k][0]
+        rec = np.concatenate([out[r][k][1] for r in range(world)])
+        idx = np.concatenate([out[r][k][2] for r in range(world)])
+        want, widx, pot = oracle.match_pt2pl(*_xyz(g), *_xyz(l), start, 0.3, 0.5, 5, 5, 0.05, tree=tree)
+        assert len(rec) == len(want) and np.array_equal(idx, widx), (k, len(rec), len(want))
+        assert np.allclose(rec["plane"], want["plane"], rtol=0, atol=1e-9)
+        assert sum(out[r][k][4] for r in range(world)) == pot  # potential_pairings: every shard adds its own points
+        for r in range(1, world):
+            assert np.array_equal(out[r][k][3], out[0][k][3]) and np.array_equal(out[r][k][0], start)
+        To, *_ = oracle.optimal_tf_gauss_newton(None, want, None, start, oprm)
+        dt, dr = oracle.pose_err_split(out[0][k][3], To)
+        assert dt < 1e-5 and dr < 1e-5, (k, dt, dr)
+    if world > 1:
+        assert ex.calls["allgather"] == 0                      # no unique-global filter: nothing to gather
+        assert ex.calls["allreduce"] == n_it * (1 + 3)         # the box + three Gauss-Newton sums per step

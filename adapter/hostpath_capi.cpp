@@ -130,6 +130,106 @@ int mp2p_hostpath_match_pt2pl(void* h, const double pose[12], const mp2p_hip_pt2
         });
 }
 
+// Matcher_Points_InlierRatio (Matcher_Points_InlierRatio.cpp:41-143) through the host layer
+int mp2p_hostpath_match_inlier_ratio(void* h, const double pose[12], const mp2p_hip_inlier_ratio_params* prm,
+                                     uint32_t icp_iteration, const uint32_t* visit, size_t n_visit, size_t* n_added)
+{
+    auto* s = static_cast<Session*>(h);
+    return guarded(
+        [&]()
+        {
+            const double t0 = now_ms();
+            Runtime&     rt = Runtime::get();
+            MatchCall    c;
+            c.ms_key = &s->dummy_ms, c.iteration = icp_iteration;
+            c.gbits = BitView{s->gbits.data(), s->ng}, c.lbits = BitView{s->lbits.data(), s->nl};
+            s->potential += (uint64_t)s->nl;  // :53
+            size_t n = 0;
+            if (s->ng && s->nl)
+            {
+                mp2p_hip_map*   m = rt.global_layer(s->gx, s->gx, s->gy, s->gz, s->ng, icp_iteration == 0);
+                mp2p_hip_cloud* l = rt.local_layer(s->lx, s->lx, s->ly, s->lz, s->nl, icp_iteration == 0);
+                n = match_inlier_ratio_layer(rt, c, m, l, pose, *prm, visit, n_visit, s->pt2pt);
+            }
+            if (n_added) *n_added = n;
+            s->last_ms[0] = now_ms() - t0;
+        });
+}
+
+// Matcher_Adaptive (Matcher_Adaptive.cpp:59-314) through the host layer; the threshold step is this library's
+// restatement of MRPT's histogram helpers here (the plugin calls MRPT's own); *ci_high_out: what it returned
+int mp2p_hostpath_match_adaptive(void* h, const double pose[12], const mp2p_hip_adaptive_params* prm,
+                                 uint32_t icp_iteration, size_t* n_pt_added, size_t* n_pl_added, double* ci_high_out)
+{
+    auto* s = static_cast<Session*>(h);
+    return guarded(
+        [&]()
+        {
+            const double t0 = now_ms();
+            Runtime&     rt = Runtime::get();
+            MatchCall    c;
+            c.ms_key = &s->dummy_ms, c.iteration = icp_iteration;
+            c.gbits = BitView{s->gbits.data(), s->ng}, c.lbits = BitView{s->lbits.data(), s->nl};
+            s->potential += (uint64_t)s->nl * prm->maxPt2PtCorrespondences;  // Matcher_Adaptive.cpp:75
+            std::pair<size_t, size_t> n{0, 0};
+            if (s->ng && s->nl)
+            {
+                mp2p_hip_map*   m = rt.global_layer(s->gx, s->gx, s->gy, s->gz, s->ng, icp_iteration == 0);
+                mp2p_hip_cloud* l = rt.local_layer(s->lx, s->lx, s->ly, s->lz, s->nl, icp_iteration == 0);
+                n = match_adaptive_layer(
+                    rt, c, m, l, pose, *prm,
+                    [&](const mp2p_hip_adaptive_hist& hist) { return mp2p_hip_adaptive_ci_high(&hist, prm->confidenceInterval); },
+                    s->pt2pt, [&](const mp2p_hip_pair_pt2pl& r) { s->pt2pl.push_back(r); }, ci_high_out);
+            }
+            if (n_pt_added) *n_pt_added = n.first;
+            if (n_pl_added) *n_pl_added = n.second;
+            s->last_ms[0] = now_ms() - t0;
+        });
+}
+
+// FilterDecimateVoxels (FilterDecimateVoxels.cpp:107-381) on the session's LOCAL layer through the host layer:
+// the decimated points into caller-provided arrays of capacity n_local; returns their number in *n_out
+int mp2p_hostpath_filter_decimate_local(void* h, const mp2p_hip_decimate_params* prm, float* ox, float* oy, float* oz,
+                                        uint32_t* src, size_t* n_out)
+{
+    auto* s = static_cast<Session*>(h);
+    return guarded(
+        [&]()
+        {
+            Runtime&              rt = Runtime::get();
+            std::vector<float>    x, y, z;
+            std::vector<uint32_t> si;
+            const size_t          m = filter_decimate(rt, s->lx, s->ly, s->lz, s->nl, *prm, x, y, z, si);
+            std::memcpy(ox, x.data(), m * 4), std::memcpy(oy, y.data(), m * 4), std::memcpy(oz, z.data(), m * 4);
+            if (src) std::memcpy(src, si.data(), m * 4);
+            *n_out = m;
+        });
+}
+
+// the layer cache of this thread's runtime: [0] cached layers, [1] cached device bytes, [2] evictions,
+// [3] full-content checks, [4] re-seen (strided) checks; set max_layers (> 0) first when given
+int mp2p_hostpath_cache(size_t max_layers, size_t out[5])
+{
+    return guarded(
+        [&]()
+        {
+            Runtime& rt = Runtime::get();
+            if (max_layers) rt.max_layers = max_layers;
+            out[0] = rt.cached_layers(), out[1] = rt.cached_bytes(), out[2] = rt.n_evictions, out[3] = rt.n_full_checks,
+            out[4] = rt.n_reseen_checks;
+        });
+}
+int mp2p_hostpath_release_layers(void* h)
+{
+    auto* s = static_cast<Session*>(h);
+    return guarded(
+        [&]()
+        {
+            Runtime& rt = Runtime::get();
+            rt.release_layer(s->gx), rt.release_layer(s->lx);
+        });
+}
+
 // Solver_GaussNewton::impl_optimal_pose on the session's host Pairings
 int mp2p_hostpath_solve_gn(void* h, const double pose0[12], const mp2p_hip_gn_params* prm, mp2p_hip_gn_result* out)
 {

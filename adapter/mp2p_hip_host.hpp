@@ -174,12 +174,19 @@ class Runtime
    public:
     mp2p_hip_ctx* ctx = nullptr;
 
+    // the device of this thread's context: device_id() before the first get() (a host application that runs one
+    // ICP object per GPU calls Runtime::device_id() = k in the thread that owns GPU k); MP2P_HIP_DEVICE otherwise
+    static int& device_id()
+    {
+        static thread_local int id = std::getenv("MP2P_HIP_DEVICE") ? std::atoi(std::getenv("MP2P_HIP_DEVICE")) : 0;
+        return id;
+    }
     static Runtime& get()
     {
         static thread_local Runtime r;
         if (!r.ctx)
         {
-            const int rc = mp2p_hip_ctx_create(0, nullptr, &r.ctx);
+            const int rc = mp2p_hip_ctx_create(device_id(), nullptr, &r.ctx);
             if (rc) throw Error(std::string("mp2p_hip_ctx_create: ") + mp2p_hip_last_error(nullptr));
         }
         return r;
@@ -199,18 +206,32 @@ class Runtime
         size_t   n       = 0;
         uint64_t sampled = 0, full = 0;
         bool     full_known = false;
+        uint64_t strided = 0;    // every 61st point (re-seen layers at ICP iteration 0)
+        bool     strided_known = false;
+        uint64_t last_use = 0;   // LRU stamp
+        size_t   bytes    = 0;   // device bytes behind the handle
     };
+    // Device copies are cached by the layer object's address.  A SLAM loop builds fresh layers per scan, so the
+    // cache is bounded: at most `max_layers` entries per kind and `byte_budget` device bytes in total
+    // (MP2P_HIP_HOST_CACHE_MB, default 16 GB of the 288); the least recently used entries go first -- never the two
+    // of the running call -- and release_layer() is the explicit hook (a layer's destructor, an ICP-end callback).
+    size_t max_layers  = 8;
+    size_t byte_budget = (std::getenv("MP2P_HIP_HOST_CACHE_MB") ? (size_t)std::atoll(std::getenv("MP2P_HIP_HOST_CACHE_MB")) : 16384) << 20;
     mp2p_hip_map* global_layer(const void* key, const float* x, const float* y, const float* z, size_t n,
                                bool full_check)
     {
         Layer& e = maps_[key];
+        e.last_use = ++clock_;
         if (!current(e, x, y, z, n, full_check))
         {
             if (e.handle) mp2p_hip_map_free(ctx, (mp2p_hip_map*)e.handle);
-            e.handle = nullptr;
+            e.handle = nullptr, e.bytes = 0;
+            evict(key);
             mp2p_hip_map* h = nullptr;
             check(mp2p_hip_map_upload(ctx, x, y, z, n, nullptr, &h));
             e.handle = h;
+            mp2p_hip_map_info info;
+            if (mp2p_hip_map_get_info(ctx, h, &info) == 0) e.bytes = (size_t)info.device_bytes;
             n_map_uploads++;
         }
         return (mp2p_hip_map*)e.handle;
@@ -219,16 +240,43 @@ class Runtime
                                 bool full_check)
     {
         Layer& e = clouds_[key];
+        e.last_use = ++clock_;
         if (!current(e, x, y, z, n, full_check))
         {
             if (e.handle) mp2p_hip_cloud_free(ctx, (mp2p_hip_cloud*)e.handle);
-            e.handle = nullptr;
+            e.handle = nullptr, e.bytes = 0;
+            evict(key);
             mp2p_hip_cloud* h = nullptr;
             check(mp2p_hip_cloud_upload(ctx, x, y, z, n, &h));
-            e.handle = h;
+            e.handle = h, e.bytes = n * 44;  // sorted copy + SoA + two index arrays
             n_cloud_uploads++;
         }
         return (mp2p_hip_cloud*)e.handle;
+    }
+    // drop the device copy of a layer (either kind) now
+    void release_layer(const void* key)
+    {
+        auto m = maps_.find(key);
+        if (m != maps_.end())
+        {
+            if (m->second.handle) mp2p_hip_map_free(ctx, (mp2p_hip_map*)m->second.handle);
+            maps_.erase(m);
+        }
+        auto c = clouds_.find(key);
+        if (c != clouds_.end())
+        {
+            if (c->second.handle) mp2p_hip_cloud_free(ctx, (mp2p_hip_cloud*)c->second.handle);
+            clouds_.erase(c);
+        }
+        token = Token();
+    }
+    size_t cached_layers() const { return maps_.size() + clouds_.size(); }
+    size_t cached_bytes() const
+    {
+        size_t b = 0;
+        for (auto& kv : maps_) b += kv.second.bytes;
+        for (auto& kv : clouds_) b += kv.second.bytes;
+        return b;
     }
     // a caller that edited a layer in place between two ICP iterations of its own loop
     void invalidate_layers()
@@ -299,6 +347,7 @@ class Runtime
         return idx_;
     }
     size_t idx_stride() const { return idx_cap_; }
+    size_t predicted_pairs = 0;  // pairs the next point-matcher call is expected to add (see match_pt2pt_layer)
     // wall time of the stages of the last matcher call [ms]: {layers + MatchState in, device work until
     // the list length is known, container resize, pair copy-out (whole window), marks (inside that
     // window: they run on the index arrays while the records are on the link), list fingerprint}
@@ -313,15 +362,82 @@ class Runtime
     }
 
    private:
-    static bool current(Layer& e, const float* x, const float* y, const float* z, size_t n, bool full_check)
+    // least recently used entries out, until both bounds hold; `keep` (the entry being filled) and whatever was
+    // used by the two most recent look-ups (the other layer of the running call) stay
+    void evict(const void* keep)
+    {
+        auto oldest = [&](std::map<const void*, Layer>& m) {
+            auto best = m.end();
+            for (auto it = m.begin(); it != m.end(); ++it)
+                if (it->first != keep && it->second.last_use + 2 <= clock_ && (best == m.end() || it->second.last_use < best->second.last_use)) best = it;
+            return best;
+        };
+        for (;;)
+        {
+            const bool over_n = maps_.size() > max_layers || clouds_.size() > max_layers, over_b = cached_bytes() > byte_budget;
+            if (!over_n && !over_b) return;
+            auto im = oldest(maps_), ic = oldest(clouds_);
+            const bool take_map = im != maps_.end() && (ic == clouds_.end() || (maps_.size() > max_layers) ||
+                                                        (!(clouds_.size() > max_layers) && im->second.last_use < ic->second.last_use));
+            if (take_map)
+            {
+                if (im->second.handle) mp2p_hip_map_free(ctx, (mp2p_hip_map*)im->second.handle);
+                maps_.erase(im);
+            }
+            else if (ic != clouds_.end())
+            {
+                if (ic->second.handle) mp2p_hip_cloud_free(ctx, (mp2p_hip_cloud*)ic->second.handle);
+                clouds_.erase(ic);
+            }
+            else
+                return;  // nothing evictable
+            token = Token();
+            n_evictions++;
+        }
+    }
+    uint64_t clock_ = 0;
+
+   public:
+    size_t n_evictions = 0, n_full_checks = 0, n_reseen_checks = 0;
+
+   private:
+    // full_check (ICP iteration 0): a layer seen for the FIRST time at this address is hashed in full (120 MB for
+    // the bench map: 5.5 ms); one that was verified in full before and still has the same address, size and 1024-point
+    // print is re-verified on every 61st point (0.2 M points: ~0.1 ms) -- QualityEvaluator_PairedRatio and every new
+    // ICP::align on the same map call the matcher at iteration 0 again.  MP2P_HIP_HOST_STRICT = always full.
+    static uint64_t strided_fingerprint(const float* x, const float* y, const float* z, size_t n)
+    {
+        uint64_t h = n;
+        for (size_t i = 0; i < n; i += 61)
+        {
+            uint32_t a, b, c;
+            std::memcpy(&a, x + i, 4), std::memcpy(&b, y + i, 4), std::memcpy(&c, z + i, 4);
+            h = mix64(h, ((uint64_t)a << 32) | b), h = mix64(h, c);
+        }
+        return h;
+    }
+    bool current(Layer& e, const float* x, const float* y, const float* z, size_t n, bool full_check)
     {
         const uint64_t s = sampled_fingerprint(x, y, z, n);
         bool           ok = e.handle && e.n == n && e.sampled == s;
-        uint64_t       f  = 0;
+        if (ok && full_check && e.full_known && !strict)
+        {
+            const uint64_t m = strided_fingerprint(x, y, z, n);
+            if (e.strided_known && e.strided == m)
+            {
+                n_reseen_checks++;
+                return true;
+            }
+            if (e.strided_known) ok = false;  // the content changed under the same address
+            e.strided = m, e.strided_known = true;
+        }
+        uint64_t f = 0;
         if (full_check || !ok)
         {
             f = full_fingerprint(x, y, z, n);
+            n_full_checks++;
             if (ok && e.full_known && e.full != f) ok = false;
+            if (!e.strided_known || !ok) e.strided = strided_fingerprint(x, y, z, n), e.strided_known = true;
         }
         if (!ok || full_check) e.full = f, e.full_known = true;
         e.n = n, e.sampled = s;
@@ -359,6 +475,134 @@ inline mp2p_hip_pairs* begin_match(Runtime& rt, const MatchCall& c, bool fresh_s
     return dp;
 }
 
+// ends an open split copy on every path out of a matcher call (an exception between begin and end would leave the
+// context with a page-locked destination and every later begin refused: ADVICE r2)
+struct CopyGuard
+{
+    Runtime& rt;
+    bool     open = false;
+    ~CopyGuard()
+    {
+        if (open) (void)mp2p_hip_pairs_copy_end(rt.ctx);
+    }
+};
+
+// the new point pairings of a matcher call (everything beyond token.n_pt) into the caller's vector; the marks the
+// matcher leaves ARE the indices of the new pairs: set from the two index arrays (8 bytes per pair, first on the
+// link) while the 36-byte records are still arriving
+template <class PairVec>
+size_t fetch_new_pt2pt(Runtime& rt, const MatchCall& c, mp2p_hip_pairs* dp, PairVec& out, bool mark_local, bool mark_global,
+                       double* t_marks_ms = nullptr)
+{
+    static_assert(sizeof(typename PairVec::value_type) == sizeof(mp2p_hip_pair_pt2pt), "pair record layout");
+    auto&    tk   = rt.token;
+    uint64_t n_pt = 0;
+    rt.check(mp2p_hip_pairs_counts(rt.ctx, dp, &n_pt, nullptr, nullptr));
+    const size_t n0 = out.size(), n = (size_t)n_pt - tk.n_pt;
+    out.resize(n0 + n);
+    auto* dst = reinterpret_cast<mp2p_hip_pair_pt2pt*>(out.data()) + n0;
+    if (n)
+    {
+        uint32_t* li = rt.idx_scratch(n);
+        uint32_t* gi = li + rt.idx_stride();
+        CopyGuard guard{rt};
+        rt.check(mp2p_hip_pairs_copy_pt2pt_begin(rt.ctx, dp, tk.n_pt, n, dst, li, gi));
+        guard.open = true;
+        rt.check(mp2p_hip_pairs_copy_wait_idx(rt.ctx));
+        const double tm = Runtime::now_ms();
+        if (mark_local && c.lbits.words)
+            for (size_t i = 0; i < n; i++) c.lbits.set(li[i]);
+        if (mark_global && c.gbits.words)
+            for (size_t i = 0; i < n; i++) c.gbits.set(gi[i]);
+        if (t_marks_ms) *t_marks_ms = Runtime::now_ms() - tm;
+        guard.open = false;
+        rt.check(mp2p_hip_pairs_copy_end(rt.ctx));
+    }
+    print_feed(tk.print_pt, dst, n);
+    tk.n_pt += n, tk.valid = true;
+    return n;
+}
+// ... and the new plane pairings (records handed to `emit`), local marks from their indices
+template <class Emit>
+size_t fetch_new_pt2pl(Runtime& rt, const MatchCall& c, mp2p_hip_pairs* dp, Emit&& emit)
+{
+    auto&    tk   = rt.token;
+    uint64_t n_pl = 0;
+    rt.check(mp2p_hip_pairs_counts(rt.ctx, dp, nullptr, &n_pl, nullptr));
+    const size_t n = (size_t)n_pl - tk.n_pl;
+    static thread_local std::vector<mp2p_hip_pair_pt2pl> rec;
+    static thread_local std::vector<uint32_t>            idx;
+    rec.resize(n), idx.resize(n);
+    if (n) rt.check(mp2p_hip_pairs_copy_pt2pl(rt.ctx, dp, tk.n_pl, n, rec.data(), idx.data()));
+    for (size_t i = 0; i < n; i++)
+    {
+        emit(rec[i]);
+        if (c.lbits.words) c.lbits.set(idx[i]);
+    }
+    print_feed(tk.print_pl, rec.data(), n);
+    tk.n_pl += n, tk.valid = true;
+    return n;
+}
+
+// Matcher_Points_InlierRatio::implMatchOneLayer (Matcher_Points_InlierRatio.cpp:41-143) on host containers: the
+// nearest neighbour of every visited point, the `inliersRatio` best kept.  Both marks are left for every emitted
+// pair (:127-131).
+template <class PairVec>
+size_t match_inlier_ratio_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2p_hip_cloud* cloud,
+                                const double pose[12], const mp2p_hip_inlier_ratio_params& prm, const uint32_t* visit,
+                                size_t n_visit, PairVec& out)
+{
+    const size_t    n_l  = mp2p_hip_cloud_size(cloud);
+    const bool      anyG = c.gbits.words && c.gbits.any(), anyL = c.lbits.words && c.lbits.any();
+    mp2p_hip_pairs* dp   = begin_match(rt, c, !anyG && !anyL, n_l, 0);
+    rt.check(mp2p_hip_cloud_set_visit_order(rt.ctx, cloud, n_visit ? visit : nullptr, n_visit));
+    mp2p_hip_mstate* ms = rt.match_state(c.gbits, c.lbits, anyG, anyL);
+    rt.check(mp2p_hip_match_inlier_ratio(rt.ctx, map, cloud, pose, &prm, ms, dp));
+    return fetch_new_pt2pt(rt, c, dp, out, true, true);
+}
+
+// Matcher_Adaptive::implMatchOneLayer (Matcher_Adaptive.cpp:59-314) on host containers, in the three steps of the
+// boundary: neighbour search + histogram on the device, the THRESHOLD on the host by the caller's function (the
+// plugin hands the 50 bins to MRPT's own CHistogram / confidenceIntervalsFromHistogram, :191-205, which removes the
+// one step this repository cannot pin; tests pass mp2p_hip_adaptive_ci_high), selection on the device.  Point
+// pairings into `out_pt`, plane pairings to `emit`; local marks for both (:260, 289-293), global marks are read only.
+// Returns {point pairs, plane pairs} added.
+template <class PairVec, class Threshold, class Emit>
+std::pair<size_t, size_t> match_adaptive_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2p_hip_cloud* cloud,
+                                               const double pose[12], const mp2p_hip_adaptive_params& prm,
+                                               Threshold&& ci_high_of, PairVec& out_pt, Emit&& emit, double* ci_high_out = nullptr)
+{
+    const size_t    n_l  = mp2p_hip_cloud_size(cloud);
+    const bool      anyG = c.gbits.words && c.gbits.any(), anyL = c.lbits.words && c.lbits.any();
+    mp2p_hip_pairs* dp   = begin_match(rt, c, !anyG && !anyL, n_l * std::max<uint32_t>(1u, prm.maxPt2PtCorrespondences), n_l);
+    rt.check(mp2p_hip_cloud_set_visit_order(rt.ctx, cloud, nullptr, 0));  // the reference throws for a subset here
+    mp2p_hip_mstate* ms = rt.match_state(c.gbits, c.lbits, anyG, anyL);
+    mp2p_hip_adaptive_hist hist;
+    rt.check(mp2p_hip_adaptive_search(rt.ctx, map, cloud, pose, &prm, ms, &hist));
+    if (!hist.valid) return {0, 0};  // no local point has a neighbour within absoluteMaxSearchDistance
+    const double ci = ci_high_of(hist);
+    if (ci_high_out) *ci_high_out = ci;
+    rt.check(mp2p_hip_adaptive_select(rt.ctx, map, cloud, &prm, ci, ms, dp));
+    const size_t n_pl = fetch_new_pt2pl(rt, c, dp, emit);
+    const size_t n_pt = fetch_new_pt2pt(rt, c, dp, out_pt, true, false);
+    return {n_pt, n_pl};
+}
+
+// FilterDecimateVoxels (mp2p_icp_filters/src/FilterDecimateVoxels.cpp:107-381) on host arrays: the decimated points
+// (and, per output point, the index of the input point it is -- NONE for an average) -- one input layer, or several
+// concatenated by the caller in layer order.  RandomPoint is not offered (mrpt::random stream): the plugin keeps the
+// reference's own code for it.
+inline size_t filter_decimate(Runtime& rt, const float* x, const float* y, const float* z, size_t n,
+                              const mp2p_hip_decimate_params& prm, std::vector<float>& ox, std::vector<float>& oy,
+                              std::vector<float>& oz, std::vector<uint32_t>& src)
+{
+    ox.resize(n), oy.resize(n), oz.resize(n), src.resize(n);
+    size_t m = 0;
+    if (n) rt.check(mp2p_hip_filter_decimate_voxels(rt.ctx, x, y, z, n, &prm, ox.data(), oy.data(), oz.data(), src.data(), &m));
+    ox.resize(m), oy.resize(m), oz.resize(m), src.resize(m);
+    return m;
+}
+
 // Matcher_Points_DistanceThreshold::implMatchOneLayer on host containers.  `out` (a vector of records
 // layout-compatible with mp2p_hip_pair_pt2pt, e.g. mrpt::tfest::TMatchingPairList) is appended to.
 // Returns the number of pairs added; *potential_add = what the reference adds to potential_pairings.
@@ -377,12 +621,18 @@ size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
     mp2p_hip_mstate* ms = rt.match_state(c.gbits, c.lbits, anyG, anyL);
     rt.stage_ms[0] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
     rt.check(mp2p_hip_match_pt2pt(rt.ctx, map, cloud, pose, &prm, ms, dp));
+    // std::vector::resize value-initialises what it adds (0.09 ms for 10^5 records): the container grows to the
+    // PREDICTED length (last call's + 10 %) while the device is still searching; the exact resize afterwards only
+    // trims, or fills the few records the prediction missed
+    const size_t n0 = out.size();
+    if (rt.predicted_pairs) out.resize(n0 + std::min(rt.predicted_pairs, n_l * (size_t)prm.pairingsPerPoint));
     // the new list length first (24 bytes, one wait), then exactly the new entries into the caller's vector
     uint64_t n_pt = 0;
     rt.check(mp2p_hip_pairs_counts(rt.ctx, dp, &n_pt, nullptr, nullptr));
     rt.stage_ms[1] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
-    const size_t n0 = out.size(), n = (size_t)n_pt - tk.n_pt;
+    const size_t n = (size_t)n_pt - tk.n_pt;
     out.resize(n0 + n);
+    rt.predicted_pairs = n + n / 10 + 64;
     rt.stage_ms[2] = (t1 = Runtime::now_ms()) - t0, t0 = t1;
     auto* dst = reinterpret_cast<mp2p_hip_pair_pt2pt*>(out.data()) + n0;
     // the marks this matcher leaves (only when global re-use is forbidden, :116-120) ARE the indices of
@@ -394,7 +644,9 @@ size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
     {
         uint32_t* li = rt.idx_scratch(n);
         uint32_t* gi = li + rt.idx_stride();
+        CopyGuard guard{rt};
         rt.check(mp2p_hip_pairs_copy_pt2pt_begin(rt.ctx, dp, tk.n_pt, n, dst, li, gi));
+        guard.open = true;
         rt.check(mp2p_hip_pairs_copy_wait_idx(rt.ctx));
         const double tm = Runtime::now_ms();
         if (marks && c.lbits.words)
@@ -402,6 +654,7 @@ size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
         if (marks && c.gbits.words)
             for (size_t i = 0; i < n; i++) c.gbits.set(gi[i]);
         t_marks = Runtime::now_ms() - tm;
+        guard.open = false;
         rt.check(mp2p_hip_pairs_copy_end(rt.ctx));
     }
     rt.stage_ms[3] = (t1 = Runtime::now_ms()) - t0, t0 = t1;

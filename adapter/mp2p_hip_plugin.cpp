@@ -30,6 +30,10 @@
 //   Solver::impl_optimal_pose                   Solver.h:100-101   (Gauss-Newton, Horn)
 //   Matcher::initialize / Solver::initialize    Matcher.h:88, Solver.h:80
 //   NearestPlaneCapable::nn_search_pt2pl        NearestPlaneCapable.h:49-50  (PointsMapPlanes layer)
+//   Matcher_Adaptive / Matcher_Points_InlierRatio  Matcher_Adaptive.cpp:59-314, Matcher_Points_InlierRatio.cpp:41-143
+//   FilterBase::filter (FilterDecimateVoxels)   FilterBase.h:62, FilterDecimateVoxels.cpp:107-381
+//   -> with these, icp-run on demos/icp-settings-kitti.yaml (Matcher_Adaptive from iteration 6, every matcher on the
+//      `decimated` layer) stays on the device path for the whole alignment
 //   registration                                register.cpp:43-69
 #include <mp2p_icp/Matcher_Points_Base.h>
 #include <mp2p_icp/NearestPlaneCapable.h>
@@ -39,9 +43,13 @@
 #include <mp2p_icp/metricmap.h>
 #include <mp2p_icp/pointcloud_bitfield.h>
 #include <mp2p_icp/robust_kernels.h>
+#include <mp2p_icp_filters/FilterBase.h>
+#include <mp2p_icp_filters/FilterDecimateVoxels.h>
+#include <mp2p_icp_filters/GetOrCreatePointLayer.h>
 #include <mrpt/core/initializer.h>
 #include <mrpt/maps/CPointsMap.h>
 #include <mrpt/maps/CSimplePointsMap.h>
+#include <mrpt/math/distributions.h>
 #include <mrpt/random/random_shuffle.h>
 #include <mrpt/rtti/CObject.h>
 
@@ -562,11 +570,318 @@ class Solver_Horn : public mp2p_icp::Solver
     }
 };
 
+
+// ================================================================================================
+// Matcher_Points_InlierRatio (Matcher_Points_InlierRatio.cpp:41-143): same YAML key, same asserts
+class Matcher_Points_InlierRatio : public mp2p_icp::Matcher_Points_Base, protected MatcherCallContext
+{
+    DEFINE_MRPT_OBJECT(Matcher_Points_InlierRatio, mp2p_icp_hip)
+   public:
+    void initialize(const mrpt::containers::yaml& params) override
+    {
+        Matcher_Points_Base::initialize(params);
+        MCP_LOAD_REQ(params, inliersRatio);  // :38
+    }
+    bool match(const mp2p_icp::metric_map_t& pcGlobal, const mp2p_icp::metric_map_t& pcLocal,
+               const mrpt::poses::CPose3D& localPose, const mp2p_icp::MatchContext& mc, mp2p_icp::MatchState& ms,
+               mp2p_icp::Pairings& out) const override
+    {
+        note_call(mc, ms);
+        return mp2p_icp::Matcher::match(pcGlobal, pcLocal, localPose, mc, ms, out);
+    }
+    double inliersRatio = 0.80;
+
+   private:
+    void implMatchOneLayer(const mrpt::maps::CMetricMap& pcGlobal, const mrpt::maps::CPointsMap& pcLocal,
+                           const mrpt::poses::CPose3D& localPose, mp2p_icp::MatchState& ms,
+                           const mp2p_icp::layer_name_t& globalName, const mp2p_icp::layer_name_t& localName,
+                           mp2p_icp::Pairings& out) const override
+    {
+        ASSERT_GT_(inliersRatio, 0.0);  // :47-48
+        ASSERT_LT_(inliersRatio, 1.0);
+        const auto* gl = mp2p_icp::MapToPointsMap(pcGlobal);
+        if (!gl) THROW_EXCEPTION("HIP matcher: the global layer must be a CPointsMap");
+        out.potential_pairings += pcLocal.size();           // :53
+        if (pcGlobal.isEmpty() || pcLocal.empty()) return;  // :56
+        mp2p_hip_inlier_ratio_params prm;
+        std::memset(&prm, 0, sizeof(prm));
+        prm.inliersRatio                            = inliersRatio;
+        prm.allowMatchAlreadyMatchedPoints          = allowMatchAlreadyMatchedPoints_;
+        prm.allowMatchAlreadyMatchedGlobalPoints    = allowMatchAlreadyMatchedGlobalPoints_;
+        prm.bounding_box_intersection_check_epsilon = bounding_box_intersection_check_epsilon_;
+        double T[12];
+        fill_pose(localPose, T);
+        auto&                       rt    = Runtime::get();
+        const std::vector<uint32_t> visit = visit_list(pcLocal.size(), maxLocalPointsPerLayer_, localPointsSampleSeed_);
+        mp2p_hip_map*               m;
+        mp2p_hip_cloud*             c;
+        layers(rt, *gl, pcLocal, m, c);
+        BitAccess gbits(ms.globalPairedBitField.point_layers.at(globalName), gl->size());
+        BitAccess lbits(ms.localPairedBitField.point_layers.at(localName), pcLocal.size());
+        MatchCall call;
+        call.ms_key = cur_ms_ ? cur_ms_ : &ms, call.iteration = cur_iteration_;
+        call.gbits = gbits.view(), call.lbits = lbits.view();
+        mp2p_hip_host::match_inlier_ratio_layer(rt, call, m, c, T, prm, visit.data(), visit.size(), out.paired_pt2pt);
+        gbits.commit(), lbits.commit();
+    }
+};
+
+// ================================================================================================
+// Matcher_Adaptive (Matcher_Adaptive.cpp:59-314): neighbour search + 50-bin histogram and the selection on the
+// device; the threshold between them by MRPT's OWN confidenceIntervalsFromHistogram (:203-205) from the 50 bins --
+// the one step whose arithmetic this repository cannot pin is thereby the reference's.  (The binning rule and
+// getHistogramNormalized -- linspace of the bin positions, counts / (count x bin width) -- are restated: two lines.)
+class Matcher_Adaptive : public mp2p_icp::Matcher_Points_Base, protected MatcherCallContext
+{
+    DEFINE_MRPT_OBJECT(Matcher_Adaptive, mp2p_icp_hip)
+   public:
+    void initialize(const mrpt::containers::yaml& params) override
+    {
+        Matcher_Points_Base::initialize(params);
+        MCP_LOAD_REQ(params, confidenceInterval);         // Matcher_Adaptive.cpp:36-49
+        MCP_LOAD_REQ(params, firstToSecondDistanceMax);
+        MCP_LOAD_REQ(params, absoluteMaxSearchDistance);
+        MCP_LOAD_OPT(params, minimumCorrDist);
+        MCP_LOAD_REQ(params, enableDetectPlanes);
+        MCP_LOAD_OPT(params, planeSearchPoints);
+        MCP_LOAD_OPT(params, planeMinimumFoundPoints);
+        MCP_LOAD_OPT(params, planeEigenThreshold);
+        MCP_LOAD_OPT(params, maxPt2PtCorrespondences);
+        MCP_LOAD_OPT(params, planeMinimumDistance);
+        ASSERT_LT_(confidenceInterval, 1.0);  // :51-57
+        ASSERT_GT_(confidenceInterval, 0.0);
+        ASSERT_GE_(planeSearchPoints, planeMinimumFoundPoints);
+        ASSERT_GE_(planeMinimumFoundPoints, 3u);
+        ASSERT_GT_(planeEigenThreshold, 0.0);
+    }
+    bool match(const mp2p_icp::metric_map_t& pcGlobal, const mp2p_icp::metric_map_t& pcLocal,
+               const mrpt::poses::CPose3D& localPose, const mp2p_icp::MatchContext& mc, mp2p_icp::MatchState& ms,
+               mp2p_icp::Pairings& out) const override
+    {
+        note_call(mc, ms);
+        return mp2p_icp::Matcher::match(pcGlobal, pcLocal, localPose, mc, ms, out);
+    }
+    double   confidenceInterval        = 0.80;
+    double   firstToSecondDistanceMax  = 1.2;
+    double   absoluteMaxSearchDistance = 5.0;
+    bool     enableDetectPlanes        = false;
+    uint32_t maxPt2PtCorrespondences   = 1;
+    uint32_t planeSearchPoints         = 8;
+    uint32_t planeMinimumFoundPoints   = 4;
+    double   planeMinimumDistance      = 0.10;
+    double   planeEigenThreshold       = 0.01;
+    double   minimumCorrDist           = 0.1;
+
+   private:
+    void implMatchOneLayer(const mrpt::maps::CMetricMap& pcGlobal, const mrpt::maps::CPointsMap& pcLocal,
+                           const mrpt::poses::CPose3D& localPose, mp2p_icp::MatchState& ms,
+                           const mp2p_icp::layer_name_t& globalName, const mp2p_icp::layer_name_t& localName,
+                           mp2p_icp::Pairings& out) const override
+    {
+        const auto* gl = mp2p_icp::MapToPointsMap(pcGlobal);
+        if (!gl) THROW_EXCEPTION("HIP matcher: the global layer must be a CPointsMap");
+        out.potential_pairings += pcLocal.size() * maxPt2PtCorrespondences;  // :75
+        if (pcGlobal.isEmpty() || pcLocal.empty()) return;
+        if (maxLocalPointsPerLayer_ != 0 && pcLocal.size() > maxLocalPointsPerLayer_)
+            THROW_EXCEPTION("Matcher_Adaptive does not support maxLocalPointsPerLayer (the reference indexes out of range there)");
+        mp2p_hip_adaptive_params prm;
+        std::memset(&prm, 0, sizeof(prm));
+        prm.confidenceInterval = confidenceInterval, prm.firstToSecondDistanceMax = firstToSecondDistanceMax;
+        prm.absoluteMaxSearchDistance = absoluteMaxSearchDistance, prm.minimumCorrDist = minimumCorrDist;
+        prm.enableDetectPlanes = enableDetectPlanes ? 1 : 0, prm.maxPt2PtCorrespondences = maxPt2PtCorrespondences;
+        prm.planeSearchPoints = planeSearchPoints, prm.planeMinimumFoundPoints = planeMinimumFoundPoints;
+        prm.planeMinimumDistance = planeMinimumDistance, prm.planeEigenThreshold = planeEigenThreshold;
+        prm.allowMatchAlreadyMatchedPoints          = allowMatchAlreadyMatchedPoints_;
+        prm.allowMatchAlreadyMatchedGlobalPoints    = allowMatchAlreadyMatchedGlobalPoints_;
+        prm.bounding_box_intersection_check_epsilon = bounding_box_intersection_check_epsilon_;
+        double T[12];
+        fill_pose(localPose, T);
+        auto&           rt = Runtime::get();
+        mp2p_hip_map*   m;
+        mp2p_hip_cloud* c;
+        layers(rt, *gl, pcLocal, m, c);
+        BitAccess gbits(ms.globalPairedBitField.point_layers.at(globalName), gl->size());
+        BitAccess lbits(ms.localPairedBitField.point_layers.at(localName), pcLocal.size());
+        MatchCall call;
+        call.ms_key = cur_ms_ ? cur_ms_ : &ms, call.iteration = cur_iteration_;
+        call.gbits = gbits.view(), call.lbits = lbits.view();
+        const double ci = 1.0 - confidenceInterval;
+        mp2p_hip_host::match_adaptive_layer(
+            rt, call, m, c, T, prm,
+            [&](const mp2p_hip_adaptive_hist& h)
+            {
+                // CHistogram::getHistogramNormalized (bin positions = linspace(min, max, 50), hits = count_i /
+                // (total x bin width)), then MRPT's own confidence limits (:197-205)
+                const size_t        nb = MP2P_HIP_ADAPTIVE_BINS;
+                std::vector<double> xs(nb), vs(nb);
+                const double        lo = h.minSqr, hi = h.maxSqr, bw = (hi - lo) / nb;
+                for (size_t i = 0; i < nb; i++)
+                {
+                    xs[i] = lo + (hi - lo) * (double)i / (double)(nb - 1);
+                    vs[i] = (h.count && bw > 0) ? (double)h.bins[i] / ((double)h.count * bw) : 0.0;
+                }
+                double ci_low = 0, ci_high = 0;
+                mrpt::math::confidenceIntervalsFromHistogram(xs, vs, ci_low, ci_high, ci);
+                return ci_high;
+            },
+            out.paired_pt2pt,
+            [&](const mp2p_hip_pair_pt2pl& r)
+            {
+                auto& p = out.paired_pt2pl.emplace_back();
+                p.pt_local = {r.pt_local[0], r.pt_local[1], r.pt_local[2]};
+                for (int k = 0; k < 4; k++) p.pl_global.plane.coefs[k] = r.plane[k];
+                p.pl_global.centroid = {r.centroid[0], r.centroid[1], r.centroid[2]};
+            });
+        gbits.commit(), lbits.commit();
+    }
+};
+
+// ================================================================================================
+// FilterDecimateVoxels (FilterDecimateVoxels.cpp:41-381) deriving the reference's FilterBase: same YAML keys; the
+// voxel decimation on the device.  RandomPoint (mrpt::random stream) is handed to the reference's own class.
+class FilterDecimateVoxels : public mp2p_icp_filters::FilterBase
+{
+    DEFINE_MRPT_OBJECT(FilterDecimateVoxels, mp2p_icp_hip)
+   public:
+    void initialize(const mrpt::containers::yaml& c) override
+    {
+        ASSERTMSG_(c.has("input_pointcloud_layer"), "YAML configuration must have an entry `input_pointcloud_layer` with a scalar or sequence.");  // :43-60
+        input_pointcloud_layer.clear();
+        auto cfgIn = c["input_pointcloud_layer"];
+        if (cfgIn.isScalar()) input_pointcloud_layer.push_back(cfgIn.as<std::string>());
+        else
+        {
+            ASSERTMSG_(cfgIn.isSequence(), "YAML configuration must have an entry `input_pointcloud_layer` with a scalar or sequence.");
+            for (int i = 0; i < (int)cfgIn.size(); i++) input_pointcloud_layer.push_back(cfgIn(i).as<std::string>());
+        }
+        ASSERT_(!input_pointcloud_layer.empty());
+        MCP_LOAD_OPT(c, error_on_missing_input_layer);  // :65-78
+        std::string decimate_method = c["decimate_method"].as<std::string>();
+        method = decimate_method.find("ClosestToAverage") != std::string::npos ? mp2p_icp_filters::DecimateMethod::ClosestToAverage
+                 : decimate_method.find("VoxelAverage") != std::string::npos   ? mp2p_icp_filters::DecimateMethod::VoxelAverage
+                 : decimate_method.find("RandomPoint") != std::string::npos    ? mp2p_icp_filters::DecimateMethod::RandomPoint
+                                                                               : mp2p_icp_filters::DecimateMethod::FirstPoint;
+        MCP_LOAD_REQ(c, output_pointcloud_layer);
+        MCP_LOAD_OPT(c, minimum_input_points_to_filter);
+        DECLARE_PARAMETER_IN_REQ(c, voxel_filter_resolution, *this);
+        if (c.has("flatten_to")) flatten_to = c["flatten_to"].as<double>();
+        if (method == mp2p_icp_filters::DecimateMethod::RandomPoint)
+        {
+            reference_ = std::make_shared<mp2p_icp_filters::FilterDecimateVoxels>();
+            reference_->initialize(c);
+        }
+    }
+
+    void filter(mp2p_icp::metric_map_t& inOut) const override
+    {
+        if (reference_) return reference_->filter(inOut);
+        checkAllParametersAreRealized();
+        std::vector<const mrpt::maps::CPointsMap*> in;  // :112-139
+        for (const auto& name : input_pointcloud_layer)
+        {
+            auto it = inOut.layers.find(name);
+            if (it == inOut.layers.end())
+            {
+                if (error_on_missing_input_layer) THROW_EXCEPTION_FMT("Input layer '%s' not found on input map.", name.c_str());
+                continue;
+            }
+            const auto* pc = mp2p_icp::MapToPointsMap(*it->second);
+            if (!pc) THROW_EXCEPTION_FMT("Layer '%s' must be of point cloud type.", name.c_str());
+            in.push_back(pc);
+        }
+        ASSERT_(!in.empty());
+        ASSERT_(!output_pointcloud_layer.empty());
+        auto outPc = mp2p_icp_filters::GetOrCreatePointLayer(inOut, output_pointcloud_layer, false,
+                                                             in.at(0)->GetRuntimeClass()->className);  // :145-151
+        // layers below minimum_input_points_to_filter pass through undecimated (:155-189)
+        std::vector<const mrpt::maps::CPointsMap*> todo;
+        for (const auto* pc : in)
+        {
+            if (minimum_input_points_to_filter == 0 || pc->size() > minimum_input_points_to_filter)
+            {
+                todo.push_back(pc);
+                continue;
+            }
+            const auto& xs = pc->getPointsBufferRef_x();
+            const auto& ys = pc->getPointsBufferRef_y();
+            for (size_t i = 0; i < xs.size(); i++)
+            {
+                if (flatten_to.has_value()) outPc->insertPointFast(xs[i], ys[i], (float)*flatten_to);
+                else outPc->insertPointFrom(*pc, i);
+            }
+        }
+        if (todo.empty()) return;
+        if (todo.size() > 1 && method != mp2p_icp_filters::DecimateMethod::FirstPoint)
+            THROW_EXCEPTION("HIP FilterDecimateVoxels: several input layers are decimated together for FirstPoint only");
+        // the input layers in order, as one array triple (one layer: its own buffers)
+        std::vector<float> cx, cy, cz;
+        const float *      px = nullptr, *py = nullptr, *pz = nullptr;
+        size_t             n = 0;
+        if (todo.size() == 1)
+        {
+            px = todo[0]->getPointsBufferRef_x().data(), py = todo[0]->getPointsBufferRef_y().data(),
+            pz = todo[0]->getPointsBufferRef_z().data(), n = todo[0]->size();
+        }
+        else
+        {
+            for (const auto* pc : todo)
+            {
+                const auto &xs = pc->getPointsBufferRef_x(), &ys = pc->getPointsBufferRef_y(), &zs = pc->getPointsBufferRef_z();
+                cx.insert(cx.end(), xs.begin(), xs.end()), cy.insert(cy.end(), ys.begin(), ys.end()), cz.insert(cz.end(), zs.begin(), zs.end());
+            }
+            px = cx.data(), py = cy.data(), pz = cz.data(), n = cx.size();
+        }
+        mp2p_hip_decimate_params prm;
+        std::memset(&prm, 0, sizeof(prm));
+        prm.voxel_filter_resolution = voxel_filter_resolution;
+        prm.decimate_method         = method == mp2p_icp_filters::DecimateMethod::ClosestToAverage ? MP2P_HIP_DECIMATE_CLOSEST_TO_AVERAGE
+                                      : method == mp2p_icp_filters::DecimateMethod::VoxelAverage   ? MP2P_HIP_DECIMATE_VOXEL_AVERAGE
+                                                                                                   : MP2P_HIP_DECIMATE_FIRST_POINT;
+        prm.has_flatten_to = flatten_to.has_value() ? 1 : 0, prm.flatten_to = flatten_to.has_value() ? (float)*flatten_to : 0.f;
+        std::vector<float>    ox, oy, oz;
+        std::vector<uint32_t> src;
+        const size_t          m = mp2p_hip_host::filter_decimate(Runtime::get(), px, py, pz, n, prm, ox, oy, oz, src);
+        outPc->reserve(outPc->size() + m);
+        for (size_t k = 0; k < m; k++)
+        {
+            // a picked input point keeps its extra fields (ring, intensity, timestamp: insertPointFrom, :236-244); an
+            // average or a flattened point is coordinates only
+            if (src[k] != 0xFFFFFFFFu && !flatten_to.has_value())
+            {
+                size_t i = src[k], li = 0;
+                while (li + 1 < todo.size() && i >= todo[li]->size()) i -= todo[li]->size(), li++;
+                outPc->insertPointFrom(*todo[li], i);
+            }
+            else
+                outPc->insertPointFast(ox[k], oy[k], oz[k]);
+        }
+        outPc->mark_as_modified();
+    }
+
+    std::vector<std::string>         input_pointcloud_layer{"raw"};
+    bool                             error_on_missing_input_layer = true;
+    std::string                      output_pointcloud_layer;
+    float                            voxel_filter_resolution       = 1.0f;
+    uint32_t                         minimum_input_points_to_filter = 0;
+    std::optional<double>            flatten_to;
+    mp2p_icp_filters::DecimateMethod method = mp2p_icp_filters::DecimateMethod::FirstPoint;
+
+   private:
+    std::shared_ptr<mp2p_icp_filters::FilterDecimateVoxels> reference_;
+};
+
 // a caller that edits a layer in place between the iterations of its OWN loop (ICP::align never does)
+// ... and one that is done with a layer (a scan's maps at the end of ICP::align): frees its device copy now; the
+// cache is bounded anyway (mp2p_hip_host::Runtime::max_layers / byte_budget, least recently used first)
+void release_layer(const void* layer) { Runtime::get().release_layer(layer); }
+
 void invalidate_layers() { Runtime::get().invalidate_layers(); }
 
 IMPLEMENTS_MRPT_OBJECT(Matcher_Points_DistanceThreshold, mp2p_icp::Matcher, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(Matcher_Point2Plane, mp2p_icp::Matcher, mp2p_icp_hip)
+IMPLEMENTS_MRPT_OBJECT(Matcher_Points_InlierRatio, mp2p_icp::Matcher, mp2p_icp_hip)
+IMPLEMENTS_MRPT_OBJECT(Matcher_Adaptive, mp2p_icp::Matcher, mp2p_icp_hip)
+IMPLEMENTS_MRPT_OBJECT(FilterDecimateVoxels, mp2p_icp_filters::FilterBase, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(Solver_Horn, mp2p_icp::Solver, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(Solver_GaussNewton, mp2p_icp::Solver, mp2p_icp_hip)
 IMPLEMENTS_SERIALIZABLE(PointsMapPlanes, CSimplePointsMap, mp2p_icp_hip)
@@ -578,6 +893,9 @@ MRPT_INITIALIZER(register_mp2p_icp_hip)
     using mrpt::rtti::registerClass;
     registerClass(CLASS_ID(mp2p_icp_hip::Matcher_Points_DistanceThreshold));
     registerClass(CLASS_ID(mp2p_icp_hip::Matcher_Point2Plane));
+    registerClass(CLASS_ID(mp2p_icp_hip::Matcher_Points_InlierRatio));
+    registerClass(CLASS_ID(mp2p_icp_hip::Matcher_Adaptive));
+    registerClass(CLASS_ID(mp2p_icp_hip::FilterDecimateVoxels));
     registerClass(CLASS_ID(mp2p_icp_hip::Solver_GaussNewton));
     registerClass(CLASS_ID(mp2p_icp_hip::Solver_Horn));
     registerClass(CLASS_ID(mp2p_icp_hip::PointsMapPlanes));

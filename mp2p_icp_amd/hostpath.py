@@ -26,6 +26,14 @@ SIGNATURES = {
                                             C.POINTER(C.c_size_t)]),
     "mp2p_hostpath_match_pt2pl": (C.c_int, [_P, _dp, C.POINTER(_lib.Pt2PlParams), C.c_uint32,
                                             C.POINTER(C.c_size_t)]),
+    "mp2p_hostpath_match_inlier_ratio": (C.c_int, [_P, _dp, C.POINTER(_lib.InlierRatioParams), C.c_uint32, _P, C.c_size_t,
+                                                   C.POINTER(C.c_size_t)]),
+    "mp2p_hostpath_match_adaptive": (C.c_int, [_P, _dp, C.POINTER(_lib.AdaptiveParams), C.c_uint32, C.POINTER(C.c_size_t),
+                                               C.POINTER(C.c_size_t), _dp]),
+    "mp2p_hostpath_filter_decimate_local": (C.c_int, [_P, C.POINTER(_lib.DecimateParams), _fp, _fp, _fp, _P,
+                                                      C.POINTER(C.c_size_t)]),
+    "mp2p_hostpath_cache": (C.c_int, [C.c_size_t, C.POINTER(C.c_size_t)]),
+    "mp2p_hostpath_release_layers": (C.c_int, [_P]),
     "mp2p_hostpath_solve_gn": (C.c_int, [_P, _dp, C.POINTER(_lib.GNParams), C.POINTER(_lib.GNResult)]),
     "mp2p_hostpath_set_pairings": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t]),
     "mp2p_hostpath_pairs_pt2pt": (_P, [_P, C.POINTER(C.c_size_t)]),
@@ -77,6 +85,7 @@ class Session:
         self._L = load()
         self._g = [np.ascontiguousarray(glob[:, k], dtype=np.float32) for k in range(3)]
         self._l = [np.ascontiguousarray(local[:, k], dtype=np.float32) for k in range(3)]
+        self._n_local = self._l[0].size
         self._h = self._L.mp2p_hostpath_open(_f(self._g[0]), _f(self._g[1]), _f(self._g[2]), self._g[0].size,
                                              _f(self._l[0]), _f(self._l[1]), _f(self._l[2]), self._l[0].size)
 
@@ -109,6 +118,37 @@ class Session:
         _check(self._L.mp2p_hostpath_match_pt2pl(self._h, T.ctypes.data_as(_dp), C.byref(prm), int(icp_iteration),
                                                  C.byref(n)))
         return n.value
+
+    def match_inlier_ratio(self, pose, prm, icp_iteration=0, visit=None):
+        T = np.ascontiguousarray(pose, dtype=np.float64)
+        n = C.c_size_t(0)
+        v = None if visit is None else np.ascontiguousarray(visit, dtype=np.uint32)
+        _check(self._L.mp2p_hostpath_match_inlier_ratio(self._h, T.ctypes.data_as(_dp), C.byref(prm), int(icp_iteration),
+                                                        None if v is None else v.ctypes.data, 0 if v is None else v.size,
+                                                        C.byref(n)))
+        return n.value
+
+    def match_adaptive(self, pose, prm, icp_iteration=0):
+        """-> (point pairs added, plane pairs added, the threshold ci_high)"""
+        T = np.ascontiguousarray(pose, dtype=np.float64)
+        a, b, ci = C.c_size_t(0), C.c_size_t(0), C.c_double(float("nan"))
+        _check(self._L.mp2p_hostpath_match_adaptive(self._h, T.ctypes.data_as(_dp), C.byref(prm), int(icp_iteration),
+                                                    C.byref(a), C.byref(b), C.byref(ci)))
+        return a.value, b.value, ci.value
+
+    def filter_decimate_local(self, prm):
+        """FilterDecimateVoxels over the session's local layer -> (points [m, 3] float32, source indices [m] uint32)"""
+        n = self._n_local
+        x, y, z = (np.zeros(max(1, n), np.float32) for _ in range(3))
+        src = np.zeros(max(1, n), np.uint32)
+        m = C.c_size_t(0)
+        _check(self._L.mp2p_hostpath_filter_decimate_local(self._h, C.byref(prm), _f(x), _f(y), _f(z), src.ctypes.data,
+                                                           C.byref(m)))
+        k = m.value
+        return np.stack([x[:k], y[:k], z[:k]], 1), src[:k]
+
+    def release_layers(self):
+        _check(self._L.mp2p_hostpath_release_layers(self._h))
 
     def solve_gn(self, pose0, gn_prm):
         T = np.ascontiguousarray(pose0, dtype=np.float64)
@@ -168,6 +208,13 @@ def counters():
     out = (C.c_size_t * 4)()
     _check(load().mp2p_hostpath_counters(out))
     return dict(map_uploads=out[0], cloud_uploads=out[1], mstate_uploads=out[2], pairings_uploads=out[3])
+
+
+def cache(max_layers=0):
+    """the layer cache of this thread's runtime: dict(layers, bytes, evictions, full_checks, reseen_checks)"""
+    out = (C.c_size_t * 5)()
+    _check(load().mp2p_hostpath_cache(int(max_layers), out))
+    return dict(zip(("layers", "bytes", "evictions", "full_checks", "reseen_checks"), [int(v) for v in out]))
 
 
 def stage_ms():

@@ -11,3 +11,4 @@ class Parameterizable
 }  // namespace mp2p_icp
 #define DECLARE_PARAMETER_REQ(Yaml__, Var__) Var__ = (Yaml__)[#Var__].as<decltype(Var__)>()
 #define DECLARE_PARAMETER_OPT(Yaml__, Var__) Var__ = (Yaml__).getOrDefault<decltype(Var__)>(#Var__, Var__)
+#define DECLARE_PARAMETER_IN_REQ(Yaml__, Var__, Parent__) Var__ = (Yaml__)[#Var__].as<decltype(Var__)>()

@@ -10,6 +10,10 @@ class yaml
     yaml operator[](const std::string& key) const;
     template <class T> T as() const;
     template <class T> T getOrDefault(const std::string& key, const T& def) const;
+    bool isSequence() const;
+    bool isScalar() const;
+    size_t size() const;
+    yaml operator()(int index) const;
 };
 }  // namespace mrpt::containers
 #define MCP_LOAD_REQ(Yaml__, Var__) Var__ = (Yaml__)[#Var__].as<decltype(Var__)>()

@@ -5,6 +5,7 @@
 #define THROW_EXCEPTION(msg) throw std::runtime_error(std::string(msg))
 #define THROW_EXCEPTION_FMT(fmt, ...) throw std::runtime_error(std::string(fmt))
 #define ASSERT_(c) do { if (!(c)) throw std::runtime_error("assert: " #c); } while (0)
+#define ASSERTMSG_(c, msg) do { if (!(c)) throw std::runtime_error(std::string(msg)); } while (0)
 #define ASSERT_GT_(a, b) ASSERT_((a) > (b))
 #define ASSERT_GE_(a, b) ASSERT_((a) >= (b))
 #define ASSERT_LE_(a, b) ASSERT_((a) <= (b))

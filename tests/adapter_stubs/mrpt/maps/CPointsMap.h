@@ -14,5 +14,10 @@ class CPointsMap : public CMetricMap
     const mrpt::aligned_std_vector<float>& getPointsBufferRef_x() const;
     const mrpt::aligned_std_vector<float>& getPointsBufferRef_y() const;
     const mrpt::aligned_std_vector<float>& getPointsBufferRef_z() const;
+    // FilterDecimateVoxels.cpp:145-189, 236-244
+    void reserve(size_t n);
+    void insertPointFast(float x, float y, float z);
+    void insertPointFrom(const CPointsMap& source, size_t sourceIndex);
+    void mark_as_modified() const;
 };
 }  // namespace mrpt::maps

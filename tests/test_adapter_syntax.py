@@ -49,7 +49,10 @@ def test_the_check_is_live():
     with tempfile.TemporaryDirectory() as d:
         for old, new in (("out.paired_pt2pt)", "out.paired_pt2pt_typo)"),
                          ("&BitField::dense_>", "&BitField::dense>"),
-                         ("sc.prior->cov_inv(i, j)", "sc.prior->cov_inverse(i, j)")):
+                         ("sc.prior->cov_inv(i, j)", "sc.prior->cov_inverse(i, j)"),
+                         ("outPc->insertPointFrom(*todo[li], i)", "outPc->insertPointFromLayer(*todo[li], i)"),
+                         ("mrpt::math::confidenceIntervalsFromHistogram(xs,", "mrpt::math::confidenceIntervalFromHistogram(xs,"),
+                         ("class FilterDecimateVoxels : public mp2p_icp_filters::FilterBase", "class FilterDecimateVoxels : public mp2p_icp_filters::FilterBaze")):
             assert old in src
             p = os.path.join(d, "bad.cpp")
             open(p, "w").write(src.replace(old, new, 1))

@@ -305,3 +305,111 @@ def test_host_path_cost_at_full_size(oracle):
     print(f"\n[host path] device-resident step {t_dev * 1e3:.3f} ms, host-container step {t_host * 1e3:.3f} ms")
     assert t_host < 4.0 * t_dev + 3e-4, (t_host, t_dev)   # loose regression bound (timing on a shared box); bench.py host_boundary reports the ratio (1.8)
     s.close()
+
+
+# ---- the SURVEY 8(f) classes through the adapter's host layer --------------------------------
+def test_inlier_ratio_through_host_containers(oracle):
+    from mp2p_icp_amd import _lib, hostpath, synthetic
+    d = synthetic.random_cloud_pair(5000, 20000, 61, outlier_frac=0.2)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(*_xyz(g))
+    s = hostpath.Session(g, l)
+    for allow_global in (0, 1):
+        prm = _lib.InlierRatioParams()
+        prm.inliersRatio, prm.allowMatchAlreadyMatchedGlobalPoints = 0.5, allow_global
+        prm.bounding_box_intersection_check_epsilon = 0.20
+        for it, pose in enumerate((d["T_init"], d["T_gt"])):
+            s.begin_iteration()
+            n = s.match_inlier_ratio(pose, prm, icp_iteration=it)
+            want, pot = oracle.match_inlier_ratio(*_xyz(g), *_xyz(l), pose, 0.5, allowMatchAlreadyMatchedGlobalPoints=bool(allow_global), tree=tree)
+            got = s.pairs_pt2pt()
+            assert n == len(want)
+            _same_pt2pt(got, want)
+            assert s.potential_pairings() == pot
+            # marks: every emitted pair, whatever the re-use flag (Matcher_Points_InlierRatio.cpp:127-131)
+            assert set(np.flatnonzero(s.bits(1)).tolist()) == set(want["localIdx"].tolist())
+            assert set(np.flatnonzero(s.bits(0)).tolist()) == set(want["globalIdx"].tolist())
+    s.close()
+
+
+def test_adaptive_through_host_containers(oracle):
+    from mp2p_icp_amd import _lib, hostpath
+    from test_gpu_matcher_adaptive import _scene
+    g, l = _scene(72)
+    kw = dict(confidenceInterval=0.8, firstToSecondDistanceMax=2.0, absoluteMaxSearchDistance=1.5, minimumCorrDist=0.1,
+              enableDetectPlanes=True, maxPt2PtCorrespondences=2, planeSearchPoints=8, planeMinimumFoundPoints=4)
+    tree = oracle.KDTree(*_xyz(g))
+    prm = _lib.AdaptiveParams()
+    for k, v in kw.items():
+        setattr(prm, k, v)
+    prm.planeMinimumDistance, prm.planeEigenThreshold, prm.bounding_box_intersection_check_epsilon = 0.10, 0.01, 0.20
+    s = hostpath.Session(g, l)
+    for it, pose in enumerate((oracle.pose_from_xyzypr(0.03, -0.02, 0.01, 0.004, 0.0, -0.002), oracle.pose_identity())):
+        r = oracle.match_adaptive(*_xyz(g), *_xyz(l), pose, tree=tree, **kw)
+        s.begin_iteration()
+        n_pt, n_pl, ci = s.match_adaptive(pose, prm, icp_iteration=it)
+        assert ci == r["ci_high"]
+        assert n_pt == len(r["pt2pt"]) and n_pl == len(r["pt2pl"]) and n_pl > 1000
+        _same_pt2pt(s.pairs_pt2pt(), r["pt2pt"])
+        got = s.pairs_pt2pl()
+        assert np.allclose(got["plane"], r["pt2pl"]["plane"], rtol=0, atol=1e-9)
+        assert np.array_equal(got["pt_local"], np.stack([r["pt2pl"]["lx"], r["pt2pl"]["ly"], r["pt2pl"]["lz"]], 1))
+        assert s.potential_pairings() == r["potential"]
+        # local marks for both kinds, global marks never (Matcher_Adaptive.cpp:260, 289-293)
+        assert set(np.flatnonzero(s.bits(1)).tolist()) == set(r["pl_local_idx"].tolist()) | set(r["pt2pt"]["localIdx"].tolist())
+        assert not s.bits(0).any()
+        # ... and the solver recognises the device-resident lists of BOTH kinds
+        c0 = hostpath.counters()["pairings_uploads"]
+        s.solve_gn(pose, _gn_prm())
+        assert hostpath.counters()["pairings_uploads"] == c0
+    s.close()
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_filter_decimate_through_host_containers(oracle, method):
+    from mp2p_icp_amd import _lib, hostpath
+    rng = np.random.default_rng(40 + method)
+    pts = rng.normal(0, 3.0, (200_000, 3)).astype(np.float32)
+    want, wsrc = oracle.filter_decimate_voxels(pts[:, 0], pts[:, 1], pts[:, 2], 0.25, method)
+    s = hostpath.Session(pts[:10], pts)
+    prm = _lib.DecimateParams()
+    prm.voxel_filter_resolution, prm.decimate_method = 0.25, method
+    got, src = s.filter_decimate_local(prm)
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(src, wsrc)
+    s.close()
+
+
+def test_layer_cache_is_bounded_and_reseen_layers_are_cheap(oracle):
+    """ADVICE r2 (unbounded cache) and VERDICT r2 #8: fresh layers per scan must not pile up in HBM; a layer seen
+    again at ICP iteration 0 is verified on a stride, not hashed in full"""
+    from mp2p_icp_amd import hostpath, synthetic
+    d = synthetic.random_cloud_pair(20_000, 60_000, 5)
+    g = d["glob"]
+    prm = _pt2pt_prm(0.8)
+    base = hostpath.cache(max_layers=3)
+    sessions = []
+    for k in range(6):  # six "scans": six different local layers (different buffers), one map
+        l = (d["local"] + np.float32(0.001 * k)).astype(np.float32)
+        s = hostpath.Session(g, l)
+        s.begin_iteration()
+        s.match_pt2pt(d["T_init"], prm, icp_iteration=0)
+        sessions.append(s)  # keep the buffers alive: distinct addresses
+    c = hostpath.cache()
+    assert c["evictions"] - base["evictions"] >= 2 and c["layers"] <= 3 + 3 + 1
+    # the first session's cloud was evicted: matching it again uploads it again, results unchanged
+    up0 = hostpath.counters()["cloud_uploads"]
+    sessions[0].begin_iteration()
+    n0 = sessions[0].match_pt2pt(d["T_init"], prm, icp_iteration=0)
+    assert hostpath.counters()["cloud_uploads"] == up0 + 1 and n0 > 0
+    # a re-seen layer at iteration 0: strided check, no full hash
+    f0 = hostpath.cache()
+    sessions[0].begin_iteration()
+    sessions[0].match_pt2pt(d["T_init"], prm, icp_iteration=0)
+    f1 = hostpath.cache()
+    assert f1["full_checks"] == f0["full_checks"] and f1["reseen_checks"] >= f0["reseen_checks"] + 2
+    # explicit release
+    sessions[0].release_layers()
+    assert hostpath.cache()["layers"] < f1["layers"]
+    for s in sessions:
+        s.close()

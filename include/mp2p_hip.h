@@ -57,6 +57,10 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx);
 const char* mp2p_hip_last_error(const mp2p_hip_ctx* ctx); /* ctx may be NULL (global text) */
 int  mp2p_hip_sync(mp2p_hip_ctx* ctx);
 void* mp2p_hip_ctx_stream(mp2p_hip_ctx* ctx);
+/* Number of device allocations (hipMalloc) the library has made since it was loaded, over all contexts.  The
+ * per-call temporaries of the solvers, matchers and filters live in scratch owned by the context, so the count stays
+ * put across steady-state calls of the same sizes (tests/test_gpu_scratch.py asserts it). */
+unsigned long long mp2p_hip_debug_alloc_count(void);
 
 /* ---- global map layer: replaces mrpt::maps::NearestNeighborsCapable of the global layer
  *      (nn_prepare_for_3d_queries, Matcher_Points_DistanceThreshold.cpp:92; MRPT's

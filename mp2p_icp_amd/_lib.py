@@ -177,6 +177,7 @@ SIGNATURES = {
     "mp2p_hip_last_error": (C.c_char_p, [_P]),
     "mp2p_hip_sync": (C.c_int, [_P]),
     "mp2p_hip_ctx_stream": (_P, [_P]),
+    "mp2p_hip_debug_alloc_count": (C.c_ulonglong, []),
     "mp2p_hip_map_upload": (C.c_int, [_P, _fp, _fp, _fp, C.c_size_t, C.POINTER(MapParams), _PP]),
     "mp2p_hip_map_upload_device": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(MapParams), _PP]),
     "mp2p_hip_map_free": (None, [_P, _P]),

@@ -58,6 +58,7 @@ static void parse_tune(Tune& t)
             else if (k == "tile_time_cap_us") t.tile_time_cap_us = (uint32_t)v;
             else if (k == "hard_radius_pct") t.hard_radius_pct = (uint32_t)v;
             else if (k == "sync_spin") t.sync_spin = (int)v;
+            else if (k == "spin_us") t.spin_us = (int)v;
             else if (k == "single_waves") t.single_waves = (uint32_t)v;
             else if (k == "xcd_map") t.xcd_map = (int)v;
             else if (k == "single_blocks_per_cu") t.single_blocks_per_cu = (uint32_t)v;
@@ -102,6 +103,7 @@ using namespace mp2p;
 extern "C" {
 
 int mp2p_hip_abi_version(void) { return MP2P_HIP_ABI_VERSION; }
+unsigned long long mp2p_hip_debug_alloc_count(void) { return mp2p::dev_alloc_counter(); }
 
 int mp2p_hip_device_count(void)
 {
@@ -177,6 +179,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->work.release(), ctx->work_q.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();
     ctx->pend.release(), ctx->pend_q.release(), ctx->q_counters.release(), ctx->nn_rec.release();
     ctx->pred_buf[0].release(), ctx->pred_buf[1].release(), ctx->pl_kth.release();
+    for (auto& b : ctx->scratch) b.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     (void)mp2p_hip_pairs_copy_end(ctx);
@@ -408,13 +411,13 @@ int mp2p_hip_mstate_upload_bits(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms, const ui
     const size_t wg = (ng + 63) / 64, wl = (nl + 63) / 64;
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure((wg + wl) * 8 + 16));
     auto* dw = reinterpret_cast<unsigned long long*>(ctx->aos_stage.p);
-    if (global_words)
+    if (global_words && ng)
     {
         MP2P_TRY_HIP(ctx, hipMemcpyAsync(dw, global_words, wg * 8, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(bits_to_bytes_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, ctx->stream, dw, ng,
                            ms->global_taken.p);
     }
-    if (local_words)
+    if (local_words && nl)
     {
         MP2P_TRY_HIP(ctx, hipMemcpyAsync(dw + wg, local_words, wl * 8, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(bits_to_bytes_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, dw + wg,
@@ -957,11 +960,11 @@ int mp2p_hip_filter_decimate_voxels(mp2p_hip_ctx* ctx, const float* x, const flo
     *n_out = 0;
     if (n == 0) return MP2P_HIP_OK;
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
-    mp2p::DevBuf<float>    in, out;
-    mp2p::DevBuf<uint32_t> src;
-    MP2P_TRY_HIP(ctx, in.alloc(3 * n));
-    MP2P_TRY_HIP(ctx, out.alloc(3 * n));
-    MP2P_TRY_HIP(ctx, src.alloc(n));
+    mp2p::Scratch<float>    in, out;
+    mp2p::Scratch<uint32_t> src;
+    MP2P_TRY_HIP(ctx, in.take(ctx, 12, 3 * n));
+    MP2P_TRY_HIP(ctx, out.take(ctx, 13, 3 * n));
+    MP2P_TRY_HIP(ctx, src.take(ctx, 14, n));
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(in.p, x, n * 4, hipMemcpyHostToDevice, ctx->stream));
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(in.p + n, y, n * 4, hipMemcpyHostToDevice, ctx->stream));
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(in.p + 2 * n, z, n * 4, hipMemcpyHostToDevice, ctx->stream));

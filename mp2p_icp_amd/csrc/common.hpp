@@ -3,11 +3,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mp2p_hip.h"
@@ -58,6 +60,14 @@ constexpr unsigned long long DIR_NONE = ~0ull;
 // ---------------------------------------------------------------------------------------
 // host-side objects behind the opaque C handles
 // ---------------------------------------------------------------------------------------
+// device allocations made through DevBuf since the library was loaded (mp2p_hip_debug_alloc_count: tests assert that a
+// steady-state iteration of a solver / matcher makes none)
+inline unsigned long long& dev_alloc_counter()
+{
+    static unsigned long long c = 0;
+    return c;
+}
+
 template <class T>
 struct DevBuf
 {
@@ -67,6 +77,7 @@ struct DevBuf
     {
         release();
         if (count == 0) return hipSuccess;
+        dev_alloc_counter()++;
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         if (e == hipSuccess) n = count;
         else p = nullptr;
@@ -119,6 +130,7 @@ struct Tune
     uint32_t single_blocks_per_cu = 0;  // ... and its grid, in workgroups per CU (0 = 40: two resident rounds at 5 waves)
     uint32_t pl_q          = 0;     // point-to-plane search: queries per wave (0 = by layer size: 8 up to 400 k points, else 32)
     int      sync_spin     = 1;     // wait for the stream by polling hipStreamQuery (lower wake-up latency)
+    int      spin_us       = 2000;  // ... tight for this long, then yielding, then (8x) the blocking wait
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
     int      claim_peek    = 1;     // plain look at the claim word before the atomic
     int      compact_fused = 1;     // compaction: bounding-box reduction folded in
@@ -223,6 +235,10 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<uint4>              work, pend;   // deferred / pending queries of the NN search
     mp2p::DevBuf<uint4>              work_q, pend_q;  // {qx, qy, qz, best_spos} of the list entries
     mp2p::DevBuf<uint32_t>           q_counters;   //   {#pending, #deferred}
+    // reusable scratch of the per-call temporaries of the solvers / matchers / filters that used to hipMalloc and
+    // hipFree 6..15 buffers per call: grown on demand, never shrunk; a slot belongs to one temporary
+    // of the function that runs (mp2p::Scratch)
+    mp2p::DevBuf<unsigned char>      scratch[16];
     mp2p::Tune                       tune;         // MP2P_HIP_TUNE (experiments; defaults otherwise)
     double                           hint_pose[12] = {};
     const void*                      hint_map   = nullptr;
@@ -302,15 +318,37 @@ struct mp2p_hip_pairs
 
 namespace mp2p
 {
+// a typed, non-owning view of one scratch slot of the context
+template <class T>
+struct Scratch
+{
+    T* p = nullptr;
+    hipError_t take(mp2p_hip_ctx* ctx, int slot, size_t count)
+    {
+        const hipError_t e = ctx->scratch[slot].ensure((count ? count : 1) * sizeof(T));
+        p                  = reinterpret_cast<T*>(ctx->scratch[slot].p);
+        return e;
+    }
+};
+// hipCUB / rocPRIM entry points take the item count as int
+#define MP2P_REQUIRE_INT_COUNT(ctx, n) MP2P_REQUIRE(ctx, (unsigned long long)(n) <= 2147483647ull, "more items than a hipCUB call takes (2^31 - 1)")
 int  set_err(mp2p_hip_ctx* ctx, int code, const char* fmt, ...);
 // hipStreamSynchronize, or (tune.sync_spin) a poll of hipStreamQuery: no wake-up latency
 inline hipError_t stream_wait(mp2p_hip_ctx* ctx)
 {
     if (!ctx->tune.sync_spin) return hipStreamSynchronize(ctx->stream);
-    for (;;)
+    // bounded: a tight poll for spin_us (one ICP step is 0.3..0.8 ms), then polls that yield the core, then the
+    // blocking wait -- a long kernel chain or a collective that waits on a slow peer must not burn a host core
+    const auto t0 = std::chrono::steady_clock::now();
+    const long spin_us = ctx->tune.spin_us;
+    for (unsigned it = 0;; ++it)
     {
         const hipError_t e = hipStreamQuery(ctx->stream);
         if (e != hipErrorNotReady) return e;
+        if ((it & 31u) != 31u) continue;
+        const long us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (us > 8 * spin_us) return hipStreamSynchronize(ctx->stream);
+        if (us > spin_us) std::this_thread::yield();
     }
 }
 void set_global_err(const char* fmt, ...);

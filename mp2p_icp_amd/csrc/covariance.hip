@@ -214,9 +214,9 @@ int covariance_run(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const double pose
         cv_pose_from_xyzypr(x, cp.T[2 * j + 1]);
         cp.s[j] = 0.5 / h;
     }
-    DevBuf<double> partials, h21;
-    MP2P_TRY_HIP(ctx, partials.alloc((size_t)CV_BLOCKS * CV_N));
-    MP2P_TRY_HIP(ctx, h21.alloc(CV_N));
+    Scratch<double> partials, h21;
+    MP2P_TRY_HIP(ctx, partials.take(ctx, 0, (size_t)CV_BLOCKS * CV_N));
+    MP2P_TRY_HIP(ctx, h21.take(ctx, 1, CV_N));
     hipLaunchKernelGGL(cov_accum_kernel, dim3(CV_BLOCKS), dim3(CV_THREADS), 0, ctx->stream,
                        P->cap_pt2pt > 0 ? P->lx.p : nullptr, P->ly.p, P->lz.p, P->gx.p, P->gy.p, P->gz.p,
                        P->cap_pt2pl > 0 ? P->pl_coef.p : nullptr, P->pl_lx.p, P->pl_ly.p, P->pl_lz.p, P->ln.p,

@@ -197,34 +197,35 @@ int filter_decimate_device(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y
     *n_out = 0;
     if (n == 0) return MP2P_HIP_OK;
     MP2P_REQUIRE(ctx, n < 0xFFFFFFF0ull, "layer too large for 32-bit indices");
-    DevBuf<unsigned long long> k0, k1;
-    DevBuf<uint32_t>           i0, i1, bad, vsrc, blocks;
-    DevBuf<unsigned char>      flag, tmp;
-    DevBuf<float>              vx, vy, vz;
-    MP2P_TRY_HIP(ctx, k0.alloc(n));
-    MP2P_TRY_HIP(ctx, k1.alloc(n));
-    MP2P_TRY_HIP(ctx, i0.alloc(n));
-    MP2P_TRY_HIP(ctx, i1.alloc(n));
-    MP2P_TRY_HIP(ctx, bad.alloc(1));
+    MP2P_REQUIRE_INT_COUNT(ctx, n);
+    Scratch<unsigned long long> k0, k1;
+    Scratch<uint32_t>           i0, i1, bad, vsrc, blocks;
+    Scratch<unsigned char>      flag, tmp;
+    Scratch<float>              vx, vy, vz;
+    MP2P_TRY_HIP(ctx, k0.take(ctx, 0, n));
+    MP2P_TRY_HIP(ctx, k1.take(ctx, 1, n));
+    MP2P_TRY_HIP(ctx, i0.take(ctx, 2, n));
+    MP2P_TRY_HIP(ctx, i1.take(ctx, 3, n));
+    MP2P_TRY_HIP(ctx, bad.take(ctx, 4, 1));
     MP2P_TRY_HIP(ctx, hipMemsetAsync(bad.p, 0, sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(dv_keys_kernel, dim3(dv_nblk(n, 256)), dim3(256), 0, ctx->stream, d_x, d_y, d_z,
                        (uint32_t)n, prm->voxel_filter_resolution, k0.p, i0.p, bad.p);
     size_t tmp_bytes = 0;
     MP2P_TRY_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0.p, k1.p, i0.p, i1.p, (int)n, 0,
                                                          63, ctx->stream));
-    MP2P_TRY_HIP(ctx, tmp.alloc(tmp_bytes ? tmp_bytes : 1));
+    MP2P_TRY_HIP(ctx, tmp.take(ctx, 5, tmp_bytes));
     MP2P_TRY_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k0.p, k1.p, i0.p, i1.p, (int)n, 0, 63,
                                                          ctx->stream));
-    MP2P_TRY_HIP(ctx, flag.alloc(n));
-    MP2P_TRY_HIP(ctx, vx.alloc(n));
-    MP2P_TRY_HIP(ctx, vy.alloc(n));
-    MP2P_TRY_HIP(ctx, vz.alloc(n));
-    MP2P_TRY_HIP(ctx, vsrc.alloc(n));
+    MP2P_TRY_HIP(ctx, flag.take(ctx, 6, n));
+    MP2P_TRY_HIP(ctx, vx.take(ctx, 7, n));
+    MP2P_TRY_HIP(ctx, vy.take(ctx, 8, n));
+    MP2P_TRY_HIP(ctx, vz.take(ctx, 9, n));
+    MP2P_TRY_HIP(ctx, vsrc.take(ctx, 10, n));
     hipLaunchKernelGGL(dv_voxels_kernel, dim3(dv_nblk(n, 256)), dim3(256), 0, ctx->stream, k1.p, i1.p,
                        (uint32_t)n, d_x, d_y, d_z, (int)prm->decimate_method, (int)prm->has_flatten_to, flag.p,
                        vx.p, vy.p, vz.p, vsrc.p);
     const uint32_t n_blocks = dv_nblk(n, DV_TILE);
-    MP2P_TRY_HIP(ctx, blocks.alloc(n_blocks + 1));
+    MP2P_TRY_HIP(ctx, blocks.take(ctx, 11, n_blocks + 1));
     hipLaunchKernelGGL(dv_count_kernel, dim3(n_blocks), dim3(DV_THREADS), 0, ctx->stream, flag.p, (uint32_t)n,
                        blocks.p);
     hipLaunchKernelGGL(dv_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, blocks.p, n_blocks);

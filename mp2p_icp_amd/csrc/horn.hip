@@ -435,16 +435,17 @@ __global__ __launch_bounds__(256) void cv_write_kernel(const uint32_t* __restric
     o_err[dst] = 0.f;
 }
 
-static int cv_append(mp2p_hip_ctx* ctx, size_t n, DevBuf<unsigned long long>& k0, DevBuf<unsigned long long>& k1,
-                     DevBuf<uint32_t>& v0, DevBuf<uint32_t>& v1, DevBuf<CvPair>& pairs,
-                     DevBuf<unsigned long long>& take, mp2p_hip_pairs* out)
+static int cv_append(mp2p_hip_ctx* ctx, size_t n, Scratch<unsigned long long>& k0, Scratch<unsigned long long>& k1,
+                     Scratch<uint32_t>& v0, Scratch<uint32_t>& v1, Scratch<CvPair>& pairs,
+                     Scratch<unsigned long long>& take, mp2p_hip_pairs* out)
 {
     if (!n) return MP2P_HIP_OK;  // :33
     size_t                tmp_bytes = 0;
-    DevBuf<unsigned char> tmp;
+    MP2P_REQUIRE_INT_COUNT(ctx, n);
+    Scratch<unsigned char> tmp;
     MP2P_TRY_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0.p, k1.p, v0.p, v1.p, (int)n, 0, 64,
                                                          ctx->stream));
-    MP2P_TRY_HIP(ctx, tmp.alloc(tmp_bytes ? tmp_bytes : 1));
+    MP2P_TRY_HIP(ctx, tmp.take(ctx, 6, tmp_bytes));
     MP2P_TRY_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k0.p, k1.p, v0.p, v1.p, (int)n, 0, 64,
                                                          ctx->stream));
     hipLaunchKernelGGL(cv_take_kernel, dim3(1), dim3(1), 0, ctx->stream, k1.p, (unsigned long long)n, out->counts.p,
@@ -466,15 +467,15 @@ int pt2ln_pl_to_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* in, const double 
     const size_t n_pl = h_counts[1], n_ln = h_counts[5];
     MP2P_REQUIRE(ctx, out->cap_pt2pt >= n_pl + n_ln, "output Pairings too small for the converted pairs");
     const size_t m = std::max<size_t>(std::max(n_pl, n_ln), 1);
-    DevBuf<unsigned long long> k0, k1, take;
-    DevBuf<uint32_t>           v0, v1;
-    DevBuf<CvPair>             pairs;
-    MP2P_TRY_HIP(ctx, k0.alloc(m));
-    MP2P_TRY_HIP(ctx, k1.alloc(m));
-    MP2P_TRY_HIP(ctx, v0.alloc(m));
-    MP2P_TRY_HIP(ctx, v1.alloc(m));
-    MP2P_TRY_HIP(ctx, pairs.alloc(m));
-    MP2P_TRY_HIP(ctx, take.alloc(2));
+    Scratch<unsigned long long> k0, k1, take;
+    Scratch<uint32_t>           v0, v1;
+    Scratch<CvPair>             pairs;
+    MP2P_TRY_HIP(ctx, k0.take(ctx, 0, m));
+    MP2P_TRY_HIP(ctx, k1.take(ctx, 1, m));
+    MP2P_TRY_HIP(ctx, v0.take(ctx, 2, m));
+    MP2P_TRY_HIP(ctx, v1.take(ctx, 3, m));
+    MP2P_TRY_HIP(ctx, pairs.take(ctx, 4, m));
+    MP2P_TRY_HIP(ctx, take.take(ctx, 5, 2));
     PoseRt T;
     for (int i = 0; i < 9; i++) T.r[i] = pose[i];
     for (int i = 0; i < 3; i++) T.t[i] = pose[9 + i];

@@ -227,6 +227,7 @@ static int morton_sort(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, co
                        size_t n, float ox, float oy, float oz, float inv_hf,
                        DevBuf<unsigned long long>* keys_out, float4* d_pts_out)
 {
+    MP2P_REQUIRE_INT_COUNT(ctx, n);
     DevBuf<unsigned long long> k0, k1;
     DevBuf<uint32_t>           i0, i1;
     MP2P_TRY_HIP(ctx, k0.alloc(n));
@@ -362,6 +363,13 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
         // iteration; each coarser level is 1/8 of the one below)
         const uint32_t     variant  = prm ? prm->no_occupancy_bitmap : 0u;
         unsigned long long dir_left = (variant & 3u) ? 0ull : (unsigned long long)ctx->tune.dir_budget_mb * (1ull << 20) / sizeof(uint2);
+        {
+            // never more than a quarter of what is free now: the directory is an accelerator, the hash table serves
+            // every level it does not cover (a host that keeps many maps resident must not run the device dry on it)
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) dir_left = std::min<unsigned long long>(dir_left, free_b / 4 / sizeof(uint2));
+            else (void)hipGetLastError();
+        }
         unsigned long long dir_total = 0;
         for (int l = 0; l < 16; l++)
         {
@@ -373,8 +381,19 @@ int build_map(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const float
         }
         if (dir_total)
         {
-            MP2P_TRY_HIP(ctx, map->dir.alloc(dir_total));
-            MP2P_TRY_HIP(ctx, hipMemsetAsync(map->dir.p, 0, dir_total * sizeof(uint2), ctx->stream));
+            const hipError_t ea = map->dir.alloc(dir_total);
+            if (ea == hipErrorOutOfMemory)
+            {
+                // degrade instead of failing the upload: no directory, every lookup probes the hash table
+                (void)hipGetLastError();
+                for (int l = 0; l < 16; l++) g.dir_off[l] = DIR_NONE;
+                dir_total = 0;
+            }
+            else
+            {
+                MP2P_TRY_HIP(ctx, ea);
+                MP2P_TRY_HIP(ctx, hipMemsetAsync(map->dir.p, 0, dir_total * sizeof(uint2), ctx->stream));
+            }
         }
         ob.dir = map->dir.p;
         for (int l = 0; l < 16; l++) ob.dir_off[l] = g.dir_off[l];

@@ -83,14 +83,15 @@ int launch_match_inlier_ratio(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const 
 
     // 2. sort the found points by (d2, later insertion first)
     const size_t n_visit = cloud->n_visit ? cloud->n_visit : cloud->n;
-    DevBuf<unsigned long long> k0, k1;
-    DevBuf<uint32_t>           v0, v1, cnt;
-    DevBuf<unsigned char>      tmp;
-    MP2P_TRY_HIP(ctx, k0.alloc(n_visit));
-    MP2P_TRY_HIP(ctx, k1.alloc(n_visit));
-    MP2P_TRY_HIP(ctx, v0.alloc(n_visit));
-    MP2P_TRY_HIP(ctx, v1.alloc(n_visit));
-    MP2P_TRY_HIP(ctx, cnt.alloc(2));
+    MP2P_REQUIRE_INT_COUNT(ctx, n_visit);
+    Scratch<unsigned long long> k0, k1;
+    Scratch<uint32_t>           v0, v1, cnt;
+    Scratch<unsigned char>      tmp;
+    MP2P_TRY_HIP(ctx, k0.take(ctx, 0, n_visit));
+    MP2P_TRY_HIP(ctx, k1.take(ctx, 1, n_visit));
+    MP2P_TRY_HIP(ctx, v0.take(ctx, 2, n_visit));
+    MP2P_TRY_HIP(ctx, v1.take(ctx, 3, n_visit));
+    MP2P_TRY_HIP(ctx, cnt.take(ctx, 4, 2));
     MP2P_TRY_HIP(ctx, hipMemsetAsync(cnt.p, 0, 2 * sizeof(uint32_t), ctx->stream));
     const uint32_t nb = (uint32_t)((n_visit + 255) / 256);
     hipLaunchKernelGGL(ir_keys_kernel, dim3(nb), dim3(256), 0, ctx->stream, ctx->nn_spos.p, ctx->nn_d2.p,
@@ -99,7 +100,7 @@ int launch_match_inlier_ratio(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const 
     size_t tmp_bytes = 0;
     MP2P_TRY_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0.p, k1.p, v0.p, v1.p, (int)n_visit,
                                                          0, 64, ctx->stream));
-    MP2P_TRY_HIP(ctx, tmp.alloc(tmp_bytes ? tmp_bytes : 1));
+    MP2P_TRY_HIP(ctx, tmp.take(ctx, 5, tmp_bytes));
     MP2P_TRY_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k0.p, k1.p, v0.p, v1.p, (int)n_visit, 0,
                                                          64, ctx->stream));
     hipLaunchKernelGGL(ir_keep_kernel, dim3(1), dim3(1), 0, ctx->stream, cnt.p, prm->inliersRatio, cnt.p + 1);

@@ -794,7 +794,9 @@ int mp2p_hip_pairs_copy_pt2pt_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, 
                                     mp2p_hip_pair_pt2pt* out, uint32_t* idx_local, uint32_t* idx_global)
 {
     if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
-    MP2P_REQUIRE(ctx, !ctx->copy_open, "copy_pt2pt_begin: the previous copy was not ended");
+    // a copy the caller never ended (an exception between begin and end on its side): finish it here -- the stream is
+    // drained and the stale host range unpinned -- rather than refusing every later copy
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);
     MP2P_REQUIRE(ctx, n > 0 && out && idx_local && idx_global && first + n <= p->cap_pt2pt,
                  "copy_pt2pt_begin: empty range, null destination or range outside the list");
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
@@ -826,7 +828,8 @@ int mp2p_hip_pairs_copy_wait_idx(mp2p_hip_ctx* ctx)
     if (!ctx) return MP2P_HIP_ERR_INVALID;
     MP2P_REQUIRE(ctx, ctx->copy_open, "copy_wait_idx without copy_pt2pt_begin");
     hipError_t e;
-    while ((e = hipEventQuery(ctx->copy_ev)) == hipErrorNotReady) {}
+    for (unsigned it = 1; (e = hipEventQuery(ctx->copy_ev)) == hipErrorNotReady; ++it)
+        if ((it & 4095u) == 0) std::this_thread::yield();
     MP2P_TRY_HIP(ctx, e);
     return MP2P_HIP_OK;
 }

@@ -218,8 +218,9 @@ def optimal_tf_horn(pairings, wp, result):
     return ok
 
 
-def pt2ln_pl_to_pt2pt(pairings, sc):
-    """pt2ln_pl_to_pt2pt.cpp:47-113 -> a new Pairings holding only the converted point pairings"""
+def pt2ln_pl_to_pt2pt(pairings, sc, reuse=None):
+    """pt2ln_pl_to_pt2pt.cpp:47-113 -> a Pairings holding only the converted point pairings (`reuse`: the
+    container of an earlier conversion on the same context, so that an ICP loop allocates it once)"""
     from .matcher import Pairings
     if sc.guessRelativePose is None:
         raise RuntimeError("ASSERT_(sc.guessRelativePose.has_value())")
@@ -232,8 +233,10 @@ def pt2ln_pl_to_pt2pt(pairings, sc):
         dev.upload_lines_planes(pairings.paired_pt2ln, pairings.paired_pl2pl)
         dev._has_lines_planes = bool(n_ln or len(pairings.paired_pl2pl))
     n_pl = dev.counts()[1]
-    out = Pairings(ctx, max(1, n_pl + n_ln), 0)
+    out = reuse if (reuse is not None and reuse.ctx is ctx and reuse is not pairings) else Pairings(ctx, max(1, n_pl + n_ln), 0)
     odev = out._ensure_dev(ctx, max(1, n_pl + n_ln), 0)
+    if out is reuse:
+        odev.clear()  # the conversion appends to an empty list (pt2ln_pl_to_pt2pt.cpp:49)
     core.pairs_pt2ln_pl_to_pt2pt(ctx, dev, sc.guessRelativePose, odev)
     out._ub = [n_pl + n_ln, 0]
     return out
@@ -264,7 +267,7 @@ class Solver_Horn(Solver):
         eff = pairings
         n_pl = pairings.device.counts()[1] if pairings.device is not None else 0
         if n_pl or len(pairings.paired_pt2ln):  # :51-55
-            eff = pt2ln_pl_to_pt2pt(pairings, sc)
+            eff = self._converted = pt2ln_pl_to_pt2pt(pairings, sc, reuse=getattr(self, "_converted", None))
         return optimal_tf_horn(eff, self.pairingsWeightParameters, out)
 
 

@@ -227,8 +227,10 @@ def _poke(Q, i):
 
 
 def test_layer_change_detection(oracle):
-    """a layer edited in place: found by the full fingerprint at ICP iteration 0 (and after
-    invalidate_layers()); later iterations of one align only pay the sampled check"""
+    """a layer edited in place between two aligns: found at ICP iteration 0 -- a layer first seen at its address is
+    hashed in full, one verified before is re-verified on every 61st point, so an edit of >= 61 consecutive points (any
+    bulk edit: motion compensation, a filter pass) is always seen; MP2P_HIP_HOST_STRICT=1 / release_layers() force the
+    full hash.  Later iterations of one align only pay the 1024-point sample."""
     from mp2p_icp_amd import hostpath, synthetic
     d = synthetic.random_cloud_pair(5000, 20000, 3)
     g, l = d["glob"], d["local"].copy()
@@ -241,9 +243,8 @@ def test_layer_change_detection(oracle):
     s.match_pt2pt(d["T_init"], prm, icp_iteration=0)  # unchanged: nothing re-uploaded
     assert hostpath.counters() == c0
     before = s.pairs_pt2pt()
-    # an interior point that the 1024-point sample does not see, moved far away
-    k = 1237
-    s._l[0][k] += 50.0
+    # an interior run that the 1024-point sample does not see, moved far away
+    s._l[0][1237:1237 + 61] += 50.0
     lm = np.stack(s._l, 1)
     tree = oracle.KDTree(*_xyz(g))
     s.begin_iteration()
@@ -325,7 +326,7 @@ def test_inlier_ratio_through_host_containers(oracle):
             got = s.pairs_pt2pt()
             assert n == len(want)
             _same_pt2pt(got, want)
-            assert s.potential_pairings() == pot
+            assert s.potential_pairings == pot
             # marks: every emitted pair, whatever the re-use flag (Matcher_Points_InlierRatio.cpp:127-131)
             assert set(np.flatnonzero(s.bits(1)).tolist()) == set(want["localIdx"].tolist())
             assert set(np.flatnonzero(s.bits(0)).tolist()) == set(want["globalIdx"].tolist())
@@ -354,7 +355,7 @@ def test_adaptive_through_host_containers(oracle):
         got = s.pairs_pt2pl()
         assert np.allclose(got["plane"], r["pt2pl"]["plane"], rtol=0, atol=1e-9)
         assert np.array_equal(got["pt_local"], np.stack([r["pt2pl"]["lx"], r["pt2pl"]["ly"], r["pt2pl"]["lz"]], 1))
-        assert s.potential_pairings() == r["potential"]
+        assert s.potential_pairings == r["potential"]
         # local marks for both kinds, global marks never (Matcher_Adaptive.cpp:260, 289-293)
         assert set(np.flatnonzero(s.bits(1)).tolist()) == set(r["pl_local_idx"].tolist()) | set(r["pt2pt"]["localIdx"].tolist())
         assert not s.bits(0).any()

@@ -395,12 +395,20 @@ def host_boundary(args, d, dev_ms):
 
 
 # ---------------------------------------------------------------------------------------------------
-def bench_config(args, which, local_rank, stream):
-    """--config c2|c3|c5: the other BASELINE configs as bench lines of their own"""
+def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
+    """--config c2|c3|c5: the other BASELINE configs as bench lines of their own.  c3 also runs sharded (--gpus N under
+    torchrun): every rank holds one scan-sized shard of an N-scan local layer (weak scaling) and the step is
+    mp2p_hip_step_sharded_pt2pl -- bounding-box all-reduce + 48 sums per inner iteration over RCCL, inside libmp2p_hip."""
     import mp2p_icp_amd as amd
     from mp2p_icp_amd import _lib, core, synthetic
     ctx = amd.Context(local_rank, stream=stream)
-    if which == "c2":
+    if which == "c3" and (world > 1 or dist is not None):
+        d = synthetic.make_scan_union_pair(120_000 * world, 10_000_000, 3001, map_scan_points=1_000_000)
+        n_shard = d["local"].shape[0] // world
+        d["local"] = np.ascontiguousarray(d["local"][rank * n_shard:(rank + 1) * n_shard])
+        label = (f"{world} x KITTI-shape scan shard (~{n_shard} pts each) vs 10 M-pt map (replicated), Matcher_Point2Plane "
+                 "(knn 5, r 0.4) + Solver_GaussNewton, sharded step")
+    elif which == "c2":
         d = synthetic.make_scan_union_pair(120_000, 2_000_000, 2001, map_scan_points=120_000)
         label = "KITTI-shape scan (~120 k pts) vs 2 M-pt map, Matcher_Points_DistanceThreshold + Solver_Horn"
     elif which == "c3":
@@ -428,7 +436,18 @@ def bench_config(args, which, local_rank, stream):
     gnp.kernel = _lib.KERNEL_CAUCHY if which == "c5" else _lib.KERNEL_GEMANMCCLURE
     gnp.kernelParam, gnp.w_pt2pt, gnp.w_pt2pl = 0.15, 1.0, 1.0
 
+    sharded = None
+    if which == "c3" and (world > 1 or dist is not None):
+        from mp2p_icp_amd.distributed import HipPlaneBackend, ShardedRegistration
+        sharded = ShardedRegistration(HipPlaneBackend(ctx, gmap, cloud, pl, gnp, pairs, local_index_offset=rank * n_l), dist)
+        if dist is not None and world == 1:
+            sharded.b.init_native_comm(dist)  # MP2P_BENCH_FORCE_DIST: a one-rank RCCL communicator
+        if world > 1 and not getattr(sharded.b, "native", False):
+            raise SystemExit("--config c3 --gpus N needs the native RCCL communicator (process group backend nccl)")
+
     def step(pose):
+        if sharded is not None:
+            return np.asarray(sharded.step(pose)[0])
         pairs.clear()
         if which == "c2":
             core.match_pt2pt(ctx, gmap, cloud, pose, pt, None, pairs)
@@ -452,17 +471,27 @@ def bench_config(args, which, local_rank, stream):
         pose = step(pose)
         k += 1
 
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         one()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     ts = []
     for _ in range(args.steps):
         t1 = time.perf_counter()
         one()
         ts.append(time.perf_counter() - t1)
-    torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
+    if dist is not None and world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
     # kernel breakdown + pairs from a replay with events
     pose, k = d["T_init"].copy(), 0
     for _ in range(args.warmup):
@@ -486,7 +515,10 @@ def bench_config(args, which, local_rank, stream):
     alg = 12.0 * n_l * (2 if which == "c5" else 1) + 12.0 * touched_lb + out_bytes
     ach = alg / (nn_ms * 1e-3) / 1e9
     return {
-        "metric": "icp_iterations_per_sec", "value": args.steps / elapsed, "unit": "iterations/s", "n_gpus": 1,
+        # N > 1: one step registers `world` scan-sized shards jointly (one pose, one 6x6 system); as on the default
+        # line the unit is one iteration over ONE scan-sized layer, hence world / t_step
+        "metric": "icp_iterations_per_sec", "value": world * args.steps / elapsed, "unit": "iterations/s", "n_gpus": world,
+        "steps_per_sec_wall": args.steps / elapsed,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 search / f64 plane fit and normal equations",
@@ -567,9 +599,18 @@ def main():
     stream = tstream.cuda_stream
 
     if args.config:
-        if world != 1:
-            raise SystemExit("--config lines are single-GPU")
-        print(json.dumps(bench_config(args, args.config, local_rank, stream)), flush=True)
+        if world != 1 and args.config != "c3":
+            raise SystemExit("--config c2 / c5 lines are single-GPU (c3 shards: mp2p_hip_step_sharded_pt2pl)")
+        if world == 1 and os.environ.get("MP2P_BENCH_FORCE_DIST") == "1":
+            # test hook: the sharded c3 code path with a one-rank RCCL communicator on a one-GPU box
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        line = bench_config(args, args.config, local_rank, stream, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
         return
 
     def barrier():

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round-3 GPU script: tools/gpu_r3.sh <tag> <steps...>   steps: smoke tests pt2pt bench benchold prof
-# writes everything under gpurun_out/<tag>/
+# tools/gpu_run.sh <tag> <steps...>   steps: smoke tests pt2pt bench bencha benchb wavea waveb   (through gpurun)
+# one bounded GPU call made of named steps; everything lands under gpurun_out/<tag>/
 tag=$1; shift
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
@@ -12,8 +12,8 @@ for step in "$@"; do
     bench)   timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo "bench rc=$?" | tee -a $out/rc.txt; tail -c 600 $out/bench.json;;
     bencha)  timeout 600 python bench.py --steps 20 --warmup 5 --scene a --no-extras --no-cpu-baseline > $out/bench_a.json 2> $out/bench_a.err; echo "bencha rc=$?" | tee -a $out/rc.txt;;
     benchb)  timeout 600 python bench.py --steps 20 --warmup 5 --scene b --no-extras --no-cpu-baseline > $out/bench_b.json 2> $out/bench_b.err; echo "benchb rc=$?" | tee -a $out/rc.txt;;
-    olda)    MP2P_HIP_TUNE=wave_kernel=0 timeout 600 python bench.py --steps 20 --warmup 5 --scene a --no-extras --no-cpu-baseline > $out/bench_old_a.json 2> $out/bench_old_a.err; echo "olda rc=$?" | tee -a $out/rc.txt;;
-    oldb)    MP2P_HIP_TUNE=wave_kernel=0 timeout 600 python bench.py --steps 20 --warmup 5 --scene b --no-extras --no-cpu-baseline > $out/bench_old_b.json 2> $out/bench_old_b.err; echo "oldb rc=$?" | tee -a $out/rc.txt;;
+    wavea)    MP2P_HIP_TUNE=wave_kernel=1 timeout 600 python bench.py --steps 20 --warmup 5 --scene a --no-extras --no-cpu-baseline > $out/bench_wave_a.json 2> $out/bench_wave_a.err; echo "wavea rc=$?" | tee -a $out/rc.txt;;
+    waveb)    MP2P_HIP_TUNE=wave_kernel=1 timeout 600 python bench.py --steps 20 --warmup 5 --scene b --no-extras --no-cpu-baseline > $out/bench_wave_b.json 2> $out/bench_wave_b.err; echo "waveb rc=$?" | tee -a $out/rc.txt;;
     *) echo "unknown step $step";;
   esac
 done

@@ -11,7 +11,7 @@ pose_name = sys.argv[1] if len(sys.argv) > 1 else "gt"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 cfg = json.loads(sys.argv[3]) if len(sys.argv) > 3 else {}
 n_l, n_g = cfg.get("n_l", 1_000_000), cfg.get("n_g", 10_000_000)
-d = bench.build_inputs(n_l, n_g, 1, 0, 1)
+d = bench.build_inputs(n_l, n_g, 1, 0, 1, cfg.get("scene", "b"))  # the headline scene
 ctx = amd.Context(0)
 g, l = d["glob"], d["local"]
 cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])

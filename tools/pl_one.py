@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
-"""One Matcher_Point2Plane configuration, a few calls (for rocprofv3 --pmc).  usage: pl_one.py [n_local]"""
+"""Matcher_Point2Plane on the C3 workload (120 k-pt scan vs 10 M-pt map; [n_local] for another scan size), a few calls at
+mid-chain poses that move a few mm per call -- the command tools/gpu_pmc.sh profiles.  usage: pl_one.py [n_local] [reps]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mp2p_icp_amd as amd
-from mp2p_icp_amd import _lib, core
-import bench
-n_l = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-d = bench.build_inputs(n_l, 10_000_000, 3001, 0, 1)
+from mp2p_icp_amd import _lib, core, synthetic
+n_l = int(sys.argv[1]) if len(sys.argv) > 1 else 120_000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+d = synthetic.make_scan_union_pair(n_l, 10_000_000, 3001, map_scan_points=1_000_000)
 ctx = amd.Context(0)
 g, l = d["glob"], d["local"]
+n_l = l.shape[0]
 gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])
 cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
 pairs = core.DevicePairs(ctx, 1, n_l)
-prm = _lib.Pt2PlParams(0.4, 0.4, 5, 5, 0.05, 0, 0.20, 0.0, 0)
-for _ in range(3):
+prm = _lib.Pt2PlParams()
+prm.distanceThreshold, prm.searchRadius, prm.knn, prm.minimumPlanePoints, prm.planeEigenThreshold = 0.4, 0.4, 5, 5, 0.05
+prm.bounding_box_intersection_check_epsilon = 0.20
+chain = amd.se3.compose(d["T_gt"], amd.se3.exp(np.array([0.05, -0.04, 0.01, 0.0, 0.0, 0.004])))
+chain_prev = amd.se3.compose(chain, amd.se3.exp(np.array([0.004, 0.002, 0.0, 0.0, 0.0, 0.001])))
+ctx.set_profiling(1)
+ms = []
+for k in range(reps):
     pairs.clear()
-    core.match_pt2pl(ctx, gmap, cloud, d["T_gt"], prm, None, pairs)
-ctx.sync()
-print(pairs.counts())
+    core.match_pt2pl(ctx, gmap, cloud, chain if (k & 1) else chain_prev, prm, None, pairs)
+    ctx.sync()
+    ms.append(ctx.stats()["ms_nn"])
+print("pairs", pairs.counts(), "search+fit ms per call", [round(m, 3) for m in ms])

@@ -590,6 +590,10 @@ typedef struct
     uint64_t nn_wave_lane_tests, nn_wave_maxlane_tests, nn_wave_inserts, nn_wave_overflows, nn_wave_rounds;
     uint64_t nn_wave_toobig;
     uint64_t nn_wave_phase_ticks[6];
+    /* Matcher_Point2Plane certificate (round 3), cumulative since the context was created and refreshed by a
+     * get_stats after a point-to-plane call at profiling level 1 or 2: queries whose previous neighbour list was
+     * proven to be their k nearest again (no search), and queries that went through the search */
+    uint64_t pl_certified, pl_searched;
 } mp2p_hip_stats;
 /* ---- mp2p_icp::covariance (mp2p_icp/src/covariance.cpp:29-141, ICP.cpp:334-337):
  *      H = J^T J of the stacked error vector w.r.t. (x, y, z, yaw, pitch, roll), J by central

@@ -154,7 +154,8 @@ class Stats(C.Structure):
                 ("nn_wave_path", C.c_uint64), ("nn_wave_lane_tests", C.c_uint64),
                 ("nn_wave_maxlane_tests", C.c_uint64), ("nn_wave_inserts", C.c_uint64),
                 ("nn_wave_overflows", C.c_uint64), ("nn_wave_rounds", C.c_uint64),
-                ("nn_wave_toobig", C.c_uint64), ("nn_wave_phase_ticks", C.c_uint64 * 6)]
+                ("nn_wave_toobig", C.c_uint64), ("nn_wave_phase_ticks", C.c_uint64 * 6),
+                ("pl_certified", C.c_uint64), ("pl_searched", C.c_uint64)]
 
 
 _P = C.c_void_p

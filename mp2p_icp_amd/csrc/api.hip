@@ -58,6 +58,10 @@ static void parse_tune(Tune& t)
             else if (k == "tile_time_cap_us") t.tile_time_cap_us = (uint32_t)v;
             else if (k == "hard_radius_pct") t.hard_radius_pct = (uint32_t)v;
             else if (k == "sync_spin") t.sync_spin = (int)v;
+            else if (k == "pl_cert") t.pl_cert = (int)v;
+            else if (k == "pl_cert_pad") t.pl_cert_pad = (uint32_t)v;
+            else if (k == "pl_cert_margin_mm") t.pl_cert_margin_mm = (uint32_t)v;
+            else if (k == "pl_hard_cand") t.pl_hard_cand = (uint32_t)v;
             else if (k == "spin_us") t.spin_us = (int)v;
             else if (k == "single_waves") t.single_waves = (uint32_t)v;
             else if (k == "xcd_map") t.xcd_map = (int)v;
@@ -179,6 +183,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->work.release(), ctx->work_q.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();
     ctx->pend.release(), ctx->pend_q.release(), ctx->q_counters.release(), ctx->nn_rec.release();
     ctx->pred_buf[0].release(), ctx->pred_buf[1].release(), ctx->pl_kth.release();
+    ctx->pl_lb.release(), ctx->pl_cost.release(), ctx->pl_hard.release(), ctx->pl_pend.release(), ctx->pl_pend_cnt.release(), ctx->pl_cert_stat.release();
     for (auto& b : ctx->scratch) b.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -740,13 +745,15 @@ int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
         ctx->stats.nn_queries = cloud->n;
         if (ctx->profiling == 2)
         {  // the k-NN kernel's own counters
-            unsigned long long c[16];
+            unsigned long long c[50];
             MP2P_TRY_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
             MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
             ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1], ctx->stats.nn_candidates_tested = c[2];
             ctx->stats.nn_tile_ticks_sum = c[3], ctx->stats.nn_max_passes_one_tile = c[4];
             ctx->stats.nn_max_candidates_one_tile = c[5], ctx->stats.nn_tile_ticks_max = c[6];
             ctx->stats.nn_cells_visited = c[7];
+            for (int i = 0; i < 24; i++) ctx->stats.nn_tile_ticks_hist[i] = c[16 + i];
+            ctx->stats.nn_single_max_candidates = c[49];  // the slowest tile: ticks << 40 | passes << 32 | candidates
         }
     }
     return rc;
@@ -1058,6 +1065,13 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
             ctx->stats.nn_points_staged = k;
         }
         ctx->stats.nn_wave_path = (uint64_t)ctx->last_wave_path;
+        if (ctx->pending_pl && ctx->pl_cert_stat.p)
+        {
+            unsigned long long c2[2];
+            MP2P_TRY_HIP(ctx, hipMemcpy(c2, ctx->pl_cert_stat.p, sizeof(c2), hipMemcpyDeviceToHost));
+            ctx->stats.pl_certified = c2[0], ctx->stats.pl_searched = c2[1];
+        }
+        ctx->pending_pl    = 0;
         ctx->pending_match = 0;
     }
     if (ctx->pending_gn)

@@ -144,6 +144,10 @@ struct Tune
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
     uint32_t wave_levels   = 0;     // nn_wave_kernel: coarsest grid level of its wide-radius groups (measured worse above 0)
     int      pl_warm       = 1;     // point-to-plane search: start radius from the previous call's k-th distance (0 = full radius)
+    int      pl_cert       = 1;     // pt2pl: skip the search of a query whose previous list is certainly still its k nearest (PlArgs::lb_io)
+    uint32_t pl_cert_pad   = 2;     // ... searchRadius + this many per mille is what a search that comes up short asks for
+    uint32_t pl_cert_margin_mm = 20; // ... voxels up to this far beyond the search radius of a pass are staged as well (the covered region's margin)
+    uint32_t pl_hard_cand  = 1500;  // pt2pl: a query whose tile staged this many candidates (per 4 queries) at the previous call is searched in the hard class, first and in smaller tiles (0 = one class)
     int      wave_mfma     = 0;     // nn_wave_kernel: distance tests on the matrix pipe as a prefilter (measured: no gain there)
     int      predict       = 0;     // wave path: queries predicted to be far served by the one-query kernel on a second stream
                                     // from the start of the call.  Measured: no gain (each kernel alone fills the register
@@ -189,7 +193,7 @@ struct mp2p_hip_ctx
                                 // {start, end} timestamp per workgroup of the search kernels
     bool        prof_all() const { return profiling == 1 || profiling == 2; }
     hipEvent_t  ev[8]     = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int         pending_match = 0, pending_gn = 0, pending_lane = 0;
+    int         pending_match = 0, pending_gn = 0, pending_lane = 0, pending_pl = 0;
     size_t      pending_map_n = 0;
     mp2p_hip_stats stats{};
     uint64_t    epoch = 0;  // claim epoch (see nn_query.hip)
@@ -215,6 +219,14 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<unsigned char>      pl_slots;     // pt2pl per-query plane slots
     mp2p::DevBuf<uint32_t>           pl_knn;       // pt2pl neighbour lists [n_local][K] (search -> fit kernel)
     mp2p::DevBuf<float>              pl_kth;       // pt2pl warm start: d2 of every query's k-th neighbour at the previous call
+    mp2p::DevBuf<uint32_t>           pl_hard;      // pt2pl: the hard class's query list
+    const void*                      pl_hard_cnt_at = nullptr;
+    bool                             pl_lists_dirty = false;
+    mp2p::DevBuf<uint32_t>           pl_cost;      // pt2pl scheduling hint: ticks of the tile that served each query at the previous call
+    mp2p::DevBuf<float>              pl_lb;        // pt2pl certificate: lower bound of the distance to every point outside the list
+    mp2p::DevBuf<uint32_t>           pl_pend;      // pt2pl: queries left to the search, a segment of 256 per block of the certificate kernel
+    mp2p::DevBuf<uint32_t>           pl_pend_cnt;
+    mp2p::DevBuf<unsigned long long> pl_cert_stat; // {queries certified, queries searched} since the context was created
     const void*                      pl_hint_map = nullptr;    //   ... and what that call was made on
     const void*                      pl_hint_cloud = nullptr;
     size_t                           pl_hint_n = 0;

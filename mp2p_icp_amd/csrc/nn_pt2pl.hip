@@ -18,6 +18,7 @@
 namespace mp2p
 {
 constexpr int      PL_CAP         = 256;
+constexpr int      PL_CB          = 256;  // queries per block of pt2pl_cert_kernel = one segment of the pending list
 constexpr int      PL_HITQ        = 8;    // queued hits per lane before the insertion chains run
 constexpr uint32_t PL_CELL_BUDGET  = 256;   // voxels per pass; measured insensitive 256..4096
 constexpr float    PL_GROUP_FACTOR = 4.0f;  // group extent in search radii; insensitive 1.5..4
@@ -49,6 +50,30 @@ struct PlArgs
     int                  use_hint;
     PoseRt               prev_pose;
     float                grp_min;   // smallest group extent [m]: tight radii must not split a tile into many passes
+    // certificate (round 3): lb_io[n_l] (Morton order) = a lower bound of the distance from the query to every map
+    // point that is NOT in its list (0: none known) -- the smaller of the nearest candidate a search rejected and the
+    // radius it covered completely.  At the next call the query has moved by `disp`: no outsider is nearer than
+    // lb - disp, so if the old neighbours, re-measured from the new position, all stay below that, the k nearest are
+    // the same points and only their order has to be re-established -- no search (pt2pl_cert_kernel).  A query with
+    // fewer than knn points in reach stays as it is while lb - disp clears the search radius (rad_cert = the radius
+    // such a search covers: a little more than searchRadius, so that this margin exists).
+    float*               lb_io;
+    // the queries left to the search, as places in the Morton-ordered copy: two lists for the layer (easy class, hard
+    // class).  A block of pt2pl_cert_kernel reserves its part of a list with one atomic, padded with NONE to whole
+    // tiles -- a tile never mixes two blocks, the lists have no holes larger than a tile, and the grid holds no empty
+    // workgroups except at its very end (per-block segments left 30..50 % of the grid empty once queries were
+    // certified, and the dispatcher's time for those showed: 3 150 waves resident instead of 4 400)
+    uint32_t*            pend;      // [n_l + blocks * Q]
+    uint32_t*            hard_list; // [hard_cap]
+    uint32_t*            list_cnt;  // {entries of pend, entries of hard_list}; zeroed by the fit kernel for the next call
+    uint32_t             hard_cap, pend_cap;
+    unsigned long long*  cert_stat; // {queries certified, queries searched, of these in the hard class} accumulated (nullptr: not counted)
+    uint32_t*            cost_io;   // [n_l] (Morton order): candidates the tile that served the query staged at the previous call
+    uint32_t             hard_cand;  // a query whose tile staged at least this many goes to the hard class (0: no classes)
+    float                rad_cert, cert_margin;
+    int                  use_cert;
+    uint32_t             timeline_n; // tiles in the grid; after their {start, end}: one word {passes << 48 | voxels << 32 | candidates} each
+    unsigned long long*  timeline;  // profiling level 4: {start, end} 100 MHz ticks per tile of pt2pl_tile_kernel (0 0: an empty tile)
 };
 
 // cyclic Jacobi, identical operation order to sym_eig_jacobi(3, ...) of the oracle
@@ -127,17 +152,22 @@ __device__ __forceinline__ float kth_d2(const float (&kd2)[K], uint32_t knn)
 // k-list; the lists are merged at the end of a pass.  All lanes scan
 // the staged voxel buckets of the wave's common search box; each lane keeps its sorted k-list in
 // registers.  Uniform control flow: must be called by the whole wave.
-template <int K, bool STRICT, int Q>
+// CERT: *lb_out = a lower bound of the (computed) distance to every point outside the final list: the nearest
+// candidate this search tested and did not keep (rej), or the radius it covered completely.
+template <int K, bool STRICT, int Q, bool CERT = false>
 __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx, float qy, float qz,
                                            bool active, float lim2, float rmax, float r0, uint32_t knn,
                                            float grp_factor, uint32_t cell_budget,
                                            unsigned long long* dbg, uint32_t* s_hit, float4* s_cand,
                                            uint32_t* s_spos, uint32_t* s_cstart,
                                            uint32_t* s_coff, float (&kd2)[K], uint32_t (&kidx)[K],
-                                           uint32_t (&kspos)[K], float grp_min = 0.f)
+                                           uint32_t (&kspos)[K], float grp_min = 0.f, float* lb_out = nullptr,
+                                           float cert_margin = 0.f, unsigned long long* tl_info = nullptr,
+                                           uint32_t* cand_out = nullptr)
 {
     float r    = fminf(r0, rmax);
     bool  done = !active;
+    float rej  = INFINITY;  // CERT: smallest d2 of a candidate tested and not kept (this pass, this lane's slice); once done: the bound
 #pragma unroll
     for (int j = 0; j < K; j++) kd2[j] = INFINITY, kidx[j] = NONE_U32, kspos[j] = NONE_U32;
     unsigned long long dbg_cand = 0, dbg_pass = 0, dbg_cells = 0;
@@ -165,6 +195,13 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
         const float rmax_t = wave_max_pos(grp ? r : 0.f);
         const float qlx = lox + rmin_t, qly = loy + rmin_t, qlz = loz + rmin_t;
         const float qhx = hix - rmin_t, qhy = hiy - rmin_t, qhz = hiz - rmin_t;
+        // the staging filter's box: the union of the group's search cubes (+ the certificate's margin); a point outside it
+        // is farther than r from every query of the group
+        const float fpad = (CERT ? cert_margin : 0.f) + 2.f * g.slack;
+        const float flx = lox - fpad, fly = loy - fpad, flz = loz - fpad, fhx = hix + fpad, fhy = hiy + fpad, fhz = hiz + fpad;
+        // CERT: a face of the pass box that was cut back to the map's bounding box has nothing beyond it
+        const bool open_lx = lox < g.bbmin[0], open_ly = loy < g.bbmin[1], open_lz = loz < g.bbmin[2];
+        const bool open_hx = hix > g.bbmax[0], open_hy = hiy > g.bbmax[1], open_hz = hiz > g.bbmax[2];
         lox = fmaxf(lox, g.bbmin[0]), loy = fmaxf(loy, g.bbmin[1]), loz = fmaxf(loz, g.bbmin[2]);
         hix = fminf(hix, g.bbmax[0]), hiy = fminf(hiy, g.bbmax[1]), hiz = fminf(hiz, g.bbmax[2]);
         const bool empty_box = (lox > hix) || (loy > hiy) || (loz > hiz);
@@ -186,7 +223,9 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
             }
         }
         const float hs     = g.hf * (float)(1u << s);
-        const float prune  = rmax_t + 4.f * g.slack;
+        // CERT: voxels up to cert_margin beyond the largest radius are staged too, so that the region this pass
+        // covers completely reaches that far beyond every query of the group (the corner voxels of the box)
+        const float prune  = rmax_t + 4.f * g.slack + (CERT ? cert_margin : 0.f);
         const float prune2 = prune * prune;
         dbg_pass++, dbg_cells += ncell;
 
@@ -195,7 +234,9 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
 #pragma unroll
         for (int j = 0; j < K; j++)
             if (grp) kd2[j] = INFINITY, kidx[j] = NONE_U32, kspos[j] = NONE_U32;
+        if (CERT && grp) rej = INFINITY;
         float kth = kth_d2(kd2, knn);  // INFINITY for the lanes of this pass
+        const float r2 = r * r;
 
         for (unsigned long long cb = 0; cb < ncell; cb += 64)
         {
@@ -225,59 +266,48 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
             s_coff[lane]   = incl - cnt;
             if (lane == 63) s_coff[64] = total;
             __syncthreads();
-            for (uint32_t base = 0; base < total; base += PL_CAP)
+            // ---- scan of the staged candidates.  With 64 different queries in a wave nearly every candidate
+            //      enters SOMEBODY's list, so an insertion chain behind a per-candidate branch runs for all of
+            //      them (~100 instructions each).  Instead a lane only notes its hits (candidates within its
+            //      current k-th distance) in a small LDS queue; the chains run when a queue is full or the
+            //      bucket ends, with most lanes busy.  A queued candidate that no longer qualifies by then falls
+            //      through the chain unchanged.
+            uint32_t hq = 0;  // hits queued by this lane
+            auto     flush = [&]()
             {
-                const uint32_t m = min((uint32_t)PL_CAP, total - base);
-                for (uint32_t t = lane; t < m; t += 64)
+                const uint32_t hmax = (uint32_t)wave_max((float)hq);  // hq <= PL_HITQ: exact in fp32
+                for (uint32_t e = 0; e < hmax; e++)
                 {
-                    const uint32_t gt = base + t;
-                    int            lo = 0, hi = 63;
-                    while (lo < hi)
+                    const bool     mine = e < hq;
+                    const uint32_t jj   = mine ? s_hit[e * 64 + lane] : 0u;
+                    const float4   c    = s_cand[jj];
+                    float          cd   = mine ? dist2(qx, qy, qz, c.x, c.y, c.z) : INFINITY;
+                    uint32_t       ci = mine ? __float_as_uint(c.w) : NONE_U32, cs = s_spos[jj];
+#pragma unroll
+                    for (int q = 0; q < K; q++)
                     {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (s_coff[mid] <= gt) lo = mid;
-                        else hi = mid - 1;
+                        const bool     less = mine && ((cd < kd2[q]) || (cd == kd2[q] && ci < kidx[q]));
+                        const float    td   = kd2[q];
+                        const uint32_t ti = kidx[q], ts = kspos[q];
+                        kd2[q]   = less ? cd : td;
+                        kidx[q]  = less ? ci : ti;
+                        kspos[q] = less ? cs : ts;
+                        cd = less ? td : cd, ci = less ? ti : ci, cs = less ? ts : cs;
                     }
-                    const uint32_t src = s_cstart[lo] + (gt - s_coff[lo]);
-                    s_cand[t]          = g.pts[src];
-                    s_spos[t]          = src;
+                    if (CERT) rej = fminf(rej, cd);  // what fell off the end: the candidate itself or the old last entry (inf: nothing)
                 }
-                __syncthreads();
-                // ---- scan.  With 64 different queries in a wave nearly every candidate enters
-                //      SOMEBODY's list, so an insertion chain behind a per-candidate branch runs for
-                //      all of them (~100 instructions each).  Instead a lane only notes its hits
-                //      (candidates within its current k-th distance) in a small LDS queue; the chains
-                //      run when a queue is full or the bucket ends, with most lanes busy.  A queued
-                //      candidate that no longer qualifies by then falls through the chain unchanged.
-                uint32_t hq = 0;  // hits queued by this lane
-                auto     flush = [&]()
-                {
-                    const uint32_t hmax = (uint32_t)wave_max((float)hq);  // hq <= PL_HITQ: exact in fp32
-                    for (uint32_t e = 0; e < hmax; e++)
+#pragma unroll
+                for (int q = 0; q < K; q++)  // only the knn nearest are kept
+                    if (q >= (int)knn)
                     {
-                        const bool     mine = e < hq;
-                        const uint32_t jj   = mine ? s_hit[e * 64 + lane] : 0u;
-                        const float4   c    = s_cand[jj];
-                        float          cd   = mine ? dist2(qx, qy, qz, c.x, c.y, c.z) : INFINITY;
-                        uint32_t       ci = mine ? __float_as_uint(c.w) : NONE_U32, cs = s_spos[jj];
-#pragma unroll
-                        for (int q = 0; q < K; q++)
-                        {
-                            const bool     less = mine && ((cd < kd2[q]) || (cd == kd2[q] && ci < kidx[q]));
-                            const float    td   = kd2[q];
-                            const uint32_t ti = kidx[q], ts = kspos[q];
-                            kd2[q]   = less ? cd : td;
-                            kidx[q]  = less ? ci : ti;
-                            kspos[q] = less ? cs : ts;
-                            cd = less ? td : cd, ci = less ? ti : ci, cs = less ? ts : cs;
-                        }
+                        if (CERT) rej = fminf(rej, kd2[q]);
+                        kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
                     }
-#pragma unroll
-                    for (int q = 0; q < K; q++)  // only the knn nearest are kept
-                        if (q >= (int)knn) kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
-                    kth = kth_d2(kd2, knn);
-                    hq  = 0;
-                };
+                kth = kth_d2(kd2, knn);
+                hq  = 0;
+            };
+            auto scan = [&](const uint32_t m)
+            {
                 // (uniform trip count: the flush inside is a wave-wide operation -- DPP / readlane
                 //  reductions -- and must be reached by every lane together)
                 for (uint32_t j0 = 0; j0 < m; j0 += 64 / Q)
@@ -286,13 +316,68 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                     const bool     jv = j < m;
                     const float4   c  = s_cand[jv ? j : 0u];
                     const float    d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
-                    const bool     in = STRICT ? (d2 < lim2) : (d2 <= lim2);
+                    // (beyond the pass radius a candidate is of no use: the pass ends the search only if the k-th lies
+                    //  inside it, and otherwise the list restarts with a larger radius.  The staged cube holds 20..100 x
+                    //  the points of the ball; without this bound they fill the lists first and run the insertion chains)
+                    const bool     in = (STRICT ? (d2 < lim2) : (d2 <= lim2)) && d2 <= r2;
                     if (jv && grp && in && d2 <= kth) s_hit[hq * 64 + lane] = j, hq++;
+                    else if (CERT && jv && grp) rej = fminf(rej, d2);
                     if (__ballot(hq >= (uint32_t)PL_HITQ) != 0ull) flush();
                 }
                 if (__ballot(hq > 0u) != 0ull) flush();
-                __syncthreads();
+            };
+            // ---- staging.  The voxels' points are fetched 256 at a time (four independent loads per lane in flight: the
+            //      tiles that set the kernel's span stage thousands of points and wait for every round trip alone), and
+            //      only those inside the group's box are kept: the voxel-aligned cube holds 20..100 x the points of the
+            //      search cubes, and a point outside the box is beyond the radius of every query of the group.  The
+            //      survivors collect in s_cand over as many fetches as fit; the scan runs when the buffer is full.
+            uint32_t                 ns    = 0;  // candidates in s_cand (wave-uniform)
+            const unsigned long long below = (1ull << lane) - 1ull;
+            for (uint32_t base = 0; base < total; base += PL_CAP)
+            {
+                const uint32_t m = min((uint32_t)PL_CAP, total - base);
+                if (ns + m > (uint32_t)PL_CAP)
+                {
+                    __syncthreads();
+                    scan(ns);
+                    __syncthreads();
+                    ns = 0;
+                }
+                uint32_t src[PL_CAP / 64];
+#pragma unroll
+                for (int u = 0; u < PL_CAP / 64; u++)
+                {
+                    const uint32_t gt = base + min((uint32_t)lane + 64u * (uint32_t)u, m - 1u);
+                    int            lo = 0, hi = 63;
+#pragma unroll
+                    for (int it = 0; it < 6; it++)
+                    {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (s_coff[mid] <= gt) lo = mid;
+                        else hi = mid - 1;
+                    }
+                    src[u] = s_cstart[lo] + (gt - s_coff[lo]);
+                }
+                float4 c[PL_CAP / 64];
+#pragma unroll
+                for (int u = 0; u < PL_CAP / 64; u++) c[u] = g.pts[src[u]];
+#pragma unroll
+                for (int u = 0; u < PL_CAP / 64; u++)
+                {
+                    const bool keep = ((uint32_t)lane + 64u * (uint32_t)u < m) && c[u].x >= flx && c[u].x <= fhx && c[u].y >= fly &&
+                                      c[u].y <= fhy && c[u].z >= flz && c[u].z <= fhz;
+                    const unsigned long long bal = __ballot(keep);
+                    if (keep)
+                    {
+                        const uint32_t pos = ns + (uint32_t)__popcll(bal & below);
+                        s_cand[pos] = c[u], s_spos[pos] = src[u];
+                    }
+                    ns += (uint32_t)__popcll(bal);
+                }
             }
+            __syncthreads();
+            if (ns) scan(ns);
+            __syncthreads();
         }
         // ---- merge the k-lists of the lanes that hold the same query (partners differ in the bits
         //      >= Q of the lane number; both end up with the merged list) ------------------------
@@ -324,10 +409,22 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                         kd2[q] = less ? cd : td, kidx[q] = less ? ci : ti, kspos[q] = less ? cs : ts;
                         cd = less ? td : cd, ci = less ? ti : ci, cs = less ? ts : cs;
                     }
+                    if (CERT && grp) rej = fminf(rej, cd);
+                }
+                if (CERT)
+                {
+                    // entries of the partner's list the early exit above did not visit are all NONE (sorted lists);
+                    // the partner's own rejects count for this query too
+                    const float orej = __shfl_xor(rej, off, 64);
+                    if (grp) rej = fminf(rej, orej);
                 }
 #pragma unroll
                 for (int q = 0; q < K; q++)
-                    if (grp && q >= (int)knn) kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
+                    if (grp && q >= (int)knn)
+                    {
+                        if (CERT) rej = fminf(rej, kd2[q]);
+                        kd2[q] = INFINITY, kidx[q] = NONE_U32, kspos[q] = NONE_U32;
+                    }
             }
         }
         if (grp)
@@ -335,7 +432,30 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
             const float gr  = r * (1.0f - 1.0f / 1024.0f) - g.slack;
             kth             = kth_d2(kd2, knn);  // INFINITY while fewer than knn are known
             if (r >= rmax || (gr > 0.f && kth < gr * gr))
+            {
                 done = true;
+                if (CERT)
+                {
+                    // What this pass staged: every voxel of the aligned box [cx0, cx0 + nx) x .. that lies within `prune`
+                    // of the group's queries.  A point that was NOT staged is therefore beyond a face of that box or
+                    // farther than prune - 4 slack; a staged one was tested: kept, or in rej.
+                    float cd = r;  // (empty box: the cube of half-width r around the query holds no map point)
+                    if (!empty_box)
+                    {
+                        const float bx0 = g.ox + (float)cx0 * hs, bx1 = g.ox + (float)(cx0 + nx) * hs;
+                        const float by0 = g.oy + (float)cy0 * hs, by1 = g.oy + (float)(cy0 + ny) * hs;
+                        const float bz0 = g.oz + (float)cz0 * hs, bz1 = g.oz + (float)(cz0 + nz) * hs;
+                        cd = prune - 4.f * g.slack;
+                        cd = fminf(cd, fminf(open_lx ? INFINITY : qx - bx0, open_hx ? INFINITY : bx1 - qx));
+                        cd = fminf(cd, fminf(open_ly ? INFINITY : qy - by0, open_hy ? INFINITY : by1 - qy));
+                        cd = fminf(cd, fminf(open_lz ? INFINITY : qz - bz0, open_hz ? INFINITY : bz1 - qz));
+                        // ... or outside the staging filter's box
+                        cd = fminf(cd, fminf(fminf(qx - flx, fhx - qx), fminf(fminf(qy - fly, fhy - qy), fminf(qz - flz, fhz - qz))));
+                    }
+                    cd  = fmaxf(cd - 2.f * g.slack, gr);  // gr: the radius the search itself relies on
+                    rej = fmaxf(0.f, fminf(sqrtf(rej), cd));  // (a finished lane is in no later pass: rej is free)
+                }
+            }
             else
             {
                 const float rn = (kth < INFINITY)
@@ -345,12 +465,18 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
             }
         }
     }
+    if (CERT && lb_out) *lb_out = rej;
+    if (tl_info && lane == 0) *tl_info = (dbg_pass << 48) | ((dbg_cells & 0xFFFFull) << 32) | (dbg_cand & 0xFFFFFFFFull);
+    if (cand_out) *cand_out = (uint32_t)min(dbg_cand, 0xFFFFFFFFull);
     if (dbg && lane == 0)
     {
         const unsigned long long dt = (unsigned long long)((long long)wall_clock64() - dbg_t0);
         atomicAdd(&dbg[0], 1ull), atomicAdd(&dbg[1], dbg_pass), atomicAdd(&dbg[2], dbg_cand), atomicAdd(&dbg[3], dt);
         atomicMax(&dbg[4], dbg_pass), atomicMax(&dbg[5], dbg_cand), atomicMax(&dbg[6], dt), atomicAdd(&dbg[7], dbg_cells);
         atomicMax(&dbg[8], dbg_cells);
+        // duration histogram (log2 of 100 MHz ticks) and the slowest tile's {ticks, passes, candidates}
+        atomicAdd(&dbg[16 + min(23, 63 - (int)__clzll((long long)(dt | 1ull)))], 1ull);
+        atomicMax(&dbg[49], (dt << 40) | ((dbg_pass & 0xFFull) << 32) | (dbg_cand & 0xFFFFFFFFull));
     }
 }
 
@@ -436,31 +562,29 @@ constexpr int PL_Q = 32;  // queries per wave (2 candidate slices)
 // to fill the chip with 32-query tiles (a KITTI scan of 120 k points = 3 750 tiles for 5 120 wave
 // slots: the kernel then lasts as long as its slowest tile; 8-query tiles cut that tile's work 4x).
 // (register budget: the occupancy the kernel had before the warm start: 5 / 4 / 3 / 2 waves per SIMD for K = 5 / 8 / 12 / 16)
-template <int K, int Q>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 5 ? 5 : (K <= 8 ? 4 : (K <= 12 ? 3 : 2)), 8))) void pt2pl_tile_kernel(const PlArgs a)
+// one tile: Q consecutive entries of a segment of a pending list (pt2pl_cert_kernel)
+template <int K, int Q, bool HARD>
+__device__ __forceinline__ void pt2pl_tile_body(const PlArgs& a, const uint32_t* __restrict__ pend, uint32_t cnt, uint32_t k,
+                                                uint32_t tile_id, float4* s_cand, uint32_t* s_spos, uint32_t* s_hit,
+                                                uint32_t* s_cstart, uint32_t* s_coff)
 {
-    __shared__ float4   s_cand[PL_CAP];
-    __shared__ uint32_t s_spos[PL_CAP];
-    __shared__ uint32_t s_hit[PL_HITQ * 64];
-    __shared__ uint32_t s_cstart[64];
-    __shared__ uint32_t s_coff[65];
-
     const GridView& g    = a.g;
     const int       lane = threadIdx.x;
-    bool            valid, visited;
-    uint32_t        orig, vrank;
-    float           qx, qy, qz;
-    transform_tile<Q>(a.pose, a.lpts, a.n_l, a.rank, a.tile_bbox, lane, valid, visited, orig, vrank, qx, qy, qz);
-    const float fin    = fadd(fadd(qx, qy), qz);
-    bool        active = visited && (fin - fin == 0.0f);
-    if (active && a.local_taken && a.local_taken[orig]) active = false;  // Matcher_Point2Plane.cpp:83-85
+    const unsigned long long tl0 = a.timeline ? wall_clock64() : 0ull;
+    const uint32_t slot  = k * Q + (uint32_t)(lane % Q);
+    const uint32_t ent   = slot < cnt ? pend[slot] : NONE_U32;  // (NONE: the padding of a block's part of the hard list)
+    const bool     valid = ent != NONE_U32;
+    const uint32_t qi    = valid ? ent : 0u;  // place in the sorted copy
+    const float4   lp    = a.lpts[qi];
+    const uint32_t orig  = __float_as_uint(lp.w);
+    float          qx, qy, qz;
+    compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
+    const bool active = valid;  // visited, finite and not taken: checked by pt2pl_cert_kernel
 
-    const uint32_t qi = blockIdx.x * Q + (uint32_t)(lane % Q);  // place in the sorted copy
-    float          r0 = a.r0;
+    float r0 = a.r0;
     if (a.use_hint && active)
     {
-        const float4 lp = a.lpts[qi];
-        float        ox, oy, oz;
+        float ox, oy, oz;
         compose_point_f(a.prev_pose, lp.x, lp.y, lp.z, ox, oy, oz);
         const float disp = sqrtf(dist2(qx, qy, qz, ox, oy, oz));
         const float kp   = a.kth_io[qi];
@@ -468,15 +592,217 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 5 ? 5 :
     }
     float    kd2[K];
     uint32_t kidx[K], kspos[K];
-    knn_search<K, false, Q>(g, lane, qx, qy, qz, active, a.radSq, a.rad * 1.002f + g.slack, r0, a.knn,
-                            a.grp_factor, a.cell_budget, a.dbg, s_hit, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos,
-                            a.grp_min);
+    float    lb = 0.f;
+    uint32_t ncand = 0;
+    knn_search<K, false, Q, true>(g, lane, qx, qy, qz, active, a.radSq, a.rad_cert, r0, a.knn,
+                                  a.grp_factor, a.cell_budget, a.dbg, s_hit, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos,
+                                  a.grp_min, &lb, a.cert_margin, a.timeline ? a.timeline + 2 * (size_t)a.timeline_n + tile_id : nullptr,
+                                  &ncand);
+    if (a.timeline && lane == 0) a.timeline[2 * (size_t)tile_id] = tl0, a.timeline[2 * (size_t)tile_id + 1] = wall_clock64();
     // the neighbour list (sorted positions, ascending (d2, idx); NONE beyond its end) for the fit kernel
     if (!valid || lane >= Q) return;
-    if (a.kth_io) a.kth_io[qi] = active ? kth_d2(kd2, a.knn) : INFINITY;
-    uint32_t* o = a.out_knn + (size_t)orig * K;
+    a.kth_io[qi]  = kth_d2(kd2, a.knn);
+    a.lb_io[qi]   = lb;
+    a.cost_io[qi] = min(ncand, 0x7FFFFFFFu) | (HARD ? 0x80000000u : 0u);  // what this query's tile staged: the next call's scheduling hint
+    uint32_t* o   = a.out_knn + (size_t)orig * K;
 #pragma unroll
-    for (int j = 0; j < K; j++) o[j] = (active && kidx[j] != NONE_U32) ? kspos[j] : NONE_U32;
+    for (int j = 0; j < K; j++) o[j] = (kidx[j] != NONE_U32) ? kspos[j] : NONE_U32;
+}
+
+// The kernel lasts as long as its slowest tiles if they start late (C3, 15 000 tiles of 8 on 5 120 wave slots: a first
+// round of 110 us, then a tail to 385 us made of tiles that take 200-300 us -- dense vegetation, several passes -- and
+// happened to start in the second round: 37 % of the wave slots busy on average).  The queries whose tile was slow at
+// the previous call (PlArgs::cost_io: its staged candidates, which its duration follows with r = 0.94) are therefore listed
+// apart (the hard class), cut into tiles of HQ < Q queries -- 64 / HQ lanes per query, half the passes -- and dispatched
+// FIRST: the workgroups [0, n_hard_tiles) of the grid.
+template <int K, int Q, int HQ>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 5 ? 5 : (K <= 8 ? 4 : (K <= 12 ? 3 : 2)), 8))) void pt2pl_tile_kernel(const PlArgs a, const uint32_t n_hard_tiles)
+{
+    __shared__ float4   s_cand[PL_CAP];
+    __shared__ uint32_t s_spos[PL_CAP];
+    __shared__ uint32_t s_hit[PL_HITQ * 64];
+    __shared__ uint32_t s_cstart[64];
+    __shared__ uint32_t s_coff[65];
+    if (blockIdx.x < n_hard_tiles)
+    {
+        const uint32_t cnt = min(a.list_cnt[1], a.hard_cap);
+        if (blockIdx.x * HQ >= cnt) return;  // wave-uniform
+        pt2pl_tile_body<K, HQ, true>(a, a.hard_list, cnt, blockIdx.x, blockIdx.x, s_cand, s_spos, s_hit, s_cstart, s_coff);
+    }
+    else
+    {
+        const uint32_t t   = blockIdx.x - n_hard_tiles;
+        const uint32_t cnt = min(a.list_cnt[0], a.pend_cap);
+        if (t * Q >= cnt) return;  // wave-uniform
+        pt2pl_tile_body<K, Q, false>(a, a.pend, cnt, t, blockIdx.x, s_cand, s_spos, s_hit, s_cstart, s_coff);
+    }
+}
+
+// ---- certificate + query list: one thread per local point (Morton order), see PlArgs::lb_io ------------------------
+// Also the per-point checks of the matcher's loop (Matcher_Point2Plane.cpp:76-85: visited, finite, not taken) and the
+// bounding boxes of the transformed points (one per wave).  A query that is not certified is appended to its
+// block's segment of the pending list, in Morton order (deterministic: block scan, no global atomics).
+template <int K, int Q, int HQ>
+__global__ __launch_bounds__(PL_CB) void pt2pl_cert_kernel(const PlArgs a)
+{
+    __shared__ uint32_t s_w[PL_CB / 64], s_h[PL_CB / 64], s_c[PL_CB / 64], s_at;
+    const GridView& g    = a.g;
+    const int       lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t  qi   = blockIdx.x * PL_CB + threadIdx.x;
+    const bool      valid = qi < a.n_l;
+    float4          lp    = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) lp = a.lpts[qi];
+    const uint32_t orig    = __float_as_uint(lp.w);
+    bool           visited = valid;
+    if (a.rank && valid) visited = a.rank[orig] != NONE_U32;
+    float qx, qy, qz;
+    compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
+    {
+        const float bx0 = wave_min_nn((visited && qx == qx) ? qx : INFINITY), by0 = wave_min_nn((visited && qy == qy) ? qy : INFINITY),
+                    bz0 = wave_min_nn((visited && qz == qz) ? qz : INFINITY);
+        const float bx1 = wave_max_nn((visited && qx == qx) ? qx : -INFINITY), by1 = wave_max_nn((visited && qy == qy) ? qy : -INFINITY),
+                    bz1 = wave_max_nn((visited && qz == qz) ? qz : -INFINITY);
+        if (lane == 0)
+        {
+            float* o = a.tile_bbox + ((size_t)blockIdx.x * (PL_CB / 64) + w) * 6;
+            o[0] = bx0, o[1] = by0, o[2] = bz0, o[3] = bx1, o[4] = by1, o[5] = bz1;
+        }
+    }
+    const float fin    = fadd(fadd(qx, qy), qz);
+    bool        active = visited && (fin - fin == 0.0f);
+    if (active && a.local_taken && a.local_taken[orig]) active = false;  // Matcher_Point2Plane.cpp:83-85
+    uint32_t* o = a.out_knn + (size_t)orig * K;
+    if (valid && !active)
+    {
+#pragma unroll
+        for (int j = 0; j < K; j++) o[j] = NONE_U32;
+        a.kth_io[qi] = INFINITY, a.lb_io[qi] = 0.f;
+    }
+    bool search = active, certified = false;
+    if (active && a.use_cert)
+    {
+        const float lb_old = a.lb_io[qi];
+        if (lb_old > 0.f)
+        {
+            float ox, oy, oz;
+            compose_point_f(a.prev_pose, lp.x, lp.y, lp.z, ox, oy, oz);
+            const float disp = sqrtf(dist2(qx, qy, qz, ox, oy, oz));
+            // bound of the outsiders at the new position; 4 slack: the rounding of the three computed distances involved
+            const float lbn = lb_old - disp * 1.00001f - 4.f * g.slack;
+            uint32_t    ks[K], ki[K];
+            float       kd[K];
+            int         m = 0;
+#pragma unroll
+            for (int j = 0; j < K; j++)
+            {
+                ks[j] = o[j];
+                kd[j] = INFINITY, ki[j] = NONE_U32;
+                if (ks[j] != NONE_U32)
+                {
+                    m++;
+                    const float4 p = g.pts[ks[j]];
+                    const float  d = dist2(qx, qy, qz, p.x, p.y, p.z);
+                    if (d <= a.radSq) kd[j] = d, ki[j] = __float_as_uint(p.w);  // a member that left the search radius drops out
+                    else ks[j] = NONE_U32;
+                }
+            }
+            // ascending (d2, idx), the order the search keeps its list in (NONE entries, d2 = inf, end up last)
+#pragma unroll
+            for (int i = 1; i < K; i++)
+#pragma unroll
+                for (int j = i; j > 0; j--)
+                {
+                    const bool sw = (kd[j] < kd[j - 1]) || (kd[j] == kd[j - 1] && ki[j] < ki[j - 1]);
+                    const float    td = kd[j];
+                    const uint32_t ti = ki[j], ts = ks[j];
+                    kd[j] = sw ? kd[j - 1] : td, ki[j] = sw ? ki[j - 1] : ti, ks[j] = sw ? ks[j - 1] : ts;
+                    kd[j - 1] = sw ? td : kd[j - 1], ki[j - 1] = sw ? ti : ki[j - 1], ks[j - 1] = sw ? ts : ks[j - 1];
+                }
+            int   m2   = 0;
+            float kmax = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; j++)
+                if (ki[j] != NONE_U32) m2++, kmax = kd[j];
+            bool ok;
+            if (m == (int)a.knn) ok = (m2 == m) && lbn > 0.f && sqrtf(kmax) < lbn;  // the same knn points are the nearest
+            else ok = lbn > a.rad * 1.000001f + g.slack;                            // still nobody else in reach
+            if (ok)
+            {
+#pragma unroll
+                for (int j = 0; j < K; j++) o[j] = ks[j];
+                a.kth_io[qi] = (m2 == (int)a.knn) ? kmax : INFINITY;
+                a.lb_io[qi]  = lbn;
+                search = false, certified = true;
+            }
+        }
+    }
+    // two classes (pt2pl_tile_kernel): the queries whose tile staged many candidates at the previous call go to the layer's
+    // hard list (a block reserves its part, padded to whole tiles of HQ, with one atomic; a part that does not fit any more
+    // stays in the easy class), the rest to the block's own segment in Morton order
+    bool hard = false;
+    if (search && a.use_hint && a.hard_cand)
+    {
+        // cost: candidates its tile staged at the previous call; bit 31: that was a (smaller) tile of the hard class --
+        // it stays there down to half the threshold, so that a query does not change class at every call
+        const uint32_t c = a.cost_io[qi];
+        hard = (c & 0x80000000u) ? (c & 0x7FFFFFFFu) >= a.hard_cand / 2u : c >= a.hard_cand;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long balh = __ballot(hard), balc = __ballot(certified);
+    if (lane == 0) s_h[w] = (uint32_t)__popcll(balh), s_c[w] = (uint32_t)__popcll(balc);
+    __syncthreads();
+    uint32_t baseh = 0, totalh = 0, ncert = 0;
+#pragma unroll
+    for (int i = 0; i < PL_CB / 64; i++)
+    {
+        if (i < w) baseh += s_h[i];
+        totalh += s_h[i], ncert += s_c[i];
+    }
+    const uint32_t padded = (totalh + (uint32_t)HQ - 1u) / (uint32_t)HQ * (uint32_t)HQ;
+    if (threadIdx.x == 0)
+    {
+        uint32_t at = NONE_U32;
+        if (padded) at = atomicAdd(&a.list_cnt[1], padded);
+        s_at = at;
+    }
+    __syncthreads();
+    uint32_t at = s_at;
+    if (at != NONE_U32 && at + padded > a.hard_cap)
+    {
+        // no room: the part of the reservation that lies inside the list is blanked (the tile kernel clamps the count to
+        // the capacity and would otherwise read what an earlier call left there); these queries stay in the easy class
+        if (threadIdx.x < padded && at + threadIdx.x < a.hard_cap) a.hard_list[at + threadIdx.x] = NONE_U32;
+        at = NONE_U32;
+    }
+    if (at == NONE_U32) hard = false, totalh = 0;
+    else
+    {
+        if (hard) a.hard_list[at + baseh + (uint32_t)__popcll(balh & below)] = qi;
+        if (threadIdx.x < padded - totalh) a.hard_list[at + totalh + threadIdx.x] = NONE_U32;
+    }
+    const bool               easy = search && !hard;
+    const unsigned long long bal  = __ballot(easy);
+    if (lane == 0) s_w[w] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < PL_CB / 64; i++)
+    {
+        if (i < w) base += s_w[i];
+        total += s_w[i];
+    }
+    const uint32_t padded_e = (total + (uint32_t)Q - 1u) / (uint32_t)Q * (uint32_t)Q;
+    if (threadIdx.x == 0) s_at = padded_e ? atomicAdd(&a.list_cnt[0], padded_e) : 0u;  // (capacity: every query + a tile per block)
+    __syncthreads();
+    const uint32_t at_e = s_at;
+    if (easy) a.pend[at_e + base + (uint32_t)__popcll(bal & below)] = qi;
+    if (threadIdx.x < padded_e - total) a.pend[at_e + total + threadIdx.x] = NONE_U32;
+    if (threadIdx.x == 0)
+    {
+        if (a.cert_stat)
+            atomicAdd(&a.cert_stat[0], (unsigned long long)ncert), atomicAdd(&a.cert_stat[1], (unsigned long long)(total + totalh)),
+                atomicAdd(&a.cert_stat[2], (unsigned long long)totalh);
+    }
 }
 
 // ---- plane fit: one thread per local point (original index) -----------------------------------
@@ -485,6 +811,7 @@ __global__ __launch_bounds__(256) void pt2pl_fit_kernel(const PlArgs a, const fl
                                                         const float* __restrict__ ly, const float* __restrict__ lz)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && a.list_cnt) a.list_cnt[0] = 0u, a.list_cnt[1] = 0u;  // the search is over: both query lists are empty for the next call
     if (i >= a.n_l) return;
     const GridView& g = a.g;
     const uint32_t* o = a.out_knn + (size_t)i * K;
@@ -687,9 +1014,20 @@ __global__ __launch_bounds__(PC_THREADS) void pl_write_kernel(const PlCompactArg
 template <int K>
 static void launch_k(const PlArgs& a, uint32_t q, const mp2p_hip_cloud* cloud, hipStream_t st)
 {
-    const uint32_t n_tiles = (a.n_l + q - 1) / q;
-    if (q == 8) hipLaunchKernelGGL((pt2pl_tile_kernel<K, 8>), dim3(n_tiles), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((pt2pl_tile_kernel<K, PL_Q>), dim3(n_tiles), dim3(64), 0, st, a);
+    const uint32_t n_blocks = (a.n_l + PL_CB - 1) / PL_CB;
+    const bool classes = a.use_hint && a.hard_cand;
+    if (q == 8)
+    {
+        const uint32_t nh = classes ? a.hard_cap / 4u : 0u;
+        hipLaunchKernelGGL((pt2pl_cert_kernel<K, 8, 4>), dim3(n_blocks), dim3(PL_CB), 0, st, a);
+        hipLaunchKernelGGL((pt2pl_tile_kernel<K, 8, 4>), dim3(nh + a.pend_cap / 8u), dim3(64), 0, st, a, nh);
+    }
+    else
+    {
+        const uint32_t nh = classes ? a.hard_cap / 8u : 0u;
+        hipLaunchKernelGGL((pt2pl_cert_kernel<K, PL_Q, 8>), dim3(n_blocks), dim3(PL_CB), 0, st, a);
+        hipLaunchKernelGGL((pt2pl_tile_kernel<K, PL_Q, 8>), dim3(nh + a.pend_cap / (uint32_t)PL_Q), dim3(64), 0, st, a, nh);
+    }
     hipLaunchKernelGGL(pt2pl_fit_kernel<K>, dim3((a.n_l + 255) / 256), dim3(256), 0, st, a, cloud->x.p, cloud->y.p,
                        cloud->z.p);
 }
@@ -704,9 +1042,23 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     const size_t   n_l     = cloud->n;
     // tile size: see pt2pl_tile_kernel (MP2P_HIP_TUNE pl_q = 8 / 32 forces one)
     const uint32_t Q       = ctx->tune.pl_q ? ctx->tune.pl_q : (n_l <= 400000 ? 8u : (uint32_t)PL_Q);
-    const uint32_t n_tiles = (uint32_t)((n_l + Q - 1) / Q);
+    const uint32_t n_cblocks = (uint32_t)((n_l + PL_CB - 1) / PL_CB);
+    const uint32_t n_boxes   = n_cblocks * (PL_CB / 64);  // one bounding box per wave of pt2pl_cert_kernel
     const uint32_t Kcap    = prm->knn <= 5 ? 5u : prm->knn <= 8 ? 8u : prm->knn <= 12 ? 12u : 16u;
-    MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_tiles * 6));
+    MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)std::max(n_boxes, 1u) * 6));
+    const uint32_t pend_cap = (uint32_t)(((n_l + Q - 1) / Q + n_cblocks) * Q);
+    MP2P_TRY_HIP(ctx, ctx->pl_pend.ensure(std::max(pend_cap, 64u)));
+    MP2P_TRY_HIP(ctx, ctx->pl_pend_cnt.ensure(2));
+    // the hard class: at most an eighth of the layer (in whole tiles), and a grid prefix of at most 8192 workgroups
+    const uint32_t hard_cap = (uint32_t)std::min<size_t>(std::max<size_t>(n_l / 8, 64), 8192u * 4u) / 8u * 8u;
+    MP2P_TRY_HIP(ctx, ctx->pl_hard.ensure(hard_cap));
+    MP2P_TRY_HIP(ctx, ctx->pl_lb.ensure(n_l ? n_l : 1));
+    MP2P_TRY_HIP(ctx, ctx->pl_cost.ensure(n_l ? n_l : 1));
+    if (!ctx->pl_cert_stat.p)
+    {
+        MP2P_TRY_HIP(ctx, ctx->pl_cert_stat.ensure(4));
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->pl_cert_stat.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    }
     MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
     MP2P_TRY_HIP(ctx, ctx->pl_slots.ensure(n_l * (7 * sizeof(double) + 1) + 64));
     MP2P_TRY_HIP(ctx, ctx->pl_knn.ensure(n_l * Kcap));
@@ -745,6 +1097,19 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
         for (int i = 0; i < 12; i++) ctx->pl_hint_pose[i] = pose[i];
     }
     a.grp_min = 2.0f * cell0;
+    a.lb_io = ctx->pl_lb.p, a.pend = ctx->pl_pend.p, a.pend_cap = pend_cap, a.cert_stat = ctx->pl_cert_stat.p;
+    a.use_cert = (a.use_hint && ctx->tune.pl_cert) ? 1 : 0;
+    a.cost_io = ctx->pl_cost.p, a.hard_cand = ctx->tune.pl_hard_cand;
+    a.hard_list = ctx->pl_hard.p, a.hard_cap = hard_cap, a.list_cnt = ctx->pl_pend_cnt.p;
+    if (ctx->pl_hard_cnt_at != (const void*)a.list_cnt || ctx->pl_lists_dirty)
+    {  // just allocated (or a call that did not get as far as its fit kernel): zero once; from then on the fit kernel leaves the counters zeroed
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(a.list_cnt, 0, 2 * sizeof(uint32_t), ctx->stream));
+        ctx->pl_hard_cnt_at = a.list_cnt;
+    }
+    // the radius a search that finds fewer than knn points has covered: searchRadius + pl_cert_pad per mille, the room
+    // the certificate of such a query has before a point outside its list could come into reach (0.2 % without it)
+    a.rad_cert = a.rad * (1.0f + 0.001f * (float)(ctx->tune.pl_cert ? std::max(2u, ctx->tune.pl_cert_pad) : 2u)) + map->view.slack;
+    a.cert_margin = ctx->tune.pl_cert ? 0.001f * (float)ctx->tune.pl_cert_margin_mm : 0.f;
     a.dbg = nullptr;
     if (ctx->profiling == 2)
     {
@@ -753,18 +1118,32 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
         a.dbg = ctx->counters.p;
     }
 
+    a.timeline = nullptr;
+    ctx->timeline_tiles = ctx->timeline_singles = 0;
+    if (ctx->profiling == 4 && phase != 2)
+    {
+        const size_t n_grid = (size_t)pend_cap / Q + (ctx->tune.pl_hard_cand ? (size_t)hard_cap / (Q == 8 ? 4 : 8) : 0);
+        // (read back as 2 x 1.5 n_grid words: the probe knows that the last third is the per-tile info)
+        const size_t n_rec = n_grid + (n_grid + 1) / 2;
+        MP2P_TRY_HIP(ctx, ctx->timeline.ensure(2 * std::max<size_t>(n_rec, 1)));
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->timeline.p, 0, 2 * n_rec * sizeof(unsigned long long), ctx->stream));
+        a.timeline = ctx->timeline.p, a.timeline_n = (uint32_t)n_grid, ctx->timeline_tiles = n_rec;
+    }
     ctx->pending_lane = 0;
+    ctx->pending_pl   = (ctx->profiling == 1 || ctx->profiling == 2) ? 1 : 0;
     if (phase != 2)
     {
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    ctx->pl_lists_dirty = true;
     if (Kcap == 5) launch_k<5>(a, Q, cloud, ctx->stream);
     else if (Kcap == 8) launch_k<8>(a, Q, cloud, ctx->stream);
     else if (Kcap == 12) launch_k<12>(a, Q, cloud, ctx->stream);
     else launch_k<16>(a, Q, cloud, ctx->stream);
+    if (hipPeekAtLastError() == hipSuccess) ctx->pl_lists_dirty = false;
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     {
-        const int rc = launch_bbox_reduce(ctx, n_tiles);
+        const int rc = launch_bbox_reduce(ctx, n_boxes);
         if (rc) return rc;
     }
     }

@@ -381,6 +381,12 @@ def host_boundary(args, d, dev_ms):
     out = {"ms_per_step": ms, "iterations_per_s": 1e3 / ms,
            "vs_device_resident_step": ms / dev_ms,
            "ms_per_step_at_icp_iteration_0": float(np.mean([ts[i] for i in first])) * 1e3 if first else None,
+           # ICP iteration 0 of a new align: the very first one uploads both layers and builds the index; a later one
+           # finds them cached and re-verifies every 61st point (state_in), then searches from a stale warm start
+           "icp_iteration_0": {"first_seen_ms": ts[0] * 1e3, "first_seen_stage_ms": stages[0],
+                               "re_seen_ms": float(np.mean([ts[i] for i in first])) * 1e3 if first else None,
+                               "re_seen_stage_ms": ({k: float(np.mean([stages[i][k] for i in first])) for k in stages[0]} if first else None),
+                               "layer_cache": hostpath.cache()},
            "stage_ms": {k: float(np.mean([stages[i][k] for i in keep])) for k in stages[0]},
            "pairs_per_step": float(np.mean([npairs[i] for i in keep])),
            "transfers": {k: c1[k] - c0[k] for k in c0},

@@ -144,7 +144,7 @@ struct Tune
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
     uint32_t wave_levels   = 0;     // nn_wave_kernel: coarsest grid level of its wide-radius groups (measured worse above 0)
     int      pl_warm       = 1;     // point-to-plane search: start radius from the previous call's k-th distance (0 = full radius)
-    int      pl_cert       = 1;     // pt2pl: skip the search of a query whose previous list is certainly still its k nearest (PlArgs::lb_io)
+    int      pl_cert       = 2;     // pt2pl: skip the search of a query whose previous list is certainly still its k nearest (PlArgs::lb_io)
     uint32_t pl_cert_pad   = 2;     // ... searchRadius + this many per mille is what a search that comes up short asks for
     uint32_t pl_cert_margin_mm = 20; // ... voxels up to this far beyond the search radius of a pass are staged as well (the covered region's margin)
     uint32_t pl_hard_cand  = 1500;  // pt2pl: a query whose tile staged this many candidates (per 4 queries) at the previous call is searched in the hard class, first and in smaller tiles (0 = one class)

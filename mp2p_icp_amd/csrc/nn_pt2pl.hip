@@ -725,7 +725,9 @@ __global__ __launch_bounds__(PL_CB) void pt2pl_cert_kernel(const PlArgs a)
                 if (ki[j] != NONE_U32) m2++, kmax = kd[j];
             bool ok;
             if (m == (int)a.knn) ok = (m2 == m) && lbn > 0.f && sqrtf(kmax) < lbn;  // the same knn points are the nearest
-            else ok = lbn > a.rad * 1.000001f + g.slack;                            // still nobody else in reach
+            // still nobody else in reach -- and nobody left: a member that drops out becomes an outsider NEARER than the
+            // bound (it may come back within reach at the next call), so such a query goes through the search
+            else ok = a.use_cert >= 2 && (m2 == m) && lbn > a.rad * 1.000001f + g.slack;
             if (ok)
             {
 #pragma unroll
@@ -1041,7 +1043,9 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
 {
     const size_t   n_l     = cloud->n;
     // tile size: see pt2pl_tile_kernel (MP2P_HIP_TUNE pl_q = 8 / 32 forces one)
-    const uint32_t Q       = ctx->tune.pl_q ? ctx->tune.pl_q : (n_l <= 400000 ? 8u : (uint32_t)PL_Q);
+    // (round 2 took 32-query tiles above 400 k points; with the insertions bounded by the pass radius and the filtered
+    //  staging the 8-query tile wins at every size: 1 M queries 1.10..1.47 ms with 32, 0.75..0.88 ms with 8)
+    const uint32_t Q       = ctx->tune.pl_q ? ctx->tune.pl_q : 8u;
     const uint32_t n_cblocks = (uint32_t)((n_l + PL_CB - 1) / PL_CB);
     const uint32_t n_boxes   = n_cblocks * (PL_CB / 64);  // one bounding box per wave of pt2pl_cert_kernel
     const uint32_t Kcap    = prm->knn <= 5 ? 5u : prm->knn <= 8 ? 8u : prm->knn <= 12 ? 12u : 16u;
@@ -1098,7 +1102,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     }
     a.grp_min = 2.0f * cell0;
     a.lb_io = ctx->pl_lb.p, a.pend = ctx->pl_pend.p, a.pend_cap = pend_cap, a.cert_stat = ctx->pl_cert_stat.p;
-    a.use_cert = (a.use_hint && ctx->tune.pl_cert) ? 1 : 0;
+    a.use_cert = (a.use_hint && ctx->tune.pl_cert) ? ctx->tune.pl_cert : 0;
     a.cost_io = ctx->pl_cost.p, a.hard_cand = ctx->tune.pl_hard_cand;
     a.hard_list = ctx->pl_hard.p, a.hard_cap = hard_cap, a.list_cnt = ctx->pl_pend_cnt.p;
     if (ctx->pl_hard_cnt_at != (const void*)a.list_cnt || ctx->pl_lists_dirty)

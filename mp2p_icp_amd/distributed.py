@@ -54,7 +54,8 @@ class HipBackend:
         self._sums = None
         self._gather = None
         self._views = None
-        self.uses_claims = not bool(pt2pt_params.allowMatchAlreadyMatchedGlobalPoints)
+        # (Pt2PlParams has no such field: Matcher_Point2Plane pairs every local point on its own)
+        self.uses_claims = not bool(getattr(pt2pt_params, "allowMatchAlreadyMatchedGlobalPoints", 1))
 
     def phase1(self, pose):
         from . import core

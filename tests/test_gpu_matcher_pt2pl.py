@@ -204,3 +204,48 @@ def test_warm_start_pose_sequence(amd, oracle, knn, radius):
         if len(got):
             assert np.allclose(got["plane"], want["plane"], rtol=0, atol=1e-9)
             assert np.allclose(got["centroid"], want["centroid"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("knn,radius", [(5, 0.4), (8, 0.6)])
+def test_certificate_pose_sequence(amd, oracle, knn, radius):
+    """the search's certificate (nn_pt2pl.hip, PlArgs::lb_io): poses that creep from millimetre to 50-micrometre steps on
+    ONE context -- a growing share of the queries skips the search because their previous neighbours are provably
+    still the nearest -- every call equal to the oracle's cold result, bit for bit; a local point that is taken in one
+    call and free in the next goes through the search again; a jump invalidates everything"""
+    from mp2p_icp_amd import _lib, core, synthetic
+    d = synthetic.make_pair(8000, 400000, 277 + knn)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    rng = np.random.default_rng(knn)
+    poses, scales = [d["T_gt"]], [1e-3, 1e-3, 3e-4, 1e-4, 5e-5, 5e-5, 3e-2, 5e-5]
+    for sc in scales:
+        poses.append(amd.se3.compose(poses[-1], amd.se3.exp(np.concatenate([rng.normal(0, sc, 3), rng.normal(0, 0.1 * sc, 3)]))))
+    ctx = amd.Context(0)
+    ctx.set_profiling(1)
+    gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])
+    cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    pairs = core.DevicePairs(ctx, 0, l.shape[0])
+    ms = core.DeviceMatchState(ctx, g.shape[0], l.shape[0])
+    prm = _lib.Pt2PlParams()
+    prm.distanceThreshold, prm.searchRadius, prm.knn, prm.minimumPlanePoints, prm.planeEigenThreshold = 0.25, radius, knn, 5, 0.05
+    prm.bounding_box_intersection_check_epsilon = 0.20
+    certified = []
+    for k, pose in enumerate(poses):
+        taken = np.zeros(l.shape[0], np.uint8)
+        if k in (2, 5):
+            taken[rng.choice(l.shape[0], 500, replace=False)] = 1  # these are skipped by this call only
+        ms.upload(np.zeros(g.shape[0], np.uint8), taken)
+        want, widx, pot = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.25, radius, knn, 5, 0.05,
+                                             tree=tree, local_taken=taken.copy())
+        pairs.clear()
+        core.match_pt2pl(ctx, gmap, cloud, pose, prm, ms, pairs)
+        st = ctx.stats()
+        certified.append(st["pl_certified"])
+        got, gidx = pairs.download_pt2pl()
+        assert len(got) == len(want) and len(want) > 500, (k, len(got), len(want))
+        assert np.array_equal(gidx, widx), k
+        assert np.allclose(got["plane"], want["plane"], rtol=0, atol=1e-9) and np.allclose(got["centroid"], want["centroid"], rtol=0, atol=1e-9), k
+    per_call = np.diff([0] + certified)
+    assert per_call[0] == 0                      # nothing to go by at the first call
+    assert per_call[4] > 0.3 * l.shape[0], per_call  # 0.1 mm steps: a good share of the queries is certified
+    assert per_call[7] < per_call[5], per_call   # the 3 cm jump leaves (next to) nothing certified

@@ -19,6 +19,7 @@ namespace mp2p
 {
 constexpr int      PL_CAP         = 256;
 constexpr int      PL_CB          = 256;  // queries per block of pt2pl_cert_kernel = one segment of the pending list
+constexpr int      PL_STAGE       = 4;    // staging loads in flight per lane (x 64 candidates per fetch)
 constexpr int      PL_HITQ        = 8;    // queued hits per lane before the insertion chains run
 constexpr uint32_t PL_CELL_BUDGET  = 256;   // voxels per pass; measured insensitive 256..4096
 constexpr float    PL_GROUP_FACTOR = 4.0f;  // group extent in search radii; insensitive 1.5..4
@@ -326,16 +327,16 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                 }
                 if (__ballot(hq > 0u) != 0ull) flush();
             };
-            // ---- staging.  The voxels' points are fetched 256 at a time (four independent loads per lane in flight: the
+            // ---- staging.  The voxels' points are fetched 64 x PL_STAGE at a time (PL_STAGE independent loads per lane in flight: the
             //      tiles that set the kernel's span stage thousands of points and wait for every round trip alone), and
             //      only those inside the group's box are kept: the voxel-aligned cube holds 20..100 x the points of the
             //      search cubes, and a point outside the box is beyond the radius of every query of the group.  The
             //      survivors collect in s_cand over as many fetches as fit; the scan runs when the buffer is full.
             uint32_t                 ns    = 0;  // candidates in s_cand (wave-uniform)
             const unsigned long long below = (1ull << lane) - 1ull;
-            for (uint32_t base = 0; base < total; base += PL_CAP)
+            for (uint32_t base = 0; base < total; base += 64u * PL_STAGE)
             {
-                const uint32_t m = min((uint32_t)PL_CAP, total - base);
+                const uint32_t m = min(64u * (uint32_t)PL_STAGE, total - base);
                 if (ns + m > (uint32_t)PL_CAP)
                 {
                     __syncthreads();
@@ -343,9 +344,9 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                     __syncthreads();
                     ns = 0;
                 }
-                uint32_t src[PL_CAP / 64];
+                uint32_t src[PL_STAGE];
 #pragma unroll
-                for (int u = 0; u < PL_CAP / 64; u++)
+                for (int u = 0; u < PL_STAGE; u++)
                 {
                     const uint32_t gt = base + min((uint32_t)lane + 64u * (uint32_t)u, m - 1u);
                     int            lo = 0, hi = 63;
@@ -358,11 +359,11 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                     }
                     src[u] = s_cstart[lo] + (gt - s_coff[lo]);
                 }
-                float4 c[PL_CAP / 64];
+                float4 c[PL_STAGE];
 #pragma unroll
-                for (int u = 0; u < PL_CAP / 64; u++) c[u] = g.pts[src[u]];
+                for (int u = 0; u < PL_STAGE; u++) c[u] = g.pts[src[u]];
 #pragma unroll
-                for (int u = 0; u < PL_CAP / 64; u++)
+                for (int u = 0; u < PL_STAGE; u++)
                 {
                     const bool keep = ((uint32_t)lane + 64u * (uint32_t)u < m) && c[u].x >= flx && c[u].x <= fhx && c[u].y >= fly &&
                                       c[u].y <= fhy && c[u].z >= flz && c[u].z <= fhz;
@@ -616,7 +617,7 @@ __device__ __forceinline__ void pt2pl_tile_body(const PlArgs& a, const uint32_t*
 // apart (the hard class), cut into tiles of HQ < Q queries -- 64 / HQ lanes per query, half the passes -- and dispatched
 // FIRST: the workgroups [0, n_hard_tiles) of the grid.
 template <int K, int Q, int HQ>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 5 ? 5 : (K <= 8 ? 4 : (K <= 12 ? 3 : 2)), 8))) void pt2pl_tile_kernel(const PlArgs a, const uint32_t n_hard_tiles)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 4 : (K <= 12 ? 3 : 2), 8))) void pt2pl_tile_kernel(const PlArgs a, const uint32_t n_hard_tiles)
 {
     __shared__ float4   s_cand[PL_CAP];
     __shared__ uint32_t s_spos[PL_CAP];
@@ -1044,8 +1045,9 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     const size_t   n_l     = cloud->n;
     // tile size: see pt2pl_tile_kernel (MP2P_HIP_TUNE pl_q = 8 / 32 forces one)
     // (round 2 took 32-query tiles above 400 k points; with the insertions bounded by the pass radius and the filtered
-    //  staging the 8-query tile wins at every size: 1 M queries 1.10..1.47 ms with 32, 0.75..0.88 ms with 8)
-    const uint32_t Q       = ctx->tune.pl_q ? ctx->tune.pl_q : 8u;
+    //  staging the 8-query tile also wins at 1 M queries: 1.10..1.47 ms with 32, 0.75..0.88 ms with 8.  At 5 M queries
+    //  with 30 % uniform outliers -- BASELINE C5 -- 32 is still 10 % ahead: 7.8 vs 8.7 ms per step)
+    const uint32_t Q       = ctx->tune.pl_q ? ctx->tune.pl_q : (n_l <= 2000000 ? 8u : (uint32_t)PL_Q);
     const uint32_t n_cblocks = (uint32_t)((n_l + PL_CB - 1) / PL_CB);
     const uint32_t n_boxes   = n_cblocks * (PL_CB / 64);  // one bounding box per wave of pt2pl_cert_kernel
     const uint32_t Kcap    = prm->knn <= 5 ? 5u : prm->knn <= 8 ? 8u : prm->knn <= 12 ? 12u : 16u;

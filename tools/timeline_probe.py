@@ -2,7 +2,7 @@
 """Occupancy over time of the two search kernels on the bench workload (profiling level 4):
 how many workgroups are resident in each slice of the kernel's duration, the share of the time
 spent below half of the peak residency (the tail), and the duration distribution of the tiles.
-usage: timeline_probe.py [n_local n_global]"""
+usage: timeline_probe.py [n_local n_global [scene a|b]]"""
 import json
 import os
 import sys
@@ -16,7 +16,8 @@ from mp2p_icp_amd import _lib, core  # noqa: E402
 
 n_l = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 n_g = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
-d = bench.build_inputs(n_l, n_g, 1, 0, 1)
+scene = sys.argv[3] if len(sys.argv) > 3 else "b"
+d = bench.build_inputs(n_l, n_g, 1, 0, 1, scene)
 ctx = amd.Context(0)
 g, l = d["glob"], d["local"]
 gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])

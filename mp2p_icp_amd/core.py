@@ -24,6 +24,13 @@ def _pose(T):
     return T
 
 
+def _free_child(ctx, free_fn, handle):
+    """finalizer of a map / cloud / MatchState / Pairings handle.  It holds the Context OBJECT, not its raw handle: the
+    garbage collector finalizes unreachable objects in no particular order, and a context destroyed before one of its
+    children made the child's free call run on freed memory (one aborted test run in round 3)."""
+    free_fn(ctx.handle, handle)
+
+
 class Context:
     """One HIP stream on one device.  stream=None: the context creates its own (non-blocking)
     stream.  Otherwise `stream` is a raw hipStream_t (int), e.g.
@@ -99,7 +106,7 @@ class GlobalMap:
                                         C.byref(h)), ctx.handle)
             self.n = x.size
         self._h = h
-        self._fin = weakref.finalize(self, L.mp2p_hip_map_free, ctx.handle, h)
+        self._fin = weakref.finalize(self, _free_child, ctx, L.mp2p_hip_map_free, h)
 
     @property
     def handle(self):
@@ -134,7 +141,7 @@ class LocalCloud:
                   ctx.handle)
             self.n = x.size
         self._h = h
-        self._fin = weakref.finalize(self, L.mp2p_hip_cloud_free, ctx.handle, h)
+        self._fin = weakref.finalize(self, _free_child, ctx, L.mp2p_hip_cloud_free, h)
 
     @property
     def handle(self):
@@ -159,7 +166,7 @@ class DeviceMatchState:
         h = C.c_void_p()
         check(ctx._L.mp2p_hip_mstate_create(ctx.handle, n_global, n_local, C.byref(h)), ctx.handle)
         self._h = h
-        self._fin = weakref.finalize(self, ctx._L.mp2p_hip_mstate_free, ctx.handle, h)
+        self._fin = weakref.finalize(self, _free_child, ctx, ctx._L.mp2p_hip_mstate_free, h)
 
     @property
     def handle(self):
@@ -194,7 +201,7 @@ class DevicePairs:
         check(ctx._L.mp2p_hip_pairs_create(ctx.handle, self.cap_pt2pt, self.cap_pt2pl, C.byref(h)),
               ctx.handle)
         self._h = h
-        self._fin = weakref.finalize(self, ctx._L.mp2p_hip_pairs_free, ctx.handle, h)
+        self._fin = weakref.finalize(self, _free_child, ctx, ctx._L.mp2p_hip_pairs_free, h)
 
     @property
     def handle(self):

@@ -754,6 +754,11 @@ int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
             ctx->stats.nn_cells_visited = c[7];
             for (int i = 0; i < 24; i++) ctx->stats.nn_tile_ticks_hist[i] = c[16 + i];
             ctx->stats.nn_single_max_candidates = c[49];  // the slowest tile: ticks << 40 | passes << 32 | candidates
+            std::vector<unsigned char> t(map->n);
+            MP2P_TRY_HIP(ctx, hipMemcpy(t.data(), ctx->scratch[15].p, t.size(), hipMemcpyDeviceToHost));
+            uint64_t k = 0;
+            for (unsigned char b : t) k += b;
+            ctx->stats.nn_points_staged = k;  // distinct map points fetched by the search (N_g,touched)
         }
     }
     return rc;

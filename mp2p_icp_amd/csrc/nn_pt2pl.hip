@@ -73,6 +73,7 @@ struct PlArgs
     uint32_t             hard_cand;  // a query whose tile staged at least this many goes to the hard class (0: no classes)
     float                rad_cert, cert_margin;
     int                  use_cert;
+    unsigned char*       touched;   // profiling level 2: one byte per map point (sorted position), set when the point is fetched
     uint32_t             timeline_n; // tiles in the grid; after their {start, end}: one word {passes << 48 | voxels << 32 | candidates} each
     unsigned long long*  timeline;  // profiling level 4: {start, end} 100 MHz ticks per tile of pt2pl_tile_kernel (0 0: an empty tile)
 };
@@ -164,7 +165,7 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                                            uint32_t* s_coff, float (&kd2)[K], uint32_t (&kidx)[K],
                                            uint32_t (&kspos)[K], float grp_min = 0.f, float* lb_out = nullptr,
                                            float cert_margin = 0.f, unsigned long long* tl_info = nullptr,
-                                           uint32_t* cand_out = nullptr)
+                                           uint32_t* cand_out = nullptr, unsigned char* touched = nullptr)
 {
     float r    = fminf(r0, rmax);
     bool  done = !active;
@@ -362,6 +363,12 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                 float4 c[PL_STAGE];
 #pragma unroll
                 for (int u = 0; u < PL_STAGE; u++) c[u] = g.pts[src[u]];
+                if (touched)
+                {
+#pragma unroll
+                    for (int u = 0; u < PL_STAGE; u++)
+                        if ((uint32_t)lane + 64u * (uint32_t)u < m) touched[src[u]] = 1;
+                }
 #pragma unroll
                 for (int u = 0; u < PL_STAGE; u++)
                 {
@@ -598,7 +605,7 @@ __device__ __forceinline__ void pt2pl_tile_body(const PlArgs& a, const uint32_t*
     knn_search<K, false, Q, true>(g, lane, qx, qy, qz, active, a.radSq, a.rad_cert, r0, a.knn,
                                   a.grp_factor, a.cell_budget, a.dbg, s_hit, s_cand, s_spos, s_cstart, s_coff, kd2, kidx, kspos,
                                   a.grp_min, &lb, a.cert_margin, a.timeline ? a.timeline + 2 * (size_t)a.timeline_n + tile_id : nullptr,
-                                  &ncand);
+                                  &ncand, a.touched);
     if (a.timeline && lane == 0) a.timeline[2 * (size_t)tile_id] = tl0, a.timeline[2 * (size_t)tile_id + 1] = wall_clock64();
     // the neighbour list (sorted positions, ascending (d2, idx); NONE beyond its end) for the fit kernel
     if (!valid || lane >= Q) return;
@@ -1116,12 +1123,16 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     // the certificate of such a query has before a point outside its list could come into reach (0.2 % without it)
     a.rad_cert = a.rad * (1.0f + 0.001f * (float)(ctx->tune.pl_cert ? std::max(2u, ctx->tune.pl_cert_pad) : 2u)) + map->view.slack;
     a.cert_margin = ctx->tune.pl_cert ? 0.001f * (float)ctx->tune.pl_cert_margin_mm : 0.f;
-    a.dbg = nullptr;
+    a.dbg = nullptr, a.touched = nullptr;
     if (ctx->profiling == 2)
     {
         MP2P_TRY_HIP(ctx, ctx->counters.ensure(64));
         MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64 * sizeof(unsigned long long), ctx->stream));
         a.dbg = ctx->counters.p;
+        // N_g,touched of SURVEY.md 8d, exactly: a byte per map point, set by the staging loop (scratch slot 15)
+        MP2P_TRY_HIP(ctx, ctx->scratch[15].ensure(map->n ? map->n : 1));
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->scratch[15].p, 0, map->n, ctx->stream));
+        a.touched = ctx->scratch[15].p;
     }
 
     a.timeline = nullptr;

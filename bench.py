@@ -400,6 +400,62 @@ def host_boundary(args, d, dev_ms):
     return out
 
 
+def cpu_baseline_config(d, which, cores):
+    """cpu_baseline of a --config line: the oracle's matcher(s) + solver of that configuration on this host's cores (and
+    the sequential loop on a tenth of the sample), mean of the initial-guess and the converged pose, on a bounded sample of
+    the local layer against the full map; the KD-tree build is excluded (amortised per map)."""
+    import oracle as orc
+    g, l = d["glob"], d["local"]
+    t0 = time.time()
+    tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    t_build = time.time() - t0
+    gxyz = (g[:, 0], g[:, 1], g[:, 2])
+
+    def run(n_s, threads):
+        ls = l[np.linspace(0, l.shape[0] - 1, n_s).astype(np.int64)]
+        lxyz = (ls[:, 0], ls[:, 1], ls[:, 2])
+        tm = ts = 0.0
+        for pose in (d["T_init"], d["T_gt"]):
+            t0 = time.time()
+            pt = pl = None
+            if which == "c2":
+                pt, _ = orc.match_pt2pt(*gxyz, *lxyz, pose, 2.0, 0.0, tree=tree, threads=threads)
+            elif which == "c3":
+                pl, _, _ = orc.match_pt2pl(*gxyz, *lxyz, pose, 0.4, 0.4, 5, 5, 0.05, tree=tree, threads=threads)
+            else:  # c5: the plane matcher, then the point matcher on what it left (sequential semantics: one thread)
+                lt, gt = np.zeros(ls.shape[0], np.uint8), np.zeros(g.shape[0], np.uint8)
+                pl, _, _ = orc.match_pt2pl(*gxyz, *lxyz, pose, 0.25, 0.4, 5, 5, 0.05, tree=tree, local_taken=lt)
+                pt, _ = orc.match_pt2pt(*gxyz, *lxyz, pose, 1.0, 0.0, tree=tree, local_taken=lt, global_taken=gt)
+            tm += time.time() - t0
+            t0 = time.time()
+            if which == "c2":
+                orc.optimal_tf_horn_wp(pt, None)
+            else:
+                prm = orc.make_gn_params(3, kernel=orc.KERNEL_CAUCHY if which == "c5" else orc.KERNEL_GEMANMCCLURE, kernelParam=0.15)
+                orc.optimal_tf_gauss_newton(pt, pl, None, pose, prm, threads=threads)
+            ts += time.time() - t0
+        scale = l.shape[0] / n_s
+        return 1.0 / ((tm + ts) / 2 * scale), tm / 2 * scale, ts / 2 * scale
+
+    if which == "c5":  # the coupled matchers only exist as the sequential loop in the oracle
+        n_1 = min(20_000, l.shape[0])
+        v1, tm1, ts1 = run(n_1, 0)
+        return {"value": v1, "unit": "iterations/s", "cores": 1, "kind": "port",
+                "sample": f"{n_1} of {l.shape[0]} local points (uniform subsample) vs the full {g.shape[0]}-point map, sequential loop; "
+                          f"mean of initial-guess and converged pose; KD-tree build {t_build:.1f}s excluded",
+                "matcher_s_per_iteration": tm1, "solver_s_per_iteration": ts1}
+    n_s = min(200_000, l.shape[0])
+    v, tm, ts = run(n_s, cores)
+    n_1 = min(max(2000, n_s // 10), l.shape[0])
+    v1, tm1, ts1 = run(n_1, 0)
+    return {"value": v, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{n_s} of {l.shape[0]} local points vs the full {g.shape[0]}-point map; mean of initial-guess and "
+                      f"converged pose; KD-tree build {t_build:.1f}s excluded (amortised per map)",
+            "matcher_s_per_iteration": tm, "solver_s_per_iteration": ts,
+            "single_thread": {"value": v1, "unit": "iterations/s", "cores": 1, "sample": f"{n_1} of {l.shape[0]} local points, sequential loop",
+                              "matcher_s_per_iteration": tm1, "solver_s_per_iteration": ts1}}
+
+
 # ---------------------------------------------------------------------------------------------------
 def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
     """--config c2|c3|c5: the other BASELINE configs as bench lines of their own.  c3 also runs sharded (--gpus N under
@@ -534,6 +590,9 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
     out_bytes = 8.0 * n_l if which == "c2" else 72.0 * float(np.mean(npl)) + (8.0 * n_l if which == "c5" else 0.0)
     alg = 12.0 * n_l * (2 if which == "c5" else 1) + 12.0 * touched_lb + out_bytes
     ach = alg / (nn_ms * 1e-3) / 1e9
+    cpu = None
+    if not args.no_cpu_baseline and world == 1 and sharded is None:
+        cpu = cpu_baseline_config(d, which, min(256, os.cpu_count() or 1))
     return {
         # N > 1: one step registers `world` scan-sized shards jointly (one pose, one 6x6 system); as on the default
         # line the unit is one iteration over ONE scan-sized layer, hence world / t_step
@@ -557,6 +616,7 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
                      "n_g_touched": touched_lb, "n_g_touched_exact": touched_exact is not None,
                      "note": ("N_g,touched counted by the instrumented search (a byte per map point fetched)" if touched_exact is not None else
                               "N_g,touched replaced by its lower bound (the pairs' own neighbours): frac is a lower bound")},
+        **({"cpu_baseline": cpu} if cpu is not None else {}),
     }
 
 

@@ -10,7 +10,9 @@ real ICP chain (step s starts from the pose step s-1 produced, restarting from t
 initial guess every 10 steps), and every step ends with the 96-byte pose read-back the
 reference's outer loop needs for its termination test.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scene a|b] [--config c2|c3|c5]
+(--config lines: the other BASELINE configurations, each with its own roofline and cpu_baseline; c3 also runs sharded
+ under --gpus N: mp2p_hip_step_sharded_pt2pl)
 
 The default line (no --config) carries, next to the contract's fields:
   roofline       the search kernels (K1+K3) against the HBM roofline

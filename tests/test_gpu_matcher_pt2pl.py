@@ -249,3 +249,66 @@ def test_certificate_pose_sequence(amd, oracle, knn, radius):
     assert per_call[0] == 0                      # nothing to go by at the first call
     assert per_call[4] > 0.3 * l.shape[0], per_call  # 0.1 mm steps: a good share of the queries is certified
     assert per_call[7] < per_call[5], per_call   # the 3 cm jump leaves (next to) nothing certified
+
+
+def _pl_prm(radius=0.4, knn=5):
+    from mp2p_icp_amd import _lib
+    prm = _lib.Pt2PlParams()
+    prm.distanceThreshold, prm.searchRadius, prm.knn, prm.minimumPlanePoints, prm.planeEigenThreshold = 0.25, radius, knn, 5, 0.05
+    prm.bounding_box_intersection_check_epsilon = 0.20
+    return prm
+
+
+def _pl_equal(oracle, core, ctx, gmap, cloud, pairs, g, l, pose, tree, radius=0.4, knn=5, idxs=None):
+    want, widx, _ = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.25, radius, knn, 5, 0.05,
+                                       tree=tree, idxs=idxs)
+    pairs.clear()
+    core.match_pt2pl(ctx, gmap, cloud, pose, _pl_prm(radius, knn), None, pairs)
+    got, gidx = pairs.download_pt2pl()
+    assert np.array_equal(gidx, widx), (len(gidx), len(widx))
+    if len(got):
+        assert np.allclose(got["plane"], want["plane"], rtol=0, atol=1e-9)
+    return len(widx)
+
+
+@pytest.mark.parametrize("n_local", [1, 7, 9, 64, 65, 257, 513])
+def test_certificate_tiny_layers(amd, oracle, n_local):
+    """query lists, their padding and the certificate on layers of a few points (one partial block, one partial tile)"""
+    from mp2p_icp_amd import core, synthetic
+    d = synthetic.make_pair(2000, 150000, 31)
+    g, l = d["glob"], np.ascontiguousarray(d["local"][:: max(1, 2000 // n_local)][:n_local])
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    ctx = amd.Context(0)
+    gmap, cloud = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2]), core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    pairs = core.DevicePairs(ctx, 0, l.shape[0])
+    pose = d["T_gt"]
+    for k in range(4):
+        _pl_equal(oracle, core, ctx, gmap, cloud, pairs, g, l, pose, tree)
+        pose = amd.se3.compose(pose, amd.se3.exp(np.array([2e-4, -1e-4, 1e-4, 0, 0, 2e-5])))
+
+
+def test_hard_class_overflow_and_visit_order_changes(amd, oracle, monkeypatch):
+    """every query in the hard class (threshold 1): the hard list overflows its capacity (an eighth of the layer) and the
+    rest stays in the easy class; then a visit list that changes between calls -- a point that was not visited has no
+    certificate and goes through the search"""
+    from mp2p_icp_amd import core, synthetic
+    monkeypatch.setenv("MP2P_HIP_TUNE", "pl_hard_cand=1")
+    d = synthetic.make_pair(6000, 300000, 41)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    ctx = amd.Context(0)
+    gmap, cloud = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2]), core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    pairs = core.DevicePairs(ctx, 0, l.shape[0])
+    pose, n = d["T_gt"], 0
+    for k in range(4):
+        n += _pl_equal(oracle, core, ctx, gmap, cloud, pairs, g, l, pose, tree)
+        pose = amd.se3.compose(pose, amd.se3.exp(np.array([3e-4, 1e-4, -1e-4, 0, 0, 3e-5])))
+    assert n > 1000
+    rng = np.random.default_rng(5)
+    for k in range(4):
+        order = rng.permutation(l.shape[0])[: 2500 + 500 * k].astype(np.uint32)
+        cloud.set_visit_order(order)
+        _pl_equal(oracle, core, ctx, gmap, cloud, pairs, g, l, pose, tree, idxs=order)
+        pose = amd.se3.compose(pose, amd.se3.exp(np.array([1e-4, 1e-4, 0, 0, 0, 1e-5])))
+    cloud.set_visit_order(None)
+    _pl_equal(oracle, core, ctx, gmap, cloud, pairs, g, l, pose, tree)

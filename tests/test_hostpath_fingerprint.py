@@ -22,3 +22,15 @@ def test_list_fingerprint(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_layer_cache_against_a_mock_library(tmp_path):
+    """Runtime's device-object cache (LRU, byte budget, re-seen / edited layers, release hooks) driven on the CPU
+    against a mock of the C-ABI calls it makes: tests/cpp/layer_cache_check.cpp"""
+    exe = str(tmp_path / "layer_cache_check")
+    cmd = ["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "adapter"),
+           os.path.join(ROOT, "tests", "cpp", "layer_cache_check.cpp"), "-o", exe, "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-3000:] + r.stderr[-1000:]

@@ -808,7 +808,8 @@ def main():
                       # launch of the first kernel + dependent-dispatch gaps + pose read-back + host wake-up; a
                       # captured hipGraph does not shorten it (profiles/r03_graph_probe.txt: 12 dependent kernels
                       # 30 us on a stream, 34 us as a graph, 15 us for ONE kernel)
-                      "step_minus_kernels": float(np.median(step_s)) * 1e3 - (nn_ms_avg + float(np.mean(rp["compact"])) + float(np.mean(rp["gn"])))},
+                      # (means on both sides: the search time is the mean over the timed steps, cold restart steps included)
+                      "step_minus_kernels": float(np.mean(step_s)) * 1e3 - (nn_ms_avg + float(np.mean(rp["compact"])) + float(np.mean(rp["gn"])))},
         "nn_stats": {"pending_after_prologue_frac": float(np.mean([r["pending"] for r in rows])) / n_l,
                      "finished_without_search_frac": float(np.mean([r["skipped"] for r in rows])) / n_l,
                      "deferred_to_one_query_kernel_frac": float(np.mean([r["deferred"] for r in rows])) / n_l,

@@ -315,6 +315,17 @@ void mp2p_hostpath_set_strict(int on)
     {
     }
 }
+// Runtime::trust_reseen (MP2P_HIP_HOST_TRUST_RESEEN): re-seen layers are re-verified on a stride at ICP iteration 0
+void mp2p_hostpath_set_trust_reseen(int on)
+{
+    try
+    {
+        Runtime::get().trust_reseen = on != 0;
+    }
+    catch (...)
+    {
+    }
+}
 void mp2p_hostpath_invalidate_layers(void)
 {
     try

@@ -85,9 +85,11 @@ inline uint64_t hash_span(const float* p, size_t n)
     }
     return h;
 }
-inline uint64_t full_fingerprint(const float* x, const float* y, const float* z, size_t n, unsigned threads = 8)
+inline uint64_t full_fingerprint(const float* x, const float* y, const float* z, size_t n, unsigned threads = 0)
 {
     if (n == 0) return 0;
+    // memory-bound: 120 MB for a 10 M-point layer; the host's memory system wants more than a handful of readers
+    if (threads == 0) threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     threads = std::max(1u, std::min<unsigned>(threads, (unsigned)(n / 65536 + 1)));
     std::vector<uint64_t>    part(3 * threads, 0);
     std::vector<std::thread> th;
@@ -233,6 +235,7 @@ class Runtime
             mp2p_hip_map_info info;
             if (mp2p_hip_map_get_info(ctx, h, &info) == 0) e.bytes = (size_t)info.device_bytes;
             n_map_uploads++;
+            evict(key);  // the byte budget again, now that this layer's bytes count
         }
         return (mp2p_hip_map*)e.handle;
     }
@@ -250,6 +253,7 @@ class Runtime
             check(mp2p_hip_cloud_upload(ctx, x, y, z, n, &h));
             e.handle = h, e.bytes = n * 44;  // sorted copy + SoA + two index arrays
             n_cloud_uploads++;
+            evict(key);
         }
         return (mp2p_hip_cloud*)e.handle;
     }
@@ -334,6 +338,10 @@ class Runtime
     size_t n_map_uploads = 0, n_cloud_uploads = 0, n_mstate_uploads = 0, n_pair_uploads = 0;
     // every solver call uploads the host Pairings (see ListPrint)
     bool strict = std::getenv("MP2P_HIP_HOST_STRICT") && std::getenv("MP2P_HIP_HOST_STRICT")[0] == '1';
+    // opt-in: a layer verified in full before is re-verified on every 61st point only at later ICP
+    // iteration-0 calls.  Off by default: an in-place edit between two align() calls that misses the stride would be
+    // matched against the stale device copy, which the reference (it queries the live map) never does.
+    bool trust_reseen = std::getenv("MP2P_HIP_HOST_TRUST_RESEEN") && std::getenv("MP2P_HIP_HOST_TRUST_RESEEN")[0] == '1';
     // page-locked scratch for the index arrays of the pairs a matcher call appended
     uint32_t* idx_scratch(size_t n)
     {
@@ -374,23 +382,32 @@ class Runtime
         };
         for (;;)
         {
-            const bool over_n = maps_.size() > max_layers || clouds_.size() > max_layers, over_b = cached_bytes() > byte_budget;
-            if (!over_n && !over_b) return;
+            const bool over_m = maps_.size() > max_layers, over_c = clouds_.size() > max_layers, over_b = cached_bytes() > byte_budget;
+            if (!over_m && !over_c && !over_b) return;
             auto im = oldest(maps_), ic = oldest(clouds_);
-            const bool take_map = im != maps_.end() && (ic == clouds_.end() || (maps_.size() > max_layers) ||
-                                                        (!(clouds_.size() > max_layers) && im->second.last_use < ic->second.last_use));
-            if (take_map)
+            // the container that is over ITS count pays (freeing entries of the other kind would not help it); the byte
+            // budget takes the least recently used entry of either kind; nothing evictable (everything left belongs
+            // to the running call) ends the loop
+            int take = 0;  // 1 = a map, 2 = a cloud
+            if (over_m && im != maps_.end()) take = 1;
+            else if (over_c && ic != clouds_.end()) take = 2;
+            else if (over_b)
+            {
+                if (im != maps_.end() && (ic == clouds_.end() || im->second.last_use < ic->second.last_use)) take = 1;
+                else if (ic != clouds_.end()) take = 2;
+            }
+            if (take == 1)
             {
                 if (im->second.handle) mp2p_hip_map_free(ctx, (mp2p_hip_map*)im->second.handle);
                 maps_.erase(im);
             }
-            else if (ic != clouds_.end())
+            else if (take == 2)
             {
                 if (ic->second.handle) mp2p_hip_cloud_free(ctx, (mp2p_hip_cloud*)ic->second.handle);
                 clouds_.erase(ic);
             }
             else
-                return;  // nothing evictable
+                return;
             token = Token();
             n_evictions++;
         }
@@ -401,10 +418,11 @@ class Runtime
     size_t n_evictions = 0, n_full_checks = 0, n_reseen_checks = 0;
 
    private:
-    // full_check (ICP iteration 0): a layer seen for the FIRST time at this address is hashed in full (120 MB for
-    // the bench map: 5.5 ms); one that was verified in full before and still has the same address, size and 1024-point
-    // print is re-verified on every 61st point (0.2 M points: ~0.1 ms) -- QualityEvaluator_PairedRatio and every new
-    // ICP::align on the same map call the matcher at iteration 0 again.  MP2P_HIP_HOST_STRICT = always full.
+    // full_check (ICP iteration 0): the layer is hashed in full (120 MB for the bench map, spread over up to 32 threads)
+    // -- what the reference's nn_prepare_for_3d_queries() after mark_as_modified() amounts to here, since the layer's
+    // modification flag is not visible from outside MRPT.  With trust_reseen (MP2P_HIP_HOST_TRUST_RESEEN=1) a layer that
+    // was verified in full before and still has the same address, size and 1024-point print is re-verified on every
+    // 61st point only (~0.1 ms): for hosts that call release_layer() / invalidate_layers() when they edit a layer.
     static uint64_t strided_fingerprint(const float* x, const float* y, const float* z, size_t n)
     {
         uint64_t h = n;
@@ -420,7 +438,7 @@ class Runtime
     {
         const uint64_t s = sampled_fingerprint(x, y, z, n);
         bool           ok = e.handle && e.n == n && e.sampled == s;
-        if (ok && full_check && e.full_known && !strict)
+        if (ok && full_check && e.full_known && trust_reseen && !strict)
         {
             const uint64_t m = strided_fingerprint(x, y, z, n);
             if (e.strided_known && e.strided == m)

@@ -225,30 +225,13 @@ def instrumented(rig, n_steps, rank, tag):
                          maxpass=st["nn_max_passes_one_tile"], pending=st["nn_lane_pending"],
                          skipped=st["nn_lane_skipped"], deferred=st["nn_single_queries"],
                          err_t=float(np.linalg.norm(_e[:3])), err_r=float(np.linalg.norm(_e[3:]))))
-        rows[-1]["wave"] = None
-        if st.get("nn_wave_path"):
-            tk = st["nn_wave_phase_ticks"]
-            rows[-1]["wave"] = dict(lane_tests=st["nn_wave_lane_tests"], maxlane_tests=st["nn_wave_maxlane_tests"],
-                                    inserts=st["nn_wave_inserts"], overflows=st["nn_wave_overflows"],
-                                    rounds=st["nn_wave_rounds"], toobig=st["nn_wave_toobig"], waves=st["nn_tiles"],
-                                    listed=st["nn_cells_visited"], staged=st["nn_candidates_tested"],
-                                    wave_ticks_sum=st["nn_tile_ticks_sum"], wave_ticks_max=st["nn_tile_ticks_max"],
-                                    phase_ticks=dict(zip(("prologue", "voxel_set", "directory", "staging", "walks", "emit"), tk)))
         log(f"[bench r{rank}] {tag} chain step {st_['s']}: err=({rows[-1]['err_t']:.3f} m, "
             f"{np.degrees(rows[-1]['err_r']):.2f} deg) pairs={rig.pairs.counts()[0]} "
             f"pending={st['nn_lane_pending']} finished-without-search={st['nn_lane_skipped']} "
             f"deferred={st['nn_single_queries']} single_cand/q="
             f"{st['nn_single_candidates'] / max(1, st['nn_single_queries']):.0f} "
             f"tile_cand/tile={st['nn_candidates_tested'] / max(1, st['nn_tiles']):.0f} "
-            f"passes/tile={st['nn_passes'] / max(1, st['nn_tiles']):.2f}"
-            + (f" | wave: tests/q={st['nn_wave_lane_tests'] / max(1, st['nn_lane_pending']):.1f} "
-               f"maxlane/wave={st['nn_wave_maxlane_tests'] / max(1, st['nn_tiles']):.0f} "
-               f"listed/wave={st['nn_cells_visited'] / max(1, st['nn_tiles']):.1f} "
-               f"rounds/wave={st['nn_wave_rounds'] / max(1, st['nn_tiles']):.2f} ovf={st['nn_wave_overflows']} "
-               f"toobig={st['nn_wave_toobig']} us/wave={st['nn_tile_ticks_sum'] / max(1, st['nn_tiles']) / 100:.2f} "
-               f"(max {st['nn_tile_ticks_max'] / 100:.1f}) phase_us/wave="
-               f"{[round(t / max(1, st['nn_tiles']) / 100, 2) for t in st['nn_wave_phase_ticks']]}"
-               if st.get("nn_wave_path") else ""))
+            f"passes/tile={st['nn_passes'] / max(1, st['nn_tiles']):.2f}")
         st_["pose"], _ = rig.reg.solve(st_["pose"])
         st_["s"] += 1
     rig.ctx.set_profiling(0)
@@ -340,7 +323,7 @@ def roofline_block(n_l, touched_mean, nn_ms_avg, tag):
         for r in csv.DictReader(open(f)):
             # the three search launches of the timed path (INSTR = false variants; the instrumented ones
             # only run in the counting replay)
-            if re.search(r"mp2p::nn_(lane_kernel<false>|tile_kernel<\d+, false|single_kernel<false|wave_kernel<false)", r["kernel"]):
+            if re.search(r"mp2p::nn_(lane_kernel<false>|tile_kernel<\d+, false|single_kernel<false)", r["kernel"]):
                 t += float(r["fetch_bytes_avg_corrected_x2"]) + float(r["write_bytes_avg"])
         if t > 0:
             out["traffic_from_profiles"] = t

@@ -580,13 +580,9 @@ typedef struct
      * finished without any search */
     double   ms_nn_lane;
     uint64_t nn_lane_searched, nn_lane_candidates, nn_lane_voxels, nn_lane_pending, nn_lane_skipped;
-    /* nn_wave_kernel (round 3; then nn_tiles = waves, nn_candidates_tested = points staged summed over
-     * waves, nn_cells_visited = voxels listed, nn_lane_pending = queries that needed a search):
-     * candidates tested summed over lanes / summed longest lane of every walk (what the waves waited
-     * for), voxel insertions, lanes that could not place a voxel, staging rounds, queries handed on for
-     * their cube's width, and 100 MHz ticks per phase summed over waves
-     * {prologue, voxel set, directory, staging, walks, records + claims} */
-    uint64_t nn_wave_path; /* 1: the last pt2pt search ran nn_wave_kernel */
+    /* reserved, always 0: the counters of round 3's one-launch search kernel (nn_wave_kernel), which was measured
+     * slower on both bench scenes and removed from the library in round 4; kept so that the struct keeps its layout */
+    uint64_t nn_wave_path;
     uint64_t nn_wave_lane_tests, nn_wave_maxlane_tests, nn_wave_inserts, nn_wave_overflows, nn_wave_rounds;
     uint64_t nn_wave_toobig;
     uint64_t nn_wave_phase_ticks[6];

@@ -55,7 +55,6 @@ static void parse_tune(Tune& t)
             const long        v = strtol(kv.c_str() + q + 1, nullptr, 10);
             if (k == "lane_cells") t.lane_cells = (uint32_t)v;
             else if (k == "tile_cand_cap") t.tile_cand_cap = (uint32_t)v;
-            else if (k == "tile_time_cap_us") t.tile_time_cap_us = (uint32_t)v;
             else if (k == "hard_radius_pct") t.hard_radius_pct = (uint32_t)v;
             else if (k == "sync_spin") t.sync_spin = (int)v;
             else if (k == "pl_cert") t.pl_cert = (int)v;
@@ -74,11 +73,12 @@ static void parse_tune(Tune& t)
             else if (k == "dir_budget_mb") t.dir_budget_mb = (uint32_t)v;
             else if (k == "claim_peek") t.claim_peek = (int)v;
             else if (k == "compact_fused") t.compact_fused = (int)v;
-            else if (k == "wave_kernel") t.wave_kernel = (int)v;
-            else if (k == "predict") t.predict = (int)v;
-            else if (k == "wave_mfma") t.wave_mfma = (int)v;
             else if (k == "pl_warm") t.pl_warm = (int)v;
-            else if (k == "wave_levels") t.wave_levels = (uint32_t)v;
+            else if (k == "tile_bricks") t.tile_bricks = (int)v;
+            else if (k == "tile_brick_budget") t.tile_brick_budget = (uint32_t)v;
+            else if (k == "hard_cand") t.hard_cand = (uint32_t)v;
+            else if (k == "copy_chunk_kb") t.copy_chunk_kb = (uint32_t)v;
+            else if (k == "copy_stage_mb") t.copy_stage_mb = (uint32_t)v;
             else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
         }
         i = j + 1;
@@ -182,12 +182,13 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->aos_stage.release(), ctx->pl_slots.release(), ctx->pl_knn.release();
     ctx->work.release(), ctx->work_q.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();
     ctx->pend.release(), ctx->pend_q.release(), ctx->q_counters.release(), ctx->nn_rec.release();
-    ctx->pred_buf[0].release(), ctx->pred_buf[1].release(), ctx->pl_kth.release();
+    ctx->pl_kth.release();
     ctx->pl_lb.release(), ctx->pl_cost.release(), ctx->pl_hard.release(), ctx->pl_pend.release(), ctx->pl_pend_cnt.release(), ctx->pl_cert_stat.release();
     for (auto& b : ctx->scratch) b.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     (void)mp2p_hip_pairs_copy_end(ctx);
+    mp2p::stage_destroy(ctx);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -1058,10 +1059,6 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
             ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1];
             ctx->stats.nn_cells_visited = c[2], ctx->stats.nn_candidates_tested = c[3];
             ctx->stats.nn_unresolved_after_first_pass = c[4];
-            ctx->stats.nn_wave_lane_tests = c[NWC_LANE_TESTS], ctx->stats.nn_wave_maxlane_tests = c[NWC_MAXLANE];
-            ctx->stats.nn_wave_inserts = c[NWC_INSERTS], ctx->stats.nn_wave_overflows = c[NWC_OVF];
-            ctx->stats.nn_wave_rounds = c[NWC_ROUNDS], ctx->stats.nn_wave_toobig = c[NWC_TOOBIG];
-            for (int i = 0; i < 6; i++) ctx->stats.nn_wave_phase_ticks[i] = c[NWC_T_PRO + i];
             ctx->stats.nn_max_candidates_one_tile = c[5], ctx->stats.nn_max_passes_one_tile = c[6];
             std::vector<unsigned char> t(ctx->pending_map_n);
             MP2P_TRY_HIP(ctx, hipMemcpy(t.data(), ctx->pl_slots.p, t.size(), hipMemcpyDeviceToHost));
@@ -1069,7 +1066,6 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
             for (unsigned char b : t) k += b;
             ctx->stats.nn_points_staged = k;
         }
-        ctx->stats.nn_wave_path = (uint64_t)ctx->last_wave_path;
         if (ctx->pending_pl && ctx->pl_cert_stat.p)
         {
             unsigned long long c2[2];

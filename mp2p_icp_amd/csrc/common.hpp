@@ -1,6 +1,9 @@
 // common.hpp -- internal declarations shared by the HIP translation units of libmp2p_hip.so
 // (gfx950 only; no CUDA shims, no host fallback).
 #pragma once
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -62,9 +65,9 @@ constexpr unsigned long long DIR_NONE = ~0ull;
 // ---------------------------------------------------------------------------------------
 // device allocations made through DevBuf since the library was loaded (mp2p_hip_debug_alloc_count: tests assert that a
 // steady-state iteration of a solver / matcher makes none)
-inline unsigned long long& dev_alloc_counter()
+inline std::atomic<unsigned long long>& dev_alloc_counter()
 {
-    static unsigned long long c = 0;
+    static std::atomic<unsigned long long> c{0};  // one context per thread / GPU: incremented concurrently
     return c;
 }
 
@@ -121,7 +124,11 @@ struct Tune
                                     // itself; 0 = none (measured: per-lane 16-byte gathers cost one L1 line each,
                                     // the tile kernel's coalesced staging serves the same queries 2.5x cheaper)
     uint32_t tile_cand_cap = 6144;  // staged candidates after which a tile hands its pending queries on
-    uint32_t tile_time_cap_us = 50; // ... and microseconds after which it does
+    int      tile_bricks   = 1;     // tile kernel: wide groups list their voxels from the level-0 occupancy bricks and stay in
+                                    // the tile (0 = round 3: a query beyond the deferral radius goes to the one-query kernel)
+    uint32_t tile_brick_budget = 512;  // ... when the group's box spans at most this many bricks
+    uint32_t hard_cand     = 2000;  // a query whose tile staged this many candidates at the previous call joins the hard class
+                                    // (dispatched first) whatever its radius; 0 = by radius only
     uint32_t hard_radius_pct = 100; // pending queries with a radius above this % of a level-0 voxel are "hard":
                                     // their tiles are dispatched first (nn_query.hip)
     int      xcd_map       = 1;     // tile kernel: one segment of the pending list per XCD (L2 locality)
@@ -142,21 +149,13 @@ struct Tune
                                     // time on scene B, +4 % on scene A
     int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
-    uint32_t wave_levels   = 0;     // nn_wave_kernel: coarsest grid level of its wide-radius groups (measured worse above 0)
     int      pl_warm       = 1;     // point-to-plane search: start radius from the previous call's k-th distance (0 = full radius)
     int      pl_cert       = 2;     // pt2pl: skip the search of a query whose previous list is certainly still its k nearest (PlArgs::lb_io)
     uint32_t pl_cert_pad   = 2;     // ... searchRadius + this many per mille is what a search that comes up short asks for
     uint32_t pl_cert_margin_mm = 20; // ... voxels up to this far beyond the search radius of a pass are staged as well (the covered region's margin)
+    uint32_t copy_chunk_kb = 2048;  // staged copy-out of the pair lists (CopyStage): bytes per DMA + event ...
+    uint32_t copy_stage_mb = 256;   // ... and the bound of the page-locked staging buffer (larger lists go in rounds)
     uint32_t pl_hard_cand  = 1500;  // pt2pl: a query whose tile staged this many candidates (per 4 queries) at the previous call is searched in the hard class, first and in smaller tiles (0 = one class)
-    int      wave_mfma     = 0;     // nn_wave_kernel: distance tests on the matrix pipe as a prefilter (measured: no gain there)
-    int      predict       = 0;     // wave path: queries predicted to be far served by the one-query kernel on a second stream
-                                    // from the start of the call.  Measured: no gain (each kernel alone fills the register
-                                    // file; run together both stretch: 216 + 106 us apart, 305 || 170 us together): off
-    int      wave_kernel   = 0;     // point-to-point search, K = 1: nn_wave_kernel (64 queries per wave, union of the lanes' cubes
-                                    // staged once, all-pairs scan) instead of nn_lane_kernel + nn_tile_kernel.  Its bulk is 3x
-                                    // faster (65 vs 186 us of lane + tile on scene A) but the waves of wide-radius queries
-                                    // (far-field walls 0.9 m off) take 150-230 us and set the kernel's span: 0.230 vs 0.186 ms
-                                    // (scene A), 0.429 vs 0.389 ms (scene B) -> the round-2 kernels stay the default
 };
 
 // multi-GPU communicator of a context (comm.hip): RCCL, or caller-provided collectives
@@ -169,6 +168,32 @@ struct Comm
     void*                 hook_user      = nullptr;
     size_t                cap_guess      = 0;  // record-list length predicted for the next iteration (0: ask)
     DevBuf<unsigned long long> pad, gathered;
+};
+
+// Device -> caller memory for the large pair lists (pairs.hip): DMA into the context's OWN page-locked buffer in
+// chunks, one event per chunk, and plain host copies from there into the caller's (pageable) container while the
+// later chunks are still on the link -- by the calling thread and one helper thread of the context.  Round 3
+// page-locked the caller's destination itself for the duration of the copy (hipHostRegister / hipHostUnregister of an
+// unaligned sub-range of the malloc heap): that made later pageable copies of the runtime from neighbouring heap
+// memory fault on the GPU ("Memory access fault by GPU node" -> abort(), GPUTEST_r03).  The
+// library no longer registers memory it does not own.
+struct CopyStage
+{
+    unsigned char*          host = nullptr;  // hipHostMalloc, grow-only
+    size_t                  cap  = 0;
+    std::vector<hipEvent_t> ev;              // one per chunk of a round
+    size_t                  chunk = 2u << 20, stage_max = 256u << 20;  // Tune::copy_chunk_kb / copy_stage_mb
+    std::mutex              mu;              // guards everything below
+    std::condition_variable cv_work, cv_done;
+    unsigned char*          out      = nullptr;  // the round in flight: chunk k = [k * chunk, ...) of `bytes`
+    size_t                  bytes    = 0, n_chunks = 0, next = 0, done = 0;
+    int                     err      = 0;        // first hipError_t a chunk's event reported
+    const unsigned char*    dev_rest = nullptr;  // what is left of a copy larger than the staging buffer
+    unsigned char*          out_rest = nullptr;
+    size_t                  rest     = 0;
+    bool                    open     = false;    // a posted copy has not been finished yet
+    std::thread             th;                  // helper (started with the first copy of more than one chunk)
+    bool                    stop     = false;
 };
 
 struct GnState
@@ -260,18 +285,12 @@ struct mp2p_hip_ctx
     mp2p::Comm                       comm;
     uint32_t last_n_tiles = 0;
     uint32_t last_q       = 64;
-    int      last_wave_path = 0;  // the last pt2pt search ran nn_wave_kernel
-    // prediction lists of the wave path (nn_query.hip, NNArgs::pred / next): ping-pong
-    mp2p::DevBuf<uint32_t> pred_buf[2];
-    int      pred_cur = 0;        // pred_buf[pred_cur] / list 3 + pred_cur is served by the next call
-    bool     pred_valid = false;  // ... and holds what the previous call predicted
-    int      nn_zero_list = -1;   // the list the last search consumed (the fused compaction re-zeroes its counters)
     void*    pinned       = nullptr;  // 4 KB of page-locked host memory for the small read-backs
     hipStream_t stream2    = nullptr;    // second search pipeline (launch_nn_pt2pt)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t copy_ev     = nullptr;    // mp2p_hip_pairs_copy_pt2pt_begin: the index arrays have arrived
-    void*      copy_locked = nullptr;    // ... the destination it page-locked
     bool       copy_open   = false;
+    mp2p::CopyStage cstage;              // staged copy-out of the pair lists (pairs.hip)
     mp2p_hip_cloud* q1_cloud = nullptr;  // mp2p_hip_nn_search_pt2pl: the one-point query layer
     mp2p_hip_pairs* q1_pairs = nullptr;
 };

@@ -1108,11 +1108,10 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
                   ctx->pl_hint_rad == prm->searchRadius && ctx->tune.pl_warm) ? 1 : 0;
     for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->pl_hint_pose[i];
     for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->pl_hint_pose[9 + i];
-    if (phase != 2)
-    {
-        ctx->pl_hint_map = map, ctx->pl_hint_cloud = cloud, ctx->pl_hint_n = n_l, ctx->pl_hint_knn = prm->knn, ctx->pl_hint_rad = prm->searchRadius;
-        for (int i = 0; i < 12; i++) ctx->pl_hint_pose[i] = pose[i];
-    }
+    // the warm-start / certificate state is committed only once the search kernels are enqueued: an error
+    // return in between must not leave a hint whose pose belongs to a call that never ran (lb_io / kth_io / pl_knn would
+    // still be an older pose's, the displacement understated and stale lists certified)
+    if (phase != 2) ctx->pl_hint_map = nullptr;
     a.grp_min = 2.0f * cell0;
     a.lb_io = ctx->pl_lb.p, a.pend = ctx->pl_pend.p, a.pend_cap = pend_cap, a.cert_stat = ctx->pl_cert_stat.p;
     a.use_cert = (a.use_hint && ctx->tune.pl_cert) ? ctx->tune.pl_cert : 0;
@@ -1160,7 +1159,12 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     else if (Kcap == 8) launch_k<8>(a, Q, cloud, ctx->stream);
     else if (Kcap == 12) launch_k<12>(a, Q, cloud, ctx->stream);
     else launch_k<16>(a, Q, cloud, ctx->stream);
-    if (hipPeekAtLastError() == hipSuccess) ctx->pl_lists_dirty = false;
+    if (hipPeekAtLastError() == hipSuccess)
+    {
+        ctx->pl_lists_dirty = false;
+        ctx->pl_hint_map = map, ctx->pl_hint_cloud = cloud, ctx->pl_hint_n = n_l, ctx->pl_hint_knn = prm->knn, ctx->pl_hint_rad = prm->searchRadius;
+        for (int i = 0; i < 12; i++) ctx->pl_hint_pose[i] = pose[i];
+    }
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     {

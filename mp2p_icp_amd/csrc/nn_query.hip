@@ -58,8 +58,10 @@ constexpr int NN_COOP_MAX = 4;    // groups of up to this many queries are defer
 constexpr int NN_CLAIM_SLOTS = 128;  // in-wave claim table (LDS)
 constexpr int NN_MAX_SEG     = 256;  // segments of a query list
 constexpr int NN_LISTS       = 3;    // 0 = pending/hard, 1 = deferred, 2 = pending/easy
-constexpr int NN_ALL_LISTS   = 5;    // + 3, 4 = the two PREDICTION lists of nn_wave.hip's flow (ping-pong)
+constexpr int NN_ALL_LISTS   = 3;
 constexpr int NN_CNT_STRIDE  = 32;   // uint32 words between two segment counters (128 bytes)
+constexpr int NN_TVLIST      = 512;  // tile kernel, wide groups: occupied voxels listed per round (LDS)
+constexpr uint32_t NN_COST_SHIFT = 8;  // result record, word 3: bit 0 = accepted, bits 8.. = what the query's tile staged
 
 struct NNArgs
 {
@@ -75,7 +77,9 @@ struct NNArgs
     uint32_t      brick_budget;      // 4x4x4 bricks per pass of the one-query-per-wave kernel
     uint32_t      lane_cells;        // widest cube (level-0 voxels per axis, <= 4) a lane searches itself; 0 = never
     uint32_t      tile_cand_cap;     // staged candidates after which a tile hands its pending queries on
-    unsigned long long tile_tick_cap;  // ... and 100 MHz ticks since the tile started (checked after each pass)
+    int           tile_bricks;       // wide groups stay in their tile: voxels of their box listed from the level-0 occupancy bricks
+    uint32_t      tile_brick_budget; // ... when the box spans at most this many bricks (else the coarser dense box)
+    uint32_t      hard_cand;         // a query whose tile staged at least this many candidates at the previous call is hard (0: by radius only)
     int           claim_dedup, claim_peek;
     int           mfma_scan;         // tile kernel, Q = 32: distance tests on the matrix pipe as a prefilter
     const unsigned char* local_taken;   // by original local index, or null
@@ -121,16 +125,6 @@ struct NNArgs
     // kernels ([n_tiles] then [single blocks]); the plain kernels only pay a uniform null test
     unsigned long long*  timeline;
     uint32_t             timeline_single_base;
-    // ---- prediction (round 3): a query the one-query-per-wave kernel had to finish is far from the map and stays
-    //      so for many ICP iterations.  Whoever finishes such a query appends its index to the NEXT list (and sets
-    //      bit 1 of the record's flag word); in the following call the list is served by nn_single_kernel<PRED> on a
-    //      second stream FROM THE START, next to nn_wave_kernel (whose lanes skip the flagged queries), instead of
-    //      after it.  Lists 3 / 4 of q_counters, same segments as the others; entries = sorted local index.
-    uint32_t*            pred;       // the list served now (null: none)
-    uint32_t*            next;       // the list being written (null: prediction off)
-    int                  pred_list, next_list;  // their indices in q_counters
-    float                again_d;    // a found distance beyond this predicts another hand-over
-    uint32_t             wave_lev_max;  // nn_wave_kernel: coarsest level its wide groups may use
 };
 
 // ---- geometry of one search pass (all values wave-uniform) -----------------------------------
@@ -214,6 +208,24 @@ __device__ __forceinline__ void lookup_voxel(const GridView& g, const PassBox& b
     }
 }
 
+// the same for a voxel given by its coordinates (the brick path of the tile kernel: the voxel is known to be occupied)
+__device__ __forceinline__ void resolve_voxel(const GridView& g, const PassBox& b, uint32_t cx, uint32_t cy, uint32_t cz,
+                                              float qlx, float qly, float qlz, float qhx, float qhy, float qhz,
+                                              float prune2, uint32_t& start, uint32_t& cnt)
+{
+    start = 0, cnt = 0;
+    const float vx0 = g.ox + (float)cx * b.hs, vy0 = g.oy + (float)cy * b.hs, vz0 = g.oz + (float)cz * b.hs;
+    const float dx = fmaxf(0.f, fmaxf(vx0 - qhx, qlx - (vx0 + b.hs)));
+    const float dy = fmaxf(0.f, fmaxf(vy0 - qhy, qly - (vy0 + b.hs)));
+    const float dz = fmaxf(0.f, fmaxf(vz0 - qhz, qlz - (vz0 + b.hs)));
+    if (dx * dx + dy * dy + dz * dz <= prune2)
+    {
+        uint32_t e = 0;
+        if (voxel_range(g, b.lev, cx, cy, cz, start, e, true)) cnt = e - start;
+        else start = 0;
+    }
+}
+
 // which voxel of the current batch holds candidate number gt (s_coff = exclusive offsets)
 __device__ __forceinline__ uint32_t locate_candidate(const uint32_t* s_cstart,
                                                      const uint32_t* s_coff, uint32_t gt)
@@ -265,7 +277,7 @@ __device__ __forceinline__ void claim_global(const NNArgs& a, uint32_t spos, uin
 // do_emit: this lane writes the record of query qi.  s_claim: NN_CLAIM_SLOTS words of LDS.
 __device__ __forceinline__ void emit_wave(const NNArgs& a, unsigned long long* s_claim, int lane, bool do_emit,
                                           uint32_t qi, uint32_t orig, bool active, float thr, float best_d2,
-                                          uint32_t best_idx, uint32_t best_spos, float lb2_all)
+                                          uint32_t best_idx, uint32_t best_spos, float lb2_all, uint32_t cost = 0u)
 {
     bool acc = do_emit && active && best_idx != NONE_U32 && best_d2 < thr;  // :259
     if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;     // :98-101
@@ -275,7 +287,8 @@ __device__ __forceinline__ void emit_wave(const NNArgs& a, unsigned long long* s
         // proved: no map point is nearer than lb2_all (min(best, threshold): every point that could pass
         // the threshold was examined; or the bound that let the search be skipped)
         const float lb2 = active ? lb2_all : 0.f;
-        a.rec[qi] = make_uint4(best_spos, __float_as_uint(best_d2), __float_as_uint(lb2), acc ? 1u : 0u);
+        a.rec[qi] = make_uint4(best_spos, __float_as_uint(best_d2), __float_as_uint(lb2),
+                               (acc ? 1u : 0u) | (min(cost, 0xFFFFFFu) << NN_COST_SHIFT));
     }
     if (!a.claims) return;               // uniform
     if (__ballot(acc) == 0ull) return;   // uniform
@@ -578,7 +591,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     const unsigned long long pmask = __ballot(pending);
     {
-        const bool               hard  = pending && r > a.r_hard;
+        // the hard class (served first by the tile kernel's grid): a wide radius, or -- from the previous call on this
+        // map and layer -- a tile that staged many candidates (dense neighbourhoods: the tile's duration follows what
+        // it stages, whatever the radius)
+        const bool               hard  = pending && (r > a.r_hard || (a.use_hint && a.hard_cand && (h.w >> NN_COST_SHIFT) >= a.hard_cand));
         const unsigned long long hmask = __ballot(hard), emask = pmask & ~hmask;
         if (hmask)
             push_lanes(a, 0, wv / a.seg_waves, hard, hmask, lane, qi, r, best_d2, best_idx, best_spos, qx, qy,
@@ -624,6 +640,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     __shared__ __attribute__((aligned(16))) uint32_t s_owner[NN_CAP];
     __shared__ uint32_t s_cstart[64];
     __shared__ uint32_t s_coff[64];
+    __shared__ uint32_t s_vox[NN_TVLIST];  // wide groups: occupied voxels of the box, 10 bits per axis relative to its corner
     // the claim table is used after the search only: it lives in the staging area (6.5 KB per tile instead
     // of 7.5: 24 tiles per CU instead of 21)
     static_assert(NN_CLAIM_SLOTS * sizeof(unsigned long long) <= NN_CAP * sizeof(float), "claim table fits s_x");
@@ -686,7 +703,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // a query whose radius already exceeds what a tile should carry goes straight to the
     // one-query-per-wave kernel
     {
-        const bool               wide  = !done && r > a.r_defer;
+        const bool               wide  = !done && !a.tile_bricks && r > a.r_defer;
         const unsigned long long wmask = __ballot(wide);
         if (wmask)
         {
@@ -735,9 +752,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         // conservative bounding box of the group's queries themselves
         const float qlx = lox + rmin_t, qly = loy + rmin_t, qlz = loz + rmin_t;
         const float qhx = hix - rmin_t, qhy = hiy - rmin_t, qhz = hiz - rmin_t;
-        const PassBox box    = choose_level(g, lox, loy, loz, hix, hiy, hiz, a.cell_budget);
+        PassBox       box    = choose_level(g, lox, loy, loz, hix, hiy, hiz, a.cell_budget);
         const float   prune  = rmax_t + 4.f * g.slack;
         const float   prune2 = prune * prune;
+        // ---- a WIDE group (its level-0 box holds more voxels than a pass resolves one by one): instead of a coarser
+        //      level -- whose voxels hold 8x the points, most of them outside every ball -- the level-0 occupancy BRICKS
+        //      of the box are read (one u64 per 4x4x4 voxels: empty space costs one load per 64 voxels), the occupied
+        //      voxels near the group are listed in LDS and only they are resolved.  This is what the one-query kernel does
+        //      for ONE query; a tile of Morton neighbours 1 m from a wall shares the whole list (round 4: such tiles
+        //      used to hand all their queries to that kernel, 19 % of the layer on scene B, each fetching its own copy).
+        bool     use_bricks = false;
+        uint32_t nbx = 0, nby = 0, nb = 0;
+        if (a.tile_bricks && box.lev > 0)
+        {
+            const PassBox b0 = choose_level(g, lox, loy, loz, hix, hiy, hiz, 0xFFFFFFFFu);
+            if (b0.lev == 0 && b0.ncell > 0 && b0.nx <= 1024u && b0.ny <= 1024u && b0.nz <= 1024u)
+            {
+                nbx = ((b0.cx0 + b0.nx - 1u) >> 2) - (b0.cx0 >> 2) + 1u, nby = ((b0.cy0 + b0.ny - 1u) >> 2) - (b0.cy0 >> 2) + 1u;
+                const uint32_t nbz = ((b0.cz0 + b0.nz - 1u) >> 2) - (b0.cz0 >> 2) + 1u;
+                const unsigned long long nbl = (unsigned long long)nbx * nby * nbz;
+                if (nbl <= a.tile_brick_budget) use_bricks = true, nb = (uint32_t)nbl, box = b0;
+            }
+        }
 
         const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
         // ---- matrix-pipe prefilter (Q = 32): d2 of 32 staged candidates x 32 queries by three
@@ -763,14 +799,75 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             b2 = hi ? 0.0f : (cqx * cqx + cqy * cqy + cqz * cqz);
             o0 = hi ? ocy : ocx, o1 = hi ? 0.0f : ocz;
         }
-        for (unsigned long long cb = 0; cb < box.ncell; cb += 64)
+        const uint32_t n_outer = use_bricks ? (nb + 63u) / 64u : 1u;
+        for (uint32_t ob = 0; ob < n_outer; ob++)
         {
-            uint32_t cnt, start;
-            float    md2_unused;
-            lookup_voxel(g, box, cb + lane, qlx, qly, qlz, qhx, qhy, qhz, prune2, start, cnt, md2_unused);
+        // one round of 64 bricks (lane = brick): the occupied voxels of the brick that lie in the box
+        unsigned long long bm = 0ull, vtotal = box.ncell;
+        uint32_t           bvx = 0, bvy = 0, bvz = 0, bincl = 0;
+        if (use_bricks)
+        {
+            const uint32_t id = ob * 64u + (uint32_t)lane;
+            if (id < nb)
+            {
+                const uint32_t row = id / nbx, ix = id - row * nbx, iz = row / nby, iy = row - iz * nby;
+                const uint32_t Bx = (box.cx0 >> 2) + ix, By = (box.cy0 >> 2) + iy, Bz = (box.cz0 >> 2) + iz;
+                bvx = Bx * 4u, bvy = By * 4u, bvz = Bz * 4u;
+                const float h4 = 4.f * box.hs;
+                const float x0 = g.ox + (float)bvx * box.hs, y0 = g.oy + (float)bvy * box.hs, z0 = g.oz + (float)bvz * box.hs;
+                const float dx = fmaxf(0.f, fmaxf(x0 - qhx, qlx - (x0 + h4)));
+                const float dy = fmaxf(0.f, fmaxf(y0 - qhy, qly - (y0 + h4)));
+                const float dz = fmaxf(0.f, fmaxf(z0 - qhz, qlz - (z0 + h4)));
+                if (dx * dx + dy * dy + dz * dz <= prune2 && Bx < g.occ_bx[0] && By < g.occ_by[0] && Bz < g.occ_bz[0])
+                {
+                    const unsigned long long word = g.occ[(size_t)g.occ_off[0] + ((size_t)Bz * g.occ_by[0] + By) * g.occ_bx[0] + Bx];
+                    bm = word & spread_x(axis_mask(Bx, box.cx0, box.cx0 + box.nx - 1u)) & spread_y(axis_mask(By, box.cy0, box.cy0 + box.ny - 1u)) &
+                         spread_z(axis_mask(Bz, box.cz0, box.cz0 + box.nz - 1u));
+                }
+            }
+            bincl  = wave_incl_scan((uint32_t)__popcll(bm), lane);
+            vtotal = (uint32_t)__builtin_amdgcn_readlane((int)bincl, 63);
+            st_cells += min(64u, nb - ob * 64u);
+        }
+        for (unsigned long long r0 = 0; r0 < vtotal; r0 += use_bricks ? (unsigned long long)NN_TVLIST : vtotal)
+        {
+        unsigned long long nv = vtotal;
+        if (use_bricks)
+        {
+            uint32_t           rank = bincl - (uint32_t)__popcll(bm);
+            unsigned long long mm   = bm;
+            while (mm)
+            {
+                const uint32_t bit = (uint32_t)__ffsll((long long)mm) - 1u;
+                mm &= mm - 1ull;
+                if (rank >= r0 && rank < r0 + NN_TVLIST)
+                    s_vox[rank - (uint32_t)r0] = ((bvz + (bit >> 4)) - box.cz0) << 20 | ((bvy + ((bit >> 2) & 3u)) - box.cy0) << 10 |
+                                                 ((bvx + (bit & 3u)) - box.cx0);
+                rank++;
+            }
+            __syncthreads();
+            nv = min((unsigned long long)NN_TVLIST, vtotal - r0);
+        }
+        for (unsigned long long cb = 0; cb < nv; cb += 64)
+        {
+            uint32_t cnt = 0, start = 0;
+            if (use_bricks)
+            {
+                if (cb + lane < nv)
+                {
+                    const uint32_t pk = s_vox[(uint32_t)cb + lane];
+                    resolve_voxel(g, box, box.cx0 + (pk & 1023u), box.cy0 + ((pk >> 10) & 1023u), box.cz0 + (pk >> 20), qlx, qly,
+                                  qlz, qhx, qhy, qhz, prune2, start, cnt);
+                }
+            }
+            else
+            {
+                float md2_unused;
+                lookup_voxel(g, box, cb + lane, qlx, qly, qlz, qhx, qhy, qhz, prune2, start, cnt, md2_unused);
+                st_cells += (uint32_t)min((unsigned long long)64, box.ncell - cb);
+            }
             const uint32_t incl  = wave_incl_scan(cnt, lane);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            st_cells += (uint32_t)min((unsigned long long)64, box.ncell - cb);
             if (total == 0) continue;  // uniform: no occupied voxel in this batch
             const uint32_t off = incl - cnt;
             s_cstart[lane] = start;
@@ -930,6 +1027,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 __syncthreads();
             }
         }
+        if (use_bricks) __syncthreads();  // the list is rewritten by the next round
+        }
+        }
 
         // ---- merge the S slices of each query slot ------------------------------------------
         if (S > 1)
@@ -954,16 +1054,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 r = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
                 // a query whose radius outgrows the voxels would drag the shared box with it:
                 // it continues alone, with the whole wave on its own candidates
-                too_wide = r > a.r_defer;
+                too_wide = !a.tile_bricks && r > a.r_defer;
             }
         }
-        // a tile that has already staged more than its budget, or has run longer than its time budget,
-        // hands ALL its unfinished queries on: tiles are dispatched in order, a few of them run 5-8x
+        // a tile that has already staged more than its budget hands ALL its unfinished queries on
+        // (a bound on WORK: round 3 also had a wall-clock bound, which made the kernel that finishes a query depend on
+        // timing -- gone with the cost-ordered dispatch below): tiles are dispatched in order, a few of them run 5-8x
         // the mean (many passes over small groups), and one of those starting late keeps a nearly empty
         // chip waiting -- measured: the chip is full for the first 45 % of the kernel's span only
         // (the one-query kernel spreads the same work evenly; results do not depend on who finishes a
         // query)
-        if (!done && (st_cand > a.tile_cand_cap || wall_clock64() - tl0 > a.tile_tick_cap)) too_wide = true;
+        if (!done && st_cand > a.tile_cand_cap) too_wide = true;
         const unsigned long long wmask = __ballot(too_wide);
         if (wmask)
         {
@@ -975,7 +1076,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // ---- output (Morton order of the local layer) + claim of the global point -----------------
     // every point that could pass the threshold was examined: no map point is nearer than min(best, threshold)
     emit_wave(a, s_claim, lane, valid && slice == 0 && !deferred, qi, orig, active, thr, best_d2, best_idx,
-              best_spos, fminf(best_d2, thr));
+              best_spos, fminf(best_d2, thr), st_cand);
 
     if (a.timeline && lane == 0)
         a.timeline[2 * (size_t)tile] = tl0, a.timeline[2 * (size_t)tile + 1] = wall_clock64();
@@ -1084,7 +1185,7 @@ constexpr int NN_VLIST = 1024;  // occupied voxels listed per round (LDS)
 // W = waves per SIMD the register allocation aims at (__launch_bounds__' second argument; 1 = the
 // compiler's own choice, 96-98 VGPRs = 5 waves): the kernel is a chain of dependent loads per query, so
 // queries in flight per CU is what it is bound by (measured variants: MP2P_HIP_TUNE single_waves)
-template <bool INSTR, int W, bool PRED = false>
+template <bool INSTR, int W>
 __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
 {
     __shared__ uint32_t s_cstart[64];
@@ -1103,7 +1204,7 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
         for (int k = 0; k < NN_MAX_SEG / 64; k++)
         {
             const uint32_t sg  = (uint32_t)(k * 64 + lane);
-            const uint32_t c   = sg < a.n_seg ? a.q_counters[((size_t)(PRED ? a.pred_list : 1) * NN_MAX_SEG + a.seg_base + sg) * NN_CNT_STRIDE] : 0u;
+            const uint32_t c   = sg < a.n_seg ? a.q_counters[((size_t)1 * NN_MAX_SEG + a.seg_base + sg) * NN_CNT_STRIDE] : 0u;
             const uint32_t inc = wave_incl_scan(c, lane);
             s_segoff[sg]       = run + inc - c;
             run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -1130,47 +1231,6 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
         float    qx, qy, qz, thr, rmax, r, best_d2;
         bool     search = true, active = true;
         float    lb2_skip = -1.f;
-        if (PRED)
-        {
-            // a predicted query: only its index is known -- the whole prologue of nn_wave_kernel for ONE query
-            // (every lane computes the same values from the same addresses)
-            qi = a.pred[item];
-            const float4 lp = a.lpts[qi];
-            const uint4  h  = a.rec[qi];
-            orig = __float_as_uint(lp.w);
-            bool visited = true;
-            if (a.rank) visited = a.rank[orig] != NONE_U32;
-            compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
-            const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));
-            thr  = fadd(a.maxDistSq, fmul(a.angSq, normSq));
-            rmax = sqrtf(thr) * 1.002f + g.slack;
-            active = visited && (normSq < INFINITY);
-            if (active && a.local_taken && a.local_taken[orig]) active = false;  // :218-220
-            r = fminf(a.r0, rmax), best_d2 = INFINITY, best_idx = NONE_U32, best_spos = NONE_U32;
-            search = active;
-            if (active)
-            {
-                float ox, oy, oz;
-                compose_point_f(a.prev_pose, lp.x, lp.y, lp.z, ox, oy, oz);
-                const float disp = sqrtf(dist2(qx, qy, qz, ox, oy, oz));
-                float       lb   = sqrtf(__uint_as_float(h.z)) * 0.99999f - disp * 1.00001f - 4.f * g.slack;
-                if (!(lb > 0.f)) lb = 0.f;
-                float hr = 0.f;
-                if (h.x < g.n)
-                {
-                    const float4 hp = g.pts[h.x];
-                    const float  hd = dist2(qx, qy, qz, hp.x, hp.y, hp.z);
-                    if (hd < INFINITY) best_d2 = hd, best_idx = __float_as_uint(hp.w), best_spos = h.x, hr = sqrtf(hd) * (1.0f + 1.0f / 512.0f) + 4.f * g.slack;
-                }
-                if (lb * 0.999f > sqrtf(thr)) search = false, lb2_skip = (lb * 0.9999f) * (lb * 0.9999f);
-                else
-                {
-                    const float cap = fmaxf(2.0f * lb, r);
-                    r = fminf(hr > 0.f ? fminf(hr, cap) : cap, rmax);
-                }
-            }
-        }
-        else
         {
             const uint4 w  = a.work[item];
             const uint4 wq = a.work_q[item];
@@ -1328,18 +1388,12 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
         {
             bool acc = active && best_idx != NONE_U32 && best_d2 < thr;         // :259
             if (acc && a.global_taken && a.global_taken[best_idx]) acc = false;  // :98-101
-            // will the next call hand this query on again?  (its neighbour is as far then as now)
-            const bool again = a.next != nullptr && active && !(sqrtf(best_d2) <= a.again_d);
             const float lb2 = !active ? 0.f : (lb2_skip >= 0.f ? lb2_skip : fminf(best_d2, thr));
-            a.rec[qi] = make_uint4(best_spos, __float_as_uint(best_d2), __float_as_uint(lb2), (acc ? 1u : 0u) | (again ? 2u : 0u));
+            // (cost: what this query alone staged -- it was handed on for being isolated, or by a tile over its budget)
+            a.rec[qi] = make_uint4(best_spos, __float_as_uint(best_d2), __float_as_uint(lb2),
+                                   (acc ? 1u : 0u) | (min(st_cand, 0xFFFFFFu) << NN_COST_SHIFT));
             if (acc && a.claims)
                 claim_global(a, best_spos, (uint32_t)(a.local_offset + (a.rank ? a.rank[orig] : orig)));
-            if (again)
-            {
-                const uint32_t seg  = (qi >> 6) / a.seg_waves;
-                const uint32_t slot = atomicAdd(a.q_counters + ((size_t)a.next_list * NN_MAX_SEG + seg) * NN_CNT_STRIDE, 1u);
-                a.next[(size_t)seg * a.seg_cap + slot] = qi;
-            }
         }
         if (INSTR && lane == 0)
         {
@@ -1362,10 +1416,6 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
     }
 }
 
-}  // namespace mp2p
-#include "nn_wave.hip"  // nn_wave_kernel: prologue + search of round 3 (uses the helpers above)
-namespace mp2p
-{
 // resets the segment counters of the two query lists
 __global__ __launch_bounds__(NN_MAX_SEG) void nn_reset_kernel(uint32_t* q_counters)
 {
@@ -1485,7 +1535,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
                                              : fminf(fmaxf(1.0f, 2.0f * cell0), 4.0f * cell0);
     a.lane_cells    = std::min<uint32_t>(ctx->tune.lane_cells, 4u);
     a.tile_cand_cap = ctx->tune.tile_cand_cap;
-    a.tile_tick_cap = (unsigned long long)ctx->tune.tile_time_cap_us * 100ull;
+    a.tile_bricks       = (ctx->tune.tile_bricks && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE) ? 1 : 0;
+    a.tile_brick_budget = ctx->tune.tile_brick_budget;
+    a.hard_cand         = ctx->tune.hard_cand;
     a.claim_dedup   = ctx->tune.claim_dedup;
     a.claim_peek    = ctx->tune.claim_peek;
     a.mfma_scan     = ctx->tune.mfma_scan;
@@ -1509,14 +1561,12 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.list_cap = (uint32_t)list_cap;
     a.r_hard   = cell0 * 0.01f * (float)ctx->tune.hard_radius_pct;
     a.xcd_map  = ctx->tune.xcd_map;
-    a.wave_lev_max = ctx->tune.wave_levels;
     const uint32_t n_tiles = 2u * ((n_seg + 7u) / 8u) * 8u * a.tiles_per_seg;  // worst case for each class: every query in it
     ctx->last_n_tiles = n_tiles;
     for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->hint_pose[i];
     for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->hint_pose[9 + i];
     a.use_hint = (ctx->hint_map == map && ctx->hint_cloud == cloud && ctx->hint_n == n_l && !prm->disable_warm_start) ? 1 : 0;
-    ctx->hint_map = map, ctx->hint_cloud = cloud, ctx->hint_n = n_l;
-    for (int i = 0; i < 12; i++) ctx->hint_pose[i] = pose[i];
+    ctx->hint_map = nullptr;  // committed after the launches: an error return in between leaves no warm start
     a.counters     = nullptr;
     a.touched      = nullptr;
     if (ctx->profiling == 2)
@@ -1542,74 +1592,13 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     }
     ctx->pending_lane = 1;
     ctx->last_n_boxes = n_waves;
-    // round 3: one kernel for prologue + search (nn_wave.hip) when the map carries the level-0 occupancy
-    // bitmap it enumerates voxels from; an explicit tile size (queries_per_wave) asks for the tile kernels
-    const bool use_wave = ctx->tune.wave_kernel && prm->queries_per_wave == 0 && map->view.occ != nullptr &&
-                          map->view.occ_off[0] != OCC_NONE && ctx->tune.pipelines < 2;
-    ctx->last_wave_path = use_wave ? 1 : 0;
-    // ---- prediction (NNArgs::pred / next): only on the wave path, with plain timing (levels 0 / 3), on a real stream
-    const bool predict = use_wave && ctx->tune.predict && (ctx->profiling == 0 || ctx->profiling == 3) && ctx->stream != nullptr &&
-                         ctx->stream != hipStreamLegacy;
-    // the list counters: cleared by the previous call's fused compaction, or here (then any prediction is gone too)
-    if (!ctx->q_counters_clean || (ctx->pred_valid && !(predict && a.use_hint)))
-    {
+    // the list counters: cleared by the previous call's fused compaction, or here
+    if (!ctx->q_counters_clean)
         hipLaunchKernelGGL(nn_reset_kernel, dim3(NN_ALL_LISTS), dim3(NN_MAX_SEG), 0, ctx->stream, a.q_counters);
-        ctx->pred_valid = false;
-    }
     ctx->q_counters_clean = false;
-    a.pred = a.next = nullptr, a.pred_list = a.next_list = 0, ctx->nn_zero_list = -1;
-    if (predict)
-    {
-        const int cur = ctx->pred_cur;
-        MP2P_TRY_HIP(ctx, ctx->pred_buf[0].ensure(list_cap));
-        MP2P_TRY_HIP(ctx, ctx->pred_buf[1].ensure(list_cap));
-        a.next = ctx->pred_buf[1 - cur].p, a.next_list = 3 + (1 - cur);
-        if (ctx->pred_valid) a.pred = ctx->pred_buf[cur].p, a.pred_list = 3 + cur;
-        // a neighbour farther than this is handed on by nn_wave_kernel (radius beyond r_defer, or a cube of 9+ voxels)
-        a.again_d = fminf(a.r_defer, 3.4f * cell0) * 0.99f;
-        ctx->nn_zero_list = 3 + cur;  // consumed by this call; the next call writes it
-        ctx->pred_cur = 1 - cur, ctx->pred_valid = true;
-    }
     // ev[0]..ev[1] brackets exactly the search kernels (the roofline kernels of bench.py)
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    if (n_tiles && use_wave)
-    {
-        const bool instr = a.counters != nullptr;
-        a.seg_base = 0, a.wave_base = 0;
-        const uint32_t sb = (uint32_t)std::min<size_t>((size_t)n_waves * 64u,
-                                                       256u * (ctx->tune.single_blocks_per_cu ? ctx->tune.single_blocks_per_cu : 40u));
-        if (a.pred)
-        {  // the predicted queries: from the start, on the second stream
-            if (!ctx->stream2)
-            {
-                // a HIGH-priority stream: its own hardware queue (two plain streams may share one -- then the two
-                // kernels run back to back), and the far queries are the critical path anyway
-                int least = 0, greatest = 0;
-                MP2P_TRY_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-                MP2P_TRY_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest));
-            }
-            if (!ctx->ev_fork) MP2P_TRY_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            if (!ctx->ev_join) MP2P_TRY_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-            MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-            MP2P_TRY_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            hipLaunchKernelGGL((nn_single_kernel<false, 1, true>), dim3(sb), dim3(64), 0, ctx->stream2, a);  // 4 waves per SIMD: 5 spill here
-            MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-        }
-        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));  // no separate prologue
-        // (the matrix-pipe prefilter buys nothing here -- the rounds wait for their staging loads, not for the tests:
-        //  0.246 vs 0.253 ms -- so the exact packed scan is the default; MP2P_HIP_TUNE wave_mfma=1 for the other)
-        if (instr) hipLaunchKernelGGL((nn_wave_kernel<true, 4, false>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
-        else if (ctx->tune.wave_mfma) hipLaunchKernelGGL((nn_wave_kernel<false, 4, true>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((nn_wave_kernel<false, 4, false>), dim3(n_waves), dim3(64), 0, ctx->stream, a);
-        if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-        if (instr) hipLaunchKernelGGL((nn_single_kernel<true, 1>), dim3(sb), dim3(64), 0, ctx->stream, a);
-        else if (ctx->tune.single_waves == 4) hipLaunchKernelGGL((nn_single_kernel<false, 1>), dim3(sb), dim3(64), 0, ctx->stream, a);
-        else if (ctx->tune.single_waves == 6) hipLaunchKernelGGL((nn_single_kernel<false, 6>), dim3(sb), dim3(64), 0, ctx->stream, a);
-        else if (ctx->tune.single_waves == 8) hipLaunchKernelGGL((nn_single_kernel<false, 8>), dim3(sb), dim3(64), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((nn_single_kernel<false, 5>), dim3(sb), dim3(64), 0, ctx->stream, a);
-        if (a.pred) MP2P_TRY_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-    }
-    else if (n_tiles)
+    if (n_tiles)
     {
         const bool instr = a.counters != nullptr;
         // ---- PIPELINES.  lane -> tile -> one-query kernel is a strict chain, and both big kernels end with
@@ -1700,6 +1689,8 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         if (rc) return rc;
     }
     MP2P_TRY_HIP(ctx, hipGetLastError());
+    ctx->hint_map = map, ctx->hint_cloud = cloud, ctx->hint_n = n_l;
+    for (int i = 0; i < 12; i++) ctx->hint_pose[i] = pose[i];
     return MP2P_HIP_OK;
 }
 

@@ -31,7 +31,6 @@ struct CompactArgs
     float*                    block_bbox;    // [n_blocks][6]
     float*                    local_bbox_out;
     uint32_t*                 q_counters;    // the search's query-list counters, re-zeroed for the next call
-    int                       zero_list;     // ... and the prediction list the search has just consumed (-1: none)
     uint32_t                  n_l;      // number of SLOTS = visited local points x K, in visiting order
     uint32_t                  K;        // pairingsPerPoint
     const uint32_t*           order;    // visit position -> original local index (null: identity)
@@ -255,8 +254,6 @@ __global__ __launch_bounds__(1024) void compact_scan_bbox_kernel(const CompactAr
         a.counts[7] = overlap ? 1ull : 0ull;
     }
     if (a.q_counters && threadIdx.x < NN_LISTS * NN_MAX_SEG) a.q_counters[(size_t)threadIdx.x * NN_CNT_STRIDE] = 0u;
-    if (a.q_counters && a.zero_list >= 0 && threadIdx.x < NN_MAX_SEG)
-        a.q_counters[((size_t)a.zero_list * NN_MAX_SEG + threadIdx.x) * NN_CNT_STRIDE] = 0u;
 }
 
 __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const CompactArgs a)
@@ -320,7 +317,6 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     MP2P_TRY_HIP(ctx, ctx->compact_flags.ensure((size_t)(n_blocks ? n_blocks : 1) * CP_THREADS));
     CompactArgs a;
     memset(&a, 0, sizeof(a));
-    a.zero_list = -1;
     a.nn_spos = ctx->nn_spos.p, a.nn_d2 = ctx->nn_d2.p, a.n_l = (uint32_t)n_l;
     a.rec = from_rec ? ctx->nn_rec.p : nullptr;
     a.K = K, a.order = order, a.n_slots_dev = n_slots_dev, a.always_mark = always_mark ? 1 : 0;
@@ -350,7 +346,7 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
         MP2P_TRY_HIP(ctx, ctx->block_bbox.ensure((size_t)n_blocks * 6));
         a.tile_bbox = ctx->tile_bbox.p, a.n_tile_boxes = ctx->last_n_boxes;
         a.block_bbox = ctx->block_bbox.p, a.local_bbox_out = ctx->local_bbox.p;
-        a.q_counters = ctx->q_counters.p, a.zero_list = ctx->nn_zero_list;
+        a.q_counters = ctx->q_counters.p;
     }
     if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (n_blocks)
@@ -606,19 +602,148 @@ static int read_counts(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, unsigned long
     return MP2P_HIP_OK;
 }
 
-// device -> caller memory.  The caller's containers are pageable (std::vector storage).  Measured on
-// the MI355X host for 3.9 MB (tools/copy_probe.hip): page-lock the destination for the duration of the
-// copy, one DMA, unlock = 0.11 ms; a plain hipMemcpy into never-seen pages 0.51 ms (0.10 once the
-// runtime has seen them); DMA into an own pinned buffer + host copy 0.19-0.27 ms.
+// ---- device -> caller memory (see mp2p::CopyStage, common.hpp) ----------------------------------------------------
+// The caller's containers are pageable (std::vector storage) and stay untouched by the runtime: the records are
+// DMA'd into the context's own page-locked buffer, chunk by chunk, and copied from there by the host.
+namespace mp2p
+{
+// one claimed chunk: wait for its DMA, copy it into the caller's container
+static void stage_chunk(mp2p_hip_ctx* ctx, size_t k)
+{
+    CopyStage&  s = ctx->cstage;
+    hipError_t  e;
+    for (unsigned it = 1; (e = hipEventQuery(s.ev[k])) == hipErrorNotReady; ++it)
+        if ((it & 1023u) == 0) std::this_thread::yield();
+    const size_t off = k * s.chunk, len = std::min(s.chunk, s.bytes - off);
+    if (e == hipSuccess) memcpy(s.out + off, s.host + off, len);
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (e != hipSuccess && !s.err) s.err = (int)e;
+    if (++s.done == s.n_chunks) s.cv_done.notify_all();
+}
+static void stage_worker(mp2p_hip_ctx* ctx)
+{
+    (void)hipSetDevice(ctx->device);
+    CopyStage&                   s = ctx->cstage;
+    std::unique_lock<std::mutex> lk(s.mu);
+    for (;;)
+    {
+        s.cv_work.wait(lk, [&] { return s.stop || s.next < s.n_chunks; });
+        if (s.stop) return;
+        const size_t k = s.next++;
+        lk.unlock();
+        stage_chunk(ctx, k);
+        lk.lock();
+    }
+}
+// enqueue one round: the first min(bytes, capacity) bytes of [dev, dev + bytes) -> the staging buffer, an event per chunk
+static int stage_round(mp2p_hip_ctx* ctx, const unsigned char* dev, unsigned char* out, size_t bytes)
+{
+    CopyStage&   s     = ctx->cstage;
+    s.chunk     = std::max<size_t>(4096, (size_t)ctx->tune.copy_chunk_kb << 10);
+    s.stage_max = std::max<size_t>(s.chunk, (size_t)ctx->tune.copy_stage_mb << 20);
+    const size_t round = std::min(bytes, s.stage_max);
+    if (s.cap < round)
+    {
+        if (s.host) (void)hipHostFree(s.host);
+        s.host = nullptr, s.cap = 0;
+        const size_t want = std::min(s.stage_max, std::max(round + round / 4, (size_t)(8u << 20)));
+        MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&s.host, want, hipHostMallocDefault));
+        s.cap = want;
+    }
+    const size_t nc = (round + s.chunk - 1) / s.chunk;
+    while (s.ev.size() < nc)
+    {
+        hipEvent_t e = nullptr;
+        MP2P_TRY_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s.ev.push_back(e);
+    }
+    for (size_t k = 0; k < nc; k++)
+    {
+        const size_t off = k * s.chunk, len = std::min(s.chunk, round - off);
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(s.host + off, dev + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        MP2P_TRY_HIP(ctx, hipEventRecord(s.ev[k], ctx->stream));
+    }
+    if (nc > 1 && !s.th.joinable()) s.th = std::thread(stage_worker, ctx);
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.out = out, s.bytes = round, s.n_chunks = nc, s.next = 0, s.done = 0;
+        s.dev_rest = dev + round, s.out_rest = out + round, s.rest = bytes - round;
+    }
+    if (nc > 1) s.cv_work.notify_one();
+    return MP2P_HIP_OK;
+}
+// start a copy; the caller may do other work before stage_finish()
+static int stage_post(mp2p_hip_ctx* ctx, const void* dev, void* out, size_t bytes)
+{
+    CopyStage& s = ctx->cstage;
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.err = 0;
+    }
+    const int rc = stage_round(ctx, static_cast<const unsigned char*>(dev), static_cast<unsigned char*>(out), bytes);
+    s.open = rc == MP2P_HIP_OK;
+    return rc;
+}
+// the calling thread joins the copy; returns when every byte has reached the caller's container
+static int stage_finish(mp2p_hip_ctx* ctx)
+{
+    CopyStage& s = ctx->cstage;
+    if (!s.open) return MP2P_HIP_OK;
+    s.open = false;
+    for (;;)
+    {
+        std::unique_lock<std::mutex> lk(s.mu);
+        while (s.next < s.n_chunks)
+        {
+            const size_t k = s.next++;
+            lk.unlock();
+            stage_chunk(ctx, k);
+            lk.lock();
+        }
+        s.cv_done.wait(lk, [&] { return s.done == s.n_chunks; });
+        const int                  err = s.err;
+        const unsigned char* const dev = s.dev_rest;
+        unsigned char* const       out = s.out_rest;
+        const size_t               rest = s.rest;
+        s.n_chunks = s.next = s.done = 0, s.rest = 0;
+        lk.unlock();
+        if (err) MP2P_TRY_HIP(ctx, (hipError_t)err);
+        if (!rest) return MP2P_HIP_OK;
+        const int rc = stage_round(ctx, dev, out, rest);  // a list beyond the staging buffer's bound: the next round
+        if (rc) return rc;
+    }
+}
+void stage_destroy(mp2p_hip_ctx* ctx)
+{
+    CopyStage& s = ctx->cstage;
+    if (s.th.joinable())
+    {
+        {
+            std::lock_guard<std::mutex> lk(s.mu);
+            s.stop = true;
+        }
+        s.cv_work.notify_all();
+        s.th.join();
+    }
+    for (hipEvent_t e : s.ev) (void)hipEventDestroy(e);
+    s.ev.clear();
+    if (s.host) (void)hipHostFree(s.host);
+    s.host = nullptr, s.cap = 0;
+}
+}  // namespace mp2p
+
+// Small lists take the runtime's own pageable path (its bounce buffers); the large ones are staged.  Round 3's
+// hipHostRegister of the destination is gone (mp2p::CopyStage).
 static int copy_out(mp2p_hip_ctx* ctx, const void* dev, void* out, size_t bytes)
 {
-    const bool lock = bytes >= (256u << 10) && hipHostRegister(out, bytes, hipHostRegisterDefault) == hipSuccess;
-    if (!lock) (void)hipGetLastError();
-    hipError_t e = hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = stream_wait(ctx);
-    if (lock) (void)hipHostUnregister(out);
-    MP2P_TRY_HIP(ctx, e);
-    return MP2P_HIP_OK;
+    if (bytes < (256u << 10))
+    {
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        MP2P_TRY_HIP(ctx, stream_wait(ctx));
+        return MP2P_HIP_OK;
+    }
+    if (const int rc = stage_post(ctx, dev, out, bytes)) return rc;
+    return stage_finish(ctx);
 }
 
 extern "C" {
@@ -810,15 +935,19 @@ int mp2p_hip_pairs_copy_pt2pt_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, 
     hipLaunchKernelGGL(pack_pt2pt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->lidx.p,
                        p->gidx.p, p->lx.p, p->ly.p, p->lz.p, p->gx.p, p->gy.p, p->gz.p, p->err.p, (uint32_t)n, d,
                        (uint32_t)first);
-    ctx->copy_locked = nullptr;
-    if (bytes >= (256u << 10) && hipHostRegister(out, bytes, hipHostRegisterDefault) == hipSuccess) ctx->copy_locked = out;
-    else (void)hipGetLastError();
     ctx->copy_open = true;
-    const hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e != hipSuccess)
+    int rc = MP2P_HIP_OK;
+    if (bytes < (256u << 10))
+    {
+        const hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = set_err(ctx, MP2P_HIP_ERR_HIP, "copy_pt2pt_begin: hipMemcpyAsync failed: %s", hipGetErrorString(e));
+    }
+    else
+        rc = stage_post(ctx, d, out, bytes);
+    if (rc)
     {
         (void)mp2p_hip_pairs_copy_end(ctx);
-        MP2P_TRY_HIP(ctx, e);
+        return rc;
     }
     return MP2P_HIP_OK;
 }
@@ -838,9 +967,10 @@ int mp2p_hip_pairs_copy_end(mp2p_hip_ctx* ctx)
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;
     if (!ctx->copy_open) return MP2P_HIP_OK;
-    const hipError_t e = stream_wait(ctx);
-    if (ctx->copy_locked) (void)hipHostUnregister(ctx->copy_locked);
-    ctx->copy_locked = nullptr, ctx->copy_open = false;
+    const int        rc = stage_finish(ctx);  // (nothing posted: returns at once)
+    const hipError_t e  = stream_wait(ctx);
+    ctx->copy_open = false;
+    if (rc) return rc;
     MP2P_TRY_HIP(ctx, e);
     return MP2P_HIP_OK;
 }

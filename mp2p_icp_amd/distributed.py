@@ -144,13 +144,30 @@ class HipBackend:
         # all-reduce MIN; the native route is taken only if every rank made it, otherwise every rank destroys
         # what it created and all fall back together.
         buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        dev = self.dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        # pre-flight: mp2p_hip_comm_init can fail on ONE rank before it reaches ncclCommInitRank (librccl
+        # not loadable there, a communicator already present) while its peers block inside it.  Every rank therefore
+        # first proves, locally, that it would get that far -- drawing an id dlopens librccl and resolves its symbols --
+        # and nobody calls comm_init unless all ranks can.
+        pre = 1
+        try:
+            probe = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+            _lib.check(self.ctx._L.mp2p_hip_comm_get_unique_id(probe))
+            if self.ctx._L.mp2p_hip_comm_size(self.ctx.handle) != 0:
+                pre = 0
+        except Exception:
+            pre = 0
+        pf = torch.tensor([pre], dtype=torch.int32, device=dev)
+        dist.all_reduce(pf, op=dist.ReduceOp.MIN, group=group)
+        if int(pf.item()) != 1:
+            raise RuntimeError("the native communicator cannot be created on every rank (librccl not loadable, or a "
+                               "communicator already present on some rank)")
         ok0 = 1
         if rank == 0:
             try:
                 _lib.check(self.ctx._L.mp2p_hip_comm_get_unique_id(buf))
             except Exception:
                 ok0 = 0
-        dev = self.dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
         t = torch.tensor([ok0] + list(buf), dtype=torch.uint8, device=dev)
         dist.broadcast(t, src=0, group=group)
         raw = bytes(t.cpu().tolist())
@@ -194,6 +211,7 @@ class HipPlaneBackend(HipBackend):
     def __init__(self, ctx, gmap, cloud, pt2pl_params, gn_params, pairs, local_index_offset=0):
         HipBackend.__init__(self, ctx, gmap, cloud, pt2pl_params, gn_params, pairs)
         self.uses_claims = False
+        self.native_only = True
         self.offset = int(local_index_offset)
 
     def step_native(self, pose):
@@ -235,6 +253,8 @@ class ShardedRegistration:
             try:
                 backend.init_native_comm(dist, group)
             except Exception as ex:  # stay on the torch.distributed route
+                if getattr(backend, "native_only", False):
+                    raise  # HipPlaneBackend: no torch.distributed route to fall back to -- the failure must not hide until step()
                 import sys
                 print(f"[mp2p_icp_amd] native RCCL communicator unavailable ({ex}); using torch.distributed",
                       file=sys.stderr)

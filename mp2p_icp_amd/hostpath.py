@@ -45,6 +45,7 @@ SIGNATURES = {
     "mp2p_hostpath_invalidate_layers": (None, []),
     "mp2p_hostpath_stage_ms": (None, [_dp]),
     "mp2p_hostpath_set_strict": (None, [C.c_int]),
+    "mp2p_hostpath_set_trust_reseen": (None, [C.c_int]),
 }
 
 
@@ -230,6 +231,12 @@ def stage_ms():
 def set_strict(on):
     """every solver call uploads the host Pairings (the plugin's MP2P_HIP_HOST_STRICT=1)"""
     load().mp2p_hostpath_set_strict(int(bool(on)))
+
+
+def set_trust_reseen(on):
+    """re-seen layers are re-verified on every 61st point instead of hashed in full at ICP iteration 0
+    (the plugin's MP2P_HIP_HOST_TRUST_RESEEN=1; off by default: ADVICE r3)"""
+    load().mp2p_hostpath_set_trust_reseen(int(bool(on)))
 
 
 def invalidate_layers():

@@ -74,16 +74,26 @@ int main()
     expect(g_uploads == 2, "two uploads for two new layers");
     map(0, false), cloud(1, false);
     expect(g_uploads == 2, "sampled check: nothing uploaded");
-    const size_t full0 = rt.n_full_checks, re0 = rt.n_reseen_checks;
+    size_t full0 = rt.n_full_checks, re0 = rt.n_reseen_checks;
     map(0, true), cloud(1, true);
-    expect(g_uploads == 2 && rt.n_full_checks == full0 && rt.n_reseen_checks == re0 + 2, "re-seen layers: strided re-check, no full hash, no upload");
+    expect(g_uploads == 2 && rt.n_full_checks == full0 + 2 && rt.n_reseen_checks == re0, "re-seen layers (default): hashed in full again, no upload");
+    // a ONE-point edit off every sample and stride is found at the next iteration 0 (the live layer decides)
+    bufs[1].y[1238] += 0.25f;
+    cloud(1, true);
+    expect(g_uploads == 3, "default: a single edited point is found at iteration 0");
+    // a host that vouches for its layers (trust_reseen): the strided re-check, no full hash
+    rt.trust_reseen = true;
+    map(0, true), cloud(1, true);  // (the stride's print of the re-uploaded layer is taken with this full check)
+    full0 = rt.n_full_checks, re0 = rt.n_reseen_checks;
+    map(0, true), cloud(1, true);
+    expect(g_uploads == 3 && rt.n_full_checks == full0 && rt.n_reseen_checks == re0 + 2, "re-seen layers (trusted): strided re-check, no full hash, no upload");
     // ---- an in-place edit of 61 consecutive points (unseen by the 1024-point sample) is found at iteration 0 only
     for (size_t i = 1237; i < 1237 + 61; i++) bufs[1].x[i] += 50.f;
     void* before = (void*)rt.local_layer(&bufs[1], bufs[1].x.data(), bufs[1].y.data(), bufs[1].z.data(), N, false);
     (void)before;  // (whether the 1024-point sample of a later iteration sees an interior run depends on the layer's size)
     const size_t up_before = g_uploads;
     void* after = cloud(1, true);
-    expect(g_uploads <= 3 && g_uploads >= up_before && g_uploads == 3, "the edit is found at iteration 0 at the latest: exactly one re-upload");
+    expect(g_uploads >= up_before && g_uploads == 4, "the edit is found at iteration 0 at the latest: exactly one re-upload");
     expect(g_live.count(after) == 1 && g_live.size() == 2, "the old copy was freed, the new one is live");
     // ---- bounded: six more clouds with max_layers = 3
     for (int k = 2; k < 8; k++) cloud(k, true);
@@ -96,7 +106,7 @@ int main()
     rt.max_layers  = 100;
     rt.byte_budget = 2500000;
     for (int k = 8; k < 12; k++) map(k, true);
-    expect(rt.cached_bytes() <= 2500000 + 1000000, "byte budget respected (up to the entry being filled)");
+    expect(rt.cached_bytes() <= 2500000, "byte budget respected, the entry just filled included");
     expect(g_live.size() == rt.cached_layers(), "live == cached after byte evictions");
     // ---- explicit hooks
     const size_t live = g_live.size();

@@ -403,12 +403,24 @@ def test_layer_cache_is_bounded_and_reseen_layers_are_cheap(oracle):
     sessions[0].begin_iteration()
     n0 = sessions[0].match_pt2pt(d["T_init"], prm, icp_iteration=0)
     assert hostpath.counters()["cloud_uploads"] == up0 + 1 and n0 > 0
-    # a re-seen layer at iteration 0: strided check, no full hash
+    # a re-seen layer at iteration 0 is hashed in full again (the default: the live layer decides) ...
     f0 = hostpath.cache()
     sessions[0].begin_iteration()
     sessions[0].match_pt2pt(d["T_init"], prm, icp_iteration=0)
     f1 = hostpath.cache()
-    assert f1["full_checks"] == f0["full_checks"] and f1["reseen_checks"] >= f0["reseen_checks"] + 2
+    assert f1["full_checks"] == f0["full_checks"] + 2 and f1["reseen_checks"] == f0["reseen_checks"]
+    # ... and on a stride only for a host that vouches for its layers (MP2P_HIP_HOST_TRUST_RESEEN=1)
+    hostpath.set_trust_reseen(True)
+    try:
+        sessions[0].begin_iteration()
+        sessions[0].match_pt2pt(d["T_init"], prm, icp_iteration=0)  # the stride's print is taken here
+        f1 = hostpath.cache()
+        sessions[0].begin_iteration()
+        sessions[0].match_pt2pt(d["T_init"], prm, icp_iteration=0)
+        f2 = hostpath.cache()
+        assert f2["full_checks"] == f1["full_checks"] and f2["reseen_checks"] >= f1["reseen_checks"] + 2
+    finally:
+        hostpath.set_trust_reseen(False)
     # explicit release
     sessions[0].release_layers()
     assert hostpath.cache()["layers"] < f1["layers"]

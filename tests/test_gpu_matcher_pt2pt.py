@@ -324,9 +324,7 @@ def test_max_local_points_visit_order(amd, oracle, K):
     assert m2._visit_order(2500) is None
 
 
-@pytest.mark.parametrize("tune", ["wave_kernel=1", "wave_kernel=1,predict=1", "wave_kernel=1,wave_mfma=1", "wave_kernel=1,wave_levels=2",
-                                  "wave_kernel=1,dir_budget_mb=0,claim_dedup=0,claim_peek=0", "pipelines=2", "mfma_scan=0", "tile_waves=5",
-                                  "dir_budget_mb=0,claim_dedup=0,claim_peek=0"])
+@pytest.mark.parametrize("tune", ["pipelines=2", "mfma_scan=0", "tile_waves=5", "dir_budget_mb=0,claim_dedup=0,claim_peek=0"])
 def test_tune_knobs_do_not_change_the_lists(amd, oracle, tune, monkeypatch):
     """MP2P_HIP_TUNE is read once per context: every setting is a measurement aid that must compute the
     same lists (two search pipelines on two streams, exact scan instead of the matrix-pipe prefilter, another
@@ -351,23 +349,3 @@ def test_tune_knobs_do_not_change_the_lists(amd, oracle, tune, monkeypatch):
         pose = amd.se3.compose(pose, amd.se3.exp(np.concatenate([rng.normal(0, 0.02, 3), rng.normal(0, 0.004, 3)])))
 
 
-@pytest.mark.parametrize("n_g,n_l,thr,ang,seed,kw", CASES[:8])
-def test_wave_kernel_parity_vs_oracle(amd, oracle, n_g, n_l, thr, ang, seed, kw, monkeypatch):
-    """nn_wave_kernel (MP2P_HIP_TUNE wave_kernel=1: 64 queries per wave, union of the lanes' cubes staged once) on the
-    random cases of test_random_parity_vs_oracle, cold and warm (three poses in a row on one context)"""
-    from mp2p_icp_amd import _lib, core, synthetic
-    d = synthetic.random_cloud_pair(n_l, n_g, seed, outlier_frac=0.1)
-    g, l = d["glob"], d["local"]
-    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
-    monkeypatch.setenv("MP2P_HIP_TUNE", "wave_kernel=1")
-    ctx = amd.Context(0)
-    gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2], **{k: v for k, v in kw.items() if k in ("cell_size", "target_per_cell")})
-    cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
-    pairs = core.DevicePairs(ctx, l.shape[0], 0)
-    prm = _lib.Pt2PtParams(thr, ang, 1, 0, 0, 0.20, 0, 0.0, 0, 0.0, 0, 0.0, 0)
-    rng = np.random.default_rng(seed)
-    for pose in (d["T_gt"], d["T_init"], amd.se3.compose(d["T_init"], amd.se3.exp(np.concatenate([rng.normal(0, 0.01, 3), rng.normal(0, 0.002, 3)])))):
-        want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, thr, ang, tree=tree)
-        pairs.clear()
-        core.match_pt2pt(ctx, gmap, cloud, pose, prm, None, pairs)
-        _assert_same_pairs(pairs.download_pt2pt(), want)

@@ -12,6 +12,5 @@ tools/gpu_prof.sh r03_bench_scene_a --scene a > /dev/null 2>&1
 tools/gpu_prof.sh r03_bench_c3 --config c3 > /dev/null 2>&1
 tools/gpu_pmc.sh r03_k5 "tools/pl_one.py 120000" pt2pl_ stats sq mem > /dev/null 2>&1
 timeout 300 python tools/timeline_probe.py 1000000 10000000 b > $O/timeline_k3_scene_b.json 2>/dev/null
-MP2P_HIP_TUNE=wave_kernel=1 timeout 300 python tools/wave_probe.py a chain > $O/wave_probe_scene_a.json 2>/dev/null
 timeout 300 python tools/pl_timeline.py 120000 0.25 2>/dev/null | tail -1 > $O/timeline_k5_c3.json
 du -sh gpurun_out; ls $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/gpu_run.sh <tag> <steps...>   steps: smoke tests pt2pt bench bencha benchb wavea waveb   (through gpurun)
+# tools/gpu_run.sh <tag> <steps...>   steps: smoke tests pt2pt bench bencha benchb   (through gpurun)
 # one bounded GPU call made of named steps; everything lands under gpurun_out/<tag>/
 tag=$1; shift
 out=gpurun_out/$tag; mkdir -p $out
@@ -12,8 +12,6 @@ for step in "$@"; do
     bench)   timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo "bench rc=$?" | tee -a $out/rc.txt; tail -c 600 $out/bench.json;;
     bencha)  timeout 600 python bench.py --steps 20 --warmup 5 --scene a --no-extras --no-cpu-baseline > $out/bench_a.json 2> $out/bench_a.err; echo "bencha rc=$?" | tee -a $out/rc.txt;;
     benchb)  timeout 600 python bench.py --steps 20 --warmup 5 --scene b --no-extras --no-cpu-baseline > $out/bench_b.json 2> $out/bench_b.err; echo "benchb rc=$?" | tee -a $out/rc.txt;;
-    wavea)    MP2P_HIP_TUNE=wave_kernel=1 timeout 600 python bench.py --steps 20 --warmup 5 --scene a --no-extras --no-cpu-baseline > $out/bench_wave_a.json 2> $out/bench_wave_a.err; echo "wavea rc=$?" | tee -a $out/rc.txt;;
-    waveb)    MP2P_HIP_TUNE=wave_kernel=1 timeout 600 python bench.py --steps 20 --warmup 5 --scene b --no-extras --no-cpu-baseline > $out/bench_wave_b.json 2> $out/bench_wave_b.err; echo "waveb rc=$?" | tee -a $out/rc.txt;;
     *) echo "unknown step $step";;
   esac
 done

@@ -130,6 +130,36 @@ int mp2p_hostpath_match_pt2pl(void* h, const double pose[12], const mp2p_hip_pt2
         });
 }
 
+// QualityEvaluator_PairedRatio::evaluate, reuse_icp_pairings = false (QualityEvaluator_PairedRatio.cpp:45-73), as the plugin's
+// mp2p_icp_hip::QualityEvaluator_PairedRatio does it: the private matcher on a fresh MatchState, only the two counts come
+// back.  *quality = pairs / potential_pairings (0 when nothing could pair), *hard_discard = quality < absolute_minimum
+int mp2p_hostpath_quality_paired_ratio(void* h, const double pose[12], const mp2p_hip_pt2pt_params* prm,
+                                       double absolute_minimum_pairing_ratio, double* quality, int* hard_discard,
+                                       size_t* n_pairs)
+{
+    auto* s = static_cast<Session*>(h);
+    return guarded(
+        [&]()
+        {
+            const double   t0        = now_ms();
+            Runtime&       rt        = Runtime::get();
+            const uint64_t potential = (uint64_t)s->nl * prm->pairingsPerPoint;  // Matcher_Points_DistanceThreshold.cpp:64
+            size_t         n         = 0;
+            if (s->ng && s->nl)
+            {
+                // matcher_.match(pcGlobal, pcLocal, localPose, {}, ...): MatchContext{} = ICP iteration 0 (:60)
+                mp2p_hip_map*   m = rt.global_layer(s->gx, s->gx, s->gy, s->gz, s->ng, true);
+                mp2p_hip_cloud* l = rt.local_layer(s->lx, s->lx, s->ly, s->lz, s->nl, true);
+                n = count_pt2pt_layer(rt, m, l, pose, *prm, nullptr, 0);
+            }
+            const double q = potential ? (double)n / (double)potential : 0.0;  // :67-70
+            if (quality) *quality = q;
+            if (hard_discard) *hard_discard = q < absolute_minimum_pairing_ratio;  // :72
+            if (n_pairs) *n_pairs = n;
+            s->last_ms[0] = now_ms() - t0;
+        });
+}
+
 // Matcher_Points_InlierRatio (Matcher_Points_InlierRatio.cpp:41-143) through the host layer
 int mp2p_hostpath_match_inlier_ratio(void* h, const double pose[12], const mp2p_hip_inlier_ratio_params* prm,
                                      uint32_t icp_iteration, const uint32_t* visit, size_t n_visit, size_t* n_added)

@@ -321,6 +321,15 @@ class Runtime
         return conv_pairs_;
     }
     size_t cap_pl() const { return cap_pl_; }
+    // the list of a quality evaluator's private matcher (count_pt2pt_layer): its own device object, so that the
+    // resident list of the running ICP iteration -- and the token that vouches for it -- stay as they are
+    mp2p_hip_pairs* quality_pairs(size_t cap)
+    {
+        if (!quality_pairs_) check(mp2p_hip_pairs_create(ctx, std::max<size_t>(cap, 1), 0, &quality_pairs_));
+        else check(mp2p_hip_pairs_reserve(ctx, quality_pairs_, cap, 0));
+        check(mp2p_hip_pairs_clear(ctx, quality_pairs_));
+        return quality_pairs_;
+    }
 
     // what the device list holds, as the matchers of this plugin built it
     struct Token
@@ -465,7 +474,7 @@ class Runtime
     std::map<std::pair<size_t, size_t>, mp2p_hip_mstate*>    mstates_;
     uint32_t*       idx_     = nullptr;
     size_t          idx_cap_ = 0;
-    mp2p_hip_pairs *dev_pairs_ = nullptr, *conv_pairs_ = nullptr;
+    mp2p_hip_pairs *dev_pairs_ = nullptr, *conv_pairs_ = nullptr, *quality_pairs_ = nullptr;
     size_t          cap_pt_ = 0, cap_pl_ = 0;
 };
 
@@ -713,6 +722,23 @@ size_t match_pt2pl_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
     print_feed(tk.print_pl, rec.data(), n);
     tk.n_pl += n, tk.valid = true;
     return n;
+}
+
+// QualityEvaluator_PairedRatio::evaluate with reuse_icp_pairings = false (QualityEvaluator_PairedRatio.cpp:57-75) runs its
+// private Matcher_Points_DistanceThreshold on a FRESH MatchState (:59) for the sake of two numbers: Pairings::size() and
+// potential_pairings (:67-70).  So nothing else comes back from the device: 24 bytes instead of 36 per pair, no marks
+// (the state is discarded), and the list lives in a device object of its own.  Called at every quality checkpoint and
+// at the end of ICP::align (ICP.cpp:259-283, 322-324) -- on the map whose index is already resident.
+inline size_t count_pt2pt_layer(Runtime& rt, mp2p_hip_map* map, mp2p_hip_cloud* cloud, const double pose[12],
+                                const mp2p_hip_pt2pt_params& prm, const uint32_t* visit, size_t n_visit)
+{
+    const size_t    n_l = mp2p_hip_cloud_size(cloud);
+    mp2p_hip_pairs* dp  = rt.quality_pairs(n_l * std::max<uint32_t>(1u, prm.pairingsPerPoint));
+    rt.check(mp2p_hip_cloud_set_visit_order(rt.ctx, cloud, n_visit ? visit : nullptr, n_visit));
+    rt.check(mp2p_hip_match_pt2pt(rt.ctx, map, cloud, pose, &prm, nullptr /* a fresh MatchState: nothing marked */, dp));
+    uint64_t n_pt = 0;
+    rt.check(mp2p_hip_pairs_counts(rt.ctx, dp, &n_pt, nullptr, nullptr));
+    return (size_t)n_pt;
 }
 
 // Pairings -> the device handle a solver reads.  The lists the matchers of this plugin produced in the

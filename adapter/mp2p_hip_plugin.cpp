@@ -34,10 +34,12 @@
 //   FilterBase::filter (FilterDecimateVoxels)   FilterBase.h:62, FilterDecimateVoxels.cpp:107-381
 //   -> with these, icp-run on demos/icp-settings-kitti.yaml (Matcher_Adaptive from iteration 6, every matcher on the
 //      `decimated` layer) stays on the device path for the whole alignment
+//   QualityEvaluator::evaluate (PairedRatio)    QualityEvaluator.h:49-51, QualityEvaluator_PairedRatio.cpp:45-73
 //   registration                                register.cpp:43-69
 #include <mp2p_icp/Matcher_Points_Base.h>
 #include <mp2p_icp/NearestPlaneCapable.h>
 #include <mp2p_icp/PairWeights.h>
+#include <mp2p_icp/QualityEvaluator.h>
 #include <mp2p_icp/Solver.h>
 #include <mp2p_icp/WeightParameters.h>
 #include <mp2p_icp/metricmap.h>
@@ -223,7 +225,34 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base, p
     double   thresholdAngularDeg = 0.50;
     uint32_t pairingsPerPoint    = 1;
 
+    // Count-only calls (mp2p_icp_hip::QualityEvaluator_PairedRatio): with allowMatchAlreadyMatchedGlobalPoints the
+    // matcher neither reads global marks nor leaves any mark (Matcher_Points_DistanceThreshold.cpp:98-101, 116-120), so
+    // on the evaluator's fresh MatchState the layer pairs are independent and only the NUMBER of pairs is wanted:
+    // nothing but two counters leaves the device.  Returns false when the flags do not allow that shortcut.
+    bool count_pairs(const mp2p_icp::metric_map_t& pcGlobal, const mp2p_icp::metric_map_t& pcLocal,
+                     const mrpt::poses::CPose3D& localPose, mp2p_icp::MatchState& ms, uint64_t& n_pairs,
+                     uint64_t& potential) const
+    {
+        if (!allowMatchAlreadyMatchedGlobalPoints_) return false;
+        mp2p_icp::Pairings tmp;
+        count_only_ = true, counted_ = 0;
+        try
+        {
+            match(pcGlobal, pcLocal, localPose, {}, ms, tmp);
+        }
+        catch (...)
+        {
+            count_only_ = false;
+            throw;
+        }
+        count_only_ = false;
+        n_pairs = counted_, potential = tmp.potential_pairings;
+        return true;
+    }
+
    private:
+    mutable bool     count_only_ = false;
+    mutable uint64_t counted_    = 0;
     void implMatchOneLayer(const mrpt::maps::CMetricMap& pcGlobal, const mrpt::maps::CPointsMap& pcLocal,
                            const mrpt::poses::CPose3D& localPose, mp2p_icp::MatchState& ms,
                            const mp2p_icp::layer_name_t& globalName, const mp2p_icp::layer_name_t& localName,
@@ -256,6 +285,11 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base, p
         mp2p_hip_map*               m;
         mp2p_hip_cloud*             c;
         layers(rt, *gl, pcLocal, m, c);
+        if (count_only_)
+        {
+            counted_ += mp2p_hip_host::count_pt2pt_layer(rt, m, c, T, prm, visit.data(), visit.size());
+            return;
+        }
         BitAccess gbits(ms.globalPairedBitField.point_layers.at(globalName), gl->size());
         BitAccess lbits(ms.localPairedBitField.point_layers.at(localName), pcLocal.size());
         MatchCall call;
@@ -870,6 +904,69 @@ class FilterDecimateVoxels : public mp2p_icp_filters::FilterBase
     std::shared_ptr<mp2p_icp_filters::FilterDecimateVoxels> reference_;
 };
 
+// ================================================================================================
+// QualityEvaluator_PairedRatio (QualityEvaluator_PairedRatio.cpp:22-75) with the HIP matcher as its private matcher.
+// The reference's class holds a concrete mp2p_icp::Matcher_Points_DistanceThreshold BY VALUE (QualityEvaluator_PairedRatio.h:60)
+// and calls it, when reuse_icp_pairings is false, at every quality checkpoint and at the end of ICP::align (ICP.cpp:259-283,
+// 322-324): with the stock evaluator in the YAML the KD-tree of the 10 M-point map would be built after all, through that
+// side door.  Quality evaluators are created by class name with an optional `plugin:` exactly like matchers
+// (ICP.cpp:559-601):
+//     quality:
+//       - class: mp2p_icp_hip::QualityEvaluator_PairedRatio
+//         plugin: libmp2p_icp_hip_plugin.so
+//         params: { reuse_icp_pairings: false, thresholdDistance: 0.10, thresholdAngularDeg: 0 }   # + the matcher's keys
+// Same YAML keys, same defaults (reuse_icp_pairings = true, absolute_minimum_pairing_ratio = 0.20, and -- for the
+// private matcher -- allowMatchAlreadyMatchedGlobalPoints = true unless the YAML says otherwise, :33-38).
+class QualityEvaluator_PairedRatio : public mp2p_icp::QualityEvaluator
+{
+    DEFINE_MRPT_OBJECT(QualityEvaluator_PairedRatio, mp2p_icp_hip)
+   public:
+    void initialize(const mrpt::containers::yaml& params) override
+    {
+        MCP_LOAD_OPT(params, reuse_icp_pairings);              // :28
+        MCP_LOAD_OPT(params, absolute_minimum_pairing_ratio);  // :29
+        if (!reuse_icp_pairings)
+        {
+            // "in quality assesment, it DOES make sense to count several times the same global point" (:33-38)
+            mrpt::containers::yaml p = params;
+            if (!p.has("allowMatchAlreadyMatchedGlobalPoints")) p["allowMatchAlreadyMatchedGlobalPoints"] = true;
+            matcher_.initialize(p);
+        }
+    }
+    Result evaluate(const mp2p_icp::metric_map_t& pcGlobal, const mp2p_icp::metric_map_t& pcLocal,
+                    const mrpt::poses::CPose3D& localPose, const mp2p_icp::Pairings& pairingsFromICP) const override
+    {
+        uint64_t n_pairs = 0, potential = 0;
+        if (reuse_icp_pairings)  // :51-55
+            n_pairs = pairingsFromICP.size(), potential = pairingsFromICP.potential_pairings;
+        else
+        {
+            mp2p_icp::MatchState ms(pcGlobal, pcLocal);  // :59
+            if (!matcher_.count_pairs(pcGlobal, pcLocal, localPose, ms, n_pairs, potential))
+            {
+                // global re-use forbidden in the YAML: the layer pairs are coupled through the marks -> the whole match
+                mp2p_icp::Pairings newPairings;
+                matcher_.match(pcGlobal, pcLocal, localPose, {}, ms, newPairings);  // :60
+                n_pairs = newPairings.size(), potential = newPairings.potential_pairings;
+            }
+        }
+        Result r;
+        r.quality      = potential ? (double)n_pairs / (double)potential : .0;  // :67-70
+        r.hard_discard = r.quality < absolute_minimum_pairing_ratio;           // :72
+        return r;
+    }
+    void attachToParameterSource(mp2p_icp::ParameterSource& source) override  // QualityEvaluator_PairedRatio.h:53-57
+    {
+        source.attach(*this);
+        source.attach(matcher_);
+    }
+
+   private:
+    Matcher_Points_DistanceThreshold matcher_;
+    bool                             reuse_icp_pairings             = true;
+    double                           absolute_minimum_pairing_ratio = 0.20;
+};
+
 // a caller that edits a layer in place between the iterations of its OWN loop (ICP::align never does)
 // ... and one that is done with a layer (a scan's maps at the end of ICP::align): frees its device copy now; the
 // cache is bounded anyway (mp2p_hip_host::Runtime::max_layers / byte_budget, least recently used first)
@@ -882,6 +979,7 @@ IMPLEMENTS_MRPT_OBJECT(Matcher_Point2Plane, mp2p_icp::Matcher, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(Matcher_Points_InlierRatio, mp2p_icp::Matcher, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(Matcher_Adaptive, mp2p_icp::Matcher, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(FilterDecimateVoxels, mp2p_icp_filters::FilterBase, mp2p_icp_hip)
+IMPLEMENTS_MRPT_OBJECT(QualityEvaluator_PairedRatio, mp2p_icp::QualityEvaluator, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(Solver_Horn, mp2p_icp::Solver, mp2p_icp_hip)
 IMPLEMENTS_MRPT_OBJECT(Solver_GaussNewton, mp2p_icp::Solver, mp2p_icp_hip)
 IMPLEMENTS_SERIALIZABLE(PointsMapPlanes, CSimplePointsMap, mp2p_icp_hip)
@@ -896,6 +994,7 @@ MRPT_INITIALIZER(register_mp2p_icp_hip)
     registerClass(CLASS_ID(mp2p_icp_hip::Matcher_Points_InlierRatio));
     registerClass(CLASS_ID(mp2p_icp_hip::Matcher_Adaptive));
     registerClass(CLASS_ID(mp2p_icp_hip::FilterDecimateVoxels));
+    registerClass(CLASS_ID(mp2p_icp_hip::QualityEvaluator_PairedRatio));
     registerClass(CLASS_ID(mp2p_icp_hip::Solver_GaussNewton));
     registerClass(CLASS_ID(mp2p_icp_hip::Solver_Horn));
     registerClass(CLASS_ID(mp2p_icp_hip::PointsMapPlanes));

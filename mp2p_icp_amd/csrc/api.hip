@@ -175,6 +175,10 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    // a copy-out the caller never ended: its later rounds still read the device staging area -- finish it before
+    // anything is released (an unknown pointer is a HOST pointer to hipMemcpyAsync: a segmentation fault, not an error)
+    (void)mp2p_hip_pairs_copy_end(ctx);
+    mp2p::stage_destroy(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->nn_spos.release(), ctx->nn_d2.release(), ctx->tile_bbox.release();
     ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release(), ctx->compact_flags.release();
@@ -187,8 +191,6 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     for (auto& b : ctx->scratch) b.release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
-    (void)mp2p_hip_pairs_copy_end(ctx);
-    mp2p::stage_destroy(ctx);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -415,6 +417,7 @@ int mp2p_hip_mstate_upload_bits(mp2p_hip_ctx* ctx, mp2p_hip_mstate* ms, const ui
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     const size_t ng = ms->global_taken.n, nl = ms->local_taken.n;
     const size_t wg = (ng + 63) / 64, wl = (nl + 63) / 64;
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure((wg + wl) * 8 + 16));
     auto* dw = reinterpret_cast<unsigned long long*>(ctx->aos_stage.p);
     if (global_words && ng)
@@ -440,6 +443,7 @@ int mp2p_hip_mstate_download_bits(mp2p_hip_ctx* ctx, const mp2p_hip_mstate* ms, 
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     const size_t ng = ms->global_taken.n, nl = ms->local_taken.n;
     const size_t wg = (ng + 63) / 64, wl = (nl + 63) / 64;
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure((wg + wl) * 8 + 16));
     auto* dw = reinterpret_cast<unsigned long long*>(ctx->aos_stage.p);
     if (global_words)

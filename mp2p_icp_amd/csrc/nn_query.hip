@@ -703,7 +703,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // a query whose radius already exceeds what a tile should carry goes straight to the
     // one-query-per-wave kernel
     {
-        const bool               wide  = !done && !a.tile_bricks && r > a.r_defer;
+        // (with the brick path a wide radius stays -- unless NO candidate is known yet: then nothing bounds the ball but the
+        //  radius itself, and the one-query kernel's nearest-voxel-first order is what finds a bound cheaply)
+        const bool               wide  = !done && r > a.r_defer && (!a.tile_bricks || best_idx == NONE_U32);
         const unsigned long long wmask = __ballot(wide);
         if (wmask)
         {
@@ -799,8 +801,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             b2 = hi ? 0.0f : (cqx * cqx + cqy * cqy + cqz * cqz);
             o0 = hi ? ocy : ocx, o1 = hi ? 0.0f : ocz;
         }
+        // the tile's budget of staged candidates also ends a pass IN FLIGHT (`over`): a group in a dense place
+        // (vegetation within a wide ball: up to 10^5 points) would otherwise run for a millisecond and be the
+        // kernel's duration; what it has not finished goes to the one-query kernel with the bounds found so far
+        bool           over    = false;
         const uint32_t n_outer = use_bricks ? (nb + 63u) / 64u : 1u;
-        for (uint32_t ob = 0; ob < n_outer; ob++)
+        for (uint32_t ob = 0; ob < n_outer && !over; ob++)
         {
         // one round of 64 bricks (lane = brick): the occupied voxels of the brick that lie in the box
         unsigned long long bm = 0ull, vtotal = box.ncell;
@@ -829,7 +835,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             vtotal = (uint32_t)__builtin_amdgcn_readlane((int)bincl, 63);
             st_cells += min(64u, nb - ob * 64u);
         }
-        for (unsigned long long r0 = 0; r0 < vtotal; r0 += use_bricks ? (unsigned long long)NN_TVLIST : vtotal)
+        for (unsigned long long r0 = 0; r0 < vtotal && !over; r0 += use_bricks ? (unsigned long long)NN_TVLIST : vtotal)
         {
         unsigned long long nv = vtotal;
         if (use_bricks)
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             __syncthreads();
             nv = min((unsigned long long)NN_TVLIST, vtotal - r0);
         }
-        for (unsigned long long cb = 0; cb < nv; cb += 64)
+        for (unsigned long long cb = 0; cb < nv && !over; cb += 64)
         {
             uint32_t cnt = 0, start = 0;
             if (use_bricks)
@@ -874,9 +880,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             s_coff[lane]   = off;
             st_cand += total;
 
-            for (uint32_t base = 0; base < total; base += NN_CAP)
+            for (uint32_t base = 0; base < total && !over; base += NN_CAP)
             {
                 const uint32_t m     = min((uint32_t)NN_CAP, total - base);
+                over = st_cand - total + base + m > a.tile_cand_cap;  // (this round is still scanned)
                 const uint32_t m_pad = (m + 31u) & ~31u;
                 // ---- stage.  Lane l fills slots 4l..4l+3 of the round.  Which voxel a slot
                 //      belongs to comes from a segmented broadcast: every occupied voxel drops
@@ -1046,7 +1053,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
 
         bool too_wide = false;
-        if (grp)
+        if (grp && !over)  // (a pass cut short has not covered its balls: nobody concludes)
         {
             if (is_final(r, rmax, best_d2, g.slack)) done = true;
             else
@@ -1054,7 +1061,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 r = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
                 // a query whose radius outgrows the voxels would drag the shared box with it:
                 // it continues alone, with the whole wave on its own candidates
-                too_wide = !a.tile_bricks && r > a.r_defer;
+                too_wide = r > a.r_defer && (!a.tile_bricks || best_idx == NONE_U32);
             }
         }
         // a tile that has already staged more than its budget hands ALL its unfinished queries on

@@ -862,6 +862,7 @@ int mp2p_hip_pairs_download_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
     if (!out || capacity < n)
         return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "download_pt2pt: capacity %zu < %llu", capacity,
                        (unsigned long long)n);
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);  // (its later rounds read the staging area)
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pt)));
     auto* d = reinterpret_cast<mp2p_hip_pair_pt2pt*>(ctx->aos_stage.p);
     hipLaunchKernelGGL(pack_pt2pt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0,
@@ -885,6 +886,7 @@ int mp2p_hip_pairs_download_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p,
     if (!out || capacity < n)
         return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "download_pt2pl: capacity %zu < %llu", capacity,
                        (unsigned long long)n);
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);  // (its later rounds read the staging area)
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pl)));
     auto* d = reinterpret_cast<mp2p_hip_pair_pt2pl*>(ctx->aos_stage.p);
     hipLaunchKernelGGL(pack_pt2pl_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0,
@@ -905,6 +907,7 @@ int mp2p_hip_pairs_copy_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t
     if (n == 0) return MP2P_HIP_OK;
     MP2P_REQUIRE(ctx, out && first + n <= p->cap_pt2pt, "copy_pt2pt: range outside the list");
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);  // (its later rounds read the staging area)
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pt)));
     auto* d = reinterpret_cast<mp2p_hip_pair_pt2pt*>(ctx->aos_stage.p);
     hipLaunchKernelGGL(pack_pt2pt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->lidx.p,
@@ -930,6 +933,7 @@ int mp2p_hip_pairs_copy_pt2pt_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, 
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(idx_global, p->gidx.p + first, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MP2P_TRY_HIP(ctx, hipEventRecord(ctx->copy_ev, ctx->stream));
     const size_t bytes = n * sizeof(mp2p_hip_pair_pt2pt);
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);  // (its later rounds read the staging area)
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(bytes));
     auto* d = reinterpret_cast<mp2p_hip_pair_pt2pt*>(ctx->aos_stage.p);
     hipLaunchKernelGGL(pack_pt2pt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->lidx.p,
@@ -982,6 +986,7 @@ int mp2p_hip_pairs_copy_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t
     if (n == 0) return MP2P_HIP_OK;
     MP2P_REQUIRE(ctx, out && first + n <= p->cap_pt2pl, "copy_pt2pl: range outside the list");
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);  // (its later rounds read the staging area)
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pl)));
     auto* d = reinterpret_cast<mp2p_hip_pair_pt2pl*>(ctx->aos_stage.p);
     hipLaunchKernelGGL(pack_pt2pl_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->pl_coef.p,
@@ -1007,6 +1012,7 @@ int mp2p_hip_pairs_download_pt2pt_from(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* 
     if (n == 0) return MP2P_HIP_OK;
     if (!out || capacity < n)
         return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "download_pt2pt_from: capacity %zu < %zu", capacity, n);
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);  // (its later rounds read the staging area)
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pt)));
     auto* d = reinterpret_cast<mp2p_hip_pair_pt2pt*>(ctx->aos_stage.p);
     hipLaunchKernelGGL(pack_pt2pt_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->lidx.p,
@@ -1032,6 +1038,7 @@ int mp2p_hip_pairs_download_pt2pl_from(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* 
     if (n == 0) return MP2P_HIP_OK;
     if (!out || capacity < n)
         return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "download_pt2pl_from: capacity %zu < %zu", capacity, n);
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);  // (its later rounds read the staging area)
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(n * sizeof(mp2p_hip_pair_pt2pl)));
     auto* d = reinterpret_cast<mp2p_hip_pair_pt2pl*>(ctx->aos_stage.p);
     hipLaunchKernelGGL(pack_pt2pl_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->pl_coef.p,
@@ -1052,6 +1059,7 @@ int mp2p_hip_pairs_upload(mp2p_hip_ctx* ctx, mp2p_hip_pairs* p, const mp2p_hip_p
         return set_err(ctx, MP2P_HIP_ERR_CAPACITY, "pairs_upload: capacity exceeded");
     const size_t bytes = std::max(n_pt2pt * sizeof(mp2p_hip_pair_pt2pt),
                                   n_pt2pl * sizeof(mp2p_hip_pair_pt2pl));
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);  // (its later rounds read the staging area)
     MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(bytes ? bytes : 1));
     if (n_pt2pt)
     {

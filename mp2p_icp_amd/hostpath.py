@@ -26,6 +26,8 @@ SIGNATURES = {
                                             C.POINTER(C.c_size_t)]),
     "mp2p_hostpath_match_pt2pl": (C.c_int, [_P, _dp, C.POINTER(_lib.Pt2PlParams), C.c_uint32,
                                             C.POINTER(C.c_size_t)]),
+    "mp2p_hostpath_quality_paired_ratio": (C.c_int, [_P, _dp, C.POINTER(_lib.Pt2PtParams), C.c_double, _dp, C.POINTER(C.c_int),
+                                                     C.POINTER(C.c_size_t)]),
     "mp2p_hostpath_match_inlier_ratio": (C.c_int, [_P, _dp, C.POINTER(_lib.InlierRatioParams), C.c_uint32, _P, C.c_size_t,
                                                    C.POINTER(C.c_size_t)]),
     "mp2p_hostpath_match_adaptive": (C.c_int, [_P, _dp, C.POINTER(_lib.AdaptiveParams), C.c_uint32, C.POINTER(C.c_size_t),
@@ -147,6 +149,16 @@ class Session:
                                                            C.byref(m)))
         k = m.value
         return np.stack([x[:k], y[:k], z[:k]], 1), src[:k]
+
+    def quality_paired_ratio(self, pose, prm, absolute_minimum_pairing_ratio=0.20):
+        """QualityEvaluator_PairedRatio::evaluate with reuse_icp_pairings = false (the plugin's
+        mp2p_icp_hip::QualityEvaluator_PairedRatio): -> (quality, hard_discard, pairs)"""
+        T = np.ascontiguousarray(pose, dtype=np.float64)
+        q, hd, n = C.c_double(0), C.c_int(0), C.c_size_t(0)
+        _check(self._L.mp2p_hostpath_quality_paired_ratio(self._h, T.ctypes.data_as(_dp), C.byref(prm),
+                                                          float(absolute_minimum_pairing_ratio), C.byref(q), C.byref(hd),
+                                                          C.byref(n)))
+        return float(q.value), bool(hd.value), int(n.value)
 
     def release_layers(self):
         _check(self._L.mp2p_hostpath_release_layers(self._h))

@@ -15,6 +15,8 @@ struct MatchContext
 };
 struct MatchState
 {
+    MatchState() = default;
+    MatchState(const metric_map_t& pcGlobal, const metric_map_t& pcLocal);  // Matcher.h:46-50
     pointcloud_bitfield_t localPairedBitField, globalPairedBitField;
 };
 class Matcher : public mrpt::rtti::CObject, public Parameterizable

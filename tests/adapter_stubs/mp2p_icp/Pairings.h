@@ -28,6 +28,7 @@ struct Pairings
     std::vector<matched_line_t>                 paired_ln2ln;
     std::vector<matched_plane_t>                paired_pl2pl;
     uint64_t                                    potential_pairings = 0;
+    virtual size_t                              size() const;   // Pairings.h:141, Pairings.cpp:143-147
     std::vector<std::pair<std::size_t, double>> point_weights;
 };
 struct OutlierIndices

@@ -3,10 +3,18 @@
 #include <mrpt/containers/yaml.h>
 namespace mp2p_icp
 {
+class Parameterizable;
+class ParameterSource  // Parameterizable.h:51-80
+{
+   public:
+    void attach(Parameterizable& obj);
+};
 class Parameterizable
 {
    public:
-    void checkAllParametersAreRealized() const;
+    virtual ~Parameterizable() = default;
+    void         checkAllParametersAreRealized() const;
+    virtual void attachToParameterSource(ParameterSource& source) { source.attach(*this); }  // :101
 };
 }  // namespace mp2p_icp
 #define DECLARE_PARAMETER_REQ(Yaml__, Var__) Var__ = (Yaml__)[#Var__].as<decltype(Var__)>()

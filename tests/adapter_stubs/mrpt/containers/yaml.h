@@ -14,6 +14,8 @@ class yaml
     bool isScalar() const;
     size_t size() const;
     yaml operator()(int index) const;
+    yaml& operator[](const std::string& key);
+    yaml& operator=(bool v);
 };
 }  // namespace mrpt::containers
 #define MCP_LOAD_REQ(Yaml__, Var__) Var__ = (Yaml__)[#Var__].as<decltype(Var__)>()

@@ -426,3 +426,39 @@ def test_layer_cache_is_bounded_and_reseen_layers_are_cheap(oracle):
     assert hostpath.cache()["layers"] < f1["layers"]
     for s in sessions:
         s.close()
+
+
+def test_quality_paired_ratio_counts_only_and_leaves_the_resident_list(oracle):
+    """mp2p_icp_hip::QualityEvaluator_PairedRatio (QualityEvaluator_PairedRatio.cpp:45-73, reuse_icp_pairings = false):
+    the private matcher on a fresh MatchState with global re-use allowed (:33-38); quality = pairs / potential pairings.
+    Only the two counts come back, and the list the iteration's own matcher left on the device is still what the solver
+    finds afterwards (no Pairings upload)."""
+    from mp2p_icp_amd import hostpath, synthetic
+    d = synthetic.make_pair(60_000, 400_000, 17)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(*_xyz(g))
+    s = hostpath.Session(g, l)
+    prm, gnp = _pt2pt_prm(1.5), _gn_prm()
+    qprm = _pt2pt_prm(0.6, allowMatchAlreadyMatchedGlobalPoints=1)
+    pose = d["T_init"].copy()
+    for it in range(3):
+        s.begin_iteration()
+        n = s.match_pt2pt(pose, prm, icp_iteration=it)
+        got = s.pairs_pt2pt().copy()
+        bits = (s.bits(0).copy(), s.bits(1).copy())
+        # a quality checkpoint between the matcher and the solver (ICP.cpp:259-283 runs it after the solver; here it
+        # is placed where it could do the most damage)
+        q, hard, npairs = s.quality_paired_ratio(pose, qprm, absolute_minimum_pairing_ratio=0.20)
+        want, pot = oracle.match_pt2pt(*_xyz(g), *_xyz(l), pose, 0.6, 0.0, tree=tree, allowMatchAlreadyMatchedGlobalPoints=True)
+        assert npairs == len(want) and pot == l.shape[0]
+        assert q == len(want) / pot and hard == (q < 0.20)
+        # nothing of the running iteration was touched
+        assert n == len(s.pairs_pt2pt()) and np.array_equal(s.pairs_pt2pt(), got)
+        assert np.array_equal(s.bits(0), bits[0]) and np.array_equal(s.bits(1), bits[1])
+        c0 = hostpath.counters()["pairings_uploads"]
+        pose, _ = s.solve_gn(pose, gnp)
+        assert hostpath.counters()["pairings_uploads"] == c0
+    # a threshold nothing passes: quality 0, discarded
+    q, hard, npairs = s.quality_paired_ratio(pose, _pt2pt_prm(1e-4, allowMatchAlreadyMatchedGlobalPoints=1))
+    assert npairs == 0 and q == 0.0 and hard
+    s.close()

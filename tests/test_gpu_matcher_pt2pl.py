@@ -251,6 +251,73 @@ def test_certificate_pose_sequence(amd, oracle, knn, radius):
     assert per_call[7] < per_call[5], per_call   # the 3 cm jump leaves (next to) nothing certified
 
 
+def test_certificate_far_from_the_origin(amd, oracle):
+    """the certificate's margins are tied to the MAP (slack = 2^-20 of its extent / largest coordinate)
+    while the rounding of a computed distance is tied to the COORDINATES.  A map 1.4 km from the origin and 500 m wide
+    (fp32 spacing 0.12 mm there, slack 1.3 mm): creeping poses, every call equal to the oracle's cold result."""
+    from mp2p_icp_amd import _lib, core, synthetic
+    d = synthetic.make_pair(6000, 300000, 911)
+    rng = np.random.default_rng(4)
+    off = np.array([1000.0, 1000.0, 20.0])
+    g = d["glob"].astype(np.float64) + off
+    # a few far points make the layer 500 m wide (the slack follows the extent)
+    far = np.stack([rng.uniform(off[0] - 250, off[0] + 250, 2000), rng.uniform(off[1] - 250, off[1] + 250, 2000),
+                    rng.uniform(off[2] - 5, off[2] + 30, 2000)], 1)
+    g = np.ascontiguousarray(np.concatenate([g, far]).astype(np.float32))
+    l = d["local"]
+    T0 = d["T_gt"].copy()
+    T0[9:12] += off
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    poses, scales = [T0], [1e-3, 5e-4, 2e-4, 1e-4, 1e-4, 5e-5, 5e-5, 2e-5, 2e-5, 1e-3]
+    for sc in scales:
+        poses.append(amd.se3.compose(poses[-1], amd.se3.exp(np.concatenate([rng.normal(0, sc, 3), rng.normal(0, 0.05 * sc, 3)]))))
+    ctx = amd.Context(0)
+    ctx.set_profiling(1)
+    gmap, cloud = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2]), core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    assert gmap.info()["bbox_max"][0] - gmap.info()["bbox_min"][0] > 450.0
+    pairs = core.DevicePairs(ctx, 0, l.shape[0])
+    certified = []
+    for k, pose in enumerate(poses):
+        n = _pl_equal(oracle, core, ctx, gmap, cloud, pairs, g, l, pose, tree)
+        assert n > 300, (k, n)
+        certified.append(ctx.stats()["pl_certified"])
+    per_call = np.diff([0] + certified)
+    assert per_call[0] == 0 and per_call[1:-1].sum() > 0, per_call  # the rule still fires out there -- and never wrongly
+
+
+@pytest.mark.timeout(900)
+def test_certificate_long_creep(amd, oracle):
+    """2 000 calls creeping 20 micrometres each in ONE direction (4 cm in all: neighbour lists change
+    many times on the way).  A certified query keeps its previous bound minus the step and slack / 4 -- the bound decays
+    call after call until a search refreshes it; it must never certify a list that the cold search would not return.
+    Checked against the oracle at every 20th call, at the 30 last calls, and wherever the certified share jumps."""
+    from mp2p_icp_amd import core, synthetic
+    d = synthetic.make_pair(3000, 200000, 577)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    step = amd.se3.exp(np.array([1.4e-5, 1.0e-5, 1.0e-5, 1.5e-7, -1.0e-7, 2.0e-7]))  # 20.5 um + 0.27 urad per call
+    ctx = amd.Context(0)
+    ctx.set_profiling(1)
+    gmap, cloud = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2]), core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    pairs = core.DevicePairs(ctx, 0, l.shape[0])
+    prm = _pl_prm()
+    pose, N = d["T_gt"], 2000
+    cert_prev, checked, cert_total = 0, 0, 0
+    for k in range(N):
+        if k % 20 == 0 or k >= N - 30:
+            assert _pl_equal(oracle, core, ctx, gmap, cloud, pairs, g, l, pose, tree) > 200, k
+            checked += 1
+        else:
+            pairs.clear()
+            core.match_pt2pl(ctx, gmap, cloud, pose, prm, None, pairs)
+        c = ctx.stats()["pl_certified"]
+        cert_total, cert_prev = c, c
+        pose = amd.se3.compose(pose, step)
+    assert checked >= 129
+    # the certificate carried most of the work (otherwise this test would not exercise the decay at all)
+    assert cert_total > 0.5 * N * l.shape[0] * 0.5, cert_total
+
+
 def _pl_prm(radius=0.4, knn=5):
     from mp2p_icp_amd import _lib
     prm = _lib.Pt2PlParams()

@@ -303,6 +303,20 @@ def stats_ms(xs):
     return {"min": float(a.min()), "median": float(np.median(a)), "max": float(a.max())}
 
 
+def csrc_sha16():
+    """fingerprint of the kernel sources (what a committed counter capture under profiles/ was taken with)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mp2p_icp_amd", "csrc", "*.h*"))) + [os.path.join(ROOT, "include", "mp2p_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+PROFILE_ROUND = "r04"
+
+
 def roofline_block(n_l, touched_mean, nn_ms_avg, tag):
     # algorithmic bytes of the search kernels per launch (SURVEY.md section 8d):
     #   12 B/query read + 12 B per distinct global point in a visited voxel + 8 B/query written
@@ -318,7 +332,15 @@ def roofline_block(n_l, touched_mean, nn_ms_avg, tag):
     # from profiles/, not a measurement of this run
     try:
         import csv
-        f = os.path.join(ROOT, "profiles", f"r03_bench_{tag}_hbm_pmc.csv")
+        f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_bench_{tag}_hbm_pmc.csv")
+        # the capture names the sources it was taken with: counters of OTHER kernels than the ones timed here are refused,
+        # loudly, instead of being quoted next to this run's time
+        meta = json.load(open(f.replace(".csv", ".meta.json")))
+        if meta.get("csrc_sha16") != csrc_sha16():
+            out["traffic_note"] = (f"STALE: {os.path.relpath(f, ROOT)} was captured with kernel sources {meta.get('csrc_sha16')}, "
+                                   f"this build is {csrc_sha16()}: re-run tools/gpu_prof.sh + tools/summarize_prof.py")
+            log("[bench] WARNING " + out["traffic_note"])
+            return out
         t = 0.0
         for r in csv.DictReader(open(f)):
             # the three search launches of the timed path (INSTR = false variants; the instrumented ones
@@ -606,6 +628,65 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
 
 
 # ---------------------------------------------------------------------------------------------------
+def sharded_default_line(args, rank, world, dist, make_rig, dev, sync, build=None):
+    """Everything of the default line that involves MORE THAN ONE RANK: the weak-scaling timing (W untimed steps, K steps
+    between two barrier + synchronize brackets, MAX over ranks) and the strong-scaling block (ONE scan split N ways).
+    make_rig(d, n_offset) -> a rig (restart / one_step / ctx.set_profiling / ctx.stats / info); dev: where the reduction
+    tensors live; sync(): drains this rank's device.  main() passes the HIP rig, cuda and torch.cuda.synchronize;
+    tests/test_distributed_gloo.py passes a rig whose compute is the CPU oracle, "cpu" and a no-op over gloo -- a dry run
+    of everything that is not a kernel, so that the first run on an 8-GPU node is a measurement, not a debug session
+    (VERDICT r3 #10).  The product never takes that route: bench.py itself only ever builds the HIP rig."""
+    import torch
+    build = build or build_inputs
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    t0 = time.time()
+    d = build(args.n_local, args.n_global, args.seed, rank, world, args.scene)
+    log(f"[bench r{rank}] inputs ready in {time.time() - t0:.1f}s: local {d['local'].shape}, global {d['glob'].shape}")
+    n_l = d["local"].shape[0]
+    rig = make_rig(d, rank * n_l)
+    info = rig.info
+    log(f"[bench r{rank}] index: cell {info['cell_size']:.3f} m, {info['n_levels']} levels, "
+        f"{info['n_cells_level0']} voxels, {info['device_bytes'] / 1e6:.0f} MB, build "
+        f"{info['build_ms']:.1f} ms (upload+build {rig.t_index * 1e3:.0f} ms)")
+
+    # ---- timed region: exactly K steps between two barrier+synchronize brackets --------------
+    # two hipEvents per step around the search kernels (the roofline kernels), read back lazily;
+    # the per-kernel breakdown comes from the untimed replay below
+    elapsed, nn_ms, step_s = timed_chain(rig, args.steps, args.warmup, barrier, events=not args.no_events)
+    log("timed steps [ms]:", " ".join("%.3f" % (1e3 * t) for t in step_s))
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- N > 1: strong scaling of ONE scan (every rank a contiguous 1/N of rank 0's scan) -------
+    strong = None
+    if world > 1:
+        try:
+            d0 = build(args.n_local, args.n_global, args.seed, 0, world, args.scene)
+            from mp2p_icp_amd.distributed import shard_range
+            b, e = shard_range(d0["local"].shape[0], rank, world)
+            ds = dict(d0, local=np.ascontiguousarray(d0["local"][b:e]))
+            rig_s = make_rig(ds, b)
+            el_s, _, _ = timed_chain(rig_s, args.steps, args.warmup, barrier, events=False)
+            ts_ = torch.tensor([el_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+            strong = {"scaling": "strong", "workload": f"ONE {d0['local'].shape[0]}-pt scan split x{world} vs the replicated map",
+                      "value": args.steps / float(ts_.item()), "unit": "iterations/s",
+                      "ms_per_step": float(ts_.item()) / args.steps * 1e3,
+                      "final_pose": [float(v) for v in rig_s.state["pose"]]}
+        except Exception as ex:  # never lose the headline line to the extra block
+            strong = {"error": repr(ex)}
+    return {"d": d, "rig": rig, "barrier": barrier, "elapsed": elapsed, "nn_ms": nn_ms, "step_s": step_s, "strong": strong}
+
+
+# ---------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -632,7 +713,7 @@ def main():
     ap.add_argument("--target-per-cell", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip scene_b / host_boundary / stability (tuning runs)")
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="local points of the CPU baseline's sample (0 = the whole layer)")
     args = ap.parse_args()
 
     import torch
@@ -680,31 +761,12 @@ def main():
             dist.destroy_process_group()
         return
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    t0 = time.time()
-    d = build_inputs(args.n_local, args.n_global, args.seed, rank, world, args.scene)
-    log(f"[bench r{rank}] inputs ready in {time.time() - t0:.1f}s: local {d['local'].shape}, global {d['glob'].shape}")
-    n_l = d["local"].shape[0]
-    rig = Rig(args, d, rank, world, dist, local_rank, stream, rank * n_l)
-    info = rig.info
-    log(f"[bench r{rank}] index: cell {info['cell_size']:.3f} m, {info['n_levels']} levels, "
-        f"{info['n_cells_level0']} voxels, {info['device_bytes'] / 1e6:.0f} MB, build "
-        f"{info['build_ms']:.1f} ms (upload+build {rig.t_index * 1e3:.0f} ms)")
-
-    # ---- timed region: exactly K steps between two barrier+synchronize brackets --------------
-    # two hipEvents per step around the search kernels (the roofline kernels), read back lazily;
-    # the per-kernel breakdown comes from the untimed replay below
-    elapsed, nn_ms, step_s = timed_chain(rig, args.steps, args.warmup, barrier, events=not args.no_events)
-    log("timed steps [ms]:", " ".join("%.3f" % (1e3 * t) for t in step_s))
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    core_ = sharded_default_line(args, rank, world, dist,
+                                 lambda d_, off: Rig(args, d_, rank, world, dist, local_rank, stream, off),
+                                 torch.device("cuda"), torch.cuda.synchronize)
+    d, rig, barrier = core_["d"], core_["rig"], core_["barrier"]
+    elapsed, nn_ms, step_s, strong = core_["elapsed"], core_["nn_ms"], core_["step_s"], core_["strong"]
+    n_l, info = d["local"].shape[0], rig.info
 
     rp = replay(rig, args.steps, args.warmup)
     log(f"[bench r{rank}] per-step kernel ms (replay; chain position = (warmup + i) % {CYCLE}): lane="
@@ -717,23 +779,6 @@ def main():
     if dist is not None:
         dist.all_reduce(pairs_total, op=dist.ReduceOp.SUM)
 
-    # ---- N > 1: strong scaling of ONE scan (every rank a contiguous 1/N of rank 0's scan) -------
-    strong = None
-    if world > 1:
-        try:
-            d0 = build_inputs(args.n_local, args.n_global, args.seed, 0, world, args.scene)
-            from mp2p_icp_amd.distributed import shard_range
-            b, e = shard_range(d0["local"].shape[0], rank, world)
-            ds = dict(d0, local=np.ascontiguousarray(d0["local"][b:e]))
-            rig_s = Rig(args, ds, rank, world, dist, local_rank, stream, b)
-            el_s, _, _ = timed_chain(rig_s, args.steps, args.warmup, barrier, events=False)
-            ts_ = torch.tensor([el_s], dtype=torch.float64, device="cuda")
-            dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
-            strong = {"scaling": "strong", "workload": f"ONE {d0['local'].shape[0]}-pt scan split x{world} vs the replicated map",
-                      "value": args.steps / float(ts_.item()), "unit": "iterations/s",
-                      "ms_per_step": float(ts_.item()) / args.steps * 1e3}
-        except Exception as ex:  # never lose the headline line to the extra block
-            strong = {"error": repr(ex)}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -860,7 +905,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only
         cores = os.cpu_count() or 1
         t0 = time.time()
-        out["cpu_baseline"] = cpu_baseline(d, args.threshold, args.gn_iters, 0.15, args.cpu_sample, cores)
+        out["cpu_baseline"] = cpu_baseline(d, args.threshold, args.gn_iters, 0.15, args.cpu_sample or d["local"].shape[0], cores)
         out["cpu_baseline"]["wall_s"] = time.time() - t0
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out), flush=True)

@@ -594,7 +594,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         // the hard class (served first by the tile kernel's grid): a wide radius, or -- from the previous call on this
         // map and layer -- a tile that staged many candidates (dense neighbourhoods: the tile's duration follows what
         // it stages, whatever the radius)
-        const bool               hard  = pending && (r > a.r_hard || (a.use_hint && a.hard_cand && (h.w >> NN_COST_SHIFT) >= a.hard_cand));
+        // (the radius is all a first call has to go by; on a scene whose pose is half a metre off nearly every radius is
+        //  "wide" and the class told nothing -- round 3's hard-first order was no order at all on scene B)
+        // By cost the WAVE is classed, not the query (its costliest query decides): the two classes are separate lists,
+        // and a wave split between them leaves two lists of fragments -- tiles made of the remains of several waves are
+        // spatially loose, stage more and run more passes (measured: 1 382 -> 1 182 it/s with per-query classes).
+        const bool               by_cost = a.use_hint && a.hard_cand != 0u;
+        const bool               costly  = __ballot(pending && (h.w >> NN_COST_SHIFT) >= a.hard_cand) != 0ull;
+        const bool               hard  = pending && (by_cost ? costly : r > a.r_hard);
         const unsigned long long hmask = __ballot(hard), emask = pmask & ~hmask;
         if (hmask)
             push_lanes(a, 0, wv / a.seg_waves, hard, hmask, lane, qi, r, best_d2, best_idx, best_spos, qx, qy,
@@ -964,11 +971,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b0, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
-                        const float m0 = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
-                        const float m1 = fminf(fminf(acc[4], acc[5]), fminf(acc[6], acc[7]));
-                        const float m2 = fminf(fminf(acc[8], acc[9]), fminf(acc[10], acc[11]));
-                        const float m3 = fminf(fminf(acc[12], acc[13]), fminf(acc[14], acc[15]));
-                        const float mn = fminf(fminf(m0, m1), fminf(m2, m3));
+                        // "is any of the 16 within the limit": the minimum of the BIT PATTERNS as signed integers -- eight
+                        // v_min3_i32 instead of fifteen fminf, each of which the compiler wraps in two canonicalising
+                        // v_max x,x (27 instructions per block, a quarter of the kernel's vector instructions).  Among
+                        // non-negative floats the integer order is the float order; a negative S (rounding of a distance
+                        // near zero) is a negative integer, hence the minimum, and is below any limit anyway; NaN (padding
+                        // slots hold +inf coordinates) is a large positive integer and never the minimum unless all are.
+                        int mi = min(min(__float_as_int(acc[0]), __float_as_int(acc[1])), __float_as_int(acc[2]));
+#pragma unroll
+                        for (int r = 3; r < 15; r += 2) mi = min(min(mi, __float_as_int(acc[r])), __float_as_int(acc[r + 1]));
+                        mi = min(mi, __float_as_int(acc[15]));
+                        const float mn = __int_as_float(mi);
                         if (!done && mn <= lim)
                         {
 #pragma unroll
@@ -1075,7 +1088,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         const unsigned long long wmask = __ballot(too_wide);
         if (wmask)
         {
-            st_defer += defer_lanes<Q>(a, seg, too_wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
+            // (the sign of the entry's radius tells the one-query kernel that the query comes from a tile over its budget:
+            //  it records a cost that puts the query's tile first again at the next call, whatever it stages alone)
+            st_defer += defer_lanes<Q>(a, seg, too_wide, wmask, lane, slice, qi, st_cand > a.tile_cand_cap ? -r : r, best_d2, best_idx,
+                                       best_spos, qx, qy, qz);
             if (too_wide) done = true, deferred = true;
         }
     }
@@ -1083,7 +1099,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // ---- output (Morton order of the local layer) + claim of the global point -----------------
     // every point that could pass the threshold was examined: no map point is nearer than min(best, threshold)
     emit_wave(a, s_claim, lane, valid && slice == 0 && !deferred, qi, orig, active, thr, best_d2, best_idx,
-              best_spos, fminf(best_d2, thr), st_cand);
+              best_spos, fminf(best_d2, thr), st_cand + 320u * st_pass);  // a pass costs what ~320 staged candidates cost
 
     if (a.timeline && lane == 0)
         a.timeline[2 * (size_t)tile] = tl0, a.timeline[2 * (size_t)tile + 1] = wall_clock64();
@@ -1236,7 +1252,7 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
         const size_t   item = (size_t)(a.seg_base + lo) * a.seg_cap + (k_item - s_segoff[lo]);
         uint32_t qi, orig, best_idx, best_spos;
         float    qx, qy, qz, thr, rmax, r, best_d2;
-        bool     search = true, active = true;
+        bool     search = true, active = true, heavy = false;
         float    lb2_skip = -1.f;
         {
             const uint4 w  = a.work[item];
@@ -1247,7 +1263,8 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
             const float normSq = fadd(fadd(fmul(qx, qx), fmul(qy, qy)), fmul(qz, qz));
             thr  = fadd(a.maxDistSq, fmul(a.angSq, normSq));
             rmax = sqrtf(thr) * 1.002f + g.slack;
-            r    = __uint_as_float(w.y);
+            r     = fabsf(__uint_as_float(w.y));
+            heavy = (w.y >> 31) != 0u;  // handed on by a tile that had spent its budget
             // wave-uniform running best (carried over from the kernel that handed the query on)
             best_d2 = __uint_as_float(w.z), best_idx = w.w, best_spos = wq.w;
         }
@@ -1398,7 +1415,7 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
             const float lb2 = !active ? 0.f : (lb2_skip >= 0.f ? lb2_skip : fminf(best_d2, thr));
             // (cost: what this query alone staged -- it was handed on for being isolated, or by a tile over its budget)
             a.rec[qi] = make_uint4(best_spos, __float_as_uint(best_d2), __float_as_uint(lb2),
-                                   (acc ? 1u : 0u) | (min(st_cand, 0xFFFFFFu) << NN_COST_SHIFT));
+                                   (acc ? 1u : 0u) | ((heavy ? 0xFFFFFFu : min(st_cand, 0xFFFFFFu)) << NN_COST_SHIFT));
             if (acc && a.claims)
                 claim_global(a, best_spos, (uint32_t)(a.local_offset + (a.rank ? a.rank[orig] : orig)));
         }

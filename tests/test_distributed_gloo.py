@@ -418,3 +418,106 @@ def test_sharded_plane_registration_gloo_world2():
         p.join(timeout=60)
     for rank, ok, msg in res:
         assert ok, f"rank {rank}: {msg}"
+
+
+# ---- bench.py's multi-rank path, dry ---------------------------------------------------------------
+class _DryCtx:
+    def set_profiling(self, level):
+        pass
+
+    def stats(self):
+        return {"ms_nn": 0.0}
+
+
+class _OracleRig:
+    """what bench.Rig is to bench.sharded_default_line, with the CPU oracle as this rank's compute"""
+
+    def __init__(self, torch, dist, d, n_offset):
+        import oracle as orc
+        from mp2p_icp_amd.distributed import ShardedRegistration
+        self.d, self.ctx, self.t_index = d, _DryCtx(), 0.0
+        self.info = {"cell_size": 0.0, "n_levels": 0, "n_cells_level0": 0, "device_bytes": 0, "build_ms": 0.0}
+        be = OracleBackend(orc, torch, d["glob"], d["local"], n_offset, 0.8, 2, orc.KERNEL_GEMANMCCLURE, 0.15)
+        self.reg = ShardedRegistration(be, dist)
+        self.restart()
+
+    def restart(self):
+        self.state = {"pose": self.d["T_init"].copy(), "s": 0}
+
+    def one_step(self):
+        st = self.state
+        st["pose"], _ = self.reg.step(st["pose"])
+        st["s"] += 1
+
+
+def _bench_dry_worker(rank, world, port, q):
+    try:
+        import argparse
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import bench
+        from mp2p_icp_amd import synthetic
+
+        def build(n_local, n_global, seed, rank_, world_, scene):
+            # (bench.build_inputs gives every rank its own scan of the same scene: same map, another local layer)
+            d = synthetic.random_cloud_pair(n_local, n_global, seed, outlier_frac=0.05)
+            if rank_:
+                d = dict(d, local=np.ascontiguousarray(d["local"][::-1]))
+            return d
+
+        args = argparse.Namespace(n_local=400, n_global=2500, seed=3, scene="b", steps=3, warmup=1, no_events=True)
+        out = bench.sharded_default_line(args, rank, world, dist, lambda d_, off: _OracleRig(torch, dist, d_, off),
+                                         torch.device("cpu"), lambda: None, build=build)
+        ok, msg = True, ""
+        # both ranks agree on the time (MAX over ranks) and on the strong-scaling block
+        both = [None] * world
+        dist.all_gather_object(both, (out["elapsed"], out["strong"], [float(v) for v in out["rig"].state["pose"]]))
+        if not (both[0][0] == both[1][0] and out["elapsed"] > 0 and len(out["step_s"]) == args.steps):
+            ok, msg = False, f"timing block: {both}"
+        st = out["strong"]
+        if ok and not (st and "error" not in st and st["value"] > 0 and both[0][1]["value"] == both[1][1]["value"]):
+            ok, msg = False, f"strong-scaling block: {st}"
+        # the ranks solved the same 6x6 redundantly: one pose (weak chain), and the strong chain's pose equals the
+        # unsharded oracle's after warmup + steps iterations of the same chain
+        if ok and both[0][2] != both[1][2]:
+            ok, msg = False, "the ranks disagree on the weak-scaling pose"
+        if ok:
+            import oracle as orc
+            d0 = build(args.n_local, args.n_global, args.seed, 0, world, "b")
+            g, l = d0["glob"], d0["local"]
+            tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
+            prm = orc.make_gn_params(2, kernel=orc.KERNEL_GEMANMCCLURE, kernelParam=0.15)
+            pose = d0["T_init"].copy()
+            for _ in range(args.warmup + args.steps):  # timed_chain: restart, W warm-up steps, K timed steps of one chain
+                want, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.8, 0.0, tree=tree)
+                pose, *_ = orc.optimal_tf_gauss_newton(want, None, None, pose, prm)
+            dt, dr = orc.pose_err_split(np.array(st["final_pose"]), pose)
+            if not (dt < 1e-9 and dr < 1e-9):
+                ok, msg = False, f"strong-scaling chain differs from the unsharded oracle: {dt} {dr}"
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok, msg))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc() + str(ex)))
+
+
+@pytest.mark.timeout(300)
+def test_bench_multi_rank_path_dry_run_gloo_world2():
+    """bench.py --gpus N without GPUs: bench.sharded_default_line (barrier brackets, MAX over ranks, strong-scaling block)
+    over gloo with an oracle-backed rig.  The product path (bench.main) only ever builds the HIP rig."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_dry_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(WORLD)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"

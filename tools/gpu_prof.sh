@@ -6,6 +6,7 @@
 # profiles/<tag>_kernel_stats.csv and profiles/<tag>_hbm_pmc.csv.
 tag=$1; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O; export TMPDIR=/tmp
+( cd $R && python -c "import bench; print(bench.csrc_sha16())" > $O/csrc_sha16.txt )
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kt -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras "$@" > $O/bench_kt.log 2>&1; echo "kt rc=$?"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/bench_fetch -o bench -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras "$@" > $O/bench_fetch.log 2>&1; echo "fetch rc=$?"

@@ -55,4 +55,9 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_hbm_pmc.csv"), "w", newline="")
         wn, wt = write.get(k, [1, 0.0])
         wk = wt / max(1, wn)
         w.writerow([k, n, f"{fk:.1f}", int(fk * 1024 * 2), f"{wk:.1f}", int(wk * 1024)])
+sha = os.path.join(prof, "csrc_sha16.txt")
+import json
+json.dump({"csrc_sha16": open(sha).read().strip() if os.path.exists(sha) else None,
+           "note": "fingerprint (bench.csrc_sha16) of mp2p_icp_amd/csrc + include/mp2p_hip.h the counters were captured with"},
+          open(os.path.join(ROOT, "profiles", f"{tag}_hbm_pmc.meta.json"), "w"))
 print("written profiles/%s_kernel_stats.csv and profiles/%s_hbm_pmc.csv" % (tag, tag))

@@ -124,10 +124,11 @@ struct Tune
                                     // itself; 0 = none (measured: per-lane 16-byte gathers cost one L1 line each,
                                     // the tile kernel's coalesced staging serves the same queries 2.5x cheaper)
     uint32_t tile_cand_cap = 6144;  // staged candidates after which a tile hands its pending queries on
+    uint32_t tile_cand_cap_easy = 0;  // ... for the tiles of the class served LAST (0 = the same)
     int      tile_bricks   = 1;     // tile kernel: wide groups list their voxels from the level-0 occupancy bricks and stay in
                                     // the tile (0 = round 3: a query beyond the deferral radius goes to the one-query kernel)
     uint32_t tile_brick_budget = 512;  // ... when the group's box spans at most this many bricks
-    uint32_t hard_cand     = 2300;  // a query whose tile staged this many candidates at the previous call joins the hard class
+    uint32_t hard_cand     = 1700;  // a query whose tile staged this many candidates at the previous call joins the hard class
                                     // (dispatched first) whatever its radius; 0 = by radius only
     uint32_t hard_radius_pct = 100; // pending queries with a radius above this % of a level-0 voxel are "hard":
                                     // their tiles are dispatched first (nn_query.hip)

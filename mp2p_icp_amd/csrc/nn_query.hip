@@ -61,6 +61,7 @@ constexpr int NN_LISTS       = 3;    // 0 = pending/hard, 1 = deferred, 2 = pend
 constexpr int NN_ALL_LISTS   = 3;
 constexpr int NN_CNT_STRIDE  = 32;   // uint32 words between two segment counters (128 bytes)
 constexpr int NN_TVLIST      = 512;  // tile kernel, wide groups: occupied voxels listed per round (LDS)
+constexpr uint32_t NN_PASS_COST  = 320; // tile kernel: what a pass costs, in staged candidates (10 us against 30 us per 960)
 constexpr uint32_t NN_COST_SHIFT = 8;  // result record, word 3: bit 0 = accepted, bits 8.. = what the query's tile staged
 
 struct NNArgs
@@ -76,7 +77,8 @@ struct NNArgs
     uint32_t      cell_budget;       // voxels of a search box per pass
     uint32_t      brick_budget;      // 4x4x4 bricks per pass of the one-query-per-wave kernel
     uint32_t      lane_cells;        // widest cube (level-0 voxels per axis, <= 4) a lane searches itself; 0 = never
-    uint32_t      tile_cand_cap;     // staged candidates after which a tile hands its pending queries on
+    uint32_t      tile_cand_cap;     // staged candidates after which a tile hands its pending queries on (the class served first ...
+    uint32_t      tile_cand_cap_easy;  // ... and the other: a long tile there was MISpredicted and starts late -- it is cut short)
     int           tile_bricks;       // wide groups stay in their tile: voxels of their box listed from the level-0 occupancy bricks
     uint32_t      tile_brick_budget; // ... when the box spans at most this many bricks (else the coarser dense box)
     uint32_t      hard_cand;         // a query whose tile staged at least this many candidates at the previous call is hard (0: by radius only)
@@ -679,6 +681,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     const uint32_t  n_pend = a.q_counters[((size_t)(cls ? 2 : 0) * NN_MAX_SEG + seg) * NN_CNT_STRIDE];
     if (tk * (uint32_t)Q >= n_pend) return;
     const unsigned long long tl0 = wall_clock64();
+    const uint32_t  cand_cap = cls ? a.tile_cand_cap_easy : a.tile_cand_cap;
     const int       qslot = lane & (Q - 1);
     const int       slice = (Q == 64) ? 0 : lane / Q;
     const bool      valid = tk * Q + qslot < n_pend;
@@ -749,6 +752,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             continue;
         }
         st_pass++;
+        st_cand += NN_PASS_COST;  // a pass is priced like this many staged candidates (budget and next call's class)
 
         // ---- search box = union of the group's cubes ---------------------------------------
         // (group members are finite: the NaN-free reductions apply)
@@ -817,7 +821,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         {
         // one round of 64 bricks (lane = brick): the occupied voxels of the brick that lie in the box
         unsigned long long bm = 0ull, vtotal = box.ncell;
-        uint32_t           bvx = 0, bvy = 0, bvz = 0, bincl = 0;
+        uint32_t           bpk = 0, bincl = 0;  // bpk: the brick's position in the box's brick grid, 10 bits per axis
         if (use_bricks)
         {
             const uint32_t id = ob * 64u + (uint32_t)lane;
@@ -825,9 +829,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             {
                 const uint32_t row = id / nbx, ix = id - row * nbx, iz = row / nby, iy = row - iz * nby;
                 const uint32_t Bx = (box.cx0 >> 2) + ix, By = (box.cy0 >> 2) + iy, Bz = (box.cz0 >> 2) + iz;
-                bvx = Bx * 4u, bvy = By * 4u, bvz = Bz * 4u;
+                bpk = iz << 20 | iy << 10 | ix;
                 const float h4 = 4.f * box.hs;
-                const float x0 = g.ox + (float)bvx * box.hs, y0 = g.oy + (float)bvy * box.hs, z0 = g.oz + (float)bvz * box.hs;
+                const float x0 = g.ox + (float)(Bx * 4u) * box.hs, y0 = g.oy + (float)(By * 4u) * box.hs, z0 = g.oz + (float)(Bz * 4u) * box.hs;
                 const float dx = fmaxf(0.f, fmaxf(x0 - qhx, qlx - (x0 + h4)));
                 const float dy = fmaxf(0.f, fmaxf(y0 - qhy, qly - (y0 + h4)));
                 const float dz = fmaxf(0.f, fmaxf(z0 - qhz, qlz - (z0 + h4)));
@@ -849,13 +853,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         {
             uint32_t           rank = bincl - (uint32_t)__popcll(bm);
             unsigned long long mm   = bm;
+            // first voxel of the brick, relative to the box's corner (may be negative: the brick grid starts at or before it)
+            const int bvx = (int)(((box.cx0 >> 2) + (bpk & 1023u)) * 4u) - (int)box.cx0, bvy = (int)(((box.cy0 >> 2) + ((bpk >> 10) & 1023u)) * 4u) - (int)box.cy0,
+                      bvz = (int)(((box.cz0 >> 2) + (bpk >> 20)) * 4u) - (int)box.cz0;
             while (mm)
             {
                 const uint32_t bit = (uint32_t)__ffsll((long long)mm) - 1u;
                 mm &= mm - 1ull;
                 if (rank >= r0 && rank < r0 + NN_TVLIST)
-                    s_vox[rank - (uint32_t)r0] = ((bvz + (bit >> 4)) - box.cz0) << 20 | ((bvy + ((bit >> 2) & 3u)) - box.cy0) << 10 |
-                                                 ((bvx + (bit & 3u)) - box.cx0);
+                    s_vox[rank - (uint32_t)r0] = (uint32_t)(bvz + (int)(bit >> 4)) << 20 | (uint32_t)(bvy + (int)((bit >> 2) & 3u)) << 10 |
+                                                 (uint32_t)(bvx + (int)(bit & 3u));
                 rank++;
             }
             __syncthreads();
@@ -890,7 +897,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             for (uint32_t base = 0; base < total && !over; base += NN_CAP)
             {
                 const uint32_t m     = min((uint32_t)NN_CAP, total - base);
-                over = st_cand - total + base + m > a.tile_cand_cap;  // (this round is still scanned)
+                over = st_cand - total + base + m > cand_cap;  // (this round is still scanned)
                 const uint32_t m_pad = (m + 31u) & ~31u;
                 // ---- stage.  Lane l fills slots 4l..4l+3 of the round.  Which voxel a slot
                 //      belongs to comes from a segmented broadcast: every occupied voxel drops
@@ -926,7 +933,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                     {
-                        c4[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
+                        // padding: FAR but finite.  An infinite coordinate makes the prefilter's S an inf - inf = NaN, and the
+                        // integer minimum over the accumulators' bit patterns (below) would pick a NaN with the sign bit set
+                        // ahead of every real candidate of the block (found by the parity suite: 897 of 904 pairs)
+                        c4[k] = make_float4(1e18f, 0.f, 0.f, __uint_as_float(NONE_U32));
                         if (t0 + k < m) c4[k] = g.pts[src[k]];
                     }
                     *reinterpret_cast<float4*>(&s_x[t0]) = make_float4(c4[0].x, c4[1].x, c4[2].x, c4[3].x);
@@ -1084,13 +1094,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         // chip waiting -- measured: the chip is full for the first 45 % of the kernel's span only
         // (the one-query kernel spreads the same work evenly; results do not depend on who finishes a
         // query)
-        if (!done && st_cand > a.tile_cand_cap) too_wide = true;
+        if (!done && st_cand > cand_cap) too_wide = true;
         const unsigned long long wmask = __ballot(too_wide);
         if (wmask)
         {
             // (the sign of the entry's radius tells the one-query kernel that the query comes from a tile over its budget:
             //  it records a cost that puts the query's tile first again at the next call, whatever it stages alone)
-            st_defer += defer_lanes<Q>(a, seg, too_wide, wmask, lane, slice, qi, st_cand > a.tile_cand_cap ? -r : r, best_d2, best_idx,
+            st_defer += defer_lanes<Q>(a, seg, too_wide, wmask, lane, slice, qi, st_cand > cand_cap ? -r : r, best_d2, best_idx,
                                        best_spos, qx, qy, qz);
             if (too_wide) done = true, deferred = true;
         }
@@ -1099,7 +1109,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // ---- output (Morton order of the local layer) + claim of the global point -----------------
     // every point that could pass the threshold was examined: no map point is nearer than min(best, threshold)
     emit_wave(a, s_claim, lane, valid && slice == 0 && !deferred, qi, orig, active, thr, best_d2, best_idx,
-              best_spos, fminf(best_d2, thr), st_cand + 320u * st_pass);  // a pass costs what ~320 staged candidates cost
+              best_spos, fminf(best_d2, thr), st_cand);
 
     if (a.timeline && lane == 0)
         a.timeline[2 * (size_t)tile] = tl0, a.timeline[2 * (size_t)tile + 1] = wall_clock64();
@@ -1108,9 +1118,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         atomicAdd(&a.counters[0], 1ull);
         atomicAdd(&a.counters[1], (unsigned long long)st_pass);
         atomicAdd(&a.counters[2], (unsigned long long)st_cells);
-        atomicAdd(&a.counters[3], (unsigned long long)st_cand);
+        atomicAdd(&a.counters[3], (unsigned long long)(st_cand - NN_PASS_COST * st_pass));
         if (st_pass > 1) atomicAdd(&a.counters[4], 1ull);
-        atomicMax(&a.counters[5], (unsigned long long)st_cand);
+        atomicMax(&a.counters[5], (unsigned long long)(st_cand - NN_PASS_COST * st_pass));
         atomicMax(&a.counters[6], (unsigned long long)st_pass);
         const unsigned long long dt = (unsigned long long)((long long)wall_clock64() - t_start);
         atomicAdd(&a.counters[7], dt);
@@ -1559,6 +1569,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
                                              : fminf(fmaxf(1.0f, 2.0f * cell0), 4.0f * cell0);
     a.lane_cells    = std::min<uint32_t>(ctx->tune.lane_cells, 4u);
     a.tile_cand_cap = ctx->tune.tile_cand_cap;
+    a.tile_cand_cap_easy = (ctx->tune.hard_cand && ctx->tune.tile_cand_cap_easy) ? ctx->tune.tile_cand_cap_easy : ctx->tune.tile_cand_cap;
     a.tile_bricks       = (ctx->tune.tile_bricks && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE) ? 1 : 0;
     a.tile_brick_budget = ctx->tune.tile_brick_budget;
     a.hard_cand         = ctx->tune.hard_cand;

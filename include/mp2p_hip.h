@@ -207,8 +207,12 @@ int  mp2p_hip_pairs_copy_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_
 /* ... and in three steps, for a caller that has work to do on the indices alone (the MatchState marks a
  * matcher leaves ARE the localIdx / globalIdx of the pairs it appended, Matcher_Points_DistanceThreshold.cpp:
  * 116-120): _begin enqueues the index arrays (into page-locked memory from mp2p_hip_host_alloc), then the
- * records (into `out`, page-locked for the duration); _wait_idx returns when the indices are there -- the
- * records are still on the link --; _end waits for the records.  One copy at a time per context. */
+ * records (DMA in chunks into the context's OWN page-locked staging buffer, copied from there into `out` by a helper
+ * thread of the context and -- in _end -- by the caller; `out` itself is never registered with the runtime: round 3
+ * page-locked it for the duration, which made later pageable copies from neighbouring heap memory fault);
+ * _wait_idx returns when the indices are there -- the records are still on the link --; _end returns when every record
+ * is in `out`.  One copy at a time per context; a copy never ended is finished by the next _begin / copy call or by
+ * mp2p_hip_ctx_destroy, so `out` must stay valid until then. */
 int  mp2p_hip_pairs_copy_pt2pt_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
                                      mp2p_hip_pair_pt2pt* out, uint32_t* idx_local, uint32_t* idx_global);
 int  mp2p_hip_pairs_copy_wait_idx(mp2p_hip_ctx* ctx);

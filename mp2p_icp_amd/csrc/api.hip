@@ -77,6 +77,7 @@ static void parse_tune(Tune& t)
             else if (k == "tile_bricks") t.tile_bricks = (int)v;
             else if (k == "tile_brick_budget") t.tile_brick_budget = (uint32_t)v;
             else if (k == "hard_cand") t.hard_cand = (uint32_t)v;
+            else if (k == "empty_room") t.empty_room = (int)v;
             else if (k == "tile_cand_cap_easy") t.tile_cand_cap_easy = (uint32_t)v;
             else if (k == "copy_chunk_kb") t.copy_chunk_kb = (uint32_t)v;
             else if (k == "copy_stage_mb") t.copy_stage_mb = (uint32_t)v;

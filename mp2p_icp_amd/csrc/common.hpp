@@ -127,6 +127,7 @@ struct Tune
     uint32_t tile_cand_cap_easy = 0;  // ... for the tiles of the class served LAST (0 = the same)
     int      tile_bricks   = 1;     // tile kernel: wide groups list their voxels from the level-0 occupancy bricks and stay in
                                     // the tile (0 = round 3: a query beyond the deferral radius goes to the one-query kernel)
+    int      empty_room    = 1;     // one-query kernel: empty-cube bound for queries with nothing in reach (they skip later calls)
     uint32_t tile_brick_budget = 512;  // ... when the group's box spans at most this many bricks
     uint32_t hard_cand     = 1700;  // a query whose tile staged this many candidates at the previous call joins the hard class
                                     // (dispatched first) whatever its radius; 0 = by radius only

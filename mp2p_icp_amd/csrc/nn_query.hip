@@ -79,6 +79,7 @@ struct NNArgs
     uint32_t      lane_cells;        // widest cube (level-0 voxels per axis, <= 4) a lane searches itself; 0 = never
     uint32_t      tile_cand_cap;     // staged candidates after which a tile hands its pending queries on (the class served first ...
     uint32_t      tile_cand_cap_easy;  // ... and the other: a long tile there was MISpredicted and starts late -- it is cut short)
+    int           empty_room;        // one-query kernel: a query with nothing in reach looks for an empty cube beyond its radius
     int           tile_bricks;       // wide groups stay in their tile: voxels of their box listed from the level-0 occupancy bricks
     uint32_t      tile_brick_budget; // ... when the box spans at most this many bricks (else the coarser dense box)
     uint32_t      hard_cand;         // a query whose tile staged at least this many candidates at the previous call is hard (0: by radius only)
@@ -647,6 +648,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[NN_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t s_spos[NN_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t s_owner[NN_CAP];
+    __shared__ __attribute__((aligned(16))) float s_n[NN_CAP];  // matrix-pipe prefilter: |c - centre|^2 of the staged points
     __shared__ uint32_t s_cstart[64];
     __shared__ uint32_t s_coff[64];
     __shared__ uint32_t s_vox[NN_TVLIST];  // wide groups: occupied voxels of the box, 10 bits per axis relative to its corner
@@ -812,10 +814,202 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             b2 = hi ? 0.0f : (cqx * cqx + cqy * cqy + cqz * cqz);
             o0 = hi ? ocy : ocx, o1 = hi ? 0.0f : ocz;
         }
+        bool over = false;
+        // one batch of <= 64 resolved voxels (lane = voxel: start, cnt): staged in rounds of NN_CAP points and tested
+        // against the tile's queries
+        auto batch = [&](uint32_t start, uint32_t cnt) __attribute__((always_inline)) {
+            const uint32_t incl  = wave_incl_scan(cnt, lane);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (total == 0) return;  // uniform: no occupied voxel in this batch
+            const uint32_t off = incl - cnt;
+            s_cstart[lane] = start;
+            s_coff[lane]   = off;
+            st_cand += total;
+
+            // ---- stage.  Lane l fills slots 4l..4l+3 of a round of NN_CAP points.  Which voxel a slot belongs to comes from
+            //      a segmented broadcast: every occupied voxel drops its id at its first slot, a prefix-max carries it to the
+            //      following slots.  The loads of round k+1 are ISSUED BEFORE round k is scanned (round 4: a round is a
+            //      dependent trip to memory, ~5 us of a 29-us tile with four or five of them; measured by adding one: +12 us)
+            //      and wait in registers; the |c'|^2 column of the prefilter has an array of its own for that (s_n).
+            uint32_t srcN[4];
+            float4   cN[4];
+            auto fetch = [&](uint32_t base, uint32_t m) __attribute__((always_inline)) {
+                *reinterpret_cast<uint4*>(&s_owner[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+                __syncthreads();
+                if (cnt > 0)
+                {
+                    if (off >= base && off < base + NN_CAP) s_owner[off - base] = (uint32_t)lane + 1u;
+                    else if (off < base && off + cnt > base) s_owner[0] = (uint32_t)lane + 1u;
+                }
+                __syncthreads();
+                const uint4    o4 = *reinterpret_cast<const uint4*>(&s_owner[4 * lane]);
+                const uint32_t p0 = o4.x, p1 = max(p0, o4.y), p2 = max(p1, o4.z), p3 = max(p2, o4.w);
+                const uint32_t in = wave_incl_max(p3, lane);
+                uint32_t       ex = __shfl_up(in, 1, 64);
+                if (lane == 0) ex = 0u;
+                const uint32_t ow[4] = {(uint32_t)max(ex, p0), (uint32_t)max(ex, p1), (uint32_t)max(ex, p2), (uint32_t)max(ex, p3)};
+                const uint32_t t0    = 4u * (uint32_t)lane;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    srcN[k] = NONE_U32;
+                    if (t0 + k < m)
+                    {
+                        const uint32_t v = ow[k] - 1u;
+                        srcN[k]          = s_cstart[v] + (base + t0 + k - s_coff[v]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    // padding: FAR but finite.  An infinite coordinate makes the prefilter's S an inf - inf = NaN, and the
+                    // integer minimum over the accumulators' bit patterns (below) would pick a NaN with the sign bit set
+                    // ahead of every real candidate of the block (found by the parity suite: 897 of 904 pairs)
+                    cN[k] = make_float4(1e18f, 0.f, 0.f, __uint_as_float(NONE_U32));
+                    if (t0 + k < m) cN[k] = g.pts[srcN[k]];
+                }
+            };
+            fetch(0u, min((uint32_t)NN_CAP, total));
+            for (uint32_t base = 0; base < total && !over; base += NN_CAP)
+            {
+                const uint32_t m     = min((uint32_t)NN_CAP, total - base);
+                over = st_cand - total + base + m > cand_cap;  // (this round is still scanned)
+                const uint32_t m_pad = (m + 31u) & ~31u;
+                {
+                    const uint32_t t0 = 4u * (uint32_t)lane;
+                    *reinterpret_cast<float4*>(&s_x[t0]) = make_float4(cN[0].x, cN[1].x, cN[2].x, cN[3].x);
+                    *reinterpret_cast<float4*>(&s_y[t0]) = make_float4(cN[0].y, cN[1].y, cN[2].y, cN[3].y);
+                    *reinterpret_cast<float4*>(&s_z[t0]) = make_float4(cN[0].z, cN[1].z, cN[2].z, cN[3].z);
+                    *reinterpret_cast<uint4*>(&s_idx[t0]) =
+                        make_uint4(__float_as_uint(cN[0].w), __float_as_uint(cN[1].w),
+                                   __float_as_uint(cN[2].w), __float_as_uint(cN[3].w));
+                    *reinterpret_cast<uint4*>(&s_spos[t0]) = make_uint4(srcN[0], srcN[1], srcN[2], srcN[3]);
+                    if (use_mfma)
+                    {  // |c - centre|^2
+                        float n4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                            const float ex = cN[k].x - ocx, ey = cN[k].y - ocy, ez = cN[k].z - ocz;
+                            n4[k] = ex * ex + ey * ey + ez * ez;
+                        }
+                        *reinterpret_cast<float4*>(&s_n[t0]) = make_float4(n4[0], n4[1], n4[2], n4[3]);
+                    }
+                    if (INSTR)
+                    {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (t0 + k < m) a.touched[srcN[k]] = 1;
+                    }
+                }
+                __syncthreads();
+                // the next round's points are on their way while this one is scanned
+                if (base + NN_CAP < total && !over) fetch(base + NN_CAP, min((uint32_t)NN_CAP, total - base - NN_CAP));
+                if (use_mfma)
+                {
+                    const bool   hi    = lane >= 32;
+                    const float* s_a0  = hi ? s_y : s_x;
+                    const float* s_a1  = hi ? s_n : s_z;
+                    const float  a2    = hi ? 0.0f : 1.0f;
+                    float        lim   = best_d2 * 1.000001f + mtol;
+                    for (uint32_t blk = 0; blk < m_pad; blk += 32u)
+                    {
+                        const uint32_t c   = blk + ((uint32_t)lane & 31u);
+                        const float    a0v = s_a0[c] - o0, a1v = s_a1[c] - o1;
+                        f32x16         acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
+                        // "is any of the 16 within the limit": the minimum of the BIT PATTERNS as signed integers -- eight
+                        // v_min3_i32 instead of fifteen fminf, each of which the compiler wraps in two canonicalising
+                        // v_max x,x (27 instructions per block, a quarter of the kernel's vector instructions).  Among
+                        // non-negative floats the integer order is the float order; a negative S (rounding of a distance
+                        // near zero) is a negative integer, hence the minimum, and is below any limit anyway; the padding
+                        // slots hold far, FINITE coordinates (a NaN with the sign bit set would win the integer minimum).
+                        // ... in four groups of four, so that the recomputation path tests only the rows of a group whose
+                        // minimum is within the limit (the sixteen sequential row tests -- a compare, an exec mask and a branch
+                        // each -- were most of what a block cost: nearly every block has SOME lane with a hit)
+                        int g4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            g4[k] = min(min(__float_as_int(acc[4 * k]), __float_as_int(acc[4 * k + 1])),
+                                        min(__float_as_int(acc[4 * k + 2]), __float_as_int(acc[4 * k + 3])));
+                        const float mn = __int_as_float(min(min(g4[0], g4[1]), min(g4[2], g4[3])));
+                        if (!done && mn <= lim)
+                        {
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                            {
+                                if (__int_as_float(g4[k]) <= lim)
+                                {
+#pragma unroll
+                                    for (int r = 4 * k; r < 4 * k + 4; r++)
+                                    {
+                                        if (acc[r] <= lim)
+                                        {
+                                            // row of register r (C/D layout of the 32x32 MFMAs)
+                                            const uint32_t j  = blk + (uint32_t)((r & 3) + 8 * (r >> 2)) + (hi ? 4u : 0u);
+                                            const float    dd = dist2(qx, qy, qz, s_x[j], s_y[j], s_z[j]);
+                                            if (dd <= best_d2)
+                                            {
+                                                const uint32_t ci = s_idx[j];
+                                                if (dd < best_d2 || ci < best_idx)
+                                                {
+                                                    best_d2   = dd;
+                                                    best_idx  = ci;
+                                                    best_spos = s_spos[j];
+                                                    lim       = best_d2 * 1.000001f + mtol;
+                                                }
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                else
+                // ---- scan: every lane tests (its slice of) the bucket against its query, 8
+                //      candidates per step on the packed-fp32 path; the update is rare
+                for (uint32_t jb = (uint32_t)slice * 8u; jb < m_pad; jb += 8u * S)
+                {
+                    const float4 xa = *reinterpret_cast<const float4*>(&s_x[jb]);
+                    const float4 xb = *reinterpret_cast<const float4*>(&s_x[jb + 4]);
+                    const float4 ya = *reinterpret_cast<const float4*>(&s_y[jb]);
+                    const float4 yb = *reinterpret_cast<const float4*>(&s_y[jb + 4]);
+                    const float4 za = *reinterpret_cast<const float4*>(&s_z[jb]);
+                    const float4 zb = *reinterpret_cast<const float4*>(&s_z[jb + 4]);
+                    const v2f d01 = dist2_pk(qx2, qy2, qz2, v2f{xa.x, xa.y}, v2f{ya.x, ya.y}, v2f{za.x, za.y});
+                    const v2f d23 = dist2_pk(qx2, qy2, qz2, v2f{xa.z, xa.w}, v2f{ya.z, ya.w}, v2f{za.z, za.w});
+                    const v2f d45 = dist2_pk(qx2, qy2, qz2, v2f{xb.x, xb.y}, v2f{yb.x, yb.y}, v2f{zb.x, zb.y});
+                    const v2f d67 = dist2_pk(qx2, qy2, qz2, v2f{xb.z, xb.w}, v2f{yb.z, yb.w}, v2f{zb.z, zb.w});
+                    const float d[8] = {d01.x, d01.y, d23.x, d23.y, d45.x, d45.y, d67.x, d67.y};
+                    const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])),
+                                           fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+                    if (!done && mn <= best_d2)
+                    {
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                        {
+                            if (d[k] <= best_d2)
+                            {
+                                const uint32_t ci = s_idx[jb + k];
+                                if (d[k] < best_d2 || ci < best_idx)
+                                {
+                                    best_d2   = d[k];
+                                    best_idx  = ci;
+                                    best_spos = s_spos[jb + k];
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        };
         // the tile's budget of staged candidates also ends a pass IN FLIGHT (`over`): a group in a dense place
         // (vegetation within a wide ball: up to 10^5 points) would otherwise run for a millisecond and be the
         // kernel's duration; what it has not finished goes to the one-query kernel with the bounds found so far
-        bool           over    = false;
         const uint32_t n_outer = use_bricks ? (nb + 63u) / 64u : 1u;
         for (uint32_t ob = 0; ob < n_outer && !over; ob++)
         {
@@ -886,176 +1080,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 lookup_voxel(g, box, cb + lane, qlx, qly, qlz, qhx, qhy, qhz, prune2, start, cnt, md2_unused);
                 st_cells += (uint32_t)min((unsigned long long)64, box.ncell - cb);
             }
-            const uint32_t incl  = wave_incl_scan(cnt, lane);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (total == 0) continue;  // uniform: no occupied voxel in this batch
-            const uint32_t off = incl - cnt;
-            s_cstart[lane] = start;
-            s_coff[lane]   = off;
-            st_cand += total;
-
-            for (uint32_t base = 0; base < total && !over; base += NN_CAP)
-            {
-                const uint32_t m     = min((uint32_t)NN_CAP, total - base);
-                over = st_cand - total + base + m > cand_cap;  // (this round is still scanned)
-                const uint32_t m_pad = (m + 31u) & ~31u;
-                // ---- stage.  Lane l fills slots 4l..4l+3 of the round.  Which voxel a slot
-                //      belongs to comes from a segmented broadcast: every occupied voxel drops
-                //      its id at its first slot, a prefix-max carries it to the following slots.
-                *reinterpret_cast<uint4*>(&s_owner[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
-                __syncthreads();
-                if (cnt > 0)
-                {
-                    if (off >= base && off < base + NN_CAP) s_owner[off - base] = (uint32_t)lane + 1u;
-                    else if (off < base && off + cnt > base) s_owner[0] = (uint32_t)lane + 1u;
-                }
-                __syncthreads();
-                {
-                    const uint4    o4 = *reinterpret_cast<const uint4*>(&s_owner[4 * lane]);
-                    const uint32_t p0 = o4.x, p1 = max(p0, o4.y), p2 = max(p1, o4.z), p3 = max(p2, o4.w);
-                    const uint32_t in = wave_incl_max(p3, lane);
-                    uint32_t       ex = __shfl_up(in, 1, 64);
-                    if (lane == 0) ex = 0u;
-                    const uint32_t ow[4] = {max(ex, p0), max(ex, p1), max(ex, p2), max(ex, p3)};
-                    const uint32_t t0    = 4u * (uint32_t)lane;
-                    uint32_t       src[4];
-                    float4         c4[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                    {
-                        src[k] = NONE_U32;
-                        if (t0 + k < m)
-                        {
-                            const uint32_t v = ow[k] - 1u;
-                            src[k]           = s_cstart[v] + (base + t0 + k - s_coff[v]);
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                    {
-                        // padding: FAR but finite.  An infinite coordinate makes the prefilter's S an inf - inf = NaN, and the
-                        // integer minimum over the accumulators' bit patterns (below) would pick a NaN with the sign bit set
-                        // ahead of every real candidate of the block (found by the parity suite: 897 of 904 pairs)
-                        c4[k] = make_float4(1e18f, 0.f, 0.f, __uint_as_float(NONE_U32));
-                        if (t0 + k < m) c4[k] = g.pts[src[k]];
-                    }
-                    *reinterpret_cast<float4*>(&s_x[t0]) = make_float4(c4[0].x, c4[1].x, c4[2].x, c4[3].x);
-                    *reinterpret_cast<float4*>(&s_y[t0]) = make_float4(c4[0].y, c4[1].y, c4[2].y, c4[3].y);
-                    *reinterpret_cast<float4*>(&s_z[t0]) = make_float4(c4[0].z, c4[1].z, c4[2].z, c4[3].z);
-                    *reinterpret_cast<uint4*>(&s_idx[t0]) =
-                        make_uint4(__float_as_uint(c4[0].w), __float_as_uint(c4[1].w),
-                                   __float_as_uint(c4[2].w), __float_as_uint(c4[3].w));
-                    *reinterpret_cast<uint4*>(&s_spos[t0]) = make_uint4(src[0], src[1], src[2], src[3]);
-                    if (use_mfma)
-                    {  // |c - centre|^2 (the lane's own four owner slots are free again: it has read them)
-                        float n4[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
-                        {
-                            const float ex = c4[k].x - ocx, ey = c4[k].y - ocy, ez = c4[k].z - ocz;
-                            n4[k] = ex * ex + ey * ey + ez * ez;
-                        }
-                        *reinterpret_cast<float4*>(&s_owner[t0]) = make_float4(n4[0], n4[1], n4[2], n4[3]);
-                    }
-                    if (INSTR)
-                    {
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            if (t0 + k < m) a.touched[src[k]] = 1;
-                    }
-                }
-                __syncthreads();
-                if (use_mfma)
-                {
-                    const float* s_n   = reinterpret_cast<const float*>(s_owner);
-                    const bool   hi    = lane >= 32;
-                    const float* s_a0  = hi ? s_y : s_x;
-                    const float* s_a1  = hi ? s_n : s_z;
-                    const float  a2    = hi ? 0.0f : 1.0f;
-                    float        lim   = best_d2 * 1.000001f + mtol;
-                    for (uint32_t blk = 0; blk < m_pad; blk += 32u)
-                    {
-                        const uint32_t c   = blk + ((uint32_t)lane & 31u);
-                        const float    a0v = s_a0[c] - o0, a1v = s_a1[c] - o1;
-                        f32x16         acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b0, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
-                        // "is any of the 16 within the limit": the minimum of the BIT PATTERNS as signed integers -- eight
-                        // v_min3_i32 instead of fifteen fminf, each of which the compiler wraps in two canonicalising
-                        // v_max x,x (27 instructions per block, a quarter of the kernel's vector instructions).  Among
-                        // non-negative floats the integer order is the float order; a negative S (rounding of a distance
-                        // near zero) is a negative integer, hence the minimum, and is below any limit anyway; NaN (padding
-                        // slots hold +inf coordinates) is a large positive integer and never the minimum unless all are.
-                        int mi = min(min(__float_as_int(acc[0]), __float_as_int(acc[1])), __float_as_int(acc[2]));
-#pragma unroll
-                        for (int r = 3; r < 15; r += 2) mi = min(min(mi, __float_as_int(acc[r])), __float_as_int(acc[r + 1]));
-                        mi = min(mi, __float_as_int(acc[15]));
-                        const float mn = __int_as_float(mi);
-                        if (!done && mn <= lim)
-                        {
-#pragma unroll
-                            for (int r = 0; r < 16; r++)
-                            {
-                                if (acc[r] <= lim)
-                                {
-                                    // row of register r (C/D layout of the 32x32 MFMAs)
-                                    const uint32_t j  = blk + (uint32_t)((r & 3) + 8 * (r >> 2)) + (hi ? 4u : 0u);
-                                    const float    dd = dist2(qx, qy, qz, s_x[j], s_y[j], s_z[j]);
-                                    if (dd <= best_d2)
-                                    {
-                                        const uint32_t ci = s_idx[j];
-                                        if (dd < best_d2 || ci < best_idx)
-                                        {
-                                            best_d2   = dd;
-                                            best_idx  = ci;
-                                            best_spos = s_spos[j];
-                                            lim       = best_d2 * 1.000001f + mtol;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                else
-                // ---- scan: every lane tests (its slice of) the bucket against its query, 8
-                //      candidates per step on the packed-fp32 path; the update is rare
-                for (uint32_t jb = (uint32_t)slice * 8u; jb < m_pad; jb += 8u * S)
-                {
-                    const float4 xa = *reinterpret_cast<const float4*>(&s_x[jb]);
-                    const float4 xb = *reinterpret_cast<const float4*>(&s_x[jb + 4]);
-                    const float4 ya = *reinterpret_cast<const float4*>(&s_y[jb]);
-                    const float4 yb = *reinterpret_cast<const float4*>(&s_y[jb + 4]);
-                    const float4 za = *reinterpret_cast<const float4*>(&s_z[jb]);
-                    const float4 zb = *reinterpret_cast<const float4*>(&s_z[jb + 4]);
-                    const v2f d01 = dist2_pk(qx2, qy2, qz2, v2f{xa.x, xa.y}, v2f{ya.x, ya.y}, v2f{za.x, za.y});
-                    const v2f d23 = dist2_pk(qx2, qy2, qz2, v2f{xa.z, xa.w}, v2f{ya.z, ya.w}, v2f{za.z, za.w});
-                    const v2f d45 = dist2_pk(qx2, qy2, qz2, v2f{xb.x, xb.y}, v2f{yb.x, yb.y}, v2f{zb.x, zb.y});
-                    const v2f d67 = dist2_pk(qx2, qy2, qz2, v2f{xb.z, xb.w}, v2f{yb.z, yb.w}, v2f{zb.z, zb.w});
-                    const float d[8] = {d01.x, d01.y, d23.x, d23.y, d45.x, d45.y, d67.x, d67.y};
-                    const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])),
-                                           fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
-                    if (!done && mn <= best_d2)
-                    {
-#pragma unroll
-                        for (int k = 0; k < 8; k++)
-                        {
-                            if (d[k] <= best_d2)
-                            {
-                                const uint32_t ci = s_idx[jb + k];
-                                if (d[k] < best_d2 || ci < best_idx)
-                                {
-                                    best_d2   = d[k];
-                                    best_idx  = ci;
-                                    best_spos = s_spos[jb + k];
-                                }
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-            }
+            batch(start, cnt);
         }
         if (use_bricks) __syncthreads();  // the list is rewritten by the next round
         }
@@ -1211,6 +1236,47 @@ __device__ __forceinline__ void scan_batch(const NNArgs& a, const GridView& g, i
     }
     __syncthreads();
     bound = fminf(bound, wave_min_pos(pd));
+}
+
+// A query with NOTHING within r_max (nn_single_kernel): is a cube of half-edge R = 2 r_max (else 1.5 r_max) around it empty?
+// A handful of coarse voxels' occupancy bits tell.  Returns the square of a lower bound of the distance to every map point,
+// or -1.
+__device__ __forceinline__ float empty_room_bound(const GridView& g, int lane, float qx, float qy, float qz, float rmax)
+{
+    for (float grow = 2.0f; grow >= 1.49f; grow -= 0.5f)
+    {
+        const float R = rmax * grow;
+        uint32_t    lev = 0;
+        while (lev + 1 < g.n_levels && g.hf * (float)(1u << (g.shift0 + lev)) < 0.5f * R) lev++;
+        if (g.occ_off[lev] == OCC_NONE) return -1.f;
+        const uint32_t sh = g.shift0 + lev;
+        const float lox = fmaxf(qx - R, g.bbmin[0]), loy = fmaxf(qy - R, g.bbmin[1]), loz = fmaxf(qz - R, g.bbmin[2]);
+        const float hix = fminf(qx + R, g.bbmax[0]), hiy = fminf(qy + R, g.bbmax[1]), hiz = fminf(qz + R, g.bbmax[2]);
+        bool occupied = false;
+        if (!((lox > hix) || (loy > hiy) || (loz > hiz)))  // (a cube off the layer's bounding box holds nothing)
+        {
+            const uint32_t cx0 = cell_fine(lox, g.ox, g.inv_hf) >> sh, cx1 = cell_fine(hix, g.ox, g.inv_hf) >> sh;
+            const uint32_t cy0 = cell_fine(loy, g.oy, g.inv_hf) >> sh, cy1 = cell_fine(hiy, g.oy, g.inv_hf) >> sh;
+            const uint32_t cz0 = cell_fine(loz, g.oz, g.inv_hf) >> sh, cz1 = cell_fine(hiz, g.oz, g.inv_hf) >> sh;
+            const uint32_t nx = cx1 - cx0 + 1u, ny = cy1 - cy0 + 1u, nz = cz1 - cz0 + 1u, n = nx * ny * nz;
+            if (nx > 8u || ny > 8u || nz > 8u) return -1.f;
+            for (uint32_t c0 = 0; c0 < n && !occupied; c0 += 64u)
+            {
+                const uint32_t c = c0 + (uint32_t)lane;
+                bool           o = false;
+                if (c < n)
+                {
+                    const uint32_t row = c / nx, ix = c - row * nx, iz = row / ny, iy = row - iz * ny;
+                    o = occ_maybe(g, lev, cx0 + ix, cy0 + iy, cz0 + iz);
+                }
+                occupied = __ballot(o) != 0ull;
+            }
+        }
+        // every map point lies outside the cube [q - R, q + R]^3 (cell_fine is monotone: a coordinate inside the interval
+        // maps into the cell range that was tested), hence farther than R
+        if (!occupied) return (R * 0.9999f - 4.f * g.slack) * (R * 0.9999f - 4.f * g.slack);
+    }
+    return -1.f;
 }
 
 constexpr int NN_VLIST = 1024;  // occupied voxels listed per round (LDS)
@@ -1418,6 +1484,18 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
             if (is_final(r, rmax, best_d2, g.slack)) break;
             r = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
         }
+        // ---- NOTHING within reach (an outlier of the local layer, metres from every surface).  The record's bound would be
+        //      the radius just covered, so the next call -- any displacement at all -- would search the whole ball again,
+        //      and the next (round 3: 3 of the 8 ms of configuration C5 were such searches).  Room is cheap for such a
+        //      query: a cube of half-edge R = 1.5 r_max .. 2 r_max around it is a handful of COARSE voxels whose occupancy
+        //      bits tell whether it is empty; if so every map point is farther than R and the warm start lets the query
+        //      skip its search until it has moved by R - r_max.
+        // ---- NOTHING within reach (an outlier of the local layer, metres from every surface).  The record's bound would be
+        //      the radius just covered, so the next call -- any displacement at all -- would search the whole ball again,
+        //      and the next (round 3: 3 of the 8 ms of configuration C5 were such searches).  Room is cheap for such a
+        //      query: if the cube of half-edge 2 r_max (else 1.5 r_max) around it is empty, every map point is farther
+        //      than that and the warm start lets the query skip its search until it has moved by the difference.
+        if (search && best_idx == NONE_U32 && a.empty_room) lb2_skip = empty_room_bound(g, lane, qx, qy, qz, rmax);
         if (lane == 0)
         {
             bool acc = active && best_idx != NONE_U32 && best_d2 < thr;         // :259
@@ -1573,6 +1651,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.tile_bricks       = (ctx->tune.tile_bricks && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE) ? 1 : 0;
     a.tile_brick_budget = ctx->tune.tile_brick_budget;
     a.hard_cand         = ctx->tune.hard_cand;
+    a.empty_room        = ctx->tune.empty_room;
     a.claim_dedup   = ctx->tune.claim_dedup;
     a.claim_peek    = ctx->tune.claim_peek;
     a.mfma_scan     = ctx->tune.mfma_scan;

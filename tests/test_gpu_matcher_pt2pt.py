@@ -241,6 +241,43 @@ def test_warm_start_pose_sequence(amd, oracle):
             assert pairs.potential_pairings == pot
 
 
+def test_outliers_with_nothing_in_reach_skip_later_calls(amd, oracle):
+    """A local point metres from every surface (30 % of BASELINE config C5's layer) searched its whole ball at EVERY call:
+    the bound it kept was the radius just covered.  The one-query kernel now looks for an empty cube of half-edge 2 r_max
+    (else 1.5 r_max) around such a query -- a handful of coarse occupancy bits -- and the warm start lets it skip while it
+    has moved less than the difference.  Lists bit-exact at every pose of a creeping sequence with a jump and a return;
+    from the third call on the far points finish without a search."""
+    from mp2p_icp_amd import _lib, core, synthetic
+    d = synthetic.random_cloud_pair(6000, 150_000, 321, outlier_frac=0.0)
+    g = d["glob"]
+    rng = np.random.default_rng(9)
+    l = d["local"].copy()
+    far = rng.choice(l.shape[0], 3000, replace=False)
+    l[far, 2] += rng.uniform(3.0, 15.0, far.size).astype(np.float32)  # metres above the surface: nothing within 0.8 m
+    l[far[:500], 2] -= 2.2                                             # ... and some in the grey zone (0.8 .. 13 m)
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    ctx = amd.Context(0)
+    ctx.set_profiling(2)
+    gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])
+    cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    pairs = core.DevicePairs(ctx, l.shape[0], 0)
+    prm = _lib.Pt2PtParams(0.8, 0.0, 1, 0, 0, 0.20, 0, 0.0, 0, 0.0, 0, 0.0, 0)
+    pose, skipped = d["T_init"], []
+    steps = [0.02, 0.02, 0.01, 0.05, 0.01, 2.5, 0.01, -2.5, 0.01]  # creep, a 2.5 m jump (beyond any room), back
+    for k in range(len(steps) + 1):
+        want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.8, 0.0, tree=tree)
+        pairs.clear()
+        core.match_pt2pt(ctx, gmap, cloud, pose, prm, None, pairs)
+        _assert_same_pairs(pairs.download_pt2pt(), want)
+        skipped.append(ctx.stats()["nn_lane_skipped"])
+        if k < len(steps):
+            pose = amd.se3.compose(pose, amd.se3.exp(np.array([steps[k], 0.3 * steps[k], 0.0, 0.0, 0.0, 0.002 * np.sign(steps[k])])))
+    assert skipped[0] == 0                      # a first call has nothing to go by
+    assert skipped[2] > 1500, skipped           # the far points have their room and skip ...
+    assert skipped[6] < skipped[5], skipped     # ... the jump uses it up (they search again) ...
+    assert skipped[9] > 1500, skipped           # ... and it is found again
+
+
 @pytest.mark.parametrize("K", [2, 3, 5, 8, 13, 16])
 @pytest.mark.parametrize("allow_global", [False, True])
 @pytest.mark.parametrize("radius_mode", [True, False])

@@ -60,9 +60,11 @@ static void blocks(const std::vector<uint64_t>& idx, double& b64, double& b128)
     std::vector<uint64_t> s(idx.size());
     for (size_t i = 0; i < idx.size(); i++) s[i] = idx[i] / 4;  // 64-byte block of a 16-byte element
     std::sort(s.begin(), s.end());
-    b64 = 64.0 * (double)(std::unique(s.begin(), s.end()) - s.begin());
+    s.erase(std::unique(s.begin(), s.end()), s.end());
+    b64 = 64.0 * (double)s.size();
     for (auto& v : s) v /= 2;
-    b128 = 128.0 * (double)(std::unique(s.begin(), s.end()) - s.begin());
+    s.erase(std::unique(s.begin(), s.end()), s.end());
+    b128 = 128.0 * (double)s.size();
 }
 
 int main()

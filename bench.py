@@ -293,9 +293,10 @@ def converging_block(rig, args):
                                             "finished_without_search_frac": st["nn_lane_skipped"] / rig.n_l,
                                             "deferred_to_one_query_kernel_frac": st["nn_single_queries"] / rig.n_l,
                                             "staged_points_per_tile": st["nn_candidates_tested"] / max(1, st["nn_tiles"])},
-            "note": "point-to-plane ICP converges where the point-to-point chain of `value` slides along the street; "
-                    "the warm start of the point matcher can only skip a query whose nearest neighbour lies beyond the "
-                    "threshold AND whose step is below ~2 mm (the stored lower bound is capped at the threshold)"}
+            "note": "point-to-plane ICP converges where the point-to-point chain of `value` slides along the street; at the "
+                    "converged pose the point matcher's steps are sub-millimetre, its tile kernel tracks a lower bound of every "
+                    "query's SECOND-nearest distance (round 4: out of the matrix-pipe prefilter's values minus their proven error "
+                    "bound) and a query whose previous neighbour is provably still the nearest skips its search"}
 
 
 def stats_ms(xs):

@@ -78,6 +78,9 @@ static void parse_tune(Tune& t)
             else if (k == "tile_brick_budget") t.tile_brick_budget = (uint32_t)v;
             else if (k == "hard_cand") t.hard_cand = (uint32_t)v;
             else if (k == "empty_room") t.empty_room = (int)v;
+            else if (k == "nn_cert") t.nn_cert = (int)v;
+            else if (k == "coop_max") t.coop_max = (uint32_t)v;
+            else if (k == "nn_cert_step_mm") t.nn_cert_step_mm = (uint32_t)v;
             else if (k == "tile_cand_cap_easy") t.tile_cand_cap_easy = (uint32_t)v;
             else if (k == "copy_chunk_kb") t.copy_chunk_kb = (uint32_t)v;
             else if (k == "copy_stage_mb") t.copy_stage_mb = (uint32_t)v;
@@ -187,7 +190,7 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release();
     ctx->aos_stage.release(), ctx->pl_slots.release(), ctx->pl_knn.release();
     ctx->work.release(), ctx->work_q.release(), ctx->tile_bbox2.release(), ctx->block_bbox.release(), ctx->exch.release(), ctx->claim_list.release();
-    ctx->pend.release(), ctx->pend_q.release(), ctx->q_counters.release(), ctx->nn_rec.release();
+    ctx->pend.release(), ctx->pend_q.release(), ctx->q_counters.release(), ctx->nn_rec.release(), ctx->nn_lb2nd.release();
     ctx->pl_kth.release();
     ctx->pl_lb.release(), ctx->pl_cost.release(), ctx->pl_hard.release(), ctx->pl_pend.release(), ctx->pl_pend_cnt.release(), ctx->pl_cert_stat.release();
     for (auto& b : ctx->scratch) b.release();

@@ -127,6 +127,10 @@ struct Tune
     uint32_t tile_cand_cap_easy = 0;  // ... for the tiles of the class served LAST (0 = the same)
     int      tile_bricks   = 1;     // tile kernel: wide groups list their voxels from the level-0 occupancy bricks and stay in
                                     // the tile (0 = round 3: a query beyond the deferral radius goes to the one-query kernel)
+    uint32_t coop_max      = 4;     // tile kernel: a group of at most this many queries is handed to the one-query kernel
+    int      nn_cert       = 1;     // point-to-point search: skip the search of a query whose previous neighbour is certainly still
+                                    // the nearest (NNArgs::lb2nd); 1 = bounds tracked after small steps only, 2 = always, 0 = off
+    uint32_t nn_cert_step_mm = 5;   // ... "small": the farthest local point moved less than this since the previous call
     int      empty_room    = 1;     // one-query kernel: empty-cube bound for queries with nothing in reach (they skip later calls)
     uint32_t tile_brick_budget = 512;  // ... when the group's box spans at most this many bricks
     uint32_t hard_cand     = 1700;  // a query whose tile staged this many candidates at the previous call joins the hard class
@@ -269,6 +273,8 @@ struct mp2p_hip_ctx
     uint32_t                         ad_knn   = 0;       //   lists held in nn_spos / nn_d2: neighbours per point,
     const void*                      ad_cloud = nullptr; //   and the handles they were searched for
     const void*                      ad_map   = nullptr;
+    mp2p::DevBuf<float>              nn_lb2nd;     // [n_local] pt2pt certificate: bound of the distance to every point but the nearest
+    bool                             nn_lb2nd_valid = false;  // ... written by the previous pt2pt call (on hint_map / hint_cloud)
     mp2p::DevBuf<uint4>              nn_rec;       // [n_local] result + warm-start records of the pt2pt search
                                                    // (Morton order of the local layer; see nn_query.hip)
     mp2p::DevBuf<uint4>              work, pend;   // deferred / pending queries of the NN search
@@ -317,6 +323,7 @@ struct mp2p_hip_cloud
     mp2p::DevBuf<float4> sorted;  // Morton-sorted (own frame) {x,y,z,idx}
     mp2p::DevBuf<float>  x, y, z; // original order (pair output)
     mp2p::DevBuf<uint32_t> pos;   // original index -> place in `sorted` (search results are kept in that order)
+    float                  radius = 0.f;  // largest |p| over the layer's points (own frame): bounds a rotation's displacement
     // optional visit order (mp2p_hip_cloud_set_visit_order): order[r] = original index visited
     // r-th, rank = its inverse (NONE for points that are not visited); n_visit == 0: all, ascending
     size_t                 n_visit = 0;

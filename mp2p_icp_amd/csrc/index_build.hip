@@ -453,6 +453,11 @@ int build_cloud(mp2p_hip_ctx* ctx, const float* d_x, const float* d_y, const flo
     if (rc) return rc;
     const float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
     const float hf  = std::max(ext * (1.0f / 1048000.0f), 1e-9f);
+    {
+        double r2 = 0;
+        for (int d = 0; d < 3; d++) r2 += (double)std::max(std::fabs(mn[d]), std::fabs(mx[d])) * std::max(std::fabs(mn[d]), std::fabs(mx[d]));
+        cloud->radius = (float)std::sqrt(r2) * 1.000001f;  // (of the bounding box's farthest corner: >= every |p|)
+    }
     MP2P_TRY_HIP(ctx, cloud->sorted.alloc(n));
     rc = morton_sort(ctx, d_x, d_y, d_z, n, mn[0], mn[1], mn[2], 1.0f / hf, nullptr,
                      cloud->sorted.p);

@@ -79,9 +79,17 @@ struct NNArgs
     uint32_t      lane_cells;        // widest cube (level-0 voxels per axis, <= 4) a lane searches itself; 0 = never
     uint32_t      tile_cand_cap;     // staged candidates after which a tile hands its pending queries on (the class served first ...
     uint32_t      tile_cand_cap_easy;  // ... and the other: a long tile there was MISpredicted and starts late -- it is cut short)
+    // ---- search-skip certificate of the point-to-point search (round 4; the rule of the point-to-plane search's, nn_pt2pl.hip):
+    //      lb2nd[qi] (Morton order) = a lower bound of the distance from the query, at the pose of the call that wrote it, to
+    //      every map point OTHER than its recorded nearest neighbour; 0 = none.  Written by every kernel that finishes a query
+    //      (the tracking build of the tile kernel derives it from the prefilter's second-smallest value minus its error bound;
+    //      everybody else writes 0 or the decayed old value); read by the lane kernel when the previous call wrote it.
+    float*        lb2nd;             // null: neither read nor written by this call
+    int           cert_read;         // the previous call on this map and layer left bounds: the lane kernel may certify
     int           empty_room;        // one-query kernel: a query with nothing in reach looks for an empty cube beyond its radius
     int           tile_bricks;       // wide groups stay in their tile: voxels of their box listed from the level-0 occupancy bricks
     uint32_t      tile_brick_budget; // ... when the box spans at most this many bricks (else the coarser dense box)
+    uint32_t      coop_max;          // a group of at most this many queries leaves its tile for the one-query kernel
     uint32_t      hard_cand;         // a query whose tile staged at least this many candidates at the previous call is hard (0: by radius only)
     int           claim_dedup, claim_peek;
     int           mfma_scan;         // tile kernel, Q = 32: distance tests on the matrix pipe as a prefilter
@@ -455,6 +463,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     //      certain to conclude.  The ball that decides the result is still searched completely,
     //      so the result is the cold result. ---------------------------------------------------
     float lb2_out = -1.f;  // >= 0: the record's bound when this kernel concludes without a search
+    float lb2nd_out = 0.f; // > 0: the previous neighbour was certified; the bound on all others, as of this pose
     if (a.use_hint && active)
     {
         float       ox, oy, oz;
@@ -480,6 +489,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
         else if (lb > r * (1.0f - 1.0f / 1024.0f) - g.slack)
             r = fminf(fmaxf(hr > 0.f ? fminf(hr, 2.0f * lb) : 2.0f * lb, r), rmax);
+        // ---- certificate: every OTHER map point was at least l2 away at the previous pose, hence at least l2 - disp now
+        //      (the triangle inequality between the two fp32 positions of the query, which both calls compute identically);
+        //      if the previous neighbour, re-measured, is nearer than that by a margin far above the rounding of a computed
+        //      distance (slack / 2 = 2^-21 of the map's extent; a computed d differs from the true one by 2^-23 relative),
+        //      it is the unique nearest neighbour the full search would return -- same point, same fp32 d2 -- and the
+        //      search is skipped.  The bound kept for the next call shrinks by the displacement.
+        if (a.cert_read && !done && hr > 0.f)
+        {
+            const float l2   = a.lb2nd[qi];
+            const float room = l2 - disp * 1.00001f - 0.25f * g.slack;
+            if (l2 > 0.f && sqrtf(best_d2) * 1.00001f + 0.5f * g.slack < room) done = true, lb2nd_out = room;
+        }
     }
 
     // ---- can this lane search its cube [q - r, q + r]^3 by itself?  At most lane_cells level-0
@@ -617,11 +638,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // a query this lane searched itself: all that could pass the threshold was examined
     emit_wave(a, s_claim, lane, valid && !pending, qi, orig, active, thr, best_d2, best_idx, best_spos,
               lb2_out >= 0.f ? lb2_out : fminf(best_d2, thr));
+    if (a.lb2nd && valid && !pending) a.lb2nd[qi] = lb2nd_out;
 
     if (INSTR)
     {
         const uint32_t n_fast = (uint32_t)__popcll(__ballot(fast && !empty_cube));
-        const uint32_t n_skip = (uint32_t)__popcll(__ballot(active && lb2_out >= 0.f));
+        const uint32_t n_skip = (uint32_t)__popcll(__ballot(active && (lb2_out >= 0.f || lb2nd_out > 0.f)));
         const uint32_t cand   = wave_sum_u32(st_cand), vox = wave_sum_u32(st_vox);
         if (lane == 0)
         {
@@ -638,7 +660,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // Tiles of Q consecutive PENDING queries.
 // 5 waves per SIMD: 96 VGPRs with 4 spilled dwords; measured +3.5 % over the compiler's own 108
 // VGPRs / 4 waves, while 6 waves (80 VGPRs, 22 spilled dwords) give the gain back
-template <int Q, bool INSTR, bool MFMA = false, int WAVES = 5>
+template <int Q, bool INSTR, bool MFMA = false, int WAVES = 5, bool CERT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void nn_tile_kernel(const NNArgs a)
 {
     constexpr int S = 64 / Q;
@@ -728,6 +750,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 
     uint32_t        st_pass = 0, st_cells = 0, st_cand = 0, st_defer = 0;
     const long long t_start = INSTR ? (long long)wall_clock64() : 0;
+    // certificate tracking (CERT): the two smallest prefilter values this lane has seen in the running pass, as bit patterns
+    // (NNArgs::lb2nd), and the bound of the query once it is final
+    constexpr bool track = CERT && MFMA && Q == 32;
+    int             t1 = 0x7FFFFFFF, t2 = 0x7FFFFFFF;
+    float           lbq = 0.f;
+    auto            ins = [&](int x) __attribute__((always_inline)) { t2 = min(t2, max(t1, x)), t1 = min(t1, x); };
 
     while (true)
     {
@@ -747,7 +775,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         const unsigned long long gmask = __ballot(grp);
 
         // ---- a group of a few isolated queries goes to the one-query-per-wave kernel -----------
-        if (__popcll(gmask) <= NN_COOP_MAX * S)
+        if (__popcll(gmask) <= (int)a.coop_max * S)
         {
             st_defer += defer_lanes<Q>(a, seg, grp, gmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
             if (grp) done = true, deferred = true;
@@ -755,6 +783,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
         st_pass++;
         st_cand += NN_PASS_COST;  // a pass is priced like this many staged candidates (budget and next call's class)
+        if (track) t1 = t2 = 0x7FFFFFFF;
 
         // ---- search box = union of the group's cubes ---------------------------------------
         // (group members are finite: the NaN-free reductions apply)
@@ -934,17 +963,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         for (int k = 0; k < 4; k++)
                             g4[k] = min(min(__float_as_int(acc[4 * k]), __float_as_int(acc[4 * k + 1])),
                                         min(__float_as_int(acc[4 * k + 2]), __float_as_int(acc[4 * k + 3])));
-                        const float mn = __int_as_float(min(min(g4[0], g4[1]), min(g4[2], g4[3])));
+                        const int   mni = min(min(g4[0], g4[1]), min(g4[2], g4[3]));
+                        const float mn  = __int_as_float(mni);
+                        // (tracking: a block none of whose values is within the limit cannot hold the nearest neighbour --
+                        //  its minimum stands for all of them; in the block that does, a group outside the limit is stood for
+                        //  by its minimum and a group within it contributes its four values one by one: the second smallest of
+                        //  what was inserted is then a lower bound of the second smallest of ALL values)
+                        if (track && !(!done && mn <= lim)) ins(mni);
                         if (!done && mn <= lim)
                         {
 #pragma unroll
                             for (int k = 0; k < 4; k++)
                             {
+                                if (track && !(__int_as_float(g4[k]) <= lim)) ins(g4[k]);
                                 if (__int_as_float(g4[k]) <= lim)
                                 {
 #pragma unroll
                                     for (int r = 4 * k; r < 4 * k + 4; r++)
                                     {
+                                        if (track) ins(__float_as_int(acc[r]));
                                         if (acc[r] <= lim)
                                         {
                                             // row of register r (C/D layout of the 32x32 MFMAs)
@@ -1100,9 +1137,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             }
         }
 
+        if (track)
+        {  // the two smallest over both slices of the query slot
+            const int o1 = __shfl_xor(t1, 32, 64), o2 = __shfl_xor(t2, 32, 64);
+            t2 = min(max(t1, o1), min(t2, o2)), t1 = min(t1, o1);
+        }
         bool too_wide = false;
         if (grp && !over)  // (a pass cut short has not covered its balls: nobody concludes)
         {
+            if (track && is_final(r, rmax, best_d2, g.slack))
+            {
+                // every staged point but the nearest has S >= t2, hence d2 >= t2 - mtol (the prefilter's proven bound; a
+                // negative pattern means a second point within rounding of the query: no bound); every point NOT staged
+                // lies beyond the radius this pass covered
+                const float cover = r * (1.0f - 1.0f / 1024.0f) - g.slack;
+                const float s2    = t2 < 0 ? 0.f : (t2 == 0x7FFFFFFF ? INFINITY : fmaxf(__int_as_float(t2) - mtol, 0.f));
+                lbq = fmaxf(fminf(sqrtf(s2) * 0.99999f - g.slack, cover), 0.f);
+            }
             if (is_final(r, rmax, best_d2, g.slack)) done = true;
             else
             {
@@ -1135,6 +1186,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // every point that could pass the threshold was examined: no map point is nearer than min(best, threshold)
     emit_wave(a, s_claim, lane, valid && slice == 0 && !deferred, qi, orig, active, thr, best_d2, best_idx,
               best_spos, fminf(best_d2, thr), st_cand);
+    if (a.lb2nd && valid && slice == 0 && !deferred) a.lb2nd[qi] = track ? lbq : 0.f;
 
     if (a.timeline && lane == 0)
         a.timeline[2 * (size_t)tile] = tl0, a.timeline[2 * (size_t)tile + 1] = wall_clock64();
@@ -1506,6 +1558,7 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
                                    (acc ? 1u : 0u) | ((heavy ? 0xFFFFFFu : min(st_cand, 0xFFFFFFu)) << NN_COST_SHIFT));
             if (acc && a.claims)
                 claim_global(a, best_spos, (uint32_t)(a.local_offset + (a.rank ? a.rank[orig] : orig)));
+            if (a.lb2nd) a.lb2nd[qi] = 0.f;  // (no certificate from this kernel)
         }
         if (INSTR && lane == 0)
         {
@@ -1651,6 +1704,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.tile_bricks       = (ctx->tune.tile_bricks && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE) ? 1 : 0;
     a.tile_brick_budget = ctx->tune.tile_brick_budget;
     a.hard_cand         = ctx->tune.hard_cand;
+    a.coop_max          = ctx->tune.coop_max;
     a.empty_room        = ctx->tune.empty_room;
     a.claim_dedup   = ctx->tune.claim_dedup;
     a.claim_peek    = ctx->tune.claim_peek;
@@ -1680,6 +1734,31 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->hint_pose[i];
     for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->hint_pose[9 + i];
     a.use_hint = (ctx->hint_map == map && ctx->hint_cloud == cloud && ctx->hint_n == n_l && !prm->disable_warm_start) ? 1 : 0;
+    // ---- search-skip certificate (NNArgs::lb2nd).  The bounds are tracked by a build of the tile kernel that costs ~25 more
+    //      instructions per block, so it runs only when the step from the previous call is small enough for a certificate to
+    //      have a chance at the next one (nn_cert = 1: the displacement of the farthest local point below nn_cert_step_mm;
+    //      2: always; 0: never); the lane kernel reads the bounds whenever the previous call left them.
+    bool cert_track = false;
+    {
+        const bool cert_read = a.use_hint && ctx->nn_lb2nd_valid && ctx->tune.nn_cert != 0;
+        if (ctx->tune.nn_cert == 2) cert_track = true;
+        else if (ctx->tune.nn_cert == 1 && a.use_hint)
+        {
+            // |T p - T' p| <= |t - t'| + |R - R'|_F |p| for every local point p
+            double dt = 0, dr = 0;
+            for (int i = 0; i < 3; i++) dt += (pose[9 + i] - ctx->hint_pose[9 + i]) * (pose[9 + i] - ctx->hint_pose[9 + i]);
+            for (int i = 0; i < 9; i++) dr += (pose[i] - ctx->hint_pose[i]) * (pose[i] - ctx->hint_pose[i]);
+            cert_track = std::sqrt(dt) + std::sqrt(dr) * (double)cloud->radius <= 1e-3 * (double)ctx->tune.nn_cert_step_mm;
+        }
+        cert_track = cert_track && Q == 32 && ctx->tune.mfma_scan && ctx->profiling != 2;
+        a.lb2nd = nullptr, a.cert_read = 0;
+        if (cert_track || cert_read)
+        {
+            MP2P_TRY_HIP(ctx, ctx->nn_lb2nd.ensure(n_l));
+            a.lb2nd = ctx->nn_lb2nd.p, a.cert_read = cert_read ? 1 : 0;
+        }
+        ctx->nn_lb2nd_valid = false;  // set again once the launches are on the stream
+    }
     ctx->hint_map = nullptr;  // committed after the launches: an error return in between leaves no warm start
     a.counters     = nullptr;
     a.touched      = nullptr;
@@ -1769,6 +1848,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
                 if (instr) hipLaunchKernelGGL((nn_tile_kernel<32, true, true>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
                 else if (ctx->tune.tile_waves == 6) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 6>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
                 else if (ctx->tune.tile_waves == 5) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 5>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
+                else if (cert_track) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 4, true>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
                 else hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 4>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
             }
             else if (Q == 32) MP2P_LAUNCH_TILE(32);
@@ -1805,6 +1885,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     MP2P_TRY_HIP(ctx, hipGetLastError());
     ctx->hint_map = map, ctx->hint_cloud = cloud, ctx->hint_n = n_l;
     for (int i = 0; i < 12; i++) ctx->hint_pose[i] = pose[i];
+    ctx->nn_lb2nd_valid = a.lb2nd != nullptr;  // every finished query's entry was written by this call
     return MP2P_HIP_OK;
 }
 

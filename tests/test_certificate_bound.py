@@ -86,3 +86,71 @@ def test_short_list_needs_every_member_to_stay():
     assert ok_bad2 and S_bad2 != _knn(pts, q2, knn, rad)[0]     # the flawed rule certifies a wrong list
     ok, _, _ = _certify(pts, S, lb, q1, 0.001, knn, rad, margin)
     assert not ok                                               # the rule as built sends the query to the search
+
+
+# ---- the point-to-point search's certificate (round 4; nn_query.hip, NNArgs::lb2nd) ----------------------------------
+def _top2_model(vals, lim, rng):
+    """what the tracking build of the tile kernel inserts for one query out of the prefilter values `vals` of a pass (in
+    blocks of 16 rows = 4 groups of 4), given the limit of the moment: a block without a value within the limit is stood for
+    by its minimum; in a block with one, a group outside the limit by its minimum, a group within it by its four values.
+    Returns the second smallest inserted value (the kernel's t2)."""
+    ins = []
+    vals = list(vals)
+    rng.shuffle(vals)
+    while len(vals) % 16:
+        vals.append(1e36)  # the padding slots
+    for b in range(0, len(vals), 16):
+        blk = vals[b:b + 16]
+        if min(blk) > lim:
+            ins.append(min(blk))
+            continue
+        for k in range(4):
+            grp = blk[4 * k:4 * k + 4]
+            if min(grp) > lim:
+                ins.append(min(grp))
+            else:
+                ins.extend(grp)
+    ins.sort()
+    return ins[1] if len(ins) > 1 else np.inf
+
+
+def test_pt2pt_certificate_rule_against_brute_force():
+    """(1) the second smallest INSERTED prefilter value is a lower bound of the second smallest of ALL values, whatever the
+    order of the candidates and whatever the limit (as long as the smallest value is within it: the nearest neighbour's
+    block is always entered); (2) the rule built on it -- previous neighbour re-measured < (bound - displacement - margin)
+    -- only ever certifies the true, unique nearest neighbour; chains of small moves with the bound decaying."""
+    rng = np.random.default_rng(11)
+    n_cert = 0
+    for trial in range(400):
+        pts = rng.uniform(-1, 1, (int(rng.integers(3, 300)), 3))
+        q = rng.uniform(-0.3, 0.3, 3)
+        d = np.linalg.norm(pts - q, axis=1)
+        tol = 1e-5
+        S = d * d + rng.uniform(-tol, tol, len(d))              # the prefilter's values: exact d2 within its error bound
+        cover = float(rng.uniform(0.3, 2.0))                    # the radius the final pass covered
+        staged = d <= cover * float(rng.uniform(1.0, 1.5))      # everything within the covered ball is staged (and more)
+        if not staged.any():
+            continue
+        best = int(np.argmin(np.where(staged, d, np.inf)))
+        lim = S[best] + float(rng.uniform(0, 0.2))              # any limit the nearest neighbour's value is within
+        t2 = _top2_model(S[staged], lim, rng)
+        true_s2 = np.sort(S[staged])[1] if staged.sum() > 1 else np.inf
+        assert t2 <= true_s2 + 1e-15
+        lb = min(np.sqrt(max(t2 - tol, 0.0)), cover)            # the kernel's bound on every point but `best`
+        others = np.delete(d, best)
+        assert (others >= lb - 1e-12).all()
+        margin = 1e-6
+        for step in range(8):
+            move = rng.normal(0, 1, 3)
+            move *= float(rng.uniform(0, 0.004)) / np.linalg.norm(move)
+            q = q + move
+            disp = float(np.linalg.norm(move))
+            room = lb - disp - margin
+            dn = np.linalg.norm(pts - q, axis=1)
+            if lb > 0 and dn[best] + margin < room:
+                assert int(np.argmin(dn)) == best and (np.delete(dn, best) > dn[best]).all(), (trial, step)
+                n_cert += 1
+                lb = room
+            else:
+                break
+    assert n_cert > 300, n_cert

@@ -241,6 +241,52 @@ def test_warm_start_pose_sequence(amd, oracle):
             assert pairs.potential_pairings == pot
 
 
+@pytest.mark.parametrize("mode", ["nn_cert=2", "nn_cert=1,nn_cert_step_mm=3"])
+def test_search_skip_certificate_pose_sequence(amd, oracle, mode, monkeypatch):
+    """the point-to-point search's certificate (nn_query.hip, NNArgs::lb2nd): poses that creep from millimetres to 20
+    micrometres on ONE context -- a growing share of the queries keeps its previous neighbour without a search, because
+    every other map point is provably farther -- every call equal to the oracle's cold result, bit for bit (indices,
+    coordinates, fp32 d2); local points taken in one call and free in the next, a 4 cm jump, and a return.  Both the
+    always-tracking mode and the adaptive one (bounds tracked only after steps below 3 mm)."""
+    from mp2p_icp_amd import _lib, core, synthetic
+    monkeypatch.setenv("MP2P_HIP_TUNE", mode)
+    d = synthetic.make_pair(30_000, 400_000, 91)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    rng = np.random.default_rng(3)
+    poses, scales = [d["T_gt"]], [2e-3, 1e-3, 1e-3, 3e-4, 1e-4, 1e-4, 5e-5, 2e-5, 2e-5, 4e-2, 2e-5, 2e-5]
+    for sc in scales:
+        poses.append(amd.se3.compose(poses[-1], amd.se3.exp(np.concatenate([rng.normal(0, sc, 3), rng.normal(0, 0.03 * sc, 3)]))))
+    poses.append(poses[3])  # back to an earlier pose
+    ctx = amd.Context(0)
+    gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2])
+    cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    pairs = core.DevicePairs(ctx, l.shape[0], 0)
+    ms = core.DeviceMatchState(ctx, g.shape[0], l.shape[0])
+    prm = _lib.Pt2PtParams(1.0, 0.0, 1, 0, 0, 0.20, 0, 0.0, 0, 0.0, 0, 0.0, 0)
+    skipped = {}
+    for k, pose in enumerate(poses):
+        lt = np.zeros(l.shape[0], np.uint8)
+        if k in (4, 7):
+            lt[rng.choice(l.shape[0], 2000, replace=False)] = 1  # skipped by this call only
+        gt = np.zeros(g.shape[0], np.uint8)
+        want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 1.0, 0.0, tree=tree,
+                                       local_taken=lt.copy(), global_taken=gt.copy())
+        # the instrumented build (profiling 2) counts the queries that finish without a search; it reads the bounds the
+        # previous (plain) call left but tracks none itself, so it is used for a look at selected poses only
+        instr = k in (6, 10, 12)
+        ctx.set_profiling(2 if instr else 0)
+        ms.upload(gt, lt)
+        pairs.clear()
+        core.match_pt2pt(ctx, gmap, cloud, pose, prm, ms, pairs)
+        _assert_same_pairs(pairs.download_pt2pt(), want)
+        if instr:
+            skipped[k] = ctx.stats()["nn_lane_skipped"]
+    assert skipped[6] > 0.15 * l.shape[0], skipped   # 0.1 mm steps: a good share is certified
+    assert skipped[10] < 0.8 * skipped[6], skipped    # the 4 cm jump itself: fewer are (a sparse neighbourhood keeps its room)
+    assert skipped[12] > 0.15 * l.shape[0], skipped   # ... and two calls later the bounds are back
+
+
 def test_outliers_with_nothing_in_reach_skip_later_calls(amd, oracle):
     """A local point metres from every surface (30 % of BASELINE config C5's layer) searched its whole ball at EVERY call:
     the bound it kept was the radius just covered.  The one-query kernel now looks for an empty cube of half-edge 2 r_max
@@ -361,7 +407,8 @@ def test_max_local_points_visit_order(amd, oracle, K):
     assert m2._visit_order(2500) is None
 
 
-@pytest.mark.parametrize("tune", ["pipelines=2", "mfma_scan=0", "tile_waves=5", "dir_budget_mb=0,claim_dedup=0,claim_peek=0"])
+@pytest.mark.parametrize("tune", ["pipelines=2", "mfma_scan=0", "tile_waves=5", "dir_budget_mb=0,claim_dedup=0,claim_peek=0", "nn_cert=2",
+                                  "nn_cert=0,tile_bricks=0,hard_cand=0,empty_room=0", "nn_cert=2,pipelines=2,tile_cand_cap=2000"])
 def test_tune_knobs_do_not_change_the_lists(amd, oracle, tune, monkeypatch):
     """MP2P_HIP_TUNE is read once per context: every setting is a measurement aid that must compute the
     same lists (two search pipelines on two streams, exact scan instead of the matrix-pipe prefilter, another

@@ -670,7 +670,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     __shared__ __attribute__((aligned(16))) uint32_t s_idx[NN_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t s_spos[NN_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t s_owner[NN_CAP];
-    __shared__ __attribute__((aligned(16))) float s_n[NN_CAP];  // matrix-pipe prefilter: |c - centre|^2 of the staged points
     __shared__ uint32_t s_cstart[64];
     __shared__ uint32_t s_coff[64];
     __shared__ uint32_t s_vox[NN_TVLIST];  // wide groups: occupied voxels of the box, 10 bits per axis relative to its corner
@@ -855,14 +854,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             s_coff[lane]   = off;
             st_cand += total;
 
-            // ---- stage.  Lane l fills slots 4l..4l+3 of a round of NN_CAP points.  Which voxel a slot belongs to comes from
-            //      a segmented broadcast: every occupied voxel drops its id at its first slot, a prefix-max carries it to the
-            //      following slots.  The loads of round k+1 are ISSUED BEFORE round k is scanned (round 4: a round is a
-            //      dependent trip to memory, ~5 us of a 29-us tile with four or five of them; measured by adding one: +12 us)
-            //      and wait in registers; the |c'|^2 column of the prefilter has an array of its own for that (s_n).
-            uint32_t srcN[4];
-            float4   cN[4];
-            auto fetch = [&](uint32_t base, uint32_t m) __attribute__((always_inline)) {
+            for (uint32_t base = 0; base < total && !over; base += NN_CAP)
+            {
+                const uint32_t m     = min((uint32_t)NN_CAP, total - base);
+                over = st_cand - total + base + m > cand_cap;  // (this round is still scanned)
+                const uint32_t m_pad = (m + 31u) & ~31u;
+                // ---- stage.  Lane l fills slots 4l..4l+3 of the round.  Which voxel a slot
+                //      belongs to comes from a segmented broadcast: every occupied voxel drops
+                //      its id at its first slot, a prefix-max carries it to the following slots.
                 *reinterpret_cast<uint4*>(&s_owner[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
                 __syncthreads();
                 if (cnt > 0)
@@ -871,71 +870,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     else if (off < base && off + cnt > base) s_owner[0] = (uint32_t)lane + 1u;
                 }
                 __syncthreads();
-                const uint4    o4 = *reinterpret_cast<const uint4*>(&s_owner[4 * lane]);
-                const uint32_t p0 = o4.x, p1 = max(p0, o4.y), p2 = max(p1, o4.z), p3 = max(p2, o4.w);
-                const uint32_t in = wave_incl_max(p3, lane);
-                uint32_t       ex = __shfl_up(in, 1, 64);
-                if (lane == 0) ex = 0u;
-                const uint32_t ow[4] = {(uint32_t)max(ex, p0), (uint32_t)max(ex, p1), (uint32_t)max(ex, p2), (uint32_t)max(ex, p3)};
-                const uint32_t t0    = 4u * (uint32_t)lane;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
                 {
-                    srcN[k] = NONE_U32;
-                    if (t0 + k < m)
+                    const uint4    o4 = *reinterpret_cast<const uint4*>(&s_owner[4 * lane]);
+                    const uint32_t p0 = o4.x, p1 = max(p0, o4.y), p2 = max(p1, o4.z), p3 = max(p2, o4.w);
+                    const uint32_t in = wave_incl_max(p3, lane);
+                    uint32_t       ex = __shfl_up(in, 1, 64);
+                    if (lane == 0) ex = 0u;
+                    const uint32_t ow[4] = {(uint32_t)max(ex, p0), (uint32_t)max(ex, p1), (uint32_t)max(ex, p2), (uint32_t)max(ex, p3)};
+                    const uint32_t t0    = 4u * (uint32_t)lane;
+                    uint32_t       src[4];
+                    float4         c4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
                     {
-                        const uint32_t v = ow[k] - 1u;
-                        srcN[k]          = s_cstart[v] + (base + t0 + k - s_coff[v]);
+                        src[k] = NONE_U32;
+                        if (t0 + k < m)
+                        {
+                            const uint32_t v = ow[k] - 1u;
+                            src[k]           = s_cstart[v] + (base + t0 + k - s_coff[v]);
+                        }
                     }
-                }
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                {
-                    // padding: FAR but finite.  An infinite coordinate makes the prefilter's S an inf - inf = NaN, and the
-                    // integer minimum over the accumulators' bit patterns (below) would pick a NaN with the sign bit set
-                    // ahead of every real candidate of the block (found by the parity suite: 897 of 904 pairs)
-                    cN[k] = make_float4(1e18f, 0.f, 0.f, __uint_as_float(NONE_U32));
-                    if (t0 + k < m) cN[k] = g.pts[srcN[k]];
-                }
-            };
-            fetch(0u, min((uint32_t)NN_CAP, total));
-            for (uint32_t base = 0; base < total && !over; base += NN_CAP)
-            {
-                const uint32_t m     = min((uint32_t)NN_CAP, total - base);
-                over = st_cand - total + base + m > cand_cap;  // (this round is still scanned)
-                const uint32_t m_pad = (m + 31u) & ~31u;
-                {
-                    const uint32_t t0 = 4u * (uint32_t)lane;
-                    *reinterpret_cast<float4*>(&s_x[t0]) = make_float4(cN[0].x, cN[1].x, cN[2].x, cN[3].x);
-                    *reinterpret_cast<float4*>(&s_y[t0]) = make_float4(cN[0].y, cN[1].y, cN[2].y, cN[3].y);
-                    *reinterpret_cast<float4*>(&s_z[t0]) = make_float4(cN[0].z, cN[1].z, cN[2].z, cN[3].z);
+                    for (int k = 0; k < 4; k++)
+                    {
+                        // padding: FAR but finite.  An infinite coordinate makes the prefilter's S an inf - inf = NaN, and the
+                        // integer minimum over the accumulators' bit patterns (below) would pick a NaN with the sign bit set
+                        // ahead of every real candidate of the block (found by the parity suite: 897 of 904 pairs)
+                        c4[k] = make_float4(1e18f, 0.f, 0.f, __uint_as_float(NONE_U32));
+                        if (t0 + k < m) c4[k] = g.pts[src[k]];
+                    }
+                    *reinterpret_cast<float4*>(&s_x[t0]) = make_float4(c4[0].x, c4[1].x, c4[2].x, c4[3].x);
+                    *reinterpret_cast<float4*>(&s_y[t0]) = make_float4(c4[0].y, c4[1].y, c4[2].y, c4[3].y);
+                    *reinterpret_cast<float4*>(&s_z[t0]) = make_float4(c4[0].z, c4[1].z, c4[2].z, c4[3].z);
                     *reinterpret_cast<uint4*>(&s_idx[t0]) =
-                        make_uint4(__float_as_uint(cN[0].w), __float_as_uint(cN[1].w),
-                                   __float_as_uint(cN[2].w), __float_as_uint(cN[3].w));
-                    *reinterpret_cast<uint4*>(&s_spos[t0]) = make_uint4(srcN[0], srcN[1], srcN[2], srcN[3]);
+                        make_uint4(__float_as_uint(c4[0].w), __float_as_uint(c4[1].w),
+                                   __float_as_uint(c4[2].w), __float_as_uint(c4[3].w));
+                    *reinterpret_cast<uint4*>(&s_spos[t0]) = make_uint4(src[0], src[1], src[2], src[3]);
                     if (use_mfma)
-                    {  // |c - centre|^2
+                    {  // |c - centre|^2 (the lane's own four owner slots are free again: it has read them)
                         float n4[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++)
                         {
-                            const float ex = cN[k].x - ocx, ey = cN[k].y - ocy, ez = cN[k].z - ocz;
+                            const float ex = c4[k].x - ocx, ey = c4[k].y - ocy, ez = c4[k].z - ocz;
                             n4[k] = ex * ex + ey * ey + ez * ez;
                         }
-                        *reinterpret_cast<float4*>(&s_n[t0]) = make_float4(n4[0], n4[1], n4[2], n4[3]);
+                        *reinterpret_cast<float4*>(&s_owner[t0]) = make_float4(n4[0], n4[1], n4[2], n4[3]);
                     }
                     if (INSTR)
                     {
 #pragma unroll
                         for (int k = 0; k < 4; k++)
-                            if (t0 + k < m) a.touched[srcN[k]] = 1;
+                            if (t0 + k < m) a.touched[src[k]] = 1;
                     }
                 }
                 __syncthreads();
-                // the next round's points are on their way while this one is scanned
-                if (base + NN_CAP < total && !over) fetch(base + NN_CAP, min((uint32_t)NN_CAP, total - base - NN_CAP));
                 if (use_mfma)
                 {
+                    const float* s_n   = reinterpret_cast<const float*>(s_owner);
                     const bool   hi    = lane >= 32;
                     const float* s_a0  = hi ? s_y : s_x;
                     const float* s_a1  = hi ? s_n : s_z;

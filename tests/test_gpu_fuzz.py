@@ -152,3 +152,64 @@ def test_fuzz_pt2pl_and_inlier_ratio(oracle, seed):
         assert np.array_equal(got["globalIdx"], r["pt2pt"]["globalIdx"]), info
         assert np.array_equal(pairs.paired_pt2pl_local_idx, r["pl_local_idx"]), info
         assert pairs.potential_pairings == r["potential"]
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_round4_search_paths(oracle, seed, monkeypatch):
+    """the point-to-point search's round-4 paths under random knobs, a fresh context per case: brick lists in the tile
+    kernel (also with a budget of 1 or 8 bricks: the coarse dense fallback), tiny candidate budgets (passes cut short in
+    flight, queries handed on with partial bounds), cost classes with a threshold everything / nothing exceeds, the
+    search-skip certificate in all three modes, the empty-room bound; pose sequences from 10^-5 to 0.3 of the scene with
+    jumps, local points taken in some calls, large and tiny thresholds.  Lists bit-exact against the oracle at every call."""
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import _lib, core
+    rng = np.random.default_rng(77000 + seed)
+    kind = KINDS[seed % len(KINDS)]
+    n_g = int(rng.integers(2000, 120000))
+    n_l = int(rng.integers(64, 12000))
+    g = _cloud(rng, kind, n_g).astype(np.float32)
+    scale = float(np.ptp(g, axis=0).max()) or 1.0
+    src = g[rng.integers(0, len(g), n_l)].astype(np.float64)
+    off = rng.normal(0, 1, (n_l, 3)) * scale * float(rng.choice([0.0, 0.002, 0.02, 0.1]))
+    l = (src + off).astype(np.float32)
+    if rng.random() < 0.6:                       # far outliers: nothing in reach
+        k = max(1, n_l // int(rng.choice([3, 10])))
+        l[:k] += (rng.uniform(-1, 1, (k, 3)) * scale * float(rng.choice([0.5, 3.0]))).astype(np.float32)
+    thr = float(rng.choice([0.005, 0.03, 0.1, 0.4, 1.5]) * scale)
+    tune = ",".join([f"nn_cert={int(rng.choice([0, 1, 2, 2]))}", f"nn_cert_step_mm={int(rng.choice([1, 50, 100000]))}",
+                     f"tile_cand_cap={int(rng.choice([6144, 600, 100]))}", f"tile_brick_budget={int(rng.choice([512, 8, 1]))}",
+                     f"hard_cand={int(rng.choice([1700, 50, 0]))}", f"tile_bricks={int(rng.choice([1, 1, 0]))}",
+                     f"empty_room={int(rng.choice([1, 1, 0]))}", f"coop_max={int(rng.choice([4, 0]))}"])
+    monkeypatch.setenv("MP2P_HIP_TUNE", tune)
+    layer_kw = {}
+    if rng.random() < 0.3:
+        layer_kw["cell_size"] = float(rng.choice([0.005, 0.03, 0.2]) * scale)
+    if rng.random() < 0.2:
+        layer_kw["no_occupancy_bitmap"] = int(rng.choice([1, 2, 4]))
+    allow_g = int(rng.random() < 0.3)
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    ctx = amd.Context(0)
+    gmap = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2], **layer_kw)
+    cloud = core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    pairs = core.DevicePairs(ctx, n_l, 0)
+    ms = core.DeviceMatchState(ctx, n_g, n_l)
+    prm = _lib.Pt2PtParams(thr, 0.0, 1, 0, allow_g, 0.20, 0, 0.0, 0, 0.0, 0, 0.0, 0)
+    T = amd.se3.exp(np.concatenate([rng.normal(0, 0.01 * scale, 3), rng.normal(0, 0.01, 3)]))
+    for step in range(7):
+        s = float(rng.choice([1e-5, 1e-4, 1e-3, 1e-2, 0.3])) * (step > 0)
+        T = amd.se3.compose(T, amd.se3.exp(np.concatenate([rng.normal(0, s * scale, 3), rng.normal(0, s, 3)])))
+        lt = np.zeros(n_l, np.uint8)
+        if rng.random() < 0.3:
+            lt[rng.integers(0, n_l, max(1, n_l // 7))] = 1
+        gt = np.zeros(n_g, np.uint8)
+        want, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, thr, 0.0, tree=tree,
+                                       allowMatchAlreadyMatchedGlobalPoints=bool(allow_g), local_taken=lt.copy(), global_taken=gt.copy())
+        ms.upload(gt, lt)
+        pairs.clear()
+        core.match_pt2pt(ctx, gmap, cloud, T, prm, ms, pairs)
+        got = pairs.download_pt2pt()
+        info = (kind, n_g, n_l, thr, tune, layer_kw, allow_g, step)
+        assert len(got) == len(want), info
+        assert np.array_equal(got["localIdx"], want["localIdx"]), info
+        assert np.array_equal(got["globalIdx"], want["globalIdx"]), info
+        assert np.array_equal(got["errorSquareAfterTransformation"].view(np.uint32), want["errSq"].view(np.uint32)), info

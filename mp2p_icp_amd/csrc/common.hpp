@@ -200,6 +200,7 @@ struct CopyStage
     bool                    open     = false;    // a posted copy has not been finished yet
     std::thread             th;                  // helper (started with the first copy of more than one chunk)
     bool                    stop     = false;
+    bool                    no_helper = false;   // the helper could not be started: the caller copies alone
 };
 
 struct GnState

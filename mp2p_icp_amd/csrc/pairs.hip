@@ -663,7 +663,18 @@ static int stage_round(mp2p_hip_ctx* ctx, const unsigned char* dev, unsigned cha
         MP2P_TRY_HIP(ctx, hipMemcpyAsync(s.host + off, dev + off, len, hipMemcpyDeviceToHost, ctx->stream));
         MP2P_TRY_HIP(ctx, hipEventRecord(s.ev[k], ctx->stream));
     }
-    if (nc > 1 && !s.th.joinable()) s.th = std::thread(stage_worker, ctx);
+    if (nc > 1 && !s.th.joinable() && !s.no_helper)
+    {
+        // (no exception may cross the C boundary: without a helper the calling thread copies every chunk itself)
+        try
+        {
+            s.th = std::thread(stage_worker, ctx);
+        }
+        catch (...)
+        {
+            s.no_helper = true;
+        }
+    }
     {
         std::lock_guard<std::mutex> lk(s.mu);
         s.out = out, s.bytes = round, s.n_chunks = nc, s.next = 0, s.done = 0;

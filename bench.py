@@ -541,27 +541,7 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
         pose = step(pose)
         k += 1
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None and world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one()
-    barrier()
-    t0 = time.perf_counter()
-    ts = []
-    for _ in range(args.steps):
-        t1 = time.perf_counter()
-        one()
-        ts.append(time.perf_counter() - t1)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None and world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, ts = timed_steps(one, args.steps, args.warmup, torch.cuda.synchronize, dist, world, torch.device("cuda"))
     # kernel breakdown + pairs from a replay with events
     pose, k = d["T_init"].copy(), 0
     for _ in range(args.warmup):
@@ -626,6 +606,37 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
                               "N_g,touched replaced by its lower bound (the pairs' own neighbours): frac is a lower bound")},
         **({"cpu_baseline": cpu} if cpu is not None else {}),
     }
+
+
+# ---------------------------------------------------------------------------------------------------
+def timed_steps(one, steps, warmup, sync, dist, world, dev):
+    """W untimed calls of one(), then exactly K between two barrier + synchronize brackets; the MAX over the ranks of the
+    elapsed time -> (elapsed_s, [step_s]).  The multi-rank core of the --config lines (bench_config); also driven over gloo
+    with an oracle-backed step in tests/test_distributed_gloo.py (the dry run of `--gpus N --config c3`)."""
+    import torch
+
+    def barrier():
+        sync()
+        if dist is not None and world > 1:
+            dist.barrier()
+        sync()
+
+    for _ in range(warmup):
+        one()
+    barrier()
+    t0 = time.perf_counter()
+    ts = []
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None and world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, ts
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -505,6 +505,59 @@ def _bench_dry_worker(rank, world, port, q):
         q.put((rank, False, traceback.format_exc() + str(ex)))
 
 
+def _bench_c3_dry_worker(rank, world, port, q):
+    """bench.py --gpus N --config c3, dry: bench.timed_steps (the multi-rank core of bench_config) around the sharded
+    point-to-plane step with the oracle as this rank's compute"""
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import bench
+        import oracle as orc
+        from mp2p_icp_amd import synthetic
+        from mp2p_icp_amd.distributed import ShardedRegistration, shard_range
+        d = synthetic.make_pair(1200, 200000, 19)
+        g, l = d["glob"], d["local"]
+        b, e = shard_range(l.shape[0], rank, world)
+        reg = ShardedRegistration(OraclePlaneBackend(orc, torch, g, l[b:e], b, 3), dist)
+        state = {"pose": d["T_init"].copy(), "k": 0}
+
+        def one():
+            if state["k"] % bench.CYCLE == 0:
+                state["pose"] = d["T_init"].copy()
+            state["pose"] = np.asarray(reg.step(state["pose"])[0])
+            state["k"] += 1
+
+        elapsed, ts = bench.timed_steps(one, 3, 1, lambda: None, dist, world, torch.device("cpu"))
+        both = [None] * world
+        dist.all_gather_object(both, (elapsed, [float(v) for v in state["pose"]]))
+        ok = elapsed > 0 and len(ts) == 3 and both[0] == both[1]  # one time (MAX over ranks), one pose on every rank
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok, "" if ok else f"c3 dry run: {both}"))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc() + str(ex)))
+
+
+@pytest.mark.timeout(300)
+def test_bench_config_c3_multi_rank_core_dry_run_gloo_world2():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_c3_dry_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(WORLD)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"
+
+
 @pytest.mark.timeout(300)
 def test_bench_multi_rank_path_dry_run_gloo_world2():
     """bench.py --gpus N without GPUs: bench.sharded_default_line (barrier brackets, MAX over ranks, strong-scaling block)

@@ -3,6 +3,8 @@ adaptive) against the CPU oracle: random geometries
 (clusters, exact lattices with many equal distances, collinear and coplanar sets, duplicates, large
 coordinate offsets, tiny extents), random thresholds / angular thresholds / pairingsPerPoint /
 voxel sizes / bitmap on-off / tile sizes, and pose sequences (warm start).  Lists must be bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -154,7 +156,11 @@ def test_fuzz_pt2pl_and_inlier_ratio(oracle, seed):
         assert pairs.potential_pairings == r["potential"]
 
 
-@pytest.mark.parametrize("seed", range(48))
+# (MP2P_FUZZ_SEEDS=a:b runs another range of seeds: the end-of-round campaign of round 4 ran 48..448, all equal)
+_R4_SEEDS = range(*[int(v) for v in os.environ.get("MP2P_FUZZ_SEEDS", "0:48").split(":")])
+
+
+@pytest.mark.parametrize("seed", _R4_SEEDS)
 def test_fuzz_round4_search_paths(oracle, seed, monkeypatch):
     """the point-to-point search's round-4 paths under random knobs, a fresh context per case: brick lists in the tile
     kernel (also with a budget of 1 or 8 bricks: the coarse dense fallback), tiny candidate budgets (passes cut short in

@@ -52,7 +52,10 @@ def test_the_check_is_live():
                          ("sc.prior->cov_inv(i, j)", "sc.prior->cov_inverse(i, j)"),
                          ("outPc->insertPointFrom(*todo[li], i)", "outPc->insertPointFromLayer(*todo[li], i)"),
                          ("mrpt::math::confidenceIntervalsFromHistogram(xs,", "mrpt::math::confidenceIntervalFromHistogram(xs,"),
-                         ("class FilterDecimateVoxels : public mp2p_icp_filters::FilterBase", "class FilterDecimateVoxels : public mp2p_icp_filters::FilterBaze")):
+                         ("class FilterDecimateVoxels : public mp2p_icp_filters::FilterBase", "class FilterDecimateVoxels : public mp2p_icp_filters::FilterBaze"),
+                         ("n_pairs = pairingsFromICP.size(), potential", "n_pairs = pairingsFromICP.sizes(), potential"),
+                         ("class QualityEvaluator_PairedRatio : public mp2p_icp::QualityEvaluator", "class QualityEvaluator_PairedRatio : public mp2p_icp::QualityEvaluatr"),
+                         ("mp2p_icp::MatchState ms(pcGlobal, pcLocal);  // :59", "mp2p_icp::MatchState ms(pcGlobal);  // :59")):
             assert old in src
             p = os.path.join(d, "bad.cpp")
             open(p, "w").write(src.replace(old, new, 1))

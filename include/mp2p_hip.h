@@ -587,7 +587,10 @@ typedef struct
     /* reserved, always 0: the counters of round 3's one-launch search kernel (nn_wave_kernel), which was measured
      * slower on both bench scenes and removed from the library in round 4; kept so that the struct keeps its layout */
     uint64_t nn_wave_path;
-    uint64_t nn_wave_lane_tests, nn_wave_maxlane_tests, nn_wave_inserts, nn_wave_overflows, nn_wave_rounds;
+    /* round 5 (nn_seltile.hip; the first two of round 3's reserved words): occupied voxels the tiles listed from the
+     * occupancy bricks, and those the matrix-pipe selection kept (resolved + staged) */
+    uint64_t nn_sel_voxels_listed, nn_sel_voxels_needed;
+    uint64_t nn_wave_inserts, nn_wave_overflows, nn_wave_rounds;
     uint64_t nn_wave_toobig;
     uint64_t nn_wave_phase_ticks[6];
     /* Matcher_Point2Plane certificate (round 3), cumulative since the context was created and refreshed by a
@@ -645,6 +648,10 @@ int mp2p_hip_filter_decimate_voxels_device(mp2p_hip_ctx* ctx, const float* d_x, 
  * 4 = 3 + a {start, end} timestamp (100 MHz ticks) per workgroup of the two search kernels of
  *     Matcher_Points_DistanceThreshold, for occupancy-over-time plots (tools/timeline_probe.py). */
 int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable);
+/* measurement knobs of a context at run time: the syntax of the environment variable MP2P_HIP_TUNE ("name=value,...",
+ * read once when the context is created; csrc/common.hpp lists the knobs).  Every setting computes the same results,
+ * except tile_sol != 0 (timing-only launches of the search, no results).  No counterpart in the reference. */
+int mp2p_hip_set_tune(mp2p_hip_ctx* ctx, const char* settings);
 /* the timestamps of the last match call at profiling level 4: 2 uint64 per record, the tile
  * kernel's workgroups first, then the one-query-per-wave kernel's; ticks_host may be NULL to
  * query the record counts */

@@ -151,8 +151,8 @@ class Stats(C.Structure):
                 ("ms_nn_lane", C.c_double), ("nn_lane_searched", C.c_uint64),
                 ("nn_lane_candidates", C.c_uint64), ("nn_lane_voxels", C.c_uint64),
                 ("nn_lane_pending", C.c_uint64), ("nn_lane_skipped", C.c_uint64),
-                ("nn_wave_path", C.c_uint64), ("nn_wave_lane_tests", C.c_uint64),
-                ("nn_wave_maxlane_tests", C.c_uint64), ("nn_wave_inserts", C.c_uint64),
+                ("nn_wave_path", C.c_uint64), ("nn_sel_voxels_listed", C.c_uint64),
+                ("nn_sel_voxels_needed", C.c_uint64), ("nn_wave_inserts", C.c_uint64),
                 ("nn_wave_overflows", C.c_uint64), ("nn_wave_rounds", C.c_uint64),
                 ("nn_wave_toobig", C.c_uint64), ("nn_wave_phase_ticks", C.c_uint64 * 6),
                 ("pl_certified", C.c_uint64), ("pl_searched", C.c_uint64)]
@@ -264,6 +264,7 @@ SIGNATURES = {
     "mp2p_hip_step_sharded_pt2pl": (C.c_int, [_P, _P, _P, _dp, C.POINTER(Pt2PlParams), C.c_uint64, C.POINTER(GNParams), _P,
                                               C.POINTER(GNResult)]),
     "mp2p_hip_set_profiling": (C.c_int, [_P, C.c_int]),
+    "mp2p_hip_set_tune": (C.c_int, [_P, C.c_char_p]),
     "mp2p_hip_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "mp2p_hip_get_timeline": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t),
                                         C.POINTER(C.c_size_t)]),

@@ -61,6 +61,10 @@ class Context:
     def set_profiling(self, on):
         check(self._L.mp2p_hip_set_profiling(self._h, int(on)), self._h)
 
+    def set_tune(self, settings):
+        """measurement knobs at run time ("name=value,..." as in MP2P_HIP_TUNE; csrc/common.hpp)"""
+        check(self._L.mp2p_hip_set_tune(self._h, str(settings).encode()), self._h)
+
     def stats(self):
         s = _lib.Stats()
         check(self._L.mp2p_hip_get_stats(self._h, C.byref(s)), self._h)

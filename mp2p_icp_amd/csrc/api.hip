@@ -37,9 +37,9 @@ int set_err(mp2p_hip_ctx* ctx, int code, const char* fmt, ...)
 }
 
 // MP2P_HIP_TUNE="lane_cells=3,tile_cand_cap=4096,claim_dedup=0": measurement knobs (common.hpp)
-static void parse_tune(Tune& t)
+static void parse_tune(Tune& t, const char* e = nullptr)
 {
-    const char* e = getenv("MP2P_HIP_TUNE");
+    if (!e) e = getenv("MP2P_HIP_TUNE");
     if (!e) return;
     std::string s(e);
     size_t      i = 0;
@@ -84,6 +84,9 @@ static void parse_tune(Tune& t)
             else if (k == "tile_cand_cap_easy") t.tile_cand_cap_easy = (uint32_t)v;
             else if (k == "copy_chunk_kb") t.copy_chunk_kb = (uint32_t)v;
             else if (k == "copy_stage_mb") t.copy_stage_mb = (uint32_t)v;
+            else if (k == "tile_select") t.tile_select = (int)v;
+            else if (k == "nn_direct") t.nn_direct = (int)v;
+            else if (k == "tile_sol") t.tile_sol = (int)v;
             else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
         }
         i = j + 1;
@@ -1013,6 +1016,13 @@ int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable)
     return MP2P_HIP_OK;
 }
 
+int mp2p_hip_set_tune(mp2p_hip_ctx* ctx, const char* settings)
+{
+    if (!ctx || !settings) return MP2P_HIP_ERR_INVALID;
+    parse_tune(ctx->tune, settings);
+    return MP2P_HIP_OK;
+}
+
 int mp2p_hip_get_timeline(mp2p_hip_ctx* ctx, uint64_t* ticks_host, size_t cap_records, size_t* n_tile_records,
                           size_t* n_single_records)
 {
@@ -1064,6 +1074,7 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
             ctx->stats.nn_single_max_passes = c[41], ctx->stats.nn_single_max_cells = c[42];
             ctx->stats.nn_lane_searched = c[44], ctx->stats.nn_lane_candidates = c[45];
             ctx->stats.nn_lane_voxels = c[46], ctx->stats.nn_lane_pending = c[47], ctx->stats.nn_lane_skipped = c[48];
+            ctx->stats.nn_sel_voxels_listed = c[49], ctx->stats.nn_sel_voxels_needed = c[50];
             for (int i = 0; i < 24; i++) ctx->stats.nn_tile_ticks_hist[i] = c[16 + i];
             ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1];
             ctx->stats.nn_cells_visited = c[2], ctx->stats.nn_candidates_tested = c[3];

@@ -161,6 +161,11 @@ struct Tune
     uint32_t pl_cert_margin_mm = 20; // ... voxels up to this far beyond the search radius of a pass are staged as well (the covered region's margin)
     uint32_t copy_chunk_kb = 2048;  // staged copy-out of the pair lists (CopyStage): bytes per DMA + event ...
     uint32_t copy_stage_mb = 256;   // ... and the bound of the page-locked staging buffer (larger lists go in rounds)
+    int      tile_select   = 1;     // pt2pt search, round 5: the voxels a tile stages are SELECTED on the matrix pipe (a voxel is staged iff
+                                    // some query's ball reaches its circumsphere) instead of by the group's bounding box (nn_seltile.hip)
+    int      nn_direct     = 1;     // ... and the per-query prologue runs in the tile itself: no lane kernel, no pending list
+    int      tile_sol      = 0;     // speed-of-light decomposition of that kernel (TIMING ONLY, no results): 1 = list + select + stage,
+                                    // 2 = + matrix-pipe prefilter; set at run time through mp2p_hip_set_tune
     uint32_t pl_hard_cand  = 1500;  // pt2pl: a query whose tile staged this many candidates (per 4 queries) at the previous call is searched in the hard class, first and in smaller tiles (0 = one class)
 };
 

@@ -127,6 +127,7 @@ struct NNArgs
     uint32_t             list_cap;
     float                r_hard;
     int                  xcd_map;
+    int                  direct;   // nn_seltile_kernel: tile t serves the queries 32 t .. of the layer itself (no lane kernel, no pending list)
     const uint32_t*      rank;  // visit rank per original local index (NONE = not visited) or null
     int                  use_hint;
     PoseRt               prev_pose;
@@ -1573,6 +1574,11 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
     }
 }
 
+}  // namespace mp2p
+// round 5: the tile kernel with matrix-pipe voxel selection and the fused prologue (the default search path)
+#include "nn_seltile.hip"
+namespace mp2p
+{
 // resets the segment counters of the two query lists
 __global__ __launch_bounds__(NN_MAX_SEG) void nn_reset_kernel(uint32_t* q_counters)
 {
@@ -1649,8 +1655,14 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     MP2P_REQUIRE(ctx, Q == 64 || Q == 32 || Q == 16, "queries_per_wave must be 64, 32 or 16");
     const uint32_t n_waves = (uint32_t)((n_l + 63) / 64);     // lane kernel
 
+    // round 5 (nn_seltile.hip): voxels selected on the matrix pipe; needs the level-0 occupancy bricks and the 32-query tile.
+    // DIRECT: the per-query prologue runs in the tile itself (no lane kernel, no pending list)
+    const bool sel    = ctx->tune.tile_select && Q == 32 && ctx->tune.mfma_scan && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE;
+    const bool direct = sel && ctx->tune.nn_direct;
+    const int  sol    = direct ? ctx->tune.tile_sol : 0;  // speed-of-light decomposition (timing only: no results, no state)
+    const uint32_t n_boxes = direct ? (uint32_t)((n_l + 31) / 32) : n_waves;  // per-tile / per-wave bounding boxes
     MP2P_TRY_HIP(ctx, ctx->nn_rec.ensure(n_l));
-    MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_waves * 6));
+    MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)std::max(n_boxes, 1u) * 6));
     MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
     // query lists in segments (NNArgs): seg_waves consecutive workgroups of the lane kernel share one
     const uint32_t seg_waves = std::max<uint32_t>(1u, (n_waves + NN_MAX_SEG - 1) / NN_MAX_SEG);
@@ -1721,7 +1733,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.list_cap = (uint32_t)list_cap;
     a.r_hard   = cell0 * 0.01f * (float)ctx->tune.hard_radius_pct;
     a.xcd_map  = ctx->tune.xcd_map;
-    const uint32_t n_tiles = 2u * ((n_seg + 7u) / 8u) * 8u * a.tiles_per_seg;  // worst case for each class: every query in it
+    a.direct   = direct ? 1 : 0;
+    // worst case for each class: every query in it (DIRECT: one class, every tile a fixed slice of the layer)
+    const uint32_t n_tiles = (direct ? 1u : 2u) * ((n_seg + 7u) / 8u) * 8u * a.tiles_per_seg;
     ctx->last_n_tiles = n_tiles;
     for (int i = 0; i < 9; i++) a.prev_pose.r[i] = ctx->hint_pose[i];
     for (int i = 0; i < 3; i++) a.prev_pose.t[i] = ctx->hint_pose[9 + i];
@@ -1742,7 +1756,8 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
             for (int i = 0; i < 9; i++) dr += (pose[i] - ctx->hint_pose[i]) * (pose[i] - ctx->hint_pose[i]);
             cert_track = std::sqrt(dt) + std::sqrt(dr) * (double)cloud->radius <= 1e-3 * (double)ctx->tune.nn_cert_step_mm;
         }
-        cert_track = cert_track && Q == 32 && ctx->tune.mfma_scan && ctx->profiling != 2;
+        cert_track = cert_track && Q == 32 && ctx->tune.mfma_scan && ctx->profiling != 2 && sol == 0 &&
+                     (sel || ctx->tune.tile_waves == 4);  // (the round-4 kernel has a tracking build for 4 waves per SIMD only)
         a.lb2nd = nullptr, a.cert_read = 0;
         if (cert_track || cert_read)
         {
@@ -1751,6 +1766,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         }
         ctx->nn_lb2nd_valid = false;  // set again once the launches are on the stream
     }
+    const void* const keep_hint_map = ctx->hint_map;
     ctx->hint_map = nullptr;  // committed after the launches: an error return in between leaves no warm start
     a.counters     = nullptr;
     a.touched      = nullptr;
@@ -1775,8 +1791,8 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         a.timeline = ctx->timeline.p;
         ctx->timeline_tiles = n_tiles, ctx->timeline_singles = single_blocks;
     }
-    ctx->pending_lane = 1;
-    ctx->last_n_boxes = n_waves;
+    ctx->pending_lane = direct ? 0 : 1;
+    ctx->last_n_boxes = n_boxes;
     // the list counters: cleared by the previous call's fused compaction, or here
     if (!ctx->q_counters_clean)
         hipLaunchKernelGGL(nn_reset_kernel, dim3(NN_ALL_LISTS), dim3(NN_MAX_SEG), 0, ctx->stream, a.q_counters);
@@ -1816,11 +1832,11 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
             ap[p].seg_base  = s0, ap[p].n_seg = s1 - s0;
             ap[p].wave_base = w0;
             wn[p]           = w1 - w0;
-            tn[p]           = 2u * ((ap[p].n_seg + 7u) / 8u) * 8u * a.tiles_per_seg;
+            tn[p]           = (direct ? 1u : 2u) * ((ap[p].n_seg + 7u) / 8u) * 8u * a.tiles_per_seg;
             const uint32_t all = 256u * (ctx->tune.single_blocks_per_cu ? ctx->tune.single_blocks_per_cu : 40u);
             sbn[p]          = (uint32_t)std::min<size_t>((size_t)wn[p] * 64u, all / P);
         }
-        for (uint32_t p = 0; p < P; p++)
+        for (uint32_t p = 0; p < P && !direct; p++)
         {
             if (instr) hipLaunchKernelGGL(nn_lane_kernel<true>, dim3(wn[p]), dim3(64), 0, st[p], ap[p]);
             else hipLaunchKernelGGL(nn_lane_kernel<false>, dim3(wn[p]), dim3(64), 0, st[p], ap[p]);
@@ -1832,9 +1848,19 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         if (instr) hipLaunchKernelGGL((nn_tile_kernel<QQ, true>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);   \
         else hipLaunchKernelGGL((nn_tile_kernel<QQ, false>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);        \
     } while (0)
+#define MP2P_LAUNCH_SEL(INSTR_, CERT_, DIRECT_, SOL_) \
+    hipLaunchKernelGGL((nn_seltile_kernel<INSTR_, CERT_, DIRECT_, 4, SOL_>), dim3(tn[p]), dim3(64), 0, st[p], ap[p])
         for (uint32_t p = 0; p < P; p++)
         {
-            if (Q == 64) MP2P_LAUNCH_TILE(64);
+            if (sel)
+            {
+                if (sol == 1) MP2P_LAUNCH_SEL(false, false, true, 1);
+                else if (sol == 2) MP2P_LAUNCH_SEL(false, false, true, 2);
+                else if (instr) { if (direct) MP2P_LAUNCH_SEL(true, false, true, 0); else MP2P_LAUNCH_SEL(true, false, false, 0); }
+                else if (cert_track) { if (direct) MP2P_LAUNCH_SEL(false, true, true, 0); else MP2P_LAUNCH_SEL(false, true, false, 0); }
+                else { if (direct) MP2P_LAUNCH_SEL(false, false, true, 0); else MP2P_LAUNCH_SEL(false, false, false, 0); }
+            }
+            else if (Q == 64) MP2P_LAUNCH_TILE(64);
             else if (Q == 32 && a.mfma_scan)
             {
                 if (instr) hipLaunchKernelGGL((nn_tile_kernel<32, true, true>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
@@ -1847,6 +1873,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
             else MP2P_LAUNCH_TILE(16);
         }
 #undef MP2P_LAUNCH_TILE
+#undef MP2P_LAUNCH_SEL
         if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         // deferred queries: the count lives on the device; a fixed grid strides over it
         for (uint32_t p = 0; p < P; p++)
@@ -1871,10 +1898,16 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if (reduce_bbox)
     {
-        int rc = launch_bbox_reduce(ctx, n_waves);
+        int rc = launch_bbox_reduce(ctx, n_boxes);
         if (rc) return rc;
     }
     MP2P_TRY_HIP(ctx, hipGetLastError());
+    if (sol != 0)
+    {  // a timing-only launch wrote no record: the warm start of the previous call stands
+        ctx->hint_map = keep_hint_map;
+        ctx->nn_lb2nd_valid = a.cert_read != 0;
+        return MP2P_HIP_OK;
+    }
     ctx->hint_map = map, ctx->hint_cloud = cloud, ctx->hint_n = n_l;
     for (int i = 0; i < 12; i++) ctx->hint_pose[i] = pose[i];
     ctx->nn_lb2nd_valid = a.lb2nd != nullptr;  // every finished query's entry was written by this call

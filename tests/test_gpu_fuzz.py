@@ -185,7 +185,9 @@ def test_fuzz_round4_search_paths(oracle, seed, monkeypatch):
     tune = ",".join([f"nn_cert={int(rng.choice([0, 1, 2, 2]))}", f"nn_cert_step_mm={int(rng.choice([1, 50, 100000]))}",
                      f"tile_cand_cap={int(rng.choice([6144, 600, 100]))}", f"tile_brick_budget={int(rng.choice([512, 8, 1]))}",
                      f"hard_cand={int(rng.choice([1700, 50, 0]))}", f"tile_bricks={int(rng.choice([1, 1, 0]))}",
-                     f"empty_room={int(rng.choice([1, 1, 0]))}", f"coop_max={int(rng.choice([4, 0]))}"])
+                     f"empty_room={int(rng.choice([1, 1, 0]))}", f"coop_max={int(rng.choice([4, 0]))}",
+                     # round 5 (drawn after the clouds and the threshold: those are the ones of round 4's campaign)
+                     f"tile_select={int(rng.choice([1, 1, 1, 0]))}", f"nn_direct={int(rng.choice([1, 1, 0]))}"])
     monkeypatch.setenv("MP2P_HIP_TUNE", tune)
     layer_kw = {}
     if rng.random() < 0.3:

@@ -408,7 +408,11 @@ def test_max_local_points_visit_order(amd, oracle, K):
 
 
 @pytest.mark.parametrize("tune", ["pipelines=2", "mfma_scan=0", "tile_waves=5", "dir_budget_mb=0,claim_dedup=0,claim_peek=0", "nn_cert=2",
-                                  "nn_cert=0,tile_bricks=0,hard_cand=0,empty_room=0", "nn_cert=2,pipelines=2,tile_cand_cap=2000"])
+                                  "nn_cert=0,tile_bricks=0,hard_cand=0,empty_room=0", "nn_cert=2,pipelines=2,tile_cand_cap=2000",
+                                  # round 5: the round-4 kernels (box rule, lane kernel + pending list), the selection behind the lane
+                                  # kernel, the fused prologue on two pipelines, tiny budgets on the new path
+                                  "tile_select=0", "nn_direct=0", "nn_direct=0,nn_cert=2,hard_cand=50", "pipelines=2,nn_cert=2",
+                                  "tile_cand_cap=300,coop_max=0", "nn_direct=0,pipelines=2,tile_cand_cap=500"])
 def test_tune_knobs_do_not_change_the_lists(amd, oracle, tune, monkeypatch):
     """MP2P_HIP_TUNE is read once per context: every setting is a measurement aid that must compute the
     same lists (two search pipelines on two streams, exact scan instead of the matrix-pipe prefilter, another

@@ -87,6 +87,7 @@ static void parse_tune(Tune& t, const char* e = nullptr)
             else if (k == "tile_select") t.tile_select = (int)v;
             else if (k == "nn_direct") t.nn_direct = (int)v;
             else if (k == "tile_sol") t.tile_sol = (int)v;
+            else if (k == "grp_all_bricks") t.grp_all_bricks = (uint32_t)v;
             else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
         }
         i = j + 1;

@@ -127,6 +127,7 @@ struct NNArgs
     uint32_t             list_cap;
     float                r_hard;
     int                  xcd_map;
+    float                grp_all_bricks;  // nn_seltile_kernel: all pending queries of a tile form one pass while their common box is at most this many bricks wide
     int                  direct;   // nn_seltile_kernel: tile t serves the queries 32 t .. of the layer itself (no lane kernel, no pending list)
     const uint32_t*      rank;  // visit rank per original local index (NONE = not visited) or null
     int                  use_hint;
@@ -1659,7 +1660,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     // DIRECT: the per-query prologue runs in the tile itself (no lane kernel, no pending list)
     const bool sel    = ctx->tune.tile_select && Q == 32 && ctx->tune.mfma_scan && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE;
     const bool direct = sel && ctx->tune.nn_direct;
-    const int  sol    = direct ? ctx->tune.tile_sol : 0;  // speed-of-light decomposition (timing only: no results, no state)
+    const int  sol    = (direct && ctx->tune.tile_sol >= 1 && ctx->tune.tile_sol <= 5) ? ctx->tune.tile_sol : 0;  // speed-of-light decomposition (timing only: no results, no state)
     const uint32_t n_boxes = direct ? (uint32_t)((n_l + 31) / 32) : n_waves;  // per-tile / per-wave bounding boxes
     MP2P_TRY_HIP(ctx, ctx->nn_rec.ensure(n_l));
     MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)std::max(n_boxes, 1u) * 6));
@@ -1703,12 +1704,12 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.r_defer = prm->defer_radius_cells > 0 ? cell0 * prm->defer_radius_cells
                                              : fminf(fmaxf(1.0f, 2.0f * cell0), 4.0f * cell0);
     a.lane_cells    = std::min<uint32_t>(ctx->tune.lane_cells, 4u);
-    a.tile_cand_cap = ctx->tune.tile_cand_cap;
-    a.tile_cand_cap_easy = (ctx->tune.hard_cand && ctx->tune.tile_cand_cap_easy) ? ctx->tune.tile_cand_cap_easy : ctx->tune.tile_cand_cap;
+    a.tile_cand_cap = ctx->tune.tile_cand_cap ? ctx->tune.tile_cand_cap : (sel ? 24576u : 6144u);
+    a.tile_cand_cap_easy = (ctx->tune.hard_cand && ctx->tune.tile_cand_cap_easy) ? ctx->tune.tile_cand_cap_easy : a.tile_cand_cap;
     a.tile_bricks       = (ctx->tune.tile_bricks && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE) ? 1 : 0;
     a.tile_brick_budget = ctx->tune.tile_brick_budget;
     a.hard_cand         = ctx->tune.hard_cand;
-    a.coop_max          = ctx->tune.coop_max;
+    a.coop_max          = ctx->tune.coop_max != 0xFFFFFFFFu ? ctx->tune.coop_max : (sel ? 0u : 4u);
     a.empty_room        = ctx->tune.empty_room;
     a.claim_dedup   = ctx->tune.claim_dedup;
     a.claim_peek    = ctx->tune.claim_peek;
@@ -1734,6 +1735,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.r_hard   = cell0 * 0.01f * (float)ctx->tune.hard_radius_pct;
     a.xcd_map  = ctx->tune.xcd_map;
     a.direct   = direct ? 1 : 0;
+    a.grp_all_bricks = (float)ctx->tune.grp_all_bricks;
     // worst case for each class: every query in it (DIRECT: one class, every tile a fixed slice of the layer)
     const uint32_t n_tiles = (direct ? 1u : 2u) * ((n_seg + 7u) / 8u) * 8u * a.tiles_per_seg;
     ctx->last_n_tiles = n_tiles;
@@ -1856,6 +1858,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
             {
                 if (sol == 1) MP2P_LAUNCH_SEL(false, false, true, 1);
                 else if (sol == 2) MP2P_LAUNCH_SEL(false, false, true, 2);
+                else if (sol == 3) MP2P_LAUNCH_SEL(false, false, true, 3);
+                else if (sol == 4) MP2P_LAUNCH_SEL(false, false, true, 4);
+                else if (sol == 5) MP2P_LAUNCH_SEL(false, false, true, 5);
                 else if (instr) { if (direct) MP2P_LAUNCH_SEL(true, false, true, 0); else MP2P_LAUNCH_SEL(true, false, false, 0); }
                 else if (cert_track) { if (direct) MP2P_LAUNCH_SEL(false, true, true, 0); else MP2P_LAUNCH_SEL(false, true, false, 0); }
                 else { if (direct) MP2P_LAUNCH_SEL(false, false, true, 0); else MP2P_LAUNCH_SEL(false, false, false, 0); }

@@ -87,8 +87,9 @@ __device__ __forceinline__ void query_prologue(const NNArgs& a, const GridView& 
     }
 }
 
-// SOL (speed-of-light decomposition, profiles/r05_tile_sol.txt; results are NOT valid): 1 = list + select + resolve + stage
-// only, 2 = + the matrix-pipe prefilter and its min-tree, no recomputation; 0 = the product
+// SOL (speed-of-light decomposition, profiles/r05_tile_sol.txt; results are NOT valid, nothing is written): the kernel cut after
+// 3 = the prologue, 4 = + pass set-up and the voxel list, 5 = + selection and directory look-up, 1 = + staging,
+// 2 = + the matrix-pipe prefilter and its min-tree (no recomputation); 0 = the product
 template <bool INSTR, bool CERT, bool DIRECT, int WAVES, int SOL = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void nn_seltile_kernel(const NNArgs a)
 {
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
     }
 
+    if (SOL == 3) done = true;
     uint32_t        st_pass = 0, st_cells = 0, st_cand = 0, st_defer = 0, st_listed = 0, st_needed = 0;
     const long long t_start = INSTR ? (long long)wall_clock64() : 0;
     constexpr bool  track = CERT;
@@ -211,11 +213,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         const unsigned long long pend = __ballot(!done);
         if (pend == 0ull) break;
         // ---- the GROUP this pass serves: the pending queries near the first pending one, of comparable radius ----------
-        const int   seed = __ffsll((long long)pend) - 1;
-        const float sx = readlane_f(qx, seed), sy = readlane_f(qy, seed), sz = readlane_f(qz, seed);
-        const float sr = readlane_f(r, seed);
-        const float G  = a.grp_factor * sr;
-        const bool  grp = !done && fabsf(qx - sx) <= G && fabsf(qy - sy) <= G && fabsf(qz - sz) <= G && r <= 2.0f * sr;
+        // (round 5: what a pass stages no longer depends on the group's box -- every voxel is tested against every query's own
+        //  ball -- so ALL pending queries form one group as long as their common box is a few bricks wide: a pass per radius
+        //  class re-lists and re-stages the same neighbourhood; only a box too wide to list cheaply is cut by the old rule)
+        bool  grp = !done;
+        // box = union of the group's cubes
+        float lox = wave_min_nn(grp ? qx - r : INFINITY), loy = wave_min_nn(grp ? qy - r : INFINITY), loz = wave_min_nn(grp ? qz - r : INFINITY);
+        float hix = wave_max_nn(grp ? qx + r : -INFINITY), hiy = wave_max_nn(grp ? qy + r : -INFINITY), hiz = wave_max_nn(grp ? qz + r : -INFINITY);
+        {
+            const float wide = a.grp_all_bricks * 4.f * hs;  // (edge of the box in bricks, about)
+            if (hix - lox > wide || hiy - loy > wide || hiz - loz > wide)
+            {
+                const int   seed = __ffsll((long long)pend) - 1;
+                const float sx = readlane_f(qx, seed), sy = readlane_f(qy, seed), sz = readlane_f(qz, seed);
+                const float sr = readlane_f(r, seed);
+                const float G  = a.grp_factor * sr;
+                grp = !done && fabsf(qx - sx) <= G && fabsf(qy - sy) <= G && fabsf(qz - sz) <= G && r <= 2.0f * sr;
+                lox = wave_min_nn(grp ? qx - r : INFINITY), loy = wave_min_nn(grp ? qy - r : INFINITY), loz = wave_min_nn(grp ? qz - r : INFINITY);
+                hix = wave_max_nn(grp ? qx + r : -INFINITY), hiy = wave_max_nn(grp ? qy + r : -INFINITY), hiz = wave_max_nn(grp ? qz + r : -INFINITY);
+            }
+        }
         const unsigned long long gmask = __ballot(grp);
         if (__popcll(gmask) <= (int)a.coop_max * 2)
         {  // a few isolated queries: the one-query kernel
@@ -227,9 +244,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         st_cand += NN_PASS_COST;
         if (track) t1 = t2 = 0x7FFFFFFF;
 
-        // ---- box = union of the group's cubes, clipped to the layer; level-0 voxels and their 4x4x4 bricks ---------------
-        float lox = wave_min_nn(grp ? qx - r : INFINITY), loy = wave_min_nn(grp ? qy - r : INFINITY), loz = wave_min_nn(grp ? qz - r : INFINITY);
-        float hix = wave_max_nn(grp ? qx + r : -INFINITY), hiy = wave_max_nn(grp ? qy + r : -INFINITY), hiz = wave_max_nn(grp ? qz + r : -INFINITY);
+        // ---- the box clipped to the layer; level-0 voxels and their 4x4x4 bricks ---------------
         const float rmin_t = wave_min_pos(grp ? r : INFINITY);
         const float rmax_t = wave_max_pos(grp ? r : 0.f);
         const float qlx = lox + rmin_t, qly = loy + rmin_t, qlz = loz + rmin_t;  // conservative box of the group's queries
@@ -446,22 +461,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             st_cells += min(64u, nb - ob * 64u);
             for (uint32_t r0 = 0; r0 < vtotal && !over; r0 += (uint32_t)NN_TVLIST)
             {
+                // the set bits of the lanes' words -> list entries (10 bits per axis relative to the box corner; as ONE integer sum:
+                // a brick may start before the corner, the listed voxels never do).  Few non-empty bricks (the normal pass: ~5):
+                // a wave-uniform loop over them, lane j = voxel j of the brick, its place from the bits below (v_mbcnt) -- ~25
+                // instructions per brick; the per-lane bit loop costs ~20 per iteration and runs as long as the fullest brick
+                unsigned long long nz = __ballot(bcnt != 0u);
+                const int          pb = bvx + bvy * 1024 + bvz * 1048576;
+                if (__popcll(nz) <= 24)
+                {
+                    const int      lj   = (lane & 3) + ((lane >> 2) & 3) * 1024 + (lane >> 4) * 1048576;
+                    const uint32_t blo  = (uint32_t)bm, bhi = (uint32_t)(bm >> 32), bbase = bincl - bcnt;
+                    while (nz)
+                    {
+                        const int b = __ffsll((long long)nz) - 1;
+                        nz &= nz - 1ull;
+                        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)blo, b), whi = (uint32_t)__builtin_amdgcn_readlane((int)bhi, b);
+                        const uint32_t rank = (uint32_t)__builtin_amdgcn_readlane((int)bbase, b) + __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
+                        const bool     has  = (((hi ? whi : wlo) >> (lane & 31)) & 1u) != 0u;
+                        if (has && rank >= r0 && rank < r0 + NN_TVLIST) s_vox[rank - r0] = (uint32_t)(__builtin_amdgcn_readlane(pb, b) + lj);
+                    }
+                }
+                else
                 {
                     uint32_t           rank = bincl - bcnt;
                     unsigned long long mm   = bm;
                     while (mm)
                     {
-                        const uint32_t bit = (uint32_t)__ffsll((long long)mm) - 1u;
+                        const int bit = __ffsll((long long)mm) - 1;
                         mm &= mm - 1ull;
-                        if (rank >= r0 && rank < r0 + NN_TVLIST)
-                            s_vox[rank - r0] = (uint32_t)(bvz + (int)(bit >> 4)) << 20 | (uint32_t)(bvy + (int)((bit >> 2) & 3u)) << 10 |
-                                               (uint32_t)(bvx + (int)(bit & 3u));
+                        if (rank >= r0 && rank < r0 + NN_TVLIST) s_vox[rank - r0] = (uint32_t)(pb + (bit & 3) + ((bit >> 2) & 3) * 1024 + (bit >> 4) * 1048576);
                         rank++;
                     }
                 }
                 __syncthreads();
                 const uint32_t nv = min((uint32_t)NN_TVLIST, vtotal - r0);
                 st_listed += nv;
+                if (SOL == 4)
+                {
+                    st_cand += s_vox[lane] & 1u;
+                    __syncthreads();
+                    continue;
+                }
                 // ---- selection: 32 listed voxels (columns) x the tile's 32 queries (rows) per three MFMAs ----------------------
                 uint32_t nsel = 0;
                 for (uint32_t vb = 0; vb < nv; vb += 32u)
@@ -506,6 +546,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         uint32_t       e  = 0;
                         if (voxel_range(g, 0u, cx0 + (pk & 1023u), cy0 + ((pk >> 10) & 1023u), cz0 + (pk >> 20), start, e, true)) cnt = e - start;
                         else start = 0;
+                    }
+                    if (SOL == 5)
+                    {
+                        st_cand += (cnt + start) & 1u;
+                        continue;
                     }
                     batch(start, cnt);
                 }
@@ -554,14 +599,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         }
     }
 
+    // ---- a query with NOTHING within reach (an outlier of the local layer): is the cube of half-edge 2 r_max (else 1.5 r_max)
+    //      around it empty?  Then that is its bound and the warm start skips it until it has moved by the difference
+    //      (nn_single_kernel has the reasoning; isolated queries used to be handed to that kernel, with the selection they stay).
+    //      The whole wave serves one such query at a time: a handful of coarse occupancy bits each.
+    float lb2_room = -1.f;
+    if (SOL == 0 && a.empty_room)
+    {
+        unsigned long long em = __ballot(valid && slice == 0 && !deferred && active && !pro_done && best_idx == NONE_U32);
+        while (em)
+        {
+            const int l = __ffsll((long long)em) - 1;
+            em &= em - 1ull;
+            const float b = empty_room_bound(g, lane, readlane_f(qx, l), readlane_f(qy, l), readlane_f(qz, l), readlane_f(rmax, l));
+            if (lane == l) lb2_room = b;
+        }
+    }
     // ---- output (Morton order of the local layer) + claim of the global point -----------------
     if (SOL == 0)
     {
         emit_wave(a, s_claim, lane, valid && slice == 0 && !deferred, qi, orig, active, thr, best_d2, best_idx, best_spos,
-                  (pro_done && lb2_out >= 0.f) ? lb2_out : fminf(best_d2, thr), st_cand);
+                  (pro_done && lb2_out >= 0.f) ? lb2_out : (lb2_room >= 0.f ? lb2_room : fminf(best_d2, thr)), st_cand);
         if (a.lb2nd && valid && slice == 0 && !deferred) a.lb2nd[qi] = pro_done ? lb2nd_out : (track ? lbq : 0.f);
     }
-    else if (best_d2 == -1.f && lane == 0) a.rec[0].x = best_idx;  // (never true: keeps the timing-only build's search alive)
+    else if ((best_d2 == -1.f || st_cand == 0xFFFFFFFFu) && lane == 0) a.rec[0].x = best_idx + st_listed + st_needed;  // (never true: keeps the timing-only build's work alive)
 
     if (a.timeline && lane == 0) a.timeline[2 * (size_t)tile] = tl0, a.timeline[2 * (size_t)tile + 1] = wall_clock64();
     if (INSTR && lane == 0)

@@ -61,11 +61,12 @@ def main():
             row["listed_last"], row["needed_last"], row["tiles_last"] = st["nn_sel_voxels_listed"], st["nn_sel_voxels_needed"], st["nn_tiles"]
             res.append(row)
             print("[ab] " + json.dumps(row), file=sys.stderr, flush=True)
-            if a.sol and "tile_select=0" not in knobs and "nn_direct=0" not in knobs:
+            if a.sol and "tile_select=0" not in knobs:
+                rig.ctx.set_tune("nn_direct=1")  # (the timing-only variants exist for the fused-prologue build)
                 # same poses, same warm start: full step k-1 (sets the warm start), then SOL launches and the full launch at pose k
                 from mp2p_icp_amd import core
                 rig.restart()
-                sol = {0: [], 1: [], 2: []}
+                sol = {0: [], 1: [], 2: [], 3: [], 4: [], 5: []}
                 poses = []
                 st_ = rig.state
                 for _ in range(12):
@@ -76,14 +77,18 @@ def main():
                 for k in range(1, 10):
                     rig.ctx.set_tune("tile_sol=0")
                     rig.reg.match(poses[k - 1])
-                    for m in (1, 2, 0):
+                    for m in (3, 4, 5, 1, 2, 0):
                         rig.ctx.set_tune(f"tile_sol={m}")
                         rig.reg.match(poses[k])
                         s = rig.ctx.stats()
                         sol[m].append(s["ms_nn_tile"])
                 rig.ctx.set_profiling(0)
                 rig.ctx.set_tune("tile_sol=0")
-                row["sol_ms"] = {"list_select_stage": float(np.mean(sol[1])), "plus_prefilter": float(np.mean(sol[2])), "full": float(np.mean(sol[0]))}
+                row["sol_ms"] = {"prologue": float(np.mean(sol[3])), "plus_list": float(np.mean(sol[4])), "plus_select_resolve": float(np.mean(sol[5])),
+                                 "plus_stage": float(np.mean(sol[1])), "plus_prefilter": float(np.mean(sol[2])), "full": float(np.mean(sol[0]))}
+                rig.ctx.set_tune("nn_direct=0")
+                if knobs:
+                    rig.ctx.set_tune(knobs)
                 print("[ab] SOL " + json.dumps(row["sol_ms"]), file=sys.stderr, flush=True)
         del rig
     json.dump(res, open(a.out, "w"), indent=1)

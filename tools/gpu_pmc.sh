@@ -11,6 +11,7 @@ pass() { ( cd /tmp && timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-for
 for step in "$@"; do
   case $step in
     timeline) timeout 300 python tools/timeline_probe.py > $O/timeline.json 2> $O/timeline.err; echo "timeline rc=$?"; cat $O/timeline.json;;
+    sq1) pass p1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY";;
     sq) pass p1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY"
         pass p2 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_WAIT_INST_LDS"
         pass p3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_WAVES_EQ_64";;
@@ -26,7 +27,7 @@ for d in ("p1","p2","p3","m1","m2","m3"):
     if not fs: continue
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for r in csv.DictReader(open(fs[-1])):
-        k = r["Kernel_Name"][:44]
+        k = r["Kernel_Name"][:${KLEN:-44}]
         if "$filt" not in k or "reset" in k: continue
         a = acc[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
     for k, v in acc.items():

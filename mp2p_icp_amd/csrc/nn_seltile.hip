@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // one class in DIRECT mode (every tile is a fixed slice of the layer), two (hard first) behind the lane kernel
     const uint32_t segs8          = (a.n_seg + 7u) / 8u;
     const uint32_t tiles_per_list = segs8 * 8u * a.tiles_per_seg;
-    const uint32_t cls            = (!DIRECT && tile >= tiles_per_list) ? 1u : 0u;
+    const uint32_t cls            = (!DIRECT && tile >= tiles_per_list) ? 1u : 0u;  // 0 = hard (first), 1 = easy
     const uint32_t tl             = tile - cls * tiles_per_list;
     uint32_t       seg, tk;
     if (a.xcd_map)
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 
     uint32_t qi = 0, orig = 0, best_idx = NONE_U32, best_spos = NONE_U32;
     float    qx = 0.f, qy = 0.f, qz = 0.f, thr = 0.f, rmax = 0.f, r = 0.f, best_d2 = INFINITY;
-    bool     active = valid, done = !valid;
+    bool     active = true, done = false;
     float    lb2_out = -1.f, lb2nd_out = 0.f;  // (DIRECT) bounds of a query the prologue finished without a search
     if (DIRECT)
     {
@@ -180,9 +180,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         rmax = sqrtf(thr) * 1.002f + g.slack;
         r    = valid ? __uint_as_float(w.y) : 0.f;
         best_d2 = __uint_as_float(w.z), best_idx = w.w, best_spos = wq.w;
+        active = valid, done = !valid;
     }
     const bool pro_done = DIRECT && valid && done;  // finished (or inactive) before any search
     bool       deferred = false;
+    // bounding box of the tile's pending queries, once per tile: a pass's box is this box grown by its widest radius (the
+    // queries do not move between passes; the six wave reductions per pass were a tenth of the pass's instructions)
+    const float tqx0 = wave_min_nn(!done ? qx : INFINITY), tqy0 = wave_min_nn(!done ? qy : INFINITY), tqz0 = wave_min_nn(!done ? qz : INFINITY);
+    const float tqx1 = wave_max_nn(!done ? qx : -INFINITY), tqy1 = wave_max_nn(!done ? qy : -INFINITY), tqz1 = wave_max_nn(!done ? qz : -INFINITY);
 
     // a query with no candidate at all and a radius beyond what a tile should carry: the one-query kernel's
     // nearest-voxel-first order finds a bound cheaply
@@ -217,22 +222,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         //  ball -- so ALL pending queries form one group as long as their common box is a few bricks wide: a pass per radius
         //  class re-lists and re-stages the same neighbourhood; only a box too wide to list cheaply is cut by the old rule)
         bool  grp = !done;
-        // box = union of the group's cubes
-        float lox = wave_min_nn(grp ? qx - r : INFINITY), loy = wave_min_nn(grp ? qy - r : INFINITY), loz = wave_min_nn(grp ? qz - r : INFINITY);
-        float hix = wave_max_nn(grp ? qx + r : -INFINITY), hiy = wave_max_nn(grp ? qy + r : -INFINITY), hiz = wave_max_nn(grp ? qz + r : -INFINITY);
+        float rmax_t = wave_max_pos(grp ? r : 0.f);
+        // box of the group's queries, and the box their balls reach (= the queries' box grown by the widest radius)
+        float qlx = tqx0, qly = tqy0, qlz = tqz0, qhx = tqx1, qhy = tqy1, qhz = tqz1;
         {
             const float wide = a.grp_all_bricks * 4.f * hs;  // (edge of the box in bricks, about)
-            if (hix - lox > wide || hiy - loy > wide || hiz - loz > wide)
+            const float w2   = 2.f * rmax_t;
+            if (qhx - qlx + w2 > wide || qhy - qly + w2 > wide || qhz - qlz + w2 > wide)
             {
+
                 const int   seed = __ffsll((long long)pend) - 1;
                 const float sx = readlane_f(qx, seed), sy = readlane_f(qy, seed), sz = readlane_f(qz, seed);
                 const float sr = readlane_f(r, seed);
                 const float G  = a.grp_factor * sr;
                 grp = !done && fabsf(qx - sx) <= G && fabsf(qy - sy) <= G && fabsf(qz - sz) <= G && r <= 2.0f * sr;
-                lox = wave_min_nn(grp ? qx - r : INFINITY), loy = wave_min_nn(grp ? qy - r : INFINITY), loz = wave_min_nn(grp ? qz - r : INFINITY);
-                hix = wave_max_nn(grp ? qx + r : -INFINITY), hiy = wave_max_nn(grp ? qy + r : -INFINITY), hiz = wave_max_nn(grp ? qz + r : -INFINITY);
+                rmax_t = wave_max_pos(grp ? r : 0.f);
+                qlx = wave_min_nn(grp ? qx : INFINITY), qly = wave_min_nn(grp ? qy : INFINITY), qlz = wave_min_nn(grp ? qz : INFINITY);
+                qhx = wave_max_nn(grp ? qx : -INFINITY), qhy = wave_max_nn(grp ? qy : -INFINITY), qhz = wave_max_nn(grp ? qz : -INFINITY);
             }
         }
+        const float lox = qlx - rmax_t, loy = qly - rmax_t, loz = qlz - rmax_t, hix = qhx + rmax_t, hiy = qhy + rmax_t, hiz = qhz + rmax_t;
         const unsigned long long gmask = __ballot(grp);
         if (__popcll(gmask) <= (int)a.coop_max * 2)
         {  // a few isolated queries: the one-query kernel
@@ -245,10 +254,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         if (track) t1 = t2 = 0x7FFFFFFF;
 
         // ---- the box clipped to the layer; level-0 voxels and their 4x4x4 bricks ---------------
-        const float rmin_t = wave_min_pos(grp ? r : INFINITY);
-        const float rmax_t = wave_max_pos(grp ? r : 0.f);
-        const float qlx = lox + rmin_t, qly = loy + rmin_t, qlz = loz + rmin_t;  // conservative box of the group's queries
-        const float qhx = hix - rmin_t, qhy = hiy - rmin_t, qhz = hiz - rmin_t;
         const float prune  = rmax_t + 4.f * g.slack;
         const float prune2 = prune * prune;
         const float ocx = 0.5f * (lox + hix), ocy = 0.5f * (loy + hiy), ocz = 0.5f * (loz + hiz);
@@ -256,14 +261,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         const float hx = 0.5f * (hix - lox) + hs, hy = 0.5f * (hiy - loy) + hs, hz = 0.5f * (hiz - loz) + hs;
         const float mtol = (hx * hx + hy * hy + hz * hz) * (1.0f / 32768.0f);
         const float cqx = qx - ocx, cqy = qy - ocy, cqz = qz - ocz;
+        // ---- K = 4: TWO v_mfma_f32_32x32x2_f32 per block instead of round 4's three (the matrix pipe is the prefilter's floor:
+        //      64 cycles per instruction and SIMD).  The term |q'|^2 is constant per column (= per lane) and moves into the lane's
+        //      limit; so that the integer min-tree still sees non-negative values the candidate side carries the offset
+        //      beta = hx^2 + hy^2 + hz^2 >= |q'|^2 (group members lie in the box):
+        //        T = [c'x c'y | c'z  |c'|^2 + beta] . [-2q'x -2q'y | -2q'z  1] = d2 - |q'|^2 + beta >= 0,   tested against lim - |q'|^2 + beta
+        //      (a lane outside the group may see negative values: it only collects upper bounds, and a missed one costs nothing but
+        //       a later update).  Every term is still bounded by 4 (hx^2 + hy^2 + hz^2): the error bound mtol stands.
+        const float beta = hx * hx + hy * hy + hz * hz;
+        const float qn2  = cqx * cqx + cqy * cqy + cqz * cqz;
         const float b0 = -2.0f * (hi ? cqy : cqx);
         const float b1 = hi ? 1.0f : -2.0f * cqz;
-        const float b2 = hi ? 0.0f : (cqx * cqx + cqy * cqy + cqz * cqz);
-        const float o0 = hi ? ocy : ocx, o1 = hi ? 0.0f : ocz;
-        // selection: row m = query: [-2q'x -2q'y | -2q'z 1 | |q'|^2 - R^2  0], R = r + rho (+ slack); a lane outside the group never needs a voxel
+        const float o0 = hi ? ocy : ocx, o1 = hi ? -beta : ocz;  // (hi lanes read |c'|^2 and ADD beta: s_n - (-beta))
+        const float loff = beta - qn2;                           // lane's limit in the shifted scale: lim + loff
+        // selection (rows = queries, columns = voxels): [-2q'x -2q'y | -2q'z  |q'|^2 - R^2 + 4 beta] . [c'x c'y | c'z 1] >= 0 for group
+        // members (|2 q'.c'| <= 2 beta, R^2 <= beta), tested per column against tol - |c'|^2 + 4 beta; R = r + rho (+ slack);
+        // a lane outside the group never needs a voxel
         const float Rq   = r + rho + 4.f * g.slack;
-        const float sel2 = hi ? 0.0f : (grp ? b2 - Rq * Rq : 1e30f);
-        const float stol = 2.0f * mtol + 1e-12f;
+        const float sel1 = hi ? (grp ? qn2 - Rq * Rq + 4.f * beta : 1e30f) : -2.0f * cqz;
+        const float stol = 4.0f * mtol + 1e-12f;
         // clipped box in level-0 voxels
         uint32_t cx0 = 0, cy0 = 0, cz0 = 0, cx1 = 0, cy1 = 0, cz1 = 0, nbx = 0, nby = 0, nb = 0;
         {
@@ -369,8 +385,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     const float* s_n  = reinterpret_cast<const float*>(s_owner);
                     const float* s_a0 = hi ? s_y : s_x;
                     const float* s_a1 = hi ? s_n : s_z;
-                    const float  a2   = hi ? 0.0f : 1.0f;
-                    float        lim  = best_d2 * 1.000001f + mtol;
+                    float        lim  = best_d2 * 1.000001f + mtol + loff;
                     for (uint32_t blk = 0; blk < m_pad; blk += 32u)
                     {
                         const uint32_t c   = blk + ((uint32_t)lane & 31u);
@@ -378,7 +393,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         f32x16         acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b0, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
                         int g4[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++)
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                                                     best_d2   = dd;
                                                     best_idx  = ci;
                                                     best_spos = s_spos[j];
-                                                    lim       = best_d2 * 1.000001f + mtol;
+                                                    lim       = best_d2 * 1.000001f + mtol + loff;
                                                 }
                                             }
                                         }
@@ -430,72 +444,71 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             }
         };
 
-        // ---- rounds of 64 bricks (lane = brick) -> occupied voxels listed in LDS -> SELECTED on the matrix pipe -> resolved -> staged ----
-        const uint32_t n_outer = (nb + 63u) / 64u;
-        for (uint32_t ob = 0; ob < n_outer && !over; ob++)
-        {
-            unsigned long long bm = 0ull;
-            int                bvx = 0, bvy = 0, bvz = 0;  // first voxel of the lane's brick, relative to (cx0, cy0, cz0)
+        // ---- bricks of the box (lane = brick) -> occupied voxels listed in LDS -> SELECTED on the matrix pipe -> resolved -> staged ----
+        // the masked occupancy word of one level-0 brick (0 when it is beyond the layer or farther from the group's queries than their
+        // widest radius) and its first voxel relative to (cx0, cy0, cz0), packed 10 bits per axis as one integer sum
+        auto brick_word = [&](bool ok, uint32_t Bx, uint32_t By, uint32_t Bz, unsigned long long& bm, int& pb) __attribute__((always_inline)) {
+            bm = 0ull;
+            pb = ((int)(Bx * 4u) - (int)cx0) + ((int)(By * 4u) - (int)cy0) * 1024 + ((int)(Bz * 4u) - (int)cz0) * 1048576;
+            if (!ok) return;
+            const float h4 = 4.f * hs;
+            const float x0 = g.ox + (float)(Bx * 4u) * hs, y0 = g.oy + (float)(By * 4u) * hs, z0 = g.oz + (float)(Bz * 4u) * hs;
+            const float dx = fmaxf(0.f, fmaxf(x0 - qhx, qlx - (x0 + h4)));
+            const float dy = fmaxf(0.f, fmaxf(y0 - qhy, qly - (y0 + h4)));
+            const float dz = fmaxf(0.f, fmaxf(z0 - qhz, qlz - (z0 + h4)));
+            if (dx * dx + dy * dy + dz * dz <= prune2 && Bx < obx && By < oby && Bz < obz)
             {
-                const uint32_t id = ob * 64u + (uint32_t)lane;
-                if (id < nb)
+                const unsigned long long word = occ0[((size_t)Bz * oby + By) * obx + Bx];
+                bm = word & spread_x(axis_mask(Bx, cx0, cx1)) & spread_y(axis_mask(By, cy0, cy1)) & spread_z(axis_mask(Bz, cz0, cz1));
+            }
+        };
+        // the set bits of the lanes' words -> list entries base + (x, y, z of the bit) in out[0 .. cap), those of rank r0 .. r0 + cap - 1.
+        // Few non-empty words (the normal pass: ~5): a wave-uniform loop over them, lane j = bit j, its place from the bits below
+        // (v_mbcnt) -- ~25 instructions per word; the per-lane bit loop costs ~20 per iteration and runs as long as the fullest word
+        auto list_bits = [&](unsigned long long bm, int pb, uint32_t bcnt, uint32_t bincl, uint32_t r0, uint32_t cap, uint32_t* out) __attribute__((always_inline)) {
+            unsigned long long nz = __ballot(bcnt != 0u);
+            if (__popcll(nz) <= 24)
+            {
+                const int      lj   = (lane & 3) + ((lane >> 2) & 3) * 1024 + (lane >> 4) * 1048576;
+                const uint32_t blo  = (uint32_t)bm, bhi = (uint32_t)(bm >> 32), bbase = bincl - bcnt;
+                // (only the words with entries in this round: a dense box is listed in several rounds, each walking all its words
+                //  made the listing quadratic -- 230 us for one tile)
+                nz &= __ballot(bbase < r0 + cap && bincl > r0);
+                while (nz)
                 {
-                    const uint32_t row = id / nbx, ix = id - row * nbx, iz = row / nby, iy = row - iz * nby;
-                    const uint32_t Bx = (cx0 >> 2) + ix, By = (cy0 >> 2) + iy, Bz = (cz0 >> 2) + iz;
-                    bvx = (int)(Bx * 4u) - (int)cx0, bvy = (int)(By * 4u) - (int)cy0, bvz = (int)(Bz * 4u) - (int)cz0;
-                    const float h4 = 4.f * hs;
-                    const float x0 = g.ox + (float)(Bx * 4u) * hs, y0 = g.oy + (float)(By * 4u) * hs, z0 = g.oz + (float)(Bz * 4u) * hs;
-                    const float dx = fmaxf(0.f, fmaxf(x0 - qhx, qlx - (x0 + h4)));
-                    const float dy = fmaxf(0.f, fmaxf(y0 - qhy, qly - (y0 + h4)));
-                    const float dz = fmaxf(0.f, fmaxf(z0 - qhz, qlz - (z0 + h4)));
-                    if (dx * dx + dy * dy + dz * dz <= prune2 && Bx < obx && By < oby && Bz < obz)
-                    {
-                        const unsigned long long word = occ0[((size_t)Bz * oby + By) * obx + Bx];
-                        bm = word & spread_x(axis_mask(Bx, cx0, cx1)) & spread_y(axis_mask(By, cy0, cy1)) & spread_z(axis_mask(Bz, cz0, cz1));
-                    }
+                    const int b = __ffsll((long long)nz) - 1;
+                    nz &= nz - 1ull;
+                    const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)blo, b), whi = (uint32_t)__builtin_amdgcn_readlane((int)bhi, b);
+                    const uint32_t rank = (uint32_t)__builtin_amdgcn_readlane((int)bbase, b) + __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
+                    const bool     has  = (((hi ? whi : wlo) >> (lane & 31)) & 1u) != 0u;
+                    if (has && rank >= r0 && rank < r0 + cap) out[rank - r0] = (uint32_t)(__builtin_amdgcn_readlane(pb, b) + lj);
                 }
             }
+            else
+            {
+                uint32_t           rank = bincl - bcnt;
+                unsigned long long mm   = (rank < r0 + cap && bincl > r0) ? bm : 0ull;
+                while (mm)
+                {
+                    const int bit = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1ull;
+                    if (rank >= r0 && rank < r0 + cap) out[rank - r0] = (uint32_t)(pb + (bit & 3) + ((bit >> 2) & 3) * 1024 + (bit >> 4) * 1048576);
+                    rank++;
+                }
+            }
+        };
+        // one round of <= 64 bricks (lane = brick: bm, pb): list, select, resolve, stage + scan
+        auto serve = [&](unsigned long long bm, int pb, uint32_t vcap) __attribute__((always_inline)) {
             const uint32_t bcnt   = (uint32_t)__popcll(bm);
             const uint32_t bincl  = wave_incl_scan(bcnt, lane);
             const uint32_t vtotal = (uint32_t)__builtin_amdgcn_readlane((int)bincl, 63);
-            st_cells += min(64u, nb - ob * 64u);
-            for (uint32_t r0 = 0; r0 < vtotal && !over; r0 += (uint32_t)NN_TVLIST)
+            if (INSTR || SOL != 0) st_cells += 64u;
+            for (uint32_t r0 = 0; r0 < vtotal && !over; r0 += vcap)
             {
-                // the set bits of the lanes' words -> list entries (10 bits per axis relative to the box corner; as ONE integer sum:
-                // a brick may start before the corner, the listed voxels never do).  Few non-empty bricks (the normal pass: ~5):
-                // a wave-uniform loop over them, lane j = voxel j of the brick, its place from the bits below (v_mbcnt) -- ~25
-                // instructions per brick; the per-lane bit loop costs ~20 per iteration and runs as long as the fullest brick
-                unsigned long long nz = __ballot(bcnt != 0u);
-                const int          pb = bvx + bvy * 1024 + bvz * 1048576;
-                if (__popcll(nz) <= 24)
-                {
-                    const int      lj   = (lane & 3) + ((lane >> 2) & 3) * 1024 + (lane >> 4) * 1048576;
-                    const uint32_t blo  = (uint32_t)bm, bhi = (uint32_t)(bm >> 32), bbase = bincl - bcnt;
-                    while (nz)
-                    {
-                        const int b = __ffsll((long long)nz) - 1;
-                        nz &= nz - 1ull;
-                        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)blo, b), whi = (uint32_t)__builtin_amdgcn_readlane((int)bhi, b);
-                        const uint32_t rank = (uint32_t)__builtin_amdgcn_readlane((int)bbase, b) + __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
-                        const bool     has  = (((hi ? whi : wlo) >> (lane & 31)) & 1u) != 0u;
-                        if (has && rank >= r0 && rank < r0 + NN_TVLIST) s_vox[rank - r0] = (uint32_t)(__builtin_amdgcn_readlane(pb, b) + lj);
-                    }
-                }
-                else
-                {
-                    uint32_t           rank = bincl - bcnt;
-                    unsigned long long mm   = bm;
-                    while (mm)
-                    {
-                        const int bit = __ffsll((long long)mm) - 1;
-                        mm &= mm - 1ull;
-                        if (rank >= r0 && rank < r0 + NN_TVLIST) s_vox[rank - r0] = (uint32_t)(pb + (bit & 3) + ((bit >> 2) & 3) * 1024 + (bit >> 4) * 1048576);
-                        rank++;
-                    }
-                }
+                list_bits(bm, pb, bcnt, bincl, r0, vcap, s_vox);
                 __syncthreads();
-                const uint32_t nv = min((uint32_t)NN_TVLIST, vtotal - r0);
-                st_listed += nv;
+                const uint32_t nv = min(vcap, vtotal - r0);
+                if (INSTR || SOL != 0) st_listed += nv;
                 if (SOL == 4)
                 {
                     st_cand += s_vox[lane] & 1u;
@@ -517,12 +530,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         ccz = (g.oz + ((float)(cz0 + (pk >> 20)) + 0.5f) * hs) - ocz;
                     }
                     const float v0 = hi ? ccy : ccx;
-                    const float v1 = hi ? (ccx * ccx + ccy * ccy + ccz * ccz) : ccz;
-                    const float v2 = hi ? 0.0f : 1.0f;
+                    const float v1 = hi ? 1.0f : ccz;
+                    const float vlim = stol - (ccx * ccx + ccy * ccy + ccz * ccz) + 4.f * beta;  // this column's limit
                     f32x16      acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, v0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, v1, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sel2, v2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sel1, v1, acc, 0, 0, 0);
                     int mni = min(min(__float_as_int(acc[0]), __float_as_int(acc[1])), min(__float_as_int(acc[2]), __float_as_int(acc[3])));
 #pragma unroll
                     for (int k = 1; k < 4; k++)
@@ -530,13 +542,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                                            min(__float_as_int(acc[4 * k + 2]), __float_as_int(acc[4 * k + 3]))));
                     // (a negative value is a negative integer: the minimum is then some value <= 0 <= stol; among the non-negative
                     //  ones the integer order is the float order)
-                    const unsigned long long nb64 = __ballot(vi < nv && __int_as_float(mni) <= stol);
+                    const unsigned long long nb64 = __ballot(vi < nv && __int_as_float(mni) <= vlim);
                     const uint32_t           m32  = (uint32_t)nb64 | (uint32_t)(nb64 >> 32);  // both halves hold the same voxel
                     if (!hi && ((m32 >> lane) & 1u)) s_vox[nsel + (uint32_t)__popc(m32 & ((1u << lane) - 1u))] = pk;  // (writes at or below vb + lane)
                     nsel += (uint32_t)__popc(m32);
                 }
                 __syncthreads();
-                st_needed += nsel;
+                if (INSTR || SOL != 0) st_needed += nsel;
                 for (uint32_t cb = 0; cb < nsel && !over; cb += 64u)
                 {
                     uint32_t cnt = 0, start = 0;
@@ -556,6 +568,78 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 }
                 __syncthreads();  // the list is rewritten by the next round
             }
+        };
+        // A box of more than one round of bricks (wide balls, or a spatially loose tile of far-field points: the box of 32 points
+        // 10 m apart holds 10^4 bricks, nearly all empty, and listing them 64 per round WAS such a tile: 150 us for 4 000
+        // candidates) is entered one level up: the level-2 occupancy word of 4x4x4 BRICKS says which of them hold anything; only
+        // those are visited.  (The lists share s_vox: voxels in its first half, bricks in the second, 256 each.)
+        const bool     two_stage = nb > 64u && g.n_levels > 2u && g.occ_off[2] != OCC_NONE;
+        const uint32_t vcap      = two_stage ? (uint32_t)NN_TVLIST / 2u : (uint32_t)NN_TVLIST;
+        uint32_t*      s_bl      = s_vox + NN_TVLIST / 2;  // listed bricks, relative to the box's first brick (10 bits per axis)
+        const uint32_t bx0 = cx0 >> 2, by0 = cy0 >> 2, bz0 = cz0 >> 2;
+        const float    inv_nbx = 1.0f / (float)max(nbx, 1u), inv_nby = 1.0f / (float)max(nby, 1u);
+        constexpr uint32_t CH = NN_TVLIST / 2;  // bricks per chunk
+        for (uint32_t chunk_lo = 0; !over; chunk_lo += CH)
+        {
+            uint32_t n_all = nb;  // bricks to visit in all
+            if (two_stage)
+            {
+                // phase A: the level-2 words of the box -> the occupied bricks of rank chunk_lo .. chunk_lo + CH - 1
+                const uint32_t bx1 = cx1 >> 2, by1 = cy1 >> 2, bz1 = cz1 >> 2;
+                const uint32_t nLx = (bx1 >> 2) - (bx0 >> 2) + 1u, nLy = (by1 >> 2) - (by0 >> 2) + 1u, nLz = (bz1 >> 2) - (bz0 >> 2) + 1u;
+                const uint32_t nL  = nLx * nLy * nLz;  // (<= nb: at most 32 768)
+                const float    inv_nLx = 1.0f / (float)nLx, inv_nLy = 1.0f / (float)nLy;
+                const unsigned long long* occ2 = g.occ + g.occ_off[2];
+                const uint32_t o2x = g.occ_bx[2], o2y = g.occ_by[2], o2z = g.occ_bz[2];
+                uint32_t T = 0;
+                for (uint32_t oL = 0; oL < nL; oL += 64u)
+                {
+                    const uint32_t id = oL + (uint32_t)lane;
+                    unsigned long long w2 = 0ull;
+                    int                pl = 0;
+                    if (id < nL)
+                    {
+                        const uint32_t row = (uint32_t)(((float)id + 0.5f) * inv_nLx), ix = id - row * nLx;
+                        const uint32_t iz  = (uint32_t)(((float)row + 0.5f) * inv_nLy), iy = row - iz * nLy;
+                        const uint32_t Lx = (bx0 >> 2) + ix, Ly = (by0 >> 2) + iy, Lz = (bz0 >> 2) + iz;
+                        pl = ((int)(Lx * 4u) - (int)bx0) + ((int)(Ly * 4u) - (int)by0) * 1024 + ((int)(Lz * 4u) - (int)bz0) * 1048576;
+                        if (Lx < o2x && Ly < o2y && Lz < o2z)
+                            w2 = occ2[((size_t)Lz * o2y + Ly) * o2x + Lx] & spread_x(axis_mask(Lx, bx0, bx1)) & spread_y(axis_mask(Ly, by0, by1)) &
+                                 spread_z(axis_mask(Lz, bz0, bz1));
+                    }
+                    const uint32_t c2 = (uint32_t)__popcll(w2), i2 = wave_incl_scan(c2, lane);
+                    list_bits(w2, pl, c2, i2 + T, chunk_lo, CH, s_bl);
+                    T += (uint32_t)__builtin_amdgcn_readlane((int)i2, 63);
+                }
+                __syncthreads();
+                n_all = T;
+            }
+            if (n_all <= chunk_lo) break;
+            const uint32_t n_in = min(CH, n_all - chunk_lo);
+            for (uint32_t b0 = 0; b0 < n_in && !over; b0 += 64u)
+            {
+                const bool ok = b0 + (uint32_t)lane < n_in;
+                uint32_t   Bx, By, Bz;
+                if (two_stage)
+                {
+                    const uint32_t pk = ok ? s_bl[b0 + (uint32_t)lane] : 0u;
+                    Bx = bx0 + (pk & 1023u), By = by0 + ((pk >> 10) & 1023u), Bz = bz0 + (pk >> 20);
+                }
+                else
+                {
+                    // (exact for nb <= 32 768: (c + 0.5) / n is at least 0.5 / n away from an integer; an integer division costs ~25 instructions)
+                    const uint32_t id  = chunk_lo + b0 + (uint32_t)lane;
+                    const uint32_t row = (uint32_t)(((float)id + 0.5f) * inv_nbx), ix = id - row * nbx;
+                    const uint32_t iz  = (uint32_t)(((float)row + 0.5f) * inv_nby), iy = row - iz * nby;
+                    Bx = bx0 + ix, By = by0 + iy, Bz = bz0 + iz;
+                }
+                unsigned long long bm;
+                int                pb;
+                brick_word(ok, Bx, By, Bz, bm, pb);
+                serve(bm, pb, vcap);
+            }
+            if (two_stage) __syncthreads();  // the brick list is rewritten by the next chunk
+            if (n_all <= chunk_lo + CH) break;
         }
 
         // ---- merge the two slices of each query slot ----------------------------------------
@@ -579,7 +663,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                 // every staged point but the nearest has S >= t2, hence d2 >= t2 - mtol; every point NOT staged lies outside
                 // the ball this pass covered
                 const float cover = r * (1.0f - 1.0f / 1024.0f) - g.slack;
-                const float s2    = t2 < 0 ? 0.f : (t2 == 0x7FFFFFFF ? INFINITY : fmaxf(__int_as_float(t2) - mtol, 0.f));
+                // (the prefilter's values are d2 - |q'|^2 + beta: back to d2, with the rounding of that offset inside the margin)
+                const float s2    = t2 < 0 ? 0.f : (t2 == 0x7FFFFFFF ? INFINITY : fmaxf(__int_as_float(t2) - loff - 1.5f * mtol, 0.f));
                 lbq = fmaxf(fminf(sqrtf(s2) * 0.99999f - g.slack, cover), 0.f);
             }
             if (fin) done = true;
@@ -624,7 +709,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     }
     else if ((best_d2 == -1.f || st_cand == 0xFFFFFFFFu) && lane == 0) a.rec[0].x = best_idx + st_listed + st_needed;  // (never true: keeps the timing-only build's work alive)
 
-    if (a.timeline && lane == 0) a.timeline[2 * (size_t)tile] = tl0, a.timeline[2 * (size_t)tile + 1] = wall_clock64();
+    // (profiling level 4: the spare high bits carry what the tile did -- staged candidates / 32, passes, rounds of 64 bricks)
+    if (a.timeline && lane == 0)
+        a.timeline[2 * (size_t)tile]     = (tl0 & 0xFFFFFFFFFFull) | ((unsigned long long)min(st_cand >> 5, 0xFFFFFFu) << 40),
+        a.timeline[2 * (size_t)tile + 1] = (wall_clock64() & 0xFFFFFFFFFFull) | ((unsigned long long)min(st_pass, 255u) << 40) |
+                                           ((unsigned long long)min(st_cells >> 6, 0xFFFFu) << 48);
     if (INSTR && lane == 0)
     {
         atomicAdd(&a.counters[0], 1ull);

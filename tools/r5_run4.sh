@@ -1,5 +1,5 @@
 #!/bin/bash
-out=gpurun_out/r5d; mkdir -p $out
+out=gpurun_out/r5e; mkdir -p $out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_matcher_pt2pt.py tests/test_gpu_fuzz.py tests/test_gpu_icp.py -x -q -m gpu > $out/pytest_pt2pt.log 2>&1
 echo "pt2pt rc=$?" | tee -a $out/rc.txt; tail -4 $out/pytest_pt2pt.log

@@ -61,6 +61,22 @@ for name, warm, pose in (("init", d["T_gt"], d["T_init"]), ("gt", d["T_init"], d
     tiles, singles = core.timeline(ctx)
     ctx.set_profiling(0)
     out = dict(pose=name, ms_nn=round(ms, 3))
+    raw = tiles.astype(np.uint64)
+    cand, npass, rounds = (raw[:, 0] >> np.uint64(40)).astype(np.int64) * 32, ((raw[:, 1] >> np.uint64(40)) & np.uint64(255)).astype(np.int64), (raw[:, 1] >> np.uint64(48)).astype(np.int64)
+    tiles = (raw & np.uint64(0xFFFFFFFFFF)).astype(np.int64)
+    tt = tiles
     out.update(profile(tiles, "tile_kernel"))
+    dur = (tt[:, 1] - tt[:, 0]) / 100.0
+    top = np.argsort(-dur)[:12]
+    t0_ = tt[tt[:, 1] > 0][:, 0].min()
+    out["longest_tiles"] = [dict(block=int(i), start_us=round(float(tt[i, 0] - t0_) / 100.0, 1), dur_us=round(float(dur[i]), 1), cand=int(cand[i]),
+                                 passes=int(npass[i]), brick_rounds=int(rounds[i])) for i in top]
+    ok = tt[:, 1] > 0
+    for name_, v in (("cand", cand), ("passes", npass), ("brick_rounds", rounds)):
+        out["corr_dur_" + name_] = round(float(np.corrcoef(dur[ok], v[ok])[0, 1]), 3)
+    out["tiles_by_passes"] = {int(k): [int((npass[ok] == k).sum()), round(float(dur[ok][npass[ok] == k].mean()), 1)] for k in np.unique(npass[ok])[:12]}
+    nz = tt[:2048][tt[:2048, 1] > 0]
+    out["first_2048_blocks"] = dict(n=int(len(nz)), dur_mean=round(float(((nz[:, 1] - nz[:, 0]) / 100.0).mean()), 1) if len(nz) else 0,
+                                   dur_max=round(float(((nz[:, 1] - nz[:, 0]) / 100.0).max()), 1) if len(nz) else 0)
     out.update(profile(singles, "single_kernel"))
     print(json.dumps(out), flush=True)

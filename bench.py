@@ -91,7 +91,9 @@ def cpu_baseline(d, threshold, gn_iters, kernel_param, sample, cores):
     tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
     t_build = time.time() - t0
 
-    def run(n_s, threads):
+    gate = []  # (pose, oracle pair list, oracle Gauss-Newton pose) of the whole layer: what the parity gate compares with
+
+    def run(n_s, threads, keep=False):
         ls = l[np.linspace(0, l.shape[0] - 1, n_s).astype(np.int64)]
         tm = ts = npairs = 0.0
         for pose in (d["T_init"], d["T_gt"]):
@@ -101,18 +103,23 @@ def cpu_baseline(d, threshold, gn_iters, kernel_param, sample, cores):
             tm += time.time() - t0
             prm = orc.make_gn_params(gn_iters, kernel=orc.KERNEL_GEMANMCCLURE, kernelParam=kernel_param)
             t0 = time.time()
-            orc.optimal_tf_gauss_newton(pairs, None, None, pose, prm, threads=threads)
+            T_new, *_ = orc.optimal_tf_gauss_newton(pairs, None, None, pose, prm, threads=threads)
             ts += time.time() - t0
             npairs += len(pairs)
+            if keep and n_s == l.shape[0]:
+                gate.append((np.array(pose), pairs, np.array(T_new)))
         scale = l.shape[0] / n_s
         t_iter = (tm + ts) / 2 * scale  # mean of the hard (initial) and easy (converged) pose
         return 1.0 / t_iter, npairs / 2 * scale / t_iter, tm / 2 * scale, ts / 2 * scale
 
     n_s = min(sample, l.shape[0])
-    v, pps, tm, ts = run(n_s, cores)
+    run(min(n_s, 50_000), cores)  # (untimed: starts the thread pool, touches the tree)
+    v, pps, tm, ts = run(n_s, cores, keep=True)
     n_1 = min(max(2000, sample // 10), l.shape[0])
     v1, pps1, tm1, ts1 = run(n_1, 0)  # threads=0: the sequential loop
     return {"value": v, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "_gate": gate,
+            "multi_thread_over_single_thread": v / v1,
             "sample": f"{n_s} of {l.shape[0]} local points (uniform subsample) vs the full "
                       f"{g.shape[0]}-point map; mean of initial-guess and converged pose; "
                       f"KD-tree build {t_build:.1f}s excluded (amortised per map)",
@@ -299,6 +306,33 @@ def converging_block(rig, args):
                     "bound) and a query whose previous neighbour is provably still the nearest skips its search"}
 
 
+def parity_gate(rig, gate):
+    """no timing is reported unless the GPU path reproduces the oracle on THIS workload.  The headline
+    layer (all queries, scene and size of `value`) is matched on the GPU at the initial guess and at the ground-truth pose --
+    cold, then once more from the warm start the first call left -- and solved; the pair lists must equal the oracle's
+    (localIdx, globalIdx, bits of errSq) and the Gauss-Newton pose must agree to 1e-5 m / 1e-5 rad."""
+    import oracle as orc
+    from mp2p_icp_amd import core
+    out = {"poses": len(gate), "pairs_equal": True, "pairs": [], "pose_err": {"trans_m": 0.0, "rot_rad": 0.0}, "matcher_calls": 0}
+    for pose, want, T_want in gate:
+        for rep in range(2):  # cold (another pose's warm start: far away), then warm from itself
+            rig.pairs.clear()
+            core.match_pt2pt(rig.ctx, rig.gmap, rig.cloud, pose, rig.prm, None, rig.pairs)
+            got = rig.pairs.download_pt2pt()
+            out["matcher_calls"] += 1
+            same = (len(got) == len(want) and np.array_equal(got["localIdx"], want["localIdx"]) and
+                    np.array_equal(got["globalIdx"], want["globalIdx"]) and
+                    np.array_equal(got["errorSquareAfterTransformation"].view(np.uint32), want["errSq"].view(np.uint32)))
+            out["pairs_equal"] = bool(out["pairs_equal"] and same)
+        out["pairs"].append(int(len(want)))
+        T_got = np.array(core.gn_solve(rig.ctx, rig.pairs, pose, rig.gnp).pose)
+        et, er = orc.pose_err_split(T_got, T_want)
+        out["pose_err"]["trans_m"] = max(out["pose_err"]["trans_m"], float(et))
+        out["pose_err"]["rot_rad"] = max(out["pose_err"]["rot_rad"], float(er))
+    out["passed"] = bool(out["pairs_equal"] and out["pose_err"]["trans_m"] <= 1e-5 and out["pose_err"]["rot_rad"] <= 1e-5)
+    return out
+
+
 def stats_ms(xs):
     a = np.asarray(xs, dtype=np.float64) * 1e3
     return {"min": float(a.min()), "median": float(np.median(a)), "max": float(a.max())}
@@ -315,7 +349,7 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def roofline_block(n_l, touched_mean, nn_ms_avg, tag):
@@ -324,7 +358,7 @@ def roofline_block(n_l, touched_mean, nn_ms_avg, tag):
     alg_bytes = 12.0 * n_l + 12.0 * touched_mean + 8.0 * n_l
     achieved = alg_bytes / (max(nn_ms_avg, 1e-9) * 1e-3) / 1e9
     out = {"bound": "hbm",
-           "kernel": "nn_lane_kernel + nn_tile_kernel + nn_single_kernel (K1+K3: transform + exact NN search)",
+           "kernel": "nn_lane_kernel + nn_seltile_kernel + nn_single_kernel (K1+K3: transform + exact NN search)",
            "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": nn_ms_avg,
            "traffic": None, "traffic_from_profiles": None}
@@ -346,7 +380,7 @@ def roofline_block(n_l, touched_mean, nn_ms_avg, tag):
         for r in csv.DictReader(open(f)):
             # the three search launches of the timed path (INSTR = false variants; the instrumented ones
             # only run in the counting replay)
-            if re.search(r"mp2p::nn_(lane_kernel<false>|tile_kernel<\d+, false|single_kernel<false)", r["kernel"]):
+            if re.search(r"mp2p::nn_(lane_kernel<false>|tile_kernel<\d+, false|seltile_kernel<false|single_kernel<false)", r["kernel"]):
                 t += float(r["fetch_bytes_avg_corrected_x2"]) + float(r["write_bytes_avg"])
         if t > 0:
             out["traffic_from_profiles"] = t
@@ -920,6 +954,23 @@ def main():
         out["cpu_baseline"] = cpu_baseline(d, args.threshold, args.gn_iters, 0.15, args.cpu_sample or d["local"].shape[0], cores)
         out["cpu_baseline"]["wall_s"] = time.time() - t0
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        # ---- the parity gate: the oracle's lists of the WHOLE headline layer were just computed ------------
+        gate = out["cpu_baseline"].pop("_gate")
+        if gate:
+            try:
+                out["parity_gate"] = parity_gate(rig, gate)
+            except Exception as ex:
+                out["parity_gate"] = {"passed": False, "error": repr(ex)}
+            if not out["parity_gate"]["passed"]:
+                log("[bench] PARITY GATE FAILED on the headline workload: no value is reported")
+                out["value_withheld"] = out.pop("value")
+                out["value"] = None
+        else:
+            out["parity_gate"] = {"skipped": "--cpu-sample below the layer's size: the oracle did not see every query"}
+    else:
+        out["parity_gate"] = {"skipped": "no CPU oracle in this run (--no-cpu-baseline, or a rank of a multi-GPU job: the gate runs at N = 1)"}
+    if isinstance(out.get("host_boundary"), dict) and "iterations_per_s" in out["host_boundary"]:
+        out["value_through_host_containers"] = out["host_boundary"]["iterations_per_s"]
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -11,6 +11,7 @@
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -569,6 +570,11 @@ struct orc_kdtree
     float        bmin[3], bmax[3];
     /* leaf-ordered copies for cache-friendly scans */
     float *      px, *py, *pz;
+    /* multi-thread baseline (orc_match_pt2pt_mt_ms): the layer's bounding box, computed once with the tree (the reference's
+     * point maps cache theirs), and the "global point taken" bytes of the unique-global filter, kept all-zero between calls
+     * (a call clears the entries it set: no 10 MB calloc per iteration) */
+    float        gmin[3], gmax[3];
+    uint8_t*     mt_taken;
 };
 
 static int32_t kd_new_node(orc_kdtree* t)
@@ -666,6 +672,18 @@ orc_kdtree* orc_kdtree_build(const float* x, const float* y, const float* z, siz
         t->py[i] = y[t->perm[i]];
         t->pz[i] = z[t->perm[i]];
     }
+    t->gmin[0] = t->gmin[1] = t->gmin[2] = FLT_MAX;
+    t->gmax[0] = t->gmax[1] = t->gmax[2] = -FLT_MAX;
+    for (size_t i = 0; i < n; i++)
+    { /* (the comparisons of bbox_of, in its order) */
+        if (x[i] < t->gmin[0]) t->gmin[0] = x[i];
+        if (y[i] < t->gmin[1]) t->gmin[1] = y[i];
+        if (z[i] < t->gmin[2]) t->gmin[2] = z[i];
+        if (x[i] > t->gmax[0]) t->gmax[0] = x[i];
+        if (y[i] > t->gmax[1]) t->gmax[1] = y[i];
+        if (z[i] > t->gmax[2]) t->gmax[2] = z[i];
+    }
+    t->mt_taken = NULL;
     return t;
 }
 
@@ -677,6 +695,7 @@ void orc_kdtree_free(orc_kdtree* t)
     free(t->px);
     free(t->py);
     free(t->pz);
+    free(t->mt_taken);
     free(t);
 }
 
@@ -865,22 +884,120 @@ size_t orc_match_pt2pt(const orc_kdtree* tree, const float* gx, const float* gy,
     return n_out;
 }
 
-/* ---- multi-threaded CPU baseline of the same contract (K==1) -------------------------------- */
+/* ---- multi-threaded CPU baseline of the same contract (K==1) --------------------------------
+ * Round 5 (the baseline must be a competently parallel port, not a flattering one): a PERSISTENT thread pool
+ * (round 4 created and joined 2 x n_threads threads per call), the global layer's bounding box cached with the tree, the
+ * "taken" bytes kept between calls, the pair records gathered in parallel; only the claim pass of the unique-global filter
+ * (lowest local index wins: a sequential dependence by definition) stays on one thread.  Same lists as the sequential loop. */
+typedef void (*pool_fn)(void* jobs, int t);
+static struct
+{
+    pthread_t       th[1024];
+    int             n;          /* threads alive */
+    pthread_mutex_t mu;
+    pthread_cond_t  cv_go, cv_done;
+    unsigned long   gen;        /* incremented per run */
+    int             n_run, n_left;
+    pool_fn         fn;
+    void*           jobs;
+    int             inited;
+} g_pool;
+
+static void* pool_main(void* arg)
+{
+    const int     me   = (int)(intptr_t)arg;
+    unsigned long seen = 0;
+    for (;;)
+    {
+        pthread_mutex_lock(&g_pool.mu);
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.cv_go, &g_pool.mu);
+        seen             = g_pool.gen;
+        const int     n  = g_pool.n_run;
+        const pool_fn fn = g_pool.fn;
+        void*         jb = g_pool.jobs;
+        pthread_mutex_unlock(&g_pool.mu);
+        if (me < n) fn(jb, me);
+        pthread_mutex_lock(&g_pool.mu);
+        if (me < n && --g_pool.n_left == 0) pthread_cond_signal(&g_pool.cv_done);
+        pthread_mutex_unlock(&g_pool.mu);
+    }
+    return NULL;
+}
+
+/* runs fn(jobs, t) for t = 0 .. n - 1 on the pool's threads and waits (one caller at a time: the baseline's use) */
+static void pool_run(pool_fn fn, void* jobs, int n)
+{
+    if (n <= 1)
+    {
+        fn(jobs, 0);
+        return;
+    }
+    if (!g_pool.inited)
+    {
+        pthread_mutex_init(&g_pool.mu, NULL);
+        pthread_cond_init(&g_pool.cv_go, NULL);
+        pthread_cond_init(&g_pool.cv_done, NULL);
+        g_pool.inited = 1;
+    }
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.n < n && g_pool.n < 1024)
+    {
+        pthread_create(&g_pool.th[g_pool.n], NULL, pool_main, (void*)(intptr_t)g_pool.n);
+        g_pool.n++;
+    }
+    g_pool.fn = fn, g_pool.jobs = jobs, g_pool.n_run = n, g_pool.n_left = n;
+    g_pool.gen++;
+    pthread_cond_broadcast(&g_pool.cv_go);
+    while (g_pool.n_left > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+}
+
 typedef struct
 {
     const orc_kdtree* tree;
-    const float *     tx, *ty, *tz;
-    size_t            b, e;
+    const float *     lx, *ly, *lz;
+    const double*     T;
+    float *           tx, *ty, *tz;
+    size_t            n_l;
+    int               n_threads;
     float             maxDistSq, angSq;
     uint32_t*         nn_idx;
     float*            nn_d2;
     const uint8_t*    skip; /* local points not to search, or NULL */
-} mt_job;
+    float (*bb)[6];         /* per-thread bounding box of the transformed points */
+    /* gather */
+    const float *     gx, *gy, *gz;
+    const uint8_t*    win;
+    const size_t*     chunk_off;
+    orc_pair_pt2pt*   out;
+} mt_ctx;
 
-static void* mt_worker(void* arg)
+static void mt_transform(void* jobs, int t)
 {
-    mt_job* j = (mt_job*)arg;
-    for (size_t i = j->b; i < j->e; i++)
+    mt_ctx*      j = (mt_ctx*)jobs;
+    const size_t b = j->n_l * (size_t)t / j->n_threads, e = j->n_l * (size_t)(t + 1) / j->n_threads;
+    float        mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t i = b; i < e; i++)
+    {
+        double g[3];
+        orc_pose_compose_point(j->T, j->lx[i], j->ly[i], j->lz[i], g);
+        const float x = (float)g[0], y = (float)g[1], z = (float)g[2];
+        j->tx[i] = x, j->ty[i] = y, j->tz[i] = z;
+        if (x < mn[0]) mn[0] = x;
+        if (y < mn[1]) mn[1] = y;
+        if (z < mn[2]) mn[2] = z;
+        if (x > mx[0]) mx[0] = x;
+        if (y > mx[1]) mx[1] = y;
+        if (z > mx[2]) mx[2] = z;
+    }
+    for (int d = 0; d < 3; d++) j->bb[t][d] = mn[d], j->bb[t][3 + d] = mx[d];
+}
+
+static void mt_search(void* jobs, int t)
+{
+    mt_ctx*      j = (mt_ctx*)jobs;
+    const size_t b = j->n_l * (size_t)t / j->n_threads, e = j->n_l * (size_t)(t + 1) / j->n_threads;
+    for (size_t i = b; i < e; i++)
     {
         if (j->skip && j->skip[i])
         {
@@ -898,27 +1015,23 @@ static void* mt_worker(void* arg)
         else
             j->nn_idx[i] = 0xFFFFFFFFu, j->nn_d2[i] = 0;
     }
-    return NULL;
 }
 
-typedef struct
+static void mt_gather(void* jobs, int t)
 {
-    const float *lx, *ly, *lz;
-    const double* T;
-    float *       tx, *ty, *tz;
-    size_t        b, e;
-} tf_job;
-
-static void* tf_worker(void* arg)
-{
-    tf_job* j = (tf_job*)arg;
-    for (size_t i = j->b; i < j->e; i++)
+    mt_ctx*      j = (mt_ctx*)jobs;
+    const size_t b = j->n_l * (size_t)t / j->n_threads, e = j->n_l * (size_t)(t + 1) / j->n_threads;
+    size_t       o = j->chunk_off[t];
+    for (size_t i = b; i < e; i++)
     {
-        double g[3];
-        orc_pose_compose_point(j->T, j->lx[i], j->ly[i], j->lz[i], g);
-        j->tx[i] = (float)g[0], j->ty[i] = (float)g[1], j->tz[i] = (float)g[2];
+        if (!j->win[i]) continue;
+        const uint32_t  g = j->nn_idx[i];
+        orc_pair_pt2pt* p = &j->out[o++];
+        p->globalIdx = g, p->localIdx = (uint32_t)i;
+        p->gx = j->gx[g], p->gy = j->gy[g], p->gz = j->gz[g];
+        p->lx = j->lx[i], p->ly = j->ly[i], p->lz = j->lz[i];
+        p->errSq = j->nn_d2[i];
     }
-    return NULL;
 }
 
 size_t orc_match_pt2pt_mt(const orc_kdtree* tree, const float* gx, const float* gy,
@@ -940,64 +1053,76 @@ size_t orc_match_pt2pt_mt_ms(const orc_kdtree* tree, const float* gx, const floa
     if (!tree || n_g == 0 || n_l == 0 || prm->pairingsPerPoint != 1) return 0;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 1024) n_threads = 1024;
+    if ((size_t)n_threads > n_l) n_threads = (int)n_l;
     float*    tx  = (float*)malloc(n_l * sizeof(float));
     float*    ty  = (float*)malloc(n_l * sizeof(float));
     float*    tz  = (float*)malloc(n_l * sizeof(float));
     uint32_t* nn  = (uint32_t*)malloc(n_l * sizeof(uint32_t));
     float*    nd  = (float*)malloc(n_l * sizeof(float));
-    pthread_t th[1024];
-    {
-        tf_job jobs[1024];
-        for (int t = 0; t < n_threads; t++)
+    uint8_t*  win = (uint8_t*)malloc(n_l);
+    float (*bb)[6] = (float (*)[6])malloc(sizeof(float[6]) * (size_t)n_threads);
+    size_t*   coff = (size_t*)malloc(sizeof(size_t) * ((size_t)n_threads + 1));
+    mt_ctx    c;
+    memset(&c, 0, sizeof(c));
+    c.tree = tree, c.lx = lx, c.ly = ly, c.lz = lz, c.T = T, c.tx = tx, c.ty = ty, c.tz = tz, c.n_l = n_l, c.n_threads = n_threads;
+    c.nn_idx = nn, c.nn_d2 = nd, c.bb = bb, c.gx = gx, c.gy = gy, c.gz = gz, c.win = win, c.chunk_off = coff, c.out = out;
+    pool_run(mt_transform, &c, n_threads);
+    float lmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int t = 0; t < n_threads; t++)
+        for (int d = 0; d < 3; d++)
         {
-            jobs[t] = (tf_job){lx, ly, lz, T, tx, ty, tz, n_l * t / n_threads,
-                               n_l * (t + 1) / n_threads};
-            pthread_create(&th[t], NULL, tf_worker, &jobs[t]);
+            if (bb[t][d] < lmin[d]) lmin[d] = bb[t][d];
+            if (bb[t][3 + d] > lmax[d]) lmax[d] = bb[t][3 + d];
         }
-        for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
-    }
-    float lmin[3], lmax[3], gmin[3], gmax[3];
-    bbox_of(tx, ty, tz, n_l, lmin, lmax);
-    bbox_of(gx, gy, gz, n_g, gmin, gmax);
     size_t n_out = 0;
-    if (bbox_intersects(gmin, gmax, lmin, lmax, (float)(prm->threshold + prm->bbox_eps)))
+    /* (the tree's cached box is the box of the points it was built on: the layer the caller passes) */
+    if (bbox_intersects(tree->gmin, tree->gmax, lmin, lmax, (float)(prm->threshold + prm->bbox_eps)))
     {
-        const float  maxDistSq = (float)(prm->threshold * prm->threshold);
-        const double angRad    = prm->thresholdAngularDeg * M_PI / 180.0;
-        const float  angSq     = (float)(angRad * angRad);
-        mt_job       jobs[1024];
-        for (int t = 0; t < n_threads; t++)
-        {
-            jobs[t] = (mt_job){tree,      tx,    ty, tz, n_l * t / n_threads,
-                               n_l * (t + 1) / n_threads, maxDistSq, angSq, nn, nd,
-                               prm->allowMatchAlreadyMatchedPoints ? NULL : local_taken};
-            pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
-        }
-        for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
-        /* sequential resolution of the unique-global filter (lowest local index wins) */
-        uint8_t* own   = NULL;
+        const double angRad = prm->thresholdAngularDeg * M_PI / 180.0;
+        c.maxDistSq = (float)(prm->threshold * prm->threshold);
+        c.angSq     = (float)(angRad * angRad);
+        c.skip      = prm->allowMatchAlreadyMatchedPoints ? NULL : local_taken;
+        pool_run(mt_search, &c, n_threads);
+        /* the claim pass of the unique-global filter (lowest local index wins): sequential by definition, one byte per
+         * query out; then the records are gathered by all threads */
         uint8_t* taken = NULL;
+        int      own   = 0;
         if (!prm->allowMatchAlreadyMatchedGlobalPoints)
-            taken = global_taken ? global_taken : (own = (uint8_t*)calloc(n_g, 1));
+        {
+            if (global_taken) taken = global_taken;
+            else
+            {
+                orc_kdtree* tw = (orc_kdtree*)tree; /* (scratch of the handle, not part of its value) */
+                if (!tw->mt_taken) tw->mt_taken = (uint8_t*)calloc(n_g, 1);
+                taken = tw->mt_taken, own = 1;
+            }
+        }
+        size_t t_of = 0, next = n_l * 1 / (size_t)n_threads;
+        coff[0]     = 0;
         for (size_t i = 0; i < n_l; i++)
         {
+            while (i >= next && t_of + 1 < (size_t)n_threads) coff[++t_of] = n_out, next = n_l * (t_of + 1) / (size_t)n_threads;
             const uint32_t g = nn[i];
-            if (g == 0xFFFFFFFFu) continue;
-            if (taken)
+            uint8_t        w = 0;
+            if (g != 0xFFFFFFFFu)
             {
-                if (taken[g]) continue;
-                taken[g] = 1;
-                if (local_taken) local_taken[i] = 1;
+                if (!taken) w = 1;
+                else if (!taken[g])
+                {
+                    taken[g] = 1, w = 1;
+                    if (local_taken) local_taken[i] = 1;
+                }
             }
-            orc_pair_pt2pt* p = &out[n_out++];
-            p->globalIdx = g, p->localIdx = (uint32_t)i;
-            p->gx = gx[g], p->gy = gy[g], p->gz = gz[g];
-            p->lx = lx[i], p->ly = ly[i], p->lz = lz[i];
-            p->errSq = nd[i];
+            win[i] = w;
+            n_out += w;
         }
-        free(own);
+        while (t_of + 1 < (size_t)n_threads) coff[++t_of] = n_out;
+        pool_run(mt_gather, &c, n_threads);
+        if (own) /* leave the scratch all-zero for the next call */
+            for (size_t i = 0; i < n_l; i++)
+                if (win[i]) taken[nn[i]] = 0;
     }
-    free(tx), free(ty), free(tz), free(nn), free(nd);
+    free(tx), free(ty), free(tz), free(nn), free(nd), free(win), free(bb), free(coff);
     return n_out;
 }
 
@@ -1912,9 +2037,10 @@ typedef struct
     double                H[36], g[6], err;
 } gn_job;
 
-static void* gn_worker(void* arg)
+static void gn_worker_body(gn_job* j);
+static void gn_pool_fn(void* jobs, int t) { gn_worker_body(&((gn_job*)jobs)[t]); }
+static void gn_worker_body(gn_job* j)
 {
-    gn_job* j = (gn_job*)arg;
     memset(j->H, 0, sizeof(j->H));
     memset(j->g, 0, sizeof(j->g));
     j->err = 0;
@@ -1940,7 +2066,6 @@ static void* gn_worker(void* arg)
         j->err += w * esq;
         accum_term(e, J1, j->dD, w, j->H, j->g);
     }
-    return NULL;
 }
 
 int orc_optimal_tf_gauss_newton_mt(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
@@ -1953,7 +2078,6 @@ int orc_optimal_tf_gauss_newton_mt(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
     double T[12];
     memcpy(T, T0, sizeof(T));
     gn_job*   jobs = (gn_job*)malloc(sizeof(gn_job) * n_threads);
-    pthread_t th[1024];
     int       iters = 0;
     for (uint32_t iter = 0; iter < prm->maxInnerLoopIterations; iter++)
     {
@@ -1968,11 +2092,10 @@ int orc_optimal_tf_gauss_newton_mt(const orc_pair_pt2pt* pt2pt, size_t n_pt2pt,
             jobs[t].b1 = n_pt2pt * t / n_threads, jobs[t].e1 = n_pt2pt * (t + 1) / n_threads;
             jobs[t].b2 = n_pt2pl * t / n_threads, jobs[t].e2 = n_pt2pl * (t + 1) / n_threads;
             jobs[t].T = T, jobs[t].dD = dD, jobs[t].prm = prm;
-            pthread_create(&th[t], NULL, gn_worker, &jobs[t]);
         }
+        pool_run(gn_pool_fn, jobs, n_threads);
         for (int t = 0; t < n_threads; t++)
         {
-            pthread_join(th[t], NULL);
             for (int i = 0; i < 36; i++) H[i] += jobs[t].H[i];
             for (int i = 0; i < 6; i++) g[i] += jobs[t].g[i];
             err += jobs[t].err;

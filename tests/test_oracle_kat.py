@@ -806,3 +806,37 @@ def test_horn_outliers_shift_the_weight_blocks(oracle):
     S_plain, _ = _visit_correspondences_py(pt, 1.0, 1.3, None, out1, cl, cg)
     U, _, Vt = np.linalg.svd(S_plain.T)
     assert not np.allclose(U @ np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))]) @ Vt, R, atol=1e-9)
+
+
+def test_multithread_baseline_equals_the_sequential_loop():
+    """bench.py's cpu_baseline (round 5: persistent thread pool, cached global bounding box, kept `taken` scratch, parallel
+    gather) must return the sequential loop's lists -- also on repeated calls (the scratch is left clean), with a MatchState,
+    with re-use of global points allowed, and for a layer that misses the map's bounding box."""
+    import oracle as orc
+    from mp2p_icp_amd import synthetic, se3
+    d = synthetic.random_cloud_pair(20_000, 60_000, 77, outlier_frac=0.1)
+    g, l = d["glob"], d["local"]
+    tree = orc.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    rng = np.random.default_rng(3)
+    pose = d["T_init"]
+    for k in range(4):
+        for allow_g in (False, True):
+            want, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.8, 0.0, tree=tree,
+                                      allowMatchAlreadyMatchedGlobalPoints=allow_g)
+            for th in (3, 8):
+                got, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.8, 0.0, tree=tree,
+                                         allowMatchAlreadyMatchedGlobalPoints=allow_g, threads=th)
+                assert got.tobytes() == want.tobytes(), (k, allow_g, th)
+        lt, gt = (rng.random(l.shape[0]) < 0.2).astype(np.uint8), (rng.random(g.shape[0]) < 0.2).astype(np.uint8)
+        lt1, gt1, lt2, gt2 = lt.copy(), gt.copy(), lt.copy(), gt.copy()
+        want, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.8, 0.0, tree=tree, local_taken=lt1, global_taken=gt1)
+        got, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, 0.8, 0.0, tree=tree, local_taken=lt2, global_taken=gt2, threads=5)
+        assert got.tobytes() == want.tobytes() and np.array_equal(lt1, lt2) and np.array_equal(gt1, gt2)
+        prm = orc.make_gn_params(3, kernel=orc.KERNEL_GEMANMCCLURE, kernelParam=0.15)
+        T1, it1, _, _ = orc.optimal_tf_gauss_newton(want, None, None, pose, prm)
+        T2, it2, _, _ = orc.optimal_tf_gauss_newton(want, None, None, pose, prm, threads=6)
+        assert it1 == it2 and orc.pose_err(T1, T2) < 1e-10
+        pose = se3.compose(pose, se3.exp(np.concatenate([rng.normal(0, 0.05, 3), rng.normal(0, 0.01, 3)])))
+    far = se3.compose(pose, se3.from_xyzypr(500.0, 0.0, 0.0))
+    got, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], far, 0.8, 0.0, tree=tree, threads=4)
+    assert len(got) == 0

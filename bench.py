@@ -117,8 +117,17 @@ def cpu_baseline(d, threshold, gn_iters, kernel_param, sample, cores):
     v, pps, tm, ts = run(n_s, cores, keep=True)
     n_1 = min(max(2000, sample // 10), l.shape[0])
     v1, pps1, tm1, ts1 = run(n_1, 0)  # threads=0: the sequential loop
+    quota = None  # the container's CPU bandwidth limit (cgroup v2 cpu.max: "<quota> <period>" or "max"): what `cores` threads can really use
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
     return {"value": v, "unit": "iterations/s", "cores": cores, "kind": "port",
-            "_gate": gate,
+            "_gate": gate, "cpu_quota_cores": quota,
+            "cpu_quota_note": "threads = os.cpu_count(); the cgroup of this container caps their total CPU time at cpu_quota_cores "
+                              "cores' worth (cpu.max), which bounds multi_thread_over_single_thread whatever the port does",
+
             "multi_thread_over_single_thread": v / v1,
             "sample": f"{n_s} of {l.shape[0]} local points (uniform subsample) vs the full "
                       f"{g.shape[0]}-point map; mean of initial-guess and converged pose; "

@@ -82,6 +82,7 @@ int mp2p_hostpath_begin_iteration(void* h)
 int mp2p_hostpath_match_pt2pt(void* h, const double pose[12], const mp2p_hip_pt2pt_params* prm,
                               uint32_t icp_iteration, const uint32_t* visit, size_t n_visit, size_t* n_added)
 {
+    mp2p_hip_host::RoctxRange range("align.3.1_matchers");
     auto* s = static_cast<Session*>(h);
     return guarded(
         [&]()
@@ -263,6 +264,7 @@ int mp2p_hostpath_release_layers(void* h)
 // Solver_GaussNewton::impl_optimal_pose on the session's host Pairings
 int mp2p_hostpath_solve_gn(void* h, const double pose0[12], const mp2p_hip_gn_params* prm, mp2p_hip_gn_result* out)
 {
+    mp2p_hip_host::RoctxRange range("align.3.2_solvers");
     auto* s = static_cast<Session*>(h);
     return guarded(
         [&]()

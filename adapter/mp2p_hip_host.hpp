@@ -31,11 +31,54 @@
 
 #include "mp2p_hip.h"
 
+#include <dlfcn.h>
+
 namespace mp2p_hip_host
 {
 struct Error : std::runtime_error
 {
     using std::runtime_error::runtime_error;
+};
+
+// roctx ranges named after the reference's profiler sections (ICP.cpp:141 "align.3.1_matchers", :162 "align.3.2_solvers";
+// SURVEY.md section 5): a rocprofv3 --marker-trace of an application that runs the plugin shows the matcher and the solver
+// calls under the names `icp-run --profiler` prints.  libroctx64 is looked up at run time (no link dependency; without it,
+// or without a profiler attached, a range costs one null test).
+struct RoctxRange
+{
+    using push_fn = int (*)(const char*);
+    using pop_fn  = int (*)();
+    static void resolve(push_fn& push, pop_fn& pop)
+    {
+        static push_fn s_push = nullptr;
+        static pop_fn  s_pop  = nullptr;
+        static const bool once  = [] {
+            void* h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+            if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
+            if (h)
+            {
+                s_push = reinterpret_cast<push_fn>(dlsym(h, "roctxRangePushA"));
+                s_pop  = reinterpret_cast<pop_fn>(dlsym(h, "roctxRangePop"));
+            }
+            return true;
+        }();
+        (void)once;
+        push = s_push, pop = s_pop;
+    }
+    pop_fn pop_ = nullptr;
+    explicit RoctxRange(const char* name)
+    {
+        push_fn push;
+        resolve(push, pop_);
+        if (push && pop_) push(name);
+        else pop_ = nullptr;
+    }
+    ~RoctxRange()
+    {
+        if (pop_) pop_();
+    }
+    RoctxRange(const RoctxRange&)            = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
 };
 
 // ---- packed bit-field view (bit i = bit (i & 63) of word i / 64) ---------------------------------

@@ -218,6 +218,7 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base, p
                const mrpt::poses::CPose3D& localPose, const mp2p_icp::MatchContext& mc, mp2p_icp::MatchState& ms,
                mp2p_icp::Pairings& out) const override
     {
+        mp2p_hip_host::RoctxRange roctx_range("align.3.1_matchers");  // the reference's profiler section (ICP.cpp:141)
         note_call(mc, ms);
         return mp2p_icp::Matcher::match(pcGlobal, pcLocal, localPose, mc, ms, out);
     }
@@ -235,24 +236,35 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base, p
     {
         if (!allowMatchAlreadyMatchedGlobalPoints_) return false;
         mp2p_icp::Pairings tmp;
-        count_only_ = true, counted_ = 0;
-        try
+        // The request travels in thread-local state scoped to THIS call (mutable members made concurrent or
+        // re-entrant evaluate() calls on one evaluator mix counts or silently return no pairs): the reference's
+        // QualityEvaluator_PairedRatio::evaluate is a stateless const method, and so is this one per thread.
+        struct Scope
         {
+            CountRequest* prev;
+            explicit Scope(CountRequest* r) : prev(count_request()) { count_request() = r; }
+            ~Scope() { count_request() = prev; }
+        };
+        CountRequest req{this, 0};
+        {
+            Scope scope(&req);
             match(pcGlobal, pcLocal, localPose, {}, ms, tmp);
         }
-        catch (...)
-        {
-            count_only_ = false;
-            throw;
-        }
-        count_only_ = false;
-        n_pairs = counted_, potential = tmp.potential_pairings;
+        n_pairs = req.counted, potential = tmp.potential_pairings;
         return true;
     }
 
    private:
-    mutable bool     count_only_ = false;
-    mutable uint64_t counted_    = 0;
+    struct CountRequest
+    {
+        const void* owner;  // the matcher the request is addressed to (a nested matcher of another object ignores it)
+        uint64_t    counted;
+    };
+    static CountRequest*& count_request()
+    {
+        static thread_local CountRequest* r = nullptr;
+        return r;
+    }
     void implMatchOneLayer(const mrpt::maps::CMetricMap& pcGlobal, const mrpt::maps::CPointsMap& pcLocal,
                            const mrpt::poses::CPose3D& localPose, mp2p_icp::MatchState& ms,
                            const mp2p_icp::layer_name_t& globalName, const mp2p_icp::layer_name_t& localName,
@@ -285,9 +297,9 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base, p
         mp2p_hip_map*               m;
         mp2p_hip_cloud*             c;
         layers(rt, *gl, pcLocal, m, c);
-        if (count_only_)
+        if (CountRequest* req = count_request(); req && req->owner == this)
         {
-            counted_ += mp2p_hip_host::count_pt2pt_layer(rt, m, c, T, prm, visit.data(), visit.size());
+            req->counted += mp2p_hip_host::count_pt2pt_layer(rt, m, c, T, prm, visit.data(), visit.size());
             return;
         }
         BitAccess gbits(ms.globalPairedBitField.point_layers.at(globalName), gl->size());
@@ -324,6 +336,7 @@ class Matcher_Point2Plane : public mp2p_icp::Matcher_Points_Base, protected Matc
                const mrpt::poses::CPose3D& localPose, const mp2p_icp::MatchContext& mc, mp2p_icp::MatchState& ms,
                mp2p_icp::Pairings& out) const override
     {
+        mp2p_hip_host::RoctxRange roctx_range("align.3.1_matchers");  // the reference's profiler section (ICP.cpp:141)
         note_call(mc, ms);
         return mp2p_icp::Matcher::match(pcGlobal, pcLocal, localPose, mc, ms, out);
     }
@@ -495,6 +508,7 @@ class Solver_GaussNewton : public mp2p_icp::Solver
     bool impl_optimal_pose(const mp2p_icp::Pairings& pairings, mp2p_icp::OptimalTF_Result& out,
                            const mp2p_icp::SolverContext& sc) const override
     {
+        mp2p_hip_host::RoctxRange roctx_range("align.3.2_solvers");  // the reference's profiler section (ICP.cpp:162)
         checkAllParametersAreRealized();
         out = mp2p_icp::OptimalTF_Result();
         ASSERT_(sc.guessRelativePose.has_value());
@@ -553,6 +567,7 @@ class Solver_Horn : public mp2p_icp::Solver
     bool impl_optimal_pose(const mp2p_icp::Pairings& pairings, mp2p_icp::OptimalTF_Result& out,
                            const mp2p_icp::SolverContext& sc) const override
     {
+        mp2p_hip_host::RoctxRange roctx_range("align.3.2_solvers");  // the reference's profiler section (ICP.cpp:162)
         out = mp2p_icp::OptimalTF_Result();
         if (!pairings.paired_ln2ln.empty()) THROW_EXCEPTION("HIP Horn: paired_ln2ln is not supported");
         if (pairings.point_weights.size() > 8) THROW_EXCEPTION("HIP Horn: more than 8 point_weights blocks are not supported");
@@ -620,6 +635,7 @@ class Matcher_Points_InlierRatio : public mp2p_icp::Matcher_Points_Base, protect
                const mrpt::poses::CPose3D& localPose, const mp2p_icp::MatchContext& mc, mp2p_icp::MatchState& ms,
                mp2p_icp::Pairings& out) const override
     {
+        mp2p_hip_host::RoctxRange roctx_range("align.3.1_matchers");  // the reference's profiler section (ICP.cpp:141)
         note_call(mc, ms);
         return mp2p_icp::Matcher::match(pcGlobal, pcLocal, localPose, mc, ms, out);
     }
@@ -692,6 +708,7 @@ class Matcher_Adaptive : public mp2p_icp::Matcher_Points_Base, protected Matcher
                const mrpt::poses::CPose3D& localPose, const mp2p_icp::MatchContext& mc, mp2p_icp::MatchState& ms,
                mp2p_icp::Pairings& out) const override
     {
+        mp2p_hip_host::RoctxRange roctx_range("align.3.1_matchers");  // the reference's profiler section (ICP.cpp:141)
         note_call(mc, ms);
         return mp2p_icp::Matcher::match(pcGlobal, pcLocal, localPose, mc, ms, out);
     }

@@ -531,6 +531,10 @@ int mp2p_hip_pairs_pt2ln_pl_to_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* in
  *      context's stream.  librccl is opened at run time, by mp2p_hip_comm_init only. ------------------ */
 #define MP2P_HIP_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
 int mp2p_hip_comm_get_unique_id(void* id_out /* MP2P_HIP_COMM_ID_BYTES */);
+/* pre-flight of mp2p_hip_comm_init without side effects: MP2P_HIP_OK iff librccl can be loaded here and the context has no
+ * communicator yet (every rank checks this before ANY rank calls mp2p_hip_comm_init: a rank that fails on its own would leave
+ * its peers blocked inside ncclCommInitRank).  No counterpart in the reference. */
+int mp2p_hip_comm_available(mp2p_hip_ctx* ctx);
 int mp2p_hip_comm_init(mp2p_hip_ctx* ctx, const void* unique_id, int rank, int nranks);
 /* caller-provided collectives instead of RCCL (another transport; tests).  Both act IN PLACE / into recv
  * on DEVICE buffers and must be ordered with `stream`; return 0 on success.

@@ -253,6 +253,7 @@ SIGNATURES = {
     "mp2p_hip_horn_outlier_flags": (C.c_int, [_P, C.POINTER(C.c_uint8), C.c_size_t]),
     "mp2p_hip_pairs_pt2ln_pl_to_pt2pt": (C.c_int, [_P, _P, _dp, _P]),
     "mp2p_hip_comm_get_unique_id": (C.c_int, [_P]),
+    "mp2p_hip_comm_available": (C.c_int, [_P]),
     "mp2p_hip_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "mp2p_hip_comm_init_hooks": (C.c_int, [_P, C.c_int, C.c_int, ALLREDUCE_FN, ALLGATHER_FN, _P]),
     "mp2p_hip_comm_destroy": (C.c_int, [_P]),

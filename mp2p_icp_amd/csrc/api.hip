@@ -187,8 +187,8 @@ void mp2p_hip_ctx_destroy(mp2p_hip_ctx* ctx)
     // a copy-out the caller never ended: its later rounds still read the device staging area -- finish it before
     // anything is released (an unknown pointer is a HOST pointer to hipMemcpyAsync: a segmentation fault, not an error)
     (void)mp2p_hip_pairs_copy_end(ctx);
+    (void)hipStreamSynchronize(ctx->stream);  // (before the staging buffer goes: no DMA into it may be in flight)
     mp2p::stage_destroy(ctx);
-    (void)hipStreamSynchronize(ctx->stream);
     ctx->nn_spos.release(), ctx->nn_d2.release(), ctx->tile_bbox.release();
     ctx->local_bbox.release(), ctx->block_counts.release(), ctx->counters.release(), ctx->compact_flags.release();
     ctx->gn_partials.release(), ctx->gn_sums.release(), ctx->gn_state.release();

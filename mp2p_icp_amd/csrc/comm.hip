@@ -193,6 +193,16 @@ int mp2p_hip_comm_get_unique_id(void* id_out)
     return MP2P_HIP_OK;
 }
 
+// side-effect-free pre-flight of mp2p_hip_comm_init: librccl loads and resolves, and the context has no communicator yet
+// (drawing a throw-away ncclUniqueId for that, as round 4 did, starts a bootstrap listener thread and socket per call)
+int mp2p_hip_comm_available(mp2p_hip_ctx* ctx)
+{
+    if (!ctx) return MP2P_HIP_ERR_INVALID;
+    if (const int rc = load_rccl(ctx)) return rc;
+    MP2P_REQUIRE(ctx, !ctx->comm.nccl && !ctx->comm.hook_allreduce, "the context already has a communicator");
+    return MP2P_HIP_OK;
+}
+
 int mp2p_hip_comm_init(mp2p_hip_ctx* ctx, const void* unique_id, int rank, int nranks)
 {
     if (!ctx) return MP2P_HIP_ERR_INVALID;

@@ -123,14 +123,14 @@ struct Tune
     uint32_t lane_cells    = 0;     // widest cube (level-0 voxels per axis) the one-query-per-lane kernel searches
                                     // itself; 0 = none (measured: per-lane 16-byte gathers cost one L1 line each,
                                     // the tile kernel's coalesced staging serves the same queries 2.5x cheaper)
-    uint32_t tile_cand_cap = 0;     // staged candidates after which a tile hands its pending queries on; 0 = 24 576 with the
-                                    // matrix-pipe selection (round 5: what a tile stages is what its balls reach, the long tiles
-                                    // start first, and a tile that gives up costs 32 one-query searches), 6 144 without
+    uint32_t tile_cand_cap = 0;     // staged candidates after which a tile hands its pending queries on; 0 = 24 576 for a large layer with
+                                    // the matrix-pipe selection (round 5: what a tile stages is what its balls reach, the long tiles
+                                    // start first, and a tile that gives up costs 32 one-query searches), else 6 144
     uint32_t tile_cand_cap_easy = 0;  // ... for the tiles of the class served LAST (0 = the same)
     int      tile_bricks   = 1;     // tile kernel: wide groups list their voxels from the level-0 occupancy bricks and stay in
                                     // the tile (0 = round 3: a query beyond the deferral radius goes to the one-query kernel)
     uint32_t coop_max      = 0xFFFFFFFFu;  // tile kernel: a group of at most this many queries is handed to the one-query kernel;
-                                    // default: 0 with the selection (an isolated query stages little: it stays), 4 without
+                                    // default: 0 for a large layer with the selection (an isolated query stages little: it stays), else 4
     int      nn_cert       = 1;     // point-to-point search: skip the search of a query whose previous neighbour is certainly still
                                     // the nearest (NNArgs::lb2nd); 1 = bounds tracked after small steps only, 2 = always, 0 = off
     uint32_t nn_cert_step_mm = 5;   // ... "small": the farthest local point moved less than this since the previous call
@@ -166,8 +166,9 @@ struct Tune
     uint32_t copy_stage_mb = 256;   // ... and the bound of the page-locked staging buffer (larger lists go in rounds)
     int      tile_select   = 1;     // pt2pt search, round 5: the voxels a tile stages are SELECTED on the matrix pipe (a voxel is staged iff
                                     // some query's ball reaches its circumsphere) instead of by the group's bounding box (nn_seltile.hip)
-    int      nn_direct     = 0;     // ... 1 = the per-query prologue runs in the tile itself: no lane kernel, no pending list (measured slower
-                                    // on the bench chain, DESIGN.md section 4: the lane kernel's cost classes start the long tiles first)
+    int      nn_direct     = -1;    // ... 1 = the per-query prologue runs in the tile itself (no lane kernel, no pending list), 0 = behind the
+                                    // lane kernel (whose cost classes start the long tiles first: measured faster on the 1 M-point bench
+                                    // chain), -1 = in the tile for small layers (<= 262 144 points) only
     uint32_t grp_all_bricks = 6;    // ... all pending queries of a tile are served by ONE pass while their common box is at most this many
                                     // 4-voxel bricks wide (0 = always the seed's neighbourhood, the rule of rounds 1-4)
     int      tile_sol      = 0;     // speed-of-light decomposition of that kernel (TIMING ONLY, no results): 1 = list + select + stage,

@@ -1659,7 +1659,12 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     // round 5 (nn_seltile.hip): voxels selected on the matrix pipe; needs the level-0 occupancy bricks and the 32-query tile.
     // DIRECT: the per-query prologue runs in the tile itself (no lane kernel, no pending list)
     const bool sel    = ctx->tune.tile_select && Q == 32 && ctx->tune.mfma_scan && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE;
-    const bool direct = sel && ctx->tune.nn_direct;
+    // a SMALL layer (at most two rounds of resident tiles: 2 x 4 096 x 32 queries) is one wave of tiles -- the kernel is as
+    // long as its longest tile, and what a long tile hands on is spread over the idle CUs by the one-query kernel: the budgets of
+    // rounds 1-4, and the prologue in the tile (no hard-first order to lose, one launch less).  Measured on configuration C2
+    // (120 k x 2 M): 3 390 it/s against 3 030 with the large-layer policy, 3 280 with round 4's kernels.
+    const bool small_layer = n_l <= 262144;
+    const bool direct = sel && (ctx->tune.nn_direct < 0 ? small_layer : ctx->tune.nn_direct != 0);
     const int  sol    = (direct && ctx->tune.tile_sol >= 1 && ctx->tune.tile_sol <= 5) ? ctx->tune.tile_sol : 0;  // speed-of-light decomposition (timing only: no results, no state)
     const uint32_t n_boxes = direct ? (uint32_t)((n_l + 31) / 32) : n_waves;  // per-tile / per-wave bounding boxes
     MP2P_TRY_HIP(ctx, ctx->nn_rec.ensure(n_l));
@@ -1704,12 +1709,12 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.r_defer = prm->defer_radius_cells > 0 ? cell0 * prm->defer_radius_cells
                                              : fminf(fmaxf(1.0f, 2.0f * cell0), 4.0f * cell0);
     a.lane_cells    = std::min<uint32_t>(ctx->tune.lane_cells, 4u);
-    a.tile_cand_cap = ctx->tune.tile_cand_cap ? ctx->tune.tile_cand_cap : (sel ? 24576u : 6144u);
+    a.tile_cand_cap = ctx->tune.tile_cand_cap ? ctx->tune.tile_cand_cap : ((sel && !small_layer) ? 24576u : 6144u);
     a.tile_cand_cap_easy = (ctx->tune.hard_cand && ctx->tune.tile_cand_cap_easy) ? ctx->tune.tile_cand_cap_easy : a.tile_cand_cap;
     a.tile_bricks       = (ctx->tune.tile_bricks && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE) ? 1 : 0;
     a.tile_brick_budget = ctx->tune.tile_brick_budget;
     a.hard_cand         = ctx->tune.hard_cand;
-    a.coop_max          = ctx->tune.coop_max != 0xFFFFFFFFu ? ctx->tune.coop_max : (sel ? 0u : 4u);
+    a.coop_max          = ctx->tune.coop_max != 0xFFFFFFFFu ? ctx->tune.coop_max : ((sel && !small_layer) ? 0u : 4u);
     a.empty_room        = ctx->tune.empty_room;
     a.claim_dedup   = ctx->tune.claim_dedup;
     a.claim_peek    = ctx->tune.claim_peek;

@@ -660,8 +660,14 @@ static int stage_round(mp2p_hip_ctx* ctx, const unsigned char* dev, unsigned cha
     for (size_t k = 0; k < nc; k++)
     {
         const size_t off = k * s.chunk, len = std::min(s.chunk, round - off);
-        MP2P_TRY_HIP(ctx, hipMemcpyAsync(s.host + off, dev + off, len, hipMemcpyDeviceToHost, ctx->stream));
-        MP2P_TRY_HIP(ctx, hipEventRecord(s.ev[k], ctx->stream));
+        hipError_t   e   = hipMemcpyAsync(s.host + off, dev + off, len, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(s.ev[k], ctx->stream);
+        if (e != hipSuccess)
+        {
+            // some chunks are already on the link, into s.host: nobody may grow / free that buffer while they fly
+            (void)hipStreamSynchronize(ctx->stream);
+            MP2P_TRY_HIP(ctx, e);
+        }
     }
     if (nc > 1 && !s.th.joinable() && !s.no_helper)
     {

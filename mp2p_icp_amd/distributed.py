@@ -147,16 +147,10 @@ class HipBackend:
         dev = self.dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
         # pre-flight: mp2p_hip_comm_init can fail on ONE rank before it reaches ncclCommInitRank (librccl
         # not loadable there, a communicator already present) while its peers block inside it.  Every rank therefore
-        # first proves, locally, that it would get that far -- drawing an id dlopens librccl and resolves its symbols --
-        # and nobody calls comm_init unless all ranks can.
-        pre = 1
-        try:
-            probe = (C.c_uint8 * _lib.COMM_ID_BYTES)()
-            _lib.check(self.ctx._L.mp2p_hip_comm_get_unique_id(probe))
-            if self.ctx._L.mp2p_hip_comm_size(self.ctx.handle) != 0:
-                pre = 0
-        except Exception:
-            pre = 0
+        # first proves, locally, that it would get that far -- mp2p_hip_comm_available dlopens librccl, resolves its symbols
+        # and looks at the context, without side effects (drawing a throw-away unique id left a bootstrap
+        # listener thread and socket behind on every rank) -- and nobody calls comm_init unless all ranks can.
+        pre = 1 if self.ctx._L.mp2p_hip_comm_available(self.ctx.handle) == 0 else 0
         pf = torch.tensor([pre], dtype=torch.int32, device=dev)
         dist.all_reduce(pf, op=dist.ReduceOp.MIN, group=group)
         if int(pf.item()) != 1:

@@ -16,6 +16,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real AMD GPU (MI355X)")
+    config.addinivalue_line("markers", "perf: wall-time bounds (needs a GPU and a quiet box); NOT part of `-m gpu`: a busy box must not "
+                                       "turn the parity suite red -- run with `-m perf`")
 
 
 def _has_gpu():
@@ -31,7 +33,7 @@ def pytest_collection_modifyitems(config, items):
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for it in items:
-        if "gpu" in it.keywords:
+        if "gpu" in it.keywords or "perf" in it.keywords:
             it.add_marker(skip)
 
 

@@ -1,0 +1,36 @@
+"""bench.py --gpus 2 launched the way the driver launches it (torch.distributed.run, one rank per "GPU"), on a one-GPU box
+through the MP2P_BENCH_SHARE_GPU test hook (both ranks on GPU 0 over gloo: RCCL refuses two ranks per device; the numbers mean
+nothing, the code path -- sharded layer, claim exchange, 48 sums all-reduced per inner iteration, strong-scaling block -- is the
+one an 8-GPU node runs).  The first hardware run must be a measurement, not a debugging session."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu():
+    env = dict(os.environ, MP2P_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--n-local", "60000", "--n-global", "600000", "--scene", "a", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "strong_scaling", "value_strong_scaling", "parity_gate"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    s = d["strong_scaling"]
+    assert "error" not in s, s
+    assert s["scaling"] == "strong" and s["value"] > 0 and d["value_strong_scaling"] == s["value"]
+    # every rank solves the same all-reduced normal equations: one pose
+    assert s["final_pose_max_abs_diff_over_ranks"] == 0.0 and s["weak_chain_final_pose_max_abs_diff_over_ranks"] == 0.0
+    assert "skipped" in d["parity_gate"]                           # the gate runs at N = 1

@@ -2,6 +2,7 @@
 (adapter/mp2p_hip_host.hpp, through adapter/hostpath_capi.cpp) against host containers -- packed
 MatchState bit-fields in and out, 36-byte / 72-byte pair records out, a solver handed host Pairings --
 checked against the CPU oracle, plus what it may and may not transfer per call."""
+import os
 import time
 
 import numpy as np
@@ -304,7 +305,9 @@ def test_host_path_cost_at_full_size(oracle):
     assert c1["mstate_uploads"] == c0["mstate_uploads"] and c1["pairings_uploads"] == c0["pairings_uploads"], trace
     assert c1["map_uploads"] - c0["map_uploads"] <= 1 and c1["cloud_uploads"] - c0["cloud_uploads"] <= 1
     print(f"\n[host path] device-resident step {t_dev * 1e3:.3f} ms, host-container step {t_host * 1e3:.3f} ms")
-    assert t_host < 10.0 * t_dev + 2e-3, (t_host, t_dev)   # loose regression bound (timing on a shared box); bench.py host_boundary reports the ratio (1.8)
+    # (the wall-time bound lives under `-m perf`: tests/test_perf_bounds.py sets MP2P_PERF_ASSERTS; bench.py host_boundary reports the ratio)
+    if os.environ.get("MP2P_PERF_ASSERTS") == "1":
+        assert t_host < 3.0 * t_dev + 1e-3, (t_host, t_dev)
     s.close()
 
 

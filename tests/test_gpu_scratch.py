@@ -2,6 +2,7 @@
 call of a given size, a steady-state call makes no device allocation (mp2p_hip_debug_alloc_count stays put).  Covers the
 call sites that used to hipMalloc/hipFree per call: pt2ln_pl_to_pt2pt + Solver_Horn (horn.hip), Matcher_Points_InlierRatio,
 Matcher_Adaptive, FilterDecimateVoxels, covariance; plus the decimation time of 1 M points."""
+import os
 import time
 
 import numpy as np
@@ -139,5 +140,7 @@ def test_decimation_of_one_million_points_device_time(amd):
     assert 100_000 < m.value < n
     print(f"decimate 1M points (FirstPoint, 0.5 m): {dt:.3f} ms per call (wall, incl. the count read-back)")
     # a timing bound in a parity suite must not decide the run on a busy box (3.4 ms was seen once in round 4 against the
-    # usual 0.3-0.5): the allocation count above is the regression check; the time is only sanity-bounded
-    assert dt < 50.0, dt
+    # usual 0.3-0.5): the allocation count above is the regression check; the wall-time bound lives under `-m perf`
+    # (tests/test_perf_bounds.py sets MP2P_PERF_ASSERTS)
+    if os.environ.get("MP2P_PERF_ASSERTS") == "1":
+        assert dt < 3.0, dt

@@ -7,7 +7,9 @@
 //   the "global point already paired"    :94-121 (claims; resolved in pairs.hip)
 //
 // Three kernels, all one wave64 per workgroup; a query is finished by the first one that can
-// (DESIGN.md section 4 has the measurements behind every choice made here):
+// (DESIGN.md section 4 has the measurements behind every choice made here).  Since round 5 the tile kernel that runs is
+// nn_seltile_kernel (nn_seltile.hip: voxels selected on the matrix pipe); nn_tile_kernel below serves maps without a
+// level-0 occupancy bitmap (beyond the bitmap budget, or built with no_occupancy_bitmap) and the 16 / 64-query tile sizes:
 //
 //  nn_lane_kernel  -- ONE QUERY PER LANE, no LDS staging, no wave-level coordination.  The lane
 //     transforms its point (K1), reads its warm-start record, and -- when the cube its search

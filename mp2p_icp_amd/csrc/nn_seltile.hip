@@ -1,31 +1,46 @@
-// nn_seltile.hip -- round 5: the tile kernel of the point-to-point search with (1) the voxels of a pass SELECTED on the
-// matrix pipe and (2) the per-query prologue fused in (no lane kernel, no pending list).  Included by nn_query.hip.
+// nn_seltile.hip -- round 5: the tile kernel of the point-to-point search with the voxels of a pass SELECTED on the matrix
+// pipe, two matrix instructions per block instead of three, and (optionally) the per-query prologue fused in.  Included by
+// nn_query.hip; DESIGN.md section 4 "Round 5" has every measurement quoted here.
 //
 // What rounds 1-4 staged for a tile of 32 Morton-consecutive queries was every occupied voxel within the widest radius of
-// the BOUNDING BOX of the group's queries.  A CPU model of the bench chain (tools/cand_model.py, scene B, warm start from the
-// previous pose) says what that rule costs: 3 900 points per tile (p95 14 000, single tiles 10^5: the "heavy" tiles that ran
-// out of budget and sent 3.6 % of the layer to the one-query kernel = 35 % of the search) against 1 000 (p95 2 700) for the
-// voxels that some query's BALL really reaches -- the box rule stages the whole slab between a wall and the tile, the balls
-// only touch the wall near each query's foot point.  The exact rule is a box test per (voxel, query) pair -- dearer than the
-// distance tests it saves.  But its sphere relaxation is a bilinear form:
+// the BOUNDING BOX of the group's queries.  A CPU model of the bench chain (tools/cand_model.py: scene B, 1 M x 10 M, warm
+// start from the previous pose) says what that rule costs: 950-2 000 points per tile, p95 3 400-4 800, single tiles 10^5
+// (the tiles that ran out of budget and sent 3.6 % of the layer to the one-query kernel = 35 % of the search) against
+// 370-790 (p95 1 200-2 800) for the voxels some query's BALL really reaches -- the box rule stages the slab between a
+// wall and the tile, the balls only touch the wall near each query's foot point.  The exact rule is a box test per
+// (voxel, query) pair -- dearer than the distance tests it saves.  Its sphere relaxation is a bilinear form:
 //
 //     voxel v is needed by query m  <=  |c_v - q_m|^2 - (r_m + rho)^2 <= 0        (c_v = centre, rho = half diagonal)
-//                                    =  -2 q'.c' + |c'|^2 + (|q'|^2 - R_m^2)
 //
-// i.e. the SAME three v_mfma_f32_32x32x2_f32 as the distance prefilter with the roles swapped: rows = the tile's 32 queries,
-// columns = 32 listed voxels, so that a LANE ends up with one voxel's values against 16 queries: an integer min-tree over its
-// 16 accumulators + one ballot say which of the 32 voxels anybody needs.  ~40 instructions per 32 voxels x 32 queries;
-// the model: 1 200 staged points per tile (sphere) vs 1 000 (exact) vs 3 900 (box).  Only the needed voxels are resolved
-// through the directory and staged; the rest of the pass (staging rounds, distance prefilter, exact recomputation of the
-// survivors, claims) is the tile kernel of round 4.  Exactness is untouched: a query is final when its best distance is
-// below the radius of the BALL whose voxels were all staged (a voxel that intersects the ball has a point within r of the
-// query, hence its centre within r + rho), the selection only errs towards staging more (tolerance = twice the prefilter's
-// proven error bound + the fp32 slack of the voxel addressing).
+// i.e. the same v_mfma_f32_32x32x2_f32 as the distance prefilter with the roles swapped: rows = the tile's 32 queries,
+// columns = 32 listed voxels, so that a LANE ends up with one voxel's values against 16 queries: an integer min-tree over
+// its 16 accumulators + one ballot say which of the 32 voxels anybody needs (~40 instructions per 32 voxels x 32 queries;
+// the model: 480-900 points per tile, within 1.15-1.3 x of the exact rule; measured: 1 119 -> 771 staged per tile, the
+// longest tile 86 000 -> 9 000, queries handed to the one-query kernel 36 000 -> 12 000 -> 480 once the budget went up).
+// Only the needed voxels are resolved through the directory and staged; the rest of a pass (staging rounds, distance
+// prefilter, exact recomputation of the survivors, claims) is the tile kernel of round 4.  Exactness is untouched: a
+// query is final when its best distance is below the radius of the BALL whose voxels were all staged (a voxel that
+// intersects the ball has a point within r of the query, hence its centre within r + rho); the selection only errs
+// towards staging more (tolerance = four times the prefilter's proven error bound + the fp32 slack of the addressing).
 //
-// Fused prologue (DIRECT): tile t serves the queries 32 t .. 32 t + 31 of the Morton-sorted local layer: transform,
-// bounding box, threshold rule, MatchState / visit list, warm start, skip certificate -- what nn_lane_kernel did -- in the
-// tile's own lanes.  On the bench chain the lane kernel concluded nothing and wrote every query to the
-// pending list for the tile kernel to read back: 64 MB, one launch and one dependent load per tile.
+// Other changes of round 5, each measured on the headline chain (tile kernel 0.325 ms in round 4):
+//   * K = 4: the constant-per-column term |q'|^2 moves from the matrix product into the lane's limit (with an offset that
+//     keeps the integer min-tree's values non-negative): TWO matrix instructions per block of 32 candidates, not three --
+//     the matrix pipe (64 cycles per instruction and SIMD) is the prefilter's floor (0.117 -> 0.081 ms of the tile kernel);
+//   * every voxel is tested against every query's OWN ball, so all pending queries of a tile form ONE pass while their
+//     common box is a few bricks wide (1.36 -> 1.25 passes per tile);
+//   * the occupied voxels are listed by a wave-uniform loop over the non-empty bricks (v_mbcnt places), and a box of more
+//     than 64 bricks is entered through the level-2 occupancy words (one u64 per 4x4x4 BRICKS): a spatially loose tile of
+//     far-field points used to list 10^4 nearly empty bricks 64 per round (150 us for 4 000 candidates);
+//   * nothing is handed to the one-query kernel for being heavy or alone any more (budget 24 576, long tiles start first by
+//     the cost classes; an isolated query's ball stages little): that kernel went from 0.19 ms to 0.02 ms;
+//   * the empty-room bound of a query with nothing in reach is found by the tile itself.
+//
+// Fused prologue (DIRECT): tile t serves the queries 32 t .. 32 t + 31 of the Morton-sorted local layer itself -- transform,
+// bounding box, threshold rule, MatchState / visit list, warm start, skip certificate: what nn_lane_kernel does -- and no
+// pending list exists.  Measured SLOWER on the 1 M-point chain (tile 0.358 vs lane 0.020 + tile 0.286 ms: without the lane
+// kernel's cost classes the long tiles start late) and faster on small layers (one launch less, nothing to order: C2
+// 3 390 vs 3 300 it/s): the launch code takes it for layers of at most 262 144 points.
 #include "device_utils.hpp"
 
 namespace mp2p

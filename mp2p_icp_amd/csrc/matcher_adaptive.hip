@@ -51,8 +51,8 @@ __global__ __launch_bounds__(64) void adaptive_knn_kernel(const AdSearchArgs a)
     __shared__ float4   s_cand[PL_CAP];
     __shared__ uint32_t s_spos[PL_CAP];
     __shared__ uint32_t s_hit[PL_HITQ * 64];
-    __shared__ uint32_t s_cstart[64];
-    __shared__ uint32_t s_coff[65];
+    __shared__ uint32_t s_cstart[PL_CELLS];
+    __shared__ uint32_t s_coff[PL_CELLS + 1];
 
     const GridView& g    = a.g;
     const int       lane = threadIdx.x;

@@ -21,6 +21,9 @@ constexpr int      PL_CAP         = 256;
 constexpr int      PL_CB          = 256;  // queries per block of pt2pl_cert_kernel = one segment of the pending list
 constexpr int      PL_STAGE       = 4;    // staging loads in flight per lane (x 64 candidates per fetch)
 constexpr int      PL_HITQ        = 8;    // queued hits per lane before the insertion chains run
+constexpr int      PL_SB          = 4;    // batches of 64 voxels resolved together (round 5): their directory loads are in flight at once and
+constexpr int      PL_CELLS       = 64 * PL_SB;  // ... their points staged and scanned as ONE bucket list (a pass of <= 256 voxels: 2-3 dependent
+                                          // round trips instead of 8; a pass of a latency-bound 8-query tile cost 19 us)
 constexpr uint32_t PL_CELL_BUDGET  = 256;   // voxels per pass; measured insensitive 256..4096
 constexpr float    PL_GROUP_FACTOR = 4.0f;  // group extent in search radii; insensitive 1.5..4
 
@@ -225,6 +228,7 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
             }
         }
         const float hs     = g.hf * (float)(1u << s);
+        const float inv_nx = 1.0f / (float)max(nx, 1u), inv_ny = 1.0f / (float)max(ny, 1u);
         // CERT: voxels up to cert_margin beyond the largest radius are staged too, so that the region this pass
         // covers completely reaches that far beyond every query of the group (the corner voxels of the box)
         const float prune  = rmax_t + 4.f * g.slack + (CERT ? cert_margin : 0.f);
@@ -240,33 +244,51 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
         float kth = kth_d2(kd2, knn);  // INFINITY for the lanes of this pass
         const float r2 = r * r;
 
-        for (unsigned long long cb = 0; cb < ncell; cb += 64)
+        for (unsigned long long cb = 0; cb < ncell; cb += PL_CELLS)
         {
-            const unsigned long long cid = cb + lane;
-            uint32_t                 cnt = 0, start = 0;
-            if (cid < ncell)
+            // ---- PL_SB batches of 64 voxels: all their directory loads first (independent), then one prefix over the 256 ----------
+            uint32_t cst[PL_SB], ccn[PL_SB];
+#pragma unroll
+            for (int u = 0; u < PL_SB; u++)
             {
-                const uint32_t ix = (uint32_t)(cid % nx), iy = (uint32_t)((cid / nx) % ny),
-                               iz = (uint32_t)(cid / ((unsigned long long)nx * ny));
-                const uint32_t cx = cx0 + ix, cy = cy0 + iy, cz = cz0 + iz;
-                const float vx0 = g.ox + (float)cx * hs, vy0 = g.oy + (float)cy * hs,
-                            vz0 = g.oz + (float)cz * hs;
-                const float dx = fmaxf(0.f, fmaxf(vx0 - qhx, qlx - (vx0 + hs)));
-                const float dy = fmaxf(0.f, fmaxf(vy0 - qhy, qly - (vy0 + hs)));
-                const float dz = fmaxf(0.f, fmaxf(vz0 - qhz, qlz - (vz0 + hs)));
-                if (dx * dx + dy * dy + dz * dz <= prune2)
+                const unsigned long long cid = cb + 64ull * (unsigned long long)u + (unsigned long long)lane;
+                uint32_t                 cnt = 0, start = 0;
+                if (cid < ncell)
                 {
-                    uint32_t e = 0;
-                    if (voxel_range(g, lev, cx, cy, cz, start, e, false)) cnt = e - start;
-                    else start = 0;
+                    uint32_t ix, iy, iz;
+                    if (ncell <= 65536ull)
+                    {   // (exact for these sizes: (c + 0.5) / n is at least 0.5 / n away from an integer; a 64-bit division is ~100 instructions)
+                        const uint32_t c32 = (uint32_t)cid, row = (uint32_t)(((float)c32 + 0.5f) * inv_nx);
+                        ix = c32 - row * nx, iz = (uint32_t)(((float)row + 0.5f) * inv_ny), iy = row - iz * ny;
+                    }
+                    else
+                        ix = (uint32_t)(cid % nx), iy = (uint32_t)((cid / nx) % ny), iz = (uint32_t)(cid / ((unsigned long long)nx * ny));
+                    const uint32_t cx = cx0 + ix, cy = cy0 + iy, cz = cz0 + iz;
+                    const float vx0 = g.ox + (float)cx * hs, vy0 = g.oy + (float)cy * hs,
+                                vz0 = g.oz + (float)cz * hs;
+                    const float dx = fmaxf(0.f, fmaxf(vx0 - qhx, qlx - (vx0 + hs)));
+                    const float dy = fmaxf(0.f, fmaxf(vy0 - qhy, qly - (vy0 + hs)));
+                    const float dz = fmaxf(0.f, fmaxf(vz0 - qhz, qlz - (vz0 + hs)));
+                    if (dx * dx + dy * dy + dz * dz <= prune2)
+                    {
+                        uint32_t e = 0;
+                        if (voxel_range(g, lev, cx, cy, cz, start, e, false)) cnt = e - start;
+                        else start = 0;
+                    }
                 }
+                cst[u] = start, ccn[u] = cnt;
             }
-            const uint32_t incl  = wave_incl_scan(cnt, lane);
-            const uint32_t total = __shfl(incl, 63, 64);
+            uint32_t total = 0;
+#pragma unroll
+            for (int u = 0; u < PL_SB; u++)
+            {
+                const uint32_t incl = wave_incl_scan(ccn[u], lane);
+                s_cstart[64 * u + lane] = cst[u];
+                s_coff[64 * u + lane]   = total + incl - ccn[u];
+                total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
             dbg_cand += total;
-            s_cstart[lane] = start;
-            s_coff[lane]   = incl - cnt;
-            if (lane == 63) s_coff[64] = total;
+            if (lane == 63) s_coff[PL_CELLS] = total;
             __syncthreads();
             // ---- scan of the staged candidates.  With 64 different queries in a wave nearly every candidate
             //      enters SOMEBODY's list, so an insertion chain behind a per-candidate branch runs for all of
@@ -350,9 +372,9 @@ __device__ __forceinline__ void knn_search(const GridView& g, int lane, float qx
                 for (int u = 0; u < PL_STAGE; u++)
                 {
                     const uint32_t gt = base + min((uint32_t)lane + 64u * (uint32_t)u, m - 1u);
-                    int            lo = 0, hi = 63;
+                    int            lo = 0, hi = PL_CELLS - 1;
 #pragma unroll
-                    for (int it = 0; it < 6; it++)
+                    for (int it = 0; it < 8; it++)
                     {
                         const int mid = (lo + hi + 1) >> 1;
                         if (s_coff[mid] <= gt) lo = mid;
@@ -629,8 +651,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 4 :
     __shared__ float4   s_cand[PL_CAP];
     __shared__ uint32_t s_spos[PL_CAP];
     __shared__ uint32_t s_hit[PL_HITQ * 64];
-    __shared__ uint32_t s_cstart[64];
-    __shared__ uint32_t s_coff[65];
+    __shared__ uint32_t s_cstart[PL_CELLS];
+    __shared__ uint32_t s_coff[PL_CELLS + 1];
     if (blockIdx.x < n_hard_tiles)
     {
         const uint32_t cnt = min(a.list_cnt[1], a.hard_cap);
@@ -899,8 +921,8 @@ __global__ __launch_bounds__(64) void pt2pt_knn_kernel(const KnnArgs a)
     __shared__ float4   s_cand[PL_CAP];
     __shared__ uint32_t s_spos[PL_CAP];
     __shared__ uint32_t s_hit[PL_HITQ * 64];
-    __shared__ uint32_t s_cstart[64];
-    __shared__ uint32_t s_coff[65];
+    __shared__ uint32_t s_cstart[PL_CELLS];
+    __shared__ uint32_t s_coff[PL_CELLS + 1];
 
     const GridView& g    = a.g;
     const int       lane = threadIdx.x;

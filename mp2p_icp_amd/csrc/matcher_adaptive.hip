@@ -249,11 +249,21 @@ int launch_adaptive_search(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2
     if (rc) return rc;
 
     uint32_t h_mm[2] = {0, 0};
+    float    h_bb[6];
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(h_mm, minmax, sizeof(h_mm), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(h_bb, ctx->local_bbox.p, sizeof(h_bb), hipMemcpyDeviceToHost, ctx->stream));
     MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memset(hist, 0, sizeof(*hist));
     ctx->ad_knn = K, ctx->ad_cloud = cloud, ctx->ad_map = map;
     if (h_mm[0] == 0xFFFFFFFFu) return MP2P_HIP_OK;  // nobody found a neighbour: hist->valid = 0
+    // Matcher_Adaptive.cpp:78-81 returns before any search when the two boxes, inflated by the epsilon only, do not meet: no
+    // histogram exists then, although queries may well have neighbours within absoluteMaxSearchDistance (the selection step
+    // applies the same test and leaves no pairing)
+    {
+        const float eps = (float)prm->bounding_box_intersection_check_epsilon;
+        for (int d = 0; d < 3; d++)
+            if (h_bb[d] - eps > map->view.bbmax[d] || h_bb[3 + d] + eps < map->view.bbmin[d]) return MP2P_HIP_OK;
+    }
     hist->valid = 1;
     memcpy(&hist->minSqr, &h_mm[0], 4), memcpy(&hist->maxSqr, &h_mm[1], 4);
     const uint32_t nb = (uint32_t)std::min<size_t>((n_l + 255) / 256, 2048);

@@ -92,7 +92,12 @@ def test_fuzz_pt2pt(oracle, seed):
         assert pairs.potential_pairings == pot
 
 
-@pytest.mark.parametrize("seed", range(14))
+# (MP2P_FUZZ_PL_SEEDS=a:b runs another range of seeds: the end-of-round campaign of round 5 ran 14:214 after the directory of the
+#  k-nearest search was changed to 256 voxels per round trip)
+_PL_SEEDS = range(*[int(v) for v in os.environ.get("MP2P_FUZZ_PL_SEEDS", "0:14").split(":")])
+
+
+@pytest.mark.parametrize("seed", _PL_SEEDS)
 def test_fuzz_pt2pl_and_inlier_ratio(oracle, seed):
     import mp2p_icp_amd as amd
     rng = np.random.default_rng(5000 + seed)

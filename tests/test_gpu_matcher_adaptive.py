@@ -181,3 +181,34 @@ def test_appends_after_another_matcher_and_errors(amd, oracle):
     m.initialize(dict(kw, planeSearchPoints=20))
     with pytest.raises(amd.Mp2pHipError):
         m.match(pcG, pcL, pose, amd.MatchContext(), amd.MatchState(pcG, pcL), amd.Pairings())
+
+
+def test_boxes_apart_but_neighbours_in_reach(amd, oracle):
+    """Matcher_Adaptive.cpp:78-81 returns before any search when the boxes of the two layers, inflated by the epsilon only, do not
+    meet -- although absoluteMaxSearchDistance would still reach across the gap: no histogram, no pairing, nothing counted
+    (found by the pt2pl / adaptive fuzz campaign of round 5, seed 852: the histogram used to be reported valid)"""
+    g, l = _scene(95, n_g=20_000, n_l=2_000)
+    l = l[50:].copy()                      # (without the far points of the scene)
+    l[:, 2] += (g[:, 2].max() - l[:, 2].min()) + 0.5   # the scan lifted 0.5 m above the map's box
+    kw = dict(confidenceInterval=0.8, firstToSecondDistanceMax=1.2, absoluteMaxSearchDistance=1.5, minimumCorrDist=0.1,
+              enableDetectPlanes=True, maxPt2PtCorrespondences=2, planeSearchPoints=8, planeMinimumFoundPoints=4)
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pose = oracle.pose_identity()
+    # neighbours ARE in reach of the search radius
+    low = np.argsort(l[:, 2])[:200]
+    assert min(tree.knn((float(l[i, 0]), float(l[i, 1]), float(l[i, 2])), 1)[1][0] for i in low) < 1.5 * 1.5
+    r = oracle.match_adaptive(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, tree=tree, **kw)
+    assert not r["hist"]["valid"] and len(r["pt2pt"]) == 0 and len(r["pt2pl"]) == 0
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g)})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    for split in (False, True):
+        m = amd.Matcher_Adaptive()
+        m.initialize(kw)
+        called = []
+        if split:
+            m.threshold_from_histogram = lambda h: called.append(h) or 1.0
+        pairs = amd.Pairings()
+        assert m.match(pcG, pcL, pose, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+        assert not m.last_histogram["valid"] and not called
+        assert len(pairs.paired_pt2pt) == 0 and len(pairs.paired_pt2pl) == 0
+        assert pairs.potential_pairings == r["potential"]

@@ -39,7 +39,11 @@ def _cloud(rng, kind, n):
 KINDS = ["uniform", "clusters", "lattice", "plane", "line", "far_offset", "tiny"]
 
 
-@pytest.mark.parametrize("seed", range(36))
+# (MP2P_FUZZ_PT_SEEDS=a:b runs another range of seeds; campaigns: profiles/r05_fuzz_campaign.txt)
+_PT_SEEDS = range(*[int(v) for v in os.environ.get("MP2P_FUZZ_PT_SEEDS", "0:36").split(":")])
+
+
+@pytest.mark.parametrize("seed", _PT_SEEDS)
 def test_fuzz_pt2pt(oracle, seed):
     import mp2p_icp_amd as amd
     rng = np.random.default_rng(1000 + seed)
@@ -227,3 +231,95 @@ def test_fuzz_round4_search_paths(oracle, seed, monkeypatch):
         assert np.array_equal(got["localIdx"], want["localIdx"]), info
         assert np.array_equal(got["globalIdx"], want["globalIdx"]), info
         assert np.array_equal(got["errorSquareAfterTransformation"].view(np.uint32), want["errSq"].view(np.uint32)), info
+
+
+# ---- Solver_GaussNewton (optimal_tf_gauss_newton.cpp:60-330): random mixes of the four pairing kinds the device holds, robust kernels,
+#      pair weights, weight blocks, priors, iteration counts; pose within 1e-5 m / 1e-5 rad of the oracle on the same lists
+#      (MP2P_FUZZ_GN_SEEDS=a:b runs another range of seeds)
+_GN_SEEDS = range(*[int(v) for v in os.environ.get("MP2P_FUZZ_GN_SEEDS", "0:24").split(":")])
+
+
+def _unit(rng, n):
+    v = rng.normal(size=(n, 3))
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("seed", _GN_SEEDS)
+def test_fuzz_gauss_newton(oracle, seed):
+    import mp2p_icp_amd as amd
+    from test_gpu_gn import KERNELS, _to_hip_pl2pl, _to_hip_pt2ln, _to_hip_pt2pl, _to_hip_pt2pt
+    rng = np.random.default_rng(9000 + seed)
+    gt = oracle.pose_from_xyzypr(*rng.uniform(-1, 1, 3), *rng.uniform(-0.15, 0.15, 3))
+    R, t = gt[:9].reshape(3, 3), gt[9:]
+    ext = float(rng.choice([2.0, 10.0, 60.0]))
+    noise = float(rng.choice([0.0, 0.002, 0.02])) * ext / 10.0
+    n_pt, n_pl, n_ln, n_pp = [int(rng.integers(0, m)) if rng.random() < 0.7 else 0 for m in (4000, 1500, 800, 400)]
+    if n_pt + n_pl + n_ln < 12:
+        n_pt += 40                                           # enough terms for a well-posed system
+    # point-to-point (a share of gross outliers for the robust kernels)
+    g = rng.uniform(-ext, ext, (n_pt, 3))
+    loc = (g - t) @ R + rng.normal(0, noise, (n_pt, 3))
+    bad = rng.random(n_pt) < float(rng.choice([0.0, 0.05]))
+    loc[bad] += rng.uniform(-1, 1, (int(bad.sum()), 3)) * ext * 0.2
+    pt = np.zeros(n_pt, oracle.PAIR_PT2PT)
+    pt["gx"], pt["gy"], pt["gz"] = g.T.astype(np.float32)
+    pt["lx"], pt["ly"], pt["lz"] = loc.T.astype(np.float32)
+    pt["globalIdx"] = pt["localIdx"] = np.arange(n_pt)
+    # point-to-plane
+    w2 = rng.uniform(-ext, ext, (n_pl, 3))
+    nrm = _unit(rng, n_pl) * rng.uniform(0.8, 1.2, (n_pl, 1))
+    pl = np.zeros(n_pl, oracle.PAIR_PT2PL)
+    pl["plane"] = np.concatenate([nrm, -(nrm * (w2 + rng.normal(0, noise, (n_pl, 3)))).sum(1)[:, None]], 1)
+    pl["centroid"] = w2
+    pl["lx"], pl["ly"], pl["lz"] = ((w2 - t) @ R).T.astype(np.float32)
+    # point-to-line
+    base = rng.uniform(-ext, ext, (n_ln, 3))
+    u = _unit(rng, n_ln)
+    on_line = base + u * rng.uniform(-ext / 2, ext / 2, (n_ln, 1))
+    ln = np.zeros(n_ln, oracle.PAIR_PT2LN)
+    ln["pbase"], ln["director"] = base, u * rng.uniform(0.9, 1.1, (n_ln, 1))
+    ln["lx"], ln["ly"], ln["lz"] = ((on_line - t) @ R + rng.normal(0, noise, (n_ln, 3))).T
+    # plane-to-plane (normals)
+    cg, ng = rng.uniform(-ext, ext, (n_pp, 3)), _unit(rng, n_pp)
+    cl, nl = (cg - t) @ R, ng @ R
+    pp = np.zeros(n_pp, oracle.PAIR_PL2PL)
+    pp["pl_global"] = np.concatenate([ng, -(ng * cg).sum(1)[:, None]], 1) * rng.uniform(0.5, 1.5, (n_pp, 1))
+    pp["c_global"] = cg
+    pp["pl_local"] = np.concatenate([nl + rng.normal(0, 0.005, (n_pp, 3)), -(nl * cl).sum(1)[:, None]], 1)
+    pp["c_local"] = cl
+    kname, kid, kparam = KERNELS[int(rng.integers(0, len(KERNELS)))]
+    kparam = float(kparam * rng.choice([0.5, 1.0, 4.0]) * ext / 10.0)
+    iters = int(rng.integers(1, 9))
+    wts = {k: float(rng.choice([0.5, 1.0, 2.5])) for k in ("pt2pt", "pt2pl", "pt2ln", "pl2pl")}
+    T0 = oracle.pose_from_xyzypr(*(np.array(amd.se3.to_xyzypr(gt)) + np.concatenate([rng.normal(0, 0.05, 3), rng.normal(0, 0.02, 3)])))
+    blocks, reset = None, 0
+    if n_pt >= 10 and rng.random() < 0.3:                    # Pairings::point_weights over the pt2pt list
+        cut = sorted(rng.choice(np.arange(1, n_pt), size=min(int(rng.integers(1, 4)), n_pt - 1), replace=False).tolist())
+        cnt = np.diff([0] + cut + [n_pt]).tolist()
+        blocks, reset = [(int(c), float(rng.choice([0.25, 1.0, 3.0]))) for c in cnt], 1
+    prior, pm, pci = None, None, None
+    if rng.random() < 0.25:
+        pm = oracle.pose_from_xyzypr(*(np.array(amd.se3.to_xyzypr(gt)) + rng.normal(0, 0.01, 6)))
+        pci = np.diag(rng.choice([0.0, 10.0, 1000.0], 6))
+        prior = amd.PosePrior(pm, pci)
+    ctx = amd.default_context()
+    p = amd.Pairings.from_host(ctx, _to_hip_pt2pt(amd, pt) if n_pt else None, _to_hip_pt2pl(amd, pl) if n_pl else None,
+                               pt2ln=_to_hip_pt2ln(ln) if n_ln else None, pl2pl=_to_hip_pl2pl(pp) if n_pp else None,
+                               point_weights=blocks)
+    s = amd.Solver_GaussNewton()
+    s.initialize({"maxIterations": iters, "robustKernel": kname, "robustKernelParam": kparam,
+                  "pair_weights": dict(wts, ln2ln=1.0)})
+    sc = amd.SolverContext()
+    sc.guessRelativePose, sc.prior = T0, prior
+    out = amd.OptimalTF_Result()
+    assert s.optimal_pose(p, out, sc)
+    To, it, H, gg = oracle.optimal_tf_gauss_newton(
+        pt if n_pt else None, pl if n_pl else None, ln if n_ln else None, T0,
+        oracle.make_gn_params(iters, kernel=kid, kernelParam=kparam, w_pt2pt=wts["pt2pt"], w_pt2pl=wts["pt2pl"], w_pt2ln=wts["pt2ln"],
+                              w_pl2pl=wts["pl2pl"], prior_mean=pm, prior_cov_inv=pci, weight_blocks=blocks,
+                              reset_weight_cursor_each_iter=reset), pl2pl=pp if n_pp else None)
+    dt, dr = oracle.pose_err_split(out.optimalPose, To)
+    info = (seed, n_pt, n_pl, n_ln, n_pp, kname, kparam, iters, wts, blocks, prior is not None, ext, noise)
+    tol = 1e-4 if prior is not None else 1e-5             # (both sides differentiate the prior numerically: test_gpu_gn.py)
+    assert oracle.pose_err(To, T0) > 1e-6, info             # (the comparison is not between two untouched guesses)
+    assert dt < tol * max(1.0, ext / 10.0) and dr < tol, (dt, dr, info)

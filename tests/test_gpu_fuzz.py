@@ -323,3 +323,56 @@ def test_fuzz_gauss_newton(oracle, seed):
     tol = 1e-4 if prior is not None else 1e-5             # (both sides differentiate the prior numerically: test_gpu_gn.py)
     assert oracle.pose_err(To, T0) > 1e-6, info             # (the comparison is not between two untouched guesses)
     assert dt < tol * max(1.0, ext / 10.0) and dr < tol, (dt, dr, info)
+
+
+# ---- Matcher_Point2Plane over pose SEQUENCES on one matcher instance: the warm start (start radius from the previous k-th distance) and
+#      the skip certificate (a query whose previous list is certainly still its k nearest is not searched) only act from the second
+#      call on; steps from 1e-5 to 0.3 of the scene, back-and-forth jumps, repeated poses
+#      (MP2P_FUZZ_PLSEQ_SEEDS=a:b runs another range of seeds)
+_PLSEQ_SEEDS = range(*[int(v) for v in os.environ.get("MP2P_FUZZ_PLSEQ_SEEDS", "0:16").split(":")])
+
+
+@pytest.mark.parametrize("seed", _PLSEQ_SEEDS)
+def test_fuzz_pt2pl_pose_sequences(oracle, seed):
+    import mp2p_icp_amd as amd
+    rng = np.random.default_rng(7000 + seed)
+    kind = KINDS[seed % len(KINDS)]
+    n_g = int(rng.integers(300, 40000))
+    n_l = int(rng.integers(1, 4000))
+    g = _cloud(rng, kind, n_g).astype(np.float32)
+    scale = float(np.ptp(g, axis=0).max()) or 1.0
+    l = (g[rng.integers(0, len(g), n_l)].astype(np.float64) + rng.normal(0, 0.01 * scale, (n_l, 3))).astype(np.float32)
+    if rng.random() < 0.4:                       # some far outliers
+        k = max(1, n_l // 8)
+        l[:k] += (rng.uniform(-1, 1, (k, 3)) * scale * 2).astype(np.float32)
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g)})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    P = dict(distanceThreshold=float(rng.choice([0.02, 0.05, 0.2])) * scale, searchRadius=float(rng.choice([0.03, 0.1, 0.3])) * scale,
+             knn=int(rng.choice([5, 6, 9, 16])), minimumPlanePoints=int(rng.choice([3, 5])),
+             planeEigenThreshold=float(rng.choice([0.01, 0.1])))
+    m = amd.Matcher_Point2Plane()
+    m.initialize(P)
+    # (poses about the cloud's centre: a rotation about the origin of a far-offset cloud is a jump of its own)
+    c = g.mean(0).astype(np.float64)
+    to_c, from_c = amd.se3.exp(np.concatenate([-c, np.zeros(3)])), amd.se3.exp(np.concatenate([c, np.zeros(3)]))
+    xi = np.concatenate([rng.normal(0, 0.01 * scale, 3), rng.normal(0, 0.01, 3)])
+    seen = []
+    for call in range(7):
+        step = float(rng.choice([0.0, 1e-5, 1e-3, 1e-2, 0.3]))
+        if seen and rng.random() < 0.2:
+            xi = seen[int(rng.integers(0, len(seen)))].copy()           # back to an earlier pose
+        else:
+            xi = xi + np.concatenate([rng.normal(0, step * scale, 3), rng.normal(0, step, 3)])
+        seen.append(xi.copy())
+        T = amd.se3.compose(from_c, amd.se3.compose(amd.se3.exp(xi), to_c))
+        want, widx, pot = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, tree=tree, **P)
+        pairs = amd.Pairings()
+        assert m.match(pcG, pcL, T, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+        info = (seed, call, kind, n_g, n_l, P, step)
+        assert np.array_equal(pairs.paired_pt2pl_local_idx, widx), info
+        if len(widx):
+            s = max(1.0, float(np.abs(want["plane"]).max()))
+            assert np.allclose(pairs.paired_pt2pl["plane"], want["plane"], rtol=0, atol=1e-9 * s), info
+            assert np.allclose(pairs.paired_pt2pl["centroid"], want["centroid"], rtol=0, atol=1e-9 * s), info
+        assert pairs.potential_pairings == pot, info

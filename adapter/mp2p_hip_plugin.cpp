@@ -514,8 +514,8 @@ class Solver_GaussNewton : public mp2p_icp::Solver
         ASSERT_(sc.guessRelativePose.has_value());
         if (!pairings.paired_ln2ln.empty())
             THROW_EXCEPTION("HIP Gauss-Newton: paired_ln2ln is not supported");
-        if (pairings.point_weights.size() > 8)
-            THROW_EXCEPTION("HIP Gauss-Newton: more than 8 point_weights blocks are not supported");
+        if (pairings.point_weights.size() > MP2P_HIP_MAX_WEIGHT_BLOCKS)
+            THROW_EXCEPTION("HIP Gauss-Newton: more than 32 point_weights blocks are not supported");
         auto& rt = Runtime::get();
 
         mp2p_hip_pairs* dp = pairings_to_device(rt, pairings);
@@ -570,7 +570,7 @@ class Solver_Horn : public mp2p_icp::Solver
         mp2p_hip_host::RoctxRange roctx_range("align.3.2_solvers");  // the reference's profiler section (ICP.cpp:162)
         out = mp2p_icp::OptimalTF_Result();
         if (!pairings.paired_ln2ln.empty()) THROW_EXCEPTION("HIP Horn: paired_ln2ln is not supported");
-        if (pairings.point_weights.size() > 8) THROW_EXCEPTION("HIP Horn: more than 8 point_weights blocks are not supported");
+        if (pairings.point_weights.size() > MP2P_HIP_MAX_WEIGHT_BLOCKS) THROW_EXCEPTION("HIP Horn: more than 32 point_weights blocks are not supported");
         auto&                 rt  = Runtime::get();
         const mp2p_hip_pairs* eff = pairings_to_device(rt, pairings);
         const auto&           wp  = pairingsWeightParameters;

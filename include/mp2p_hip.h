@@ -432,6 +432,8 @@ enum
     MP2P_HIP_KERNEL_GEMANMCCLURE = 1,
     MP2P_HIP_KERNEL_CAUCHY       = 2
 };
+/* Pairings::point_weights blocks a solver call takes (round 5: 32; 8 before) */
+#define MP2P_HIP_MAX_WEIGHT_BLOCKS 32
 
 typedef struct
 {
@@ -444,10 +446,11 @@ typedef struct
     int32_t  has_prior;              /* SolverContext::prior */
     double   prior_mean[12];
     double   prior_cov_inv[36];
-    /* Pairings::point_weights run-length blocks for pt2pt; 0 blocks = none.  At most 8. */
+    /* Pairings::point_weights run-length blocks for pt2pt; 0 blocks = none.  At most MP2P_HIP_MAX_WEIGHT_BLOCKS
+     * (one block per layer pair that produced pairings, Matcher_Points_Base.cpp:121-125). */
     uint32_t n_weight_blocks;
-    uint64_t weight_block_count[8];
-    double   weight_block_w[8];
+    uint64_t weight_block_count[MP2P_HIP_MAX_WEIGHT_BLOCKS];
+    double   weight_block_w[MP2P_HIP_MAX_WEIGHT_BLOCKS];
     double   w_pt2ln, w_pl2pl;       /* PairWeights, for the host-produced lists */
 } mp2p_hip_gn_params;
 
@@ -489,7 +492,7 @@ typedef struct
     double  robust_kernel_param;
     int32_t has_current_estimate;
     double  current_estimate[12]; /* currentEstimateForRobust */
-    /* Pairings::point_weights (count, weight) blocks; 0 = one block of weight 1; at most 8 */
+    /* Pairings::point_weights (count, weight) blocks; 0 = one block of weight 1; at most MP2P_HIP_MAX_WEIGHT_BLOCKS */
     uint32_t      n_weight_blocks;
     const size_t* weight_block_count;
     const double* weight_block_w;

@@ -22,6 +22,7 @@ assert PAIR_PT2PT.itemsize == 36 and PAIR_PT2PL.itemsize == 72
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 KERNEL_NONE, KERNEL_GEMANMCCLURE, KERNEL_CAUCHY = 0, 1, 2
+MAX_WEIGHT_BLOCKS = 32  # MP2P_HIP_MAX_WEIGHT_BLOCKS
 GN_NSUMS = 48
 
 
@@ -117,8 +118,8 @@ class GNParams(C.Structure):
                 ("maxCost", C.c_double), ("kernel", C.c_int32), ("kernelParam", C.c_double),
                 ("w_pt2pt", C.c_double), ("w_pt2pl", C.c_double), ("has_prior", C.c_int32),
                 ("prior_mean", C.c_double * 12), ("prior_cov_inv", C.c_double * 36),
-                ("n_weight_blocks", C.c_uint32), ("weight_block_count", C.c_uint64 * 8),
-                ("weight_block_w", C.c_double * 8), ("w_pt2ln", C.c_double), ("w_pl2pl", C.c_double)]
+                ("n_weight_blocks", C.c_uint32), ("weight_block_count", C.c_uint64 * MAX_WEIGHT_BLOCKS),
+                ("weight_block_w", C.c_double * MAX_WEIGHT_BLOCKS), ("w_pt2ln", C.c_double), ("w_pl2pl", C.c_double)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)

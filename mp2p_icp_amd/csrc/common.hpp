@@ -280,7 +280,7 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<unsigned long long> timeline;     // profiling level 4: {start, end} ticks per workgroup
     size_t                           timeline_tiles = 0, timeline_singles = 0;
     mp2p::DevBuf<unsigned char>      horn_flags;   // Horn: scale-outlier flag per point pairing
-    mp2p::DevBuf<unsigned long long> horn_bounds;  //   first pair of each point_weights block, [8] = error
+    mp2p::DevBuf<unsigned long long> horn_bounds;  //   first pair of each point_weights block, [MP2P_HIP_MAX_WEIGHT_BLOCKS] = error
     size_t                           horn_n = 0;   //   pairings the flags belong to
     mp2p::DevBuf<unsigned long long> ad_hist;      // Matcher_Adaptive: 50 bins, count, {min,max} words
     uint32_t                         ad_knn   = 0;       //   lists held in nn_spos / nn_d2: neighbours per point,

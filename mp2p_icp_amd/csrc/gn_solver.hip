@@ -37,8 +37,8 @@ struct GnKernelPrm
     double c, c2;
     double w_pt2pt, w_pt2pl, w_pt2ln, w_pl2pl;
     uint32_t           n_blocks;  // weight blocks
-    unsigned long long blk_end[8];
-    double             blk_w[8];
+    unsigned long long blk_end[MP2P_HIP_MAX_WEIGHT_BLOCKS];
+    double             blk_w[MP2P_HIP_MAX_WEIGHT_BLOCKS];
 };
 
 // the linearisation point of the first inner iteration, as a kernel argument
@@ -723,7 +723,7 @@ static GnKernelPrm make_kernel_prm(const mp2p_hip_gn_params& p)
     k.w_pt2ln = p.w_pt2ln, k.w_pl2pl = p.w_pl2pl;
     k.n_blocks = p.n_weight_blocks;
     unsigned long long end = 0;
-    for (uint32_t b = 0; b < p.n_weight_blocks && b < 8; b++)
+    for (uint32_t b = 0; b < p.n_weight_blocks && b < MP2P_HIP_MAX_WEIGHT_BLOCKS; b++)
     {
         end += p.weight_block_count[b];
         k.blk_end[b] = end;
@@ -754,7 +754,7 @@ int gn_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* pairs, const double pose0[
              const mp2p_hip_gn_params* prm, bool lazy_init)
 {
     MP2P_REQUIRE(ctx, pairs && pose0 && prm, "null argument");
-    MP2P_REQUIRE(ctx, prm->n_weight_blocks <= 8, "at most 8 point_weights blocks are supported");
+    MP2P_REQUIRE(ctx, prm->n_weight_blocks <= MP2P_HIP_MAX_WEIGHT_BLOCKS, "at most 32 point_weights blocks are supported");
     // Pairings::point_weights semantics of this build: block b covers the next
     // weight_block_count[b] point pairings, at EVERY inner iteration.  The reference's cursor
     // (optimal_tf_gauss_newton.cpp:66-68, 159-167) is not reset between inner iterations (from the

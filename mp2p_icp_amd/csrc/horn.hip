@@ -25,8 +25,8 @@ struct HornKernelPrm
     GnKernelPrm        rk;  // robust kernel (kernel, c, c2)
     double             est[12];
     uint32_t           n_blocks;  // point_weights blocks (0: one block of weight 1)
-    unsigned long long blk_count[8];
-    double             blk_w[8];
+    unsigned long long blk_count[MP2P_HIP_MAX_WEIGHT_BLOCKS];
+    double             blk_w[MP2P_HIP_MAX_WEIGHT_BLOCKS];
 };
 
 // sums of the non-flagged pairs: global xyz, local xyz, their number
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(GN_THREADS) void horn_centroid_kernel(
 
 // The weight-block cursor of visit_correspondences.h:113-119 only moves on VISITED pairs (flagged
 // ones are skipped before it), by one block per pair: bounds[b] = first pair of block b as that
-// loop would see it.  One wave; bounds[8] = 1 when pairs remain after the last block (the
+// loop would see it.  One wave; bounds[MP2P_HIP_MAX_WEIGHT_BLOCKS] = 1 when pairs remain after the last block (the
 // reference then reads past point_weights.end()).
 __global__ __launch_bounds__(64) void horn_block_bounds_kernel(const unsigned char* __restrict__ outlier,
                                                                const unsigned long long* __restrict__ counts,
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(64) void horn_block_bounds_kernel(const unsigned ch
     }
     if (lane == 0)
     {
-        for (uint32_t k = b + 1; k < 8; k++) bounds[k] = n;
-        bounds[8] = (unsigned long long)bad;
+        for (uint32_t k = b + 1; k < MP2P_HIP_MAX_WEIGHT_BLOCKS; k++) bounds[k] = n;
+        bounds[MP2P_HIP_MAX_WEIGHT_BLOCKS] = (unsigned long long)bad;
     }
 }
 
@@ -255,7 +255,7 @@ static int horn_pass(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const HornKerne
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(h, sums, 20 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     unsigned long long bad_blocks = 0;
     if (k.n_blocks)
-        MP2P_TRY_HIP(ctx, hipMemcpyAsync(&bad_blocks, ctx->horn_bounds.p + 8, sizeof(bad_blocks),
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(&bad_blocks, ctx->horn_bounds.p + MP2P_HIP_MAX_WEIGHT_BLOCKS, sizeof(bad_blocks),
                                          hipMemcpyDeviceToHost, ctx->stream));
     MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
     MP2P_REQUIRE(ctx, bad_blocks == 0, "Pairings::point_weights blocks cover fewer pairs than paired_pt2pt");
@@ -269,12 +269,12 @@ int horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const mp2p_hip_horn_p
     memset(res, 0, sizeof(*res));
     // optimal_tf_horn.cpp:207-209
     MP2P_REQUIRE(ctx, w->w_pt2pt >= 0.0 && w->w_ln2ln >= 0.0 && w->w_pl2pl >= 0.0, "pair weights must be >= 0");
-    MP2P_REQUIRE(ctx, w->n_weight_blocks <= 8, "at most 8 point_weights blocks are supported");
+    MP2P_REQUIRE(ctx, w->n_weight_blocks <= MP2P_HIP_MAX_WEIGHT_BLOCKS, "at most 32 point_weights blocks are supported");
     MP2P_REQUIRE(ctx, w->robust_kernel == MP2P_HIP_KERNEL_NONE || w->has_current_estimate,
                  "robust kernel needs currentEstimateForRobust (visit_correspondences.h:197)");
     MP2P_TRY_HIP(ctx, ctx->gn_partials.ensure((size_t)GN_BLOCKS * NS));  // >= HORN_BLOCKS*16
     MP2P_TRY_HIP(ctx, ctx->gn_sums.ensure(NS));
-    MP2P_TRY_HIP(ctx, ctx->horn_bounds.ensure(16));
+    MP2P_TRY_HIP(ctx, ctx->horn_bounds.ensure(MP2P_HIP_MAX_WEIGHT_BLOCKS + 8));
     unsigned long long h_counts[8];
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(h_counts, P->counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, ctx->stream));
     MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));

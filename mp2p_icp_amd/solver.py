@@ -127,8 +127,8 @@ class Solver_GaussNewton(Solver):
             p.prior_cov_inv = (C.c_double * 36)(*sc.prior.cov_inv.ravel())
         p.n_weight_blocks = 0
         if point_weights:
-            if len(point_weights) > 8:
-                raise ValueError("at most 8 point_weights blocks are supported")
+            if len(point_weights) > _lib.MAX_WEIGHT_BLOCKS:
+                raise ValueError("at most 32 point_weights blocks are supported")
             p.n_weight_blocks = len(point_weights)
             for i, (cnt, w) in enumerate(point_weights):
                 p.weight_block_count[i] = int(cnt)

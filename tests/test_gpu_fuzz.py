@@ -294,7 +294,7 @@ def test_fuzz_gauss_newton(oracle, seed):
     T0 = oracle.pose_from_xyzypr(*(np.array(amd.se3.to_xyzypr(gt)) + np.concatenate([rng.normal(0, 0.05, 3), rng.normal(0, 0.02, 3)])))
     blocks, reset = None, 0
     if n_pt >= 10 and rng.random() < 0.3:                    # Pairings::point_weights over the pt2pt list
-        cut = sorted(rng.choice(np.arange(1, n_pt), size=min(int(rng.integers(1, 4)), n_pt - 1), replace=False).tolist())
+        cut = sorted(rng.choice(np.arange(1, n_pt), size=min(int(rng.integers(1, 32)), n_pt - 1), replace=False).tolist())
         cnt = np.diff([0] + cut + [n_pt]).tolist()
         blocks, reset = [(int(c), float(rng.choice([0.25, 1.0, 3.0]))) for c in cnt], 1
     prior, pm, pci = None, None, None

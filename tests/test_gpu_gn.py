@@ -385,3 +385,37 @@ def test_covariance_vs_oracle(amd, oracle):
     cov, Hg, pd = core.covariance(ctx, p.device, gt)
     wc, wH, wok = oracle.covariance(None, None, None, pp, gt)
     assert pd == wok
+
+
+def test_more_than_eight_weight_blocks(amd, oracle):
+    """up to MP2P_HIP_MAX_WEIGHT_BLOCKS = 32 `point_weights` blocks (one per layer pair that produced pairings,
+    Matcher_Points_Base.cpp:121-125; rounds 1-4 took 8): Gauss-Newton over 1 and 4 inner iterations and Horn against the oracle,
+    33 blocks refused"""
+    from mp2p_icp_amd.solver import WeightParameters, optimal_tf_horn
+    rng = np.random.default_rng(77)
+    n = 6000
+    l = rng.uniform(-10, 10, (n, 3))
+    g = l + rng.normal(0, 0.05, (n, 3)) + np.array([0.15, -0.1, 0.05])
+    pt = np.zeros(n, oracle.PAIR_PT2PT)
+    pt["lx"], pt["ly"], pt["lz"] = l.T.astype(np.float32)
+    pt["gx"], pt["gy"], pt["gz"] = g.T.astype(np.float32)
+    for nb in (9, 20, 32):
+        cut = np.sort(rng.choice(np.arange(1, n), nb - 1, replace=False))
+        blocks = [(int(c), float(w)) for c, w in zip(np.diff(np.concatenate([[0], cut, [n]])), rng.choice([0.25, 0.5, 1.0, 2.0, 4.0], nb))]
+        for iters in (1, 4):
+            out = _solve(amd, pt, None, None, {"maxIterations": iters, "robustKernel": "RobustKernel::GemanMcClure",
+                                               "robustKernelParam": 0.3}, point_weights=blocks)
+            To, it, H, gg = oracle.optimal_tf_gauss_newton(
+                pt, None, None, oracle.pose_identity(),
+                oracle.make_gn_params(iters, kernel=oracle.KERNEL_GEMANMCCLURE, kernelParam=0.3, weight_blocks=blocks,
+                                      reset_weight_cursor_each_iter=1))
+            assert _close(oracle, out.optimalPose, To), (nb, iters)
+            assert np.allclose(out.gn["H"], H, rtol=1e-9, atol=1e-9 * np.abs(H).max())
+        # Horn with the same blocks
+        To, rc, fl = oracle.optimal_tf_horn_wp(pt, None, point_weights=blocks)
+        res = amd.OptimalTF_Result()
+        p = amd.Pairings.from_host(amd.default_context(), _to_hip_pt2pt(amd, pt), point_weights=blocks)
+        assert optimal_tf_horn(p, WeightParameters(), res) and rc == 1
+        assert _close(oracle, res.optimalPose, To), nb
+    with pytest.raises((ValueError, amd.Mp2pHipError)):
+        _solve(amd, pt, None, None, {"maxIterations": 1}, point_weights=[(1, 1.0)] * 32 + [(n - 32, 1.0)])

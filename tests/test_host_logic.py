@@ -155,7 +155,8 @@ def test_solver_gating_and_parameters(amd):
     assert p.kernelParam == pytest.approx(0.3) and p.n_weight_blocks == 2 and p.minDelta == 1e-7
     assert (p.weight_block_count[1], p.weight_block_w[1]) == (20, 2.0)
     with pytest.raises(ValueError):
-        g.gn_params(amd.SolverContext(), point_weights=[(1, 1.0)] * 9)
+        g.gn_params(amd.SolverContext(), point_weights=[(1, 1.0)] * 33)   # MP2P_HIP_MAX_WEIGHT_BLOCKS = 32
+    assert g.gn_params(amd.SolverContext(), point_weights=[(1, 1.0)] * 32).n_weight_blocks == 32
 
     w = WeightParameters()
     w.load_from({"use_scale_outlier_detector": True, "robust_kernel": "RobustKernel::GemanMcClure",

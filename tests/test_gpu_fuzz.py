@@ -376,3 +376,68 @@ def test_fuzz_pt2pl_pose_sequences(oracle, seed):
             assert np.allclose(pairs.paired_pt2pl["plane"], want["plane"], rtol=0, atol=1e-9 * s), info
             assert np.allclose(pairs.paired_pt2pl["centroid"], want["centroid"], rtol=0, atol=1e-9 * s), info
         assert pairs.potential_pairings == pot, info
+
+
+# ---- Matcher_Points_Base::impl_match over random LAYER configurations (Matcher_Points_Base.cpp:30-130): 1-3 global x 1-3 local layers of
+#      random sizes, default same-name matching or a random `pointLayerMatches` list (weights on some entries, entries naming layers a map
+#      lacks), the MatchState flags; pair order, `point_weights` blocks and `potential_pairings` against the oracle run layer pair by layer
+#      pair in std::map order with the MatchState bits carried along (MP2P_FUZZ_LAYER_SEEDS=a:b runs another range of seeds)
+_LAYER_SEEDS = range(*[int(v) for v in os.environ.get("MP2P_FUZZ_LAYER_SEEDS", "0:12").split(":")])
+
+
+@pytest.mark.parametrize("seed", _LAYER_SEEDS)
+def test_fuzz_layer_configurations(oracle, seed):
+    import mp2p_icp_amd as amd
+    from test_gpu_multilayer import _oracle_layers, _same
+    rng = np.random.default_rng(11000 + seed)
+    kind = KINDS[seed % (len(KINDS) - 1)]                                  # (not "tiny")
+    base = _cloud(rng, kind, int(rng.integers(2000, 20000))).astype(np.float32)
+    scale = float(np.ptp(base, axis=0).max()) or 1.0
+    names = ["a", "b", "c", "d"]
+    G = {n: base[rng.random(len(base)) < rng.uniform(0.2, 0.9)] for n in rng.choice(names, int(rng.integers(1, 4)), replace=False)}
+    G = {k: (v if len(v) else base[:5]) for k, v in G.items()}
+    L = {}
+    for n in rng.choice(names, int(rng.integers(1, 4)), replace=False):
+        k = int(rng.integers(1, 1500))
+        L[n] = (base[rng.integers(0, len(base), k)].astype(np.float64) + rng.normal(0, 0.01 * scale, (k, 3))).astype(np.float32)
+    thr = float(rng.choice([0.02, 0.05, 0.2])) * scale
+    allow_l, allow_g = bool(rng.random() < 0.3), bool(rng.random() < 0.3)
+    T = amd.se3.exp(np.concatenate([rng.normal(0, 0.005 * scale, 3), np.zeros(3)]))
+    params = {"threshold": thr, "thresholdAngularDeg": 0.0, "allowMatchAlreadyMatchedPoints": allow_l,
+              "allowMatchAlreadyMatchedGlobalPoints": allow_g}
+    throws = False
+    if rng.random() < 0.3:                                                  # default: every global layer against its namesake
+        plan = [(n, n, None) for n in sorted(G)]                            # (a missing namesake is skipped, :74-78)
+    else:
+        cfg, seen = [], set()
+        for _ in range(int(rng.integers(1, 6))):
+            gn = str(rng.choice(names))
+            ln = str(rng.choice(names if rng.random() < 0.15 else sorted(L)))   # (now and then a layer the local map lacks)
+            if (gn, ln) in seen:
+                continue
+            seen.add((gn, ln))
+            e = {"global": gn, "local": ln}
+            if rng.random() < 0.6:
+                e["weight"] = float(rng.choice([0.5, 1.0, 2.0]))
+            cfg.append(e)
+        params["pointLayerMatches"] = cfg
+        # the loop runs over the global map's layers in name order, then that layer's entries in local-name order (:40-67); every
+        # configured entry carries a weight (1 when not given), and one naming a local layer the map lacks throws (:79-86)
+        plan = [(e["global"], e["local"], e.get("weight", 1.0)) for e in sorted(cfg, key=lambda e: (e["global"], e["local"]))
+                if e["global"] in G]
+        throws = any(ln not in L for _, ln, _ in plan)
+    pcG = amd.metric_map_t({k: amd.PointLayer(v) for k, v in G.items()})
+    pcL = amd.metric_map_t({k: amd.PointLayer(v) for k, v in L.items()})
+    m = amd.Matcher_Points_DistanceThreshold()
+    m.initialize(params)
+    pairs = amd.Pairings()
+    info = (seed, kind, {k: len(v) for k, v in G.items()}, {k: len(v) for k, v in L.items()}, params)
+    if throws:
+        with pytest.raises(RuntimeError, match="not found"):
+            m.match(pcG, pcL, T, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+        return
+    assert m.match(pcG, pcL, T, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs), info
+    want, blocks, pot = _oracle_layers(oracle, G, L, T, thr, plan, allow_local=allow_l, allow_global=allow_g)
+    _same(pairs.paired_pt2pt, want)
+    assert pairs.point_weights == blocks, (pairs.point_weights, blocks, info)
+    assert pairs.potential_pairings == pot, info

@@ -441,3 +441,53 @@ def test_fuzz_layer_configurations(oracle, seed):
     _same(pairs.paired_pt2pt, want)
     assert pairs.point_weights == blocks, (pairs.point_weights, blocks, info)
     assert pairs.potential_pairings == pot, info
+
+
+# ---- optimal_tf_horn with WeightParameters (optimal_tf_horn.cpp:77-252, visit_correspondences.h:38-212): random scenes, pair weights,
+#      robust kernels with an estimate, the scale outlier detector, up to 32 point_weights blocks (incl. blocks that run out: the reference
+#      throws); pose 1e-5, flagged outliers equal (MP2P_FUZZ_HORN_SEEDS=a:b runs another range of seeds)
+_HORN_SEEDS = range(*[int(v) for v in os.environ.get("MP2P_FUZZ_HORN_SEEDS", "0:16").split(":")])
+
+
+@pytest.mark.parametrize("seed", _HORN_SEEDS)
+def test_fuzz_horn(oracle, seed):
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd.solver import WeightParameters, optimal_tf_horn
+    from test_gpu_gn import _to_hip_pl2pl, _to_hip_pt2pt
+    from test_oracle_kat import horn_scene
+    rng = np.random.default_rng(13000 + seed)
+    n_pt, n_pl = int(rng.integers(3, 6000)), int(rng.integers(0, 300)) if rng.random() < 0.5 else 0
+    n_out = int(n_pt * rng.choice([0.0, 0.05, 0.2]))
+    gt, pt, pl = horn_scene(oracle, 14000 + seed, n_pt=n_pt, n_pl=n_pl, noise=float(rng.choice([0.0, 0.01, 0.05])), outliers=n_out)
+    kw = dict(w_pt2pt=float(rng.choice([0.3, 1.0, 2.0])), w_pl2pl=float(rng.choice([0.5, 1.0, 4.0])))
+    if rng.random() < 0.4:
+        kw.update(use_scale_outlier_detector=True, scale_outlier_threshold=float(rng.choice([1.05, 1.2, 1.5])))
+    if rng.random() < 0.4:
+        kw.update(robust_kernel=int(rng.choice([1, 2])), robust_kernel_param=float(rng.choice([0.3, 1.0])),
+                  currentEstimateForRobust=gt if rng.random() < 0.5 else oracle.pose_identity())
+    blocks = None
+    if n_pt >= 40 and rng.random() < 0.4:
+        cut = np.sort(rng.choice(np.arange(1, n_pt), int(rng.integers(1, 32)), replace=False))
+        cnt = np.diff(np.concatenate([[0], cut, [n_pt]])).tolist()
+        if rng.random() < 0.15:
+            cnt[-1] = max(1, cnt[-1] // 2)                                  # blocks that cover fewer pairs than the list
+        blocks = [(int(c), float(rng.choice([0.25, 1.0, 3.0]))) for c in cnt]
+    okw = {{"currentEstimateForRobust": "current_estimate"}.get(k, k): v for k, v in kw.items()}
+    To, rc, fl = oracle.optimal_tf_horn_wp(pt, pl if n_pl else None, point_weights=blocks, **okw)
+    w = WeightParameters()
+    for k, v in kw.items():
+        setattr(w.pair_weights, k[2:], v) if k.startswith("w_") else setattr(w, k, v)
+    p = amd.Pairings.from_host(amd.default_context(), _to_hip_pt2pt(amd, pt), point_weights=blocks,
+                               pl2pl=_to_hip_pl2pl(pl) if n_pl else None)
+    out = amd.OptimalTF_Result()
+    info = (seed, n_pt, n_pl, n_out, kw.keys(), None if blocks is None else len(blocks), rc)
+    if rc == -1:                                                            # where the reference throws
+        with pytest.raises((amd.Mp2pHipError, RuntimeError, ValueError)):
+            optimal_tf_horn(p, w, out)
+        return
+    ok = optimal_tf_horn(p, w, out)
+    assert bool(ok) == (rc == 1), info
+    if rc == 1:
+        dt, dr = oracle.pose_err_split(out.optimalPose, To)
+        assert dt < 1e-5 and dr < 1e-5, (dt, dr, info)
+        assert out.outliers == np.flatnonzero(fl).tolist(), info

@@ -491,3 +491,32 @@ def test_fuzz_horn(oracle, seed):
         dt, dr = oracle.pose_err_split(out.optimalPose, To)
         assert dt < 1e-5 and dr < 1e-5, (dt, dr, info)
         assert out.outliers == np.flatnonzero(fl).tolist(), info
+
+
+# ---- FilterDecimateVoxels (FilterDecimateVoxels.cpp, PointCloudToVoxelGrid.cpp:57-92): random geometries (far offsets, lattices whose
+#      points sit on voxel faces, duplicates, both signs), resolutions, the three deterministic methods, flatten_to; points and source
+#      indices bit for bit (MP2P_FUZZ_DECIM_SEEDS=a:b runs another range of seeds)
+_DECIM_SEEDS = range(*[int(v) for v in os.environ.get("MP2P_FUZZ_DECIM_SEEDS", "0:14").split(":")])
+
+
+@pytest.mark.parametrize("seed", _DECIM_SEEDS)
+def test_fuzz_filter_decimate(oracle, seed):
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import core
+    rng = np.random.default_rng(15000 + seed)
+    kind = KINDS[seed % len(KINDS)]
+    pts = _cloud(rng, kind, int(rng.integers(1, 40000))).astype(np.float32)
+    if rng.random() < 0.5:
+        pts -= pts.mean(0).astype(np.float32)                               # both signs: the cells that touch 0
+    if rng.random() < 0.3 and len(pts) > 20:
+        pts[len(pts) // 2:len(pts) // 2 + len(pts) // 10] = pts[:len(pts) // 10]   # duplicates
+    scale = float(np.ptp(pts, axis=0).max()) or 1.0
+    res = float(rng.choice([0.003, 0.02, 0.1, 0.5])) * scale
+    method = int(rng.integers(0, 3))
+    flat = float(rng.normal(0, scale)) if rng.random() < 0.25 else None
+    want, wsrc = oracle.filter_decimate_voxels(pts[:, 0], pts[:, 1], pts[:, 2], res, method, flatten_to=flat)
+    xyz, src = core.filter_decimate_voxels(amd.default_context(), pts[:, 0], pts[:, 1], pts[:, 2], res, method, flatten_to=flat)
+    info = (seed, kind, len(pts), res, method, flat)
+    assert xyz.shape == want.shape, info
+    assert np.array_equal(xyz.view(np.uint32), want.view(np.uint32)), info
+    assert np.array_equal(src, wsrc), info

@@ -520,3 +520,49 @@ def test_fuzz_filter_decimate(oracle, seed):
     assert xyz.shape == want.shape, info
     assert np.array_equal(xyz.view(np.uint32), want.view(np.uint32)), info
     assert np.array_equal(src, wsrc), info
+
+
+# ---- the HOST path of the boundary (adapter/mp2p_hip_host.hpp through libmp2p_hip_hostpath.so): packed MatchState words in, pair records
+#      and marks out, over layer sizes that are no multiple of 64, random pre-marked bits (none / sparse / dense / all), the allow flags,
+#      and TWO matcher calls in one ICP iteration (the second sees the marks of the first); lists and bit-fields against the oracle
+#      (MP2P_FUZZ_HOST_SEEDS=a:b runs another range of seeds)
+_HOST_SEEDS = range(*[int(v) for v in os.environ.get("MP2P_FUZZ_HOST_SEEDS", "0:12").split(":")])
+
+
+@pytest.mark.parametrize("seed", _HOST_SEEDS)
+def test_fuzz_host_path_match_state(oracle, seed):
+    from mp2p_icp_amd import hostpath
+    from test_gpu_boundary_hostpath import _pt2pt_prm, _same_pt2pt, _xyz
+    import mp2p_icp_amd as amd
+    rng = np.random.default_rng(17000 + seed)
+    kind = KINDS[seed % (len(KINDS) - 1)]
+    g = _cloud(rng, kind, int(rng.integers(70, 30000))).astype(np.float32)
+    scale = float(np.ptp(g, axis=0).max()) or 1.0
+    n_l = int(rng.integers(1, 5000))
+    l = (g[rng.integers(0, len(g), n_l)].astype(np.float64) + rng.normal(0, 0.01 * scale, (n_l, 3))).astype(np.float32)
+    dens = [float(rng.choice([0.0, 0.0, 0.02, 0.5, 1.0])) for _ in range(2)]
+    lt0, gt0 = rng.random(n_l) < dens[0], rng.random(len(g)) < dens[1]
+    tree = oracle.KDTree(*_xyz(g))
+    T = amd.se3.exp(np.concatenate([rng.normal(0, 0.005 * scale, 3), np.zeros(3)]))
+    s = hostpath.Session(g, l)
+    try:
+        s.begin_iteration()
+        if lt0.any():
+            s.set_bits(1, lt0)
+        if gt0.any():
+            s.set_bits(0, gt0)
+        lt, gt = lt0.astype(np.uint8), gt0.astype(np.uint8)
+        want_all = []
+        for call in range(2):
+            thr = float(rng.choice([0.02, 0.05, 0.2])) * scale
+            al, ag = bool(rng.random() < 0.3), bool(rng.random() < 0.3)
+            s.match_pt2pt(T, _pt2pt_prm(thr, allowMatchAlreadyMatchedPoints=int(al), allowMatchAlreadyMatchedGlobalPoints=int(ag)))
+            want, _ = oracle.match_pt2pt(*_xyz(g), *_xyz(l), T, thr, 0.0, tree=tree, local_taken=lt, global_taken=gt,
+                                         allowMatchAlreadyMatchedPoints=al, allowMatchAlreadyMatchedGlobalPoints=ag)
+            want_all.append(want)
+            info = (seed, call, kind, len(g), n_l, dens, thr, al, ag)
+            got = s.pairs_pt2pt()                                           # the session's list: both calls' pairs, in call order
+            _same_pt2pt(got, np.concatenate(want_all))
+            assert np.array_equal(s.bits(1), lt.astype(bool)) and np.array_equal(s.bits(0), gt.astype(bool)), info
+    finally:
+        s.close()

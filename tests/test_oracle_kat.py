@@ -840,3 +840,82 @@ def test_multithread_baseline_equals_the_sequential_loop():
     far = se3.compose(pose, se3.from_xyzypr(500.0, 0.0, 0.0))
     got, _ = orc.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], far, 0.8, 0.0, tree=tree, threads=4)
     assert len(got) == 0
+
+
+# ---- the oracle's matcher against a definition written in numpy alone (no KD-tree, none of the oracle's own helpers): every parity claim
+#      of the GPU path rests on the oracle, and the reference's own matcher test holds a single configuration.  Random geometries incl.
+#      lattices (exact ties: the lowest index wins), duplicates, clouds far from the origin, degenerate ones; sequential, with the tree,
+#      and multi-threaded.
+@pytest.mark.parametrize("seed", range(21))
+def test_oracle_matcher_vs_numpy_definition(oracle, seed):
+    from test_gpu_fuzz import KINDS, _cloud
+    rng = np.random.default_rng(21000 + seed)
+    kind = KINDS[seed % len(KINDS)]
+    g = _cloud(rng, kind, int(rng.integers(20, 3000))).astype(np.float32)
+    if rng.random() < 0.4 and len(g) > 20:
+        g[len(g) // 2:len(g) // 2 + len(g) // 10] = g[:len(g) // 10]       # duplicates
+    scale = float(np.ptp(g, axis=0).max()) or 1.0
+    n_l = int(rng.integers(1, 400))
+    l = (g[rng.integers(0, len(g), n_l)].astype(np.float64) + rng.normal(0, 0.01 * scale, (n_l, 3)) * rng.integers(0, 2)).astype(np.float32)
+    thr = float(rng.choice([0.01, 0.05, 0.3])) * scale
+    allow_l, allow_g = bool(rng.random() < 0.3), bool(rng.random() < 0.3)
+    T = oracle.pose_from_xyzypr(*rng.normal(0, 0.01 * scale, 3), 0.0, 0.0, 0.0)
+    lt0, gt0 = (rng.random(n_l) < 0.2).astype(np.uint8), (rng.random(len(g)) < 0.2).astype(np.uint8)
+    # ---- the definition (Matcher_Points_DistanceThreshold.cpp:94-121, 214-259) ----
+    tx, ty, tz, _, _ = oracle.transform_local_to_global(l[:, 0], l[:, 1], l[:, 2], T)
+    lt, gt = lt0.copy(), gt0.copy()
+    thr2 = np.float32(thr * thr)
+    exp = []
+    for i in range(n_l):
+        if not allow_l and lt[i]:
+            continue
+        dx, dy, dz = tx[i] - g[:, 0], ty[i] - g[:, 1], tz[i] - g[:, 2]
+        d2 = (dx * dx + dy * dy) + dz * dz                                  # fp32, the reference's sequence
+        j = int(np.argmin(d2))                                              # first minimum = lowest index
+        if not d2[j] < thr2:
+            continue
+        if not allow_g and gt[j]:
+            continue
+        exp.append((i, j, d2[j]))
+        if not allow_g:                                                      # marks are only left when global re-use is forbidden
+            lt[i], gt[j] = 1, 1
+    for mode in ("sequential", "tree", "threads"):
+        a, b = lt0.copy(), gt0.copy()
+        kw = dict(allowMatchAlreadyMatchedPoints=allow_l, allowMatchAlreadyMatchedGlobalPoints=allow_g, local_taken=a, global_taken=b)
+        if mode != "sequential":
+            kw["tree"] = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+        if mode == "threads":
+            kw["threads"] = 4
+        got, pot = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], T, thr, 0.0, **kw)
+        info = (seed, kind, mode, len(g), n_l, thr, allow_l, allow_g)
+        assert [(int(p["localIdx"]), int(p["globalIdx"])) for p in got] == [(i, j) for i, j, _ in exp], info
+        assert np.array_equal(got["errSq"].view(np.uint32), np.array([d for _, _, d in exp], np.float32).view(np.uint32)), info
+        assert np.array_equal(a, lt) and np.array_equal(b, gt), info
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_oracle_knn_vs_numpy_definition(oracle, seed):
+    """the k-nearest / radius-bounded search behind Matcher_Point2Plane, Matcher_Adaptive and pairingsPerPoint > 1 against a numpy sort by
+    (distance, index) -- lattices and duplicates make exact ties, the lowest index first"""
+    from test_gpu_fuzz import KINDS, _cloud
+    rng = np.random.default_rng(22000 + seed)
+    kind = KINDS[seed % len(KINDS)]
+    g = _cloud(rng, kind, int(rng.integers(20, 4000))).astype(np.float32)
+    if rng.random() < 0.4 and len(g) > 20:
+        g[len(g) // 2:len(g) // 2 + len(g) // 10] = g[:len(g) // 10]
+    scale = float(np.ptp(g, axis=0).max()) or 1.0
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    qs = np.concatenate([g[rng.integers(0, len(g), 40)].astype(np.float64) + rng.normal(0, 0.02 * scale, (40, 3)),
+                         g[rng.integers(0, len(g), 10)].astype(np.float64)]).astype(np.float32)   # (some queries ON map points)
+    for q in qs:
+        dx, dy, dz = q[0] - g[:, 0], q[1] - g[:, 1], q[2] - g[:, 2]
+        d2 = (dx * dx + dy * dy) + dz * dz
+        order = np.lexsort((np.arange(len(g)), d2))
+        for k, md in ((1, -1.0), (5, -1.0), (9, float(np.float32((0.05 * scale) ** 2))), (16, float(np.float32((0.2 * scale) ** 2)))):
+            want = order[:k]
+            if md >= 0:
+                want = want[d2[want] < np.float32(md)]                  # (nanoflann's RadiusResultSet: strictly inside)
+            ti, td = tree.knn(q, k, md)
+            # (which of several EQUIDISTANT points at the cut enters the list is the lowest index; inside the list the order is by distance)
+            assert np.array_equal(td, d2[want]), (seed, kind, k, md)
+            assert np.array_equal(ti, want), (seed, kind, k, md)

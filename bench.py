@@ -605,17 +605,30 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
     # pairs' own neighbours; the fraction below is therefore a LOWER bound of the roofline fraction
     touched_lb = float(np.mean(npt)) + min(float(g.shape[0]), knn * float(np.mean(npl)))
     touched_exact = None
-    if which == "c3" and sharded is None:
-        # ... and exactly, for the point-to-plane search: the instrumented call marks every map point its staging loop
-        # fetches (profiling level 2), counted over three mid-chain steps
+    if sharded is None:
+        # ... and exactly: the instrumented call of every matcher of the step marks each map point its staging loop fetches
+        # (profiling level 2; the marks are cleared per call, a point both matchers of C5 fetch counts twice: it is read twice),
+        # counted over three mid-chain steps
         cnt = []
         for _ in range(3):
+            t = 0
             ctx.set_profiling(2)
             pairs.clear()
-            core.match_pt2pl(ctx, gmap, cloud, pose, pl, None, pairs)
-            cnt.append(ctx.stats()["nn_points_staged"])
+            if which == "c2":
+                core.match_pt2pt(ctx, gmap, cloud, pose, pt, None, pairs)
+                t += ctx.stats()["nn_points_staged"]
+            elif which == "c3":
+                core.match_pt2pl(ctx, gmap, cloud, pose, pl, None, pairs)
+                t += ctx.stats()["nn_points_staged"]
+            else:
+                ms_dev.reset()
+                core.match_pt2pl(ctx, gmap, cloud, pose, pl, ms_dev, pairs)
+                t += ctx.stats()["nn_points_staged"]
+                core.match_pt2pt(ctx, gmap, cloud, pose, pt, ms_dev, pairs)
+                t += ctx.stats()["nn_points_staged"]
             ctx.set_profiling(0)
-            pose = np.array(core.gn_solve(ctx, pairs, pose, gnp).pose)
+            cnt.append(t)
+            pose = np.asarray(core.horn_solve(ctx, pairs)[0]) if which == "c2" else np.array(core.gn_solve(ctx, pairs, pose, gnp).pose)
         touched_exact = float(np.mean(cnt))
         touched_lb = touched_exact
     out_bytes = 8.0 * n_l if which == "c2" else 72.0 * float(np.mean(npl)) + (8.0 * n_l if which == "c5" else 0.0)

@@ -42,8 +42,10 @@ struct Error : std::runtime_error
 
 // roctx ranges named after the reference's profiler sections (ICP.cpp:141 "align.3.1_matchers", :162 "align.3.2_solvers";
 // SURVEY.md section 5): a rocprofv3 --marker-trace of an application that runs the plugin shows the matcher and the solver
-// calls under the names `icp-run --profiler` prints.  libroctx64 is looked up at run time (no link dependency; without it,
-// or without a profiler attached, a range costs one null test).
+// calls under the names `icp-run --profiler` prints.  libroctx64 is looked up at run time (no link dependency) and only
+// when asked for: MP2P_HIP_ROCTX=1 opens it, otherwise it is used only if the process has loaded it already (RTLD_NOLOAD:
+// a profiler that attaches brings it) -- a plain run of the plugin opens no library as a side effect, and a
+// range then costs one null test.
 struct RoctxRange
 {
     using push_fn = int (*)(const char*);
@@ -53,8 +55,10 @@ struct RoctxRange
         static push_fn s_push = nullptr;
         static pop_fn  s_pop  = nullptr;
         static const bool once  = [] {
-            void* h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
-            if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
+            const char* want = std::getenv("MP2P_HIP_ROCTX");
+            const int   mode = RTLD_LAZY | RTLD_LOCAL | ((want && want[0] == '1') ? 0 : RTLD_NOLOAD);
+            void* h = dlopen("libroctx64.so", mode);
+            if (!h) h = dlopen("libroctx64.so.4", mode);
             if (h)
             {
                 s_push = reinterpret_cast<push_fn>(dlsym(h, "roctxRangePushA"));
@@ -240,6 +244,9 @@ class Runtime
         static thread_local Runtime r;
         if (!r.ctx)
         {
+            // this translation unit's view of mp2p_hip.h against the library it was loaded with (ABI version + struct sizes):
+            // a plugin built against an older header stops here, not inside a solver that reads its weights from moved fields
+            if (MP2P_HIP_ABI_CHECK() != MP2P_HIP_OK) throw Error(std::string("libmp2p_hip ABI mismatch: ") + mp2p_hip_last_error(nullptr));
             const int rc = mp2p_hip_ctx_create(device_id(), nullptr, &r.ctx);
             if (rc) throw Error(std::string("mp2p_hip_ctx_create: ") + mp2p_hip_last_error(nullptr));
         }

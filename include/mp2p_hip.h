@@ -29,7 +29,12 @@
 extern "C" {
 #endif
 
-#define MP2P_HIP_ABI_VERSION 3
+/* Bumped whenever the layout of a public struct, the meaning of an argument or a return code changes.
+ *   4 (round 6): mp2p_hip_gn_params carries 32 weight blocks (8 before: w_pt2ln / w_pl2pl moved by 384 bytes);
+ *                mp2p_hip_abi_check; mp2p_hip_set_tune reports unknown / creation-time knobs as MP2P_HIP_ERR_INVALID.
+ * tests/test_abi.py hashes sizeof / offsetof of every public struct against tests/golden/abi_layout.json and fails when
+ * the table changes without this number changing. */
+#define MP2P_HIP_ABI_VERSION 4
 
 enum
 {
@@ -49,6 +54,15 @@ typedef struct mp2p_hip_mstate mp2p_hip_mstate; /* device-resident MatchState bi
 
 /* ---- context ------------------------------------------------------------------------ */
 int  mp2p_hip_abi_version(void);
+/* The caller's view of the header against the library's: MP2P_HIP_OK iff `header_version` == the library's
+ * MP2P_HIP_ABI_VERSION and the sizes of the parameter / result structs the caller was compiled with are the
+ * library's (a plugin built against an older header must not get as far as a solver call that reads its weights from
+ * the wrong offsets).  Use the macro: MP2P_HIP_ABI_CHECK() at load time (the adapter does, in its MRPT_INITIALIZER). */
+int  mp2p_hip_abi_check(int header_version, size_t sizeof_pt2pt_params, size_t sizeof_pt2pl_params,
+                        size_t sizeof_gn_params, size_t sizeof_gn_result, size_t sizeof_stats);
+#define MP2P_HIP_ABI_CHECK()                                                                             \
+    mp2p_hip_abi_check(MP2P_HIP_ABI_VERSION, sizeof(mp2p_hip_pt2pt_params), sizeof(mp2p_hip_pt2pl_params), \
+                       sizeof(mp2p_hip_gn_params), sizeof(mp2p_hip_gn_result), sizeof(mp2p_hip_stats))
 int  mp2p_hip_device_count(void);
 /* stream: a hipStream_t to enqueue on (e.g. the host framework's current stream) or NULL to
  * create a private non-blocking one.  To share the null stream pass hipStreamLegacy, not 0. */
@@ -657,7 +671,11 @@ int mp2p_hip_filter_decimate_voxels_device(mp2p_hip_ctx* ctx, const float* d_x, 
 int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable);
 /* measurement knobs of a context at run time: the syntax of the environment variable MP2P_HIP_TUNE ("name=value,...",
  * read once when the context is created; csrc/common.hpp lists the knobs).  Every setting computes the same results,
- * except tile_sol != 0 (timing-only launches of the search, no results).  No counterpart in the reference. */
+ * except tile_sol != 0 (timing-only launches of the search, no results): that knob is accepted ONLY here, only while
+ * profiling is on (mp2p_hip_set_profiling != 0), never from the environment, and a match call made under it appends
+ * NOTHING to the caller's list (only potential_pairings grows): the records of a timing launch are never compacted.  An unknown or malformed knob, or one that is
+ * consumed when the context is created (copy_stage_mb, copy_chunk_kb, dir_budget_mb, spin_us, sync_spin, pipelines),
+ * is refused with MP2P_HIP_ERR_INVALID and nothing of the string is applied.  No counterpart in the reference. */
 int mp2p_hip_set_tune(mp2p_hip_ctx* ctx, const char* settings);
 /* the timestamps of the last match call at profiling level 4: 2 uint64 per record, the tile
  * kernel's workgroups first, then the one-query-per-wave kernel's; ticks_host may be NULL to

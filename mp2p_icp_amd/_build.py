@@ -77,7 +77,7 @@ def build_hostpath(force=False, verbose=False):
     cxx = shutil.which("g++") or "g++"
     cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", HOSTPATH_SRC,
            "-I" + os.path.join(HERE, "..", "include"), "-I" + ADAPTER_DIR, "-L" + HERE, "-lmp2p_hip",
-           "-Wl,-rpath,$ORIGIN", "-lpthread", "-o", HOSTPATH_LIB + ".tmp"]
+           "-Wl,-rpath,$ORIGIN", "-lpthread", "-ldl", "-o", HOSTPATH_LIB + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("g++ failed on the host-path library:\n" + r.stderr[-8000:])

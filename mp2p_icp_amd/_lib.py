@@ -20,6 +20,7 @@ PAIR_PT2PL = np.dtype(
     [("plane", "<f8", (4,)), ("centroid", "<f8", (3,)), ("pt_local", "<f4", (3,)), ("_pad", "<f4")])
 assert PAIR_PT2PT.itemsize == 36 and PAIR_PT2PL.itemsize == 72
 
+ABI_VERSION = 4  # MP2P_HIP_ABI_VERSION of include/mp2p_hip.h
 OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 KERNEL_NONE, KERNEL_GEMANMCCLURE, KERNEL_CAUCHY = 0, 1, 2
 MAX_WEIGHT_BLOCKS = 32  # MP2P_HIP_MAX_WEIGHT_BLOCKS
@@ -173,6 +174,7 @@ COMM_ID_BYTES = 128
 # name -> (restype, argtypes).  tests/test_abi.py checks this table against include/mp2p_hip.h.
 SIGNATURES = {
     "mp2p_hip_abi_version": (C.c_int, []),
+    "mp2p_hip_abi_check": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     "mp2p_hip_device_count": (C.c_int, []),
     "mp2p_hip_ctx_create": (C.c_int, [C.c_int, _P, _PP]),
     "mp2p_hip_ctx_destroy": (None, [_P]),
@@ -309,13 +311,23 @@ def load():
                 raise ImportError(
                     f"libmp2p_hip.so is missing and could not be built ({e}); "
                     "mp2p_icp_amd has no CPU fallback") from e
+            # a stale library is only acceptable when it still speaks this ABI (checked below) -- say so, loudly
+            import sys
+            print(f"[mp2p_icp_amd] WARNING: libmp2p_hip.so is older than its sources and could not be rebuilt ({e}); "
+                  "loading it as it is (the ABI check below decides)", file=sys.stderr)
     L = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError = symbol missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if L.mp2p_hip_abi_version() != 3:
-        raise ImportError("libmp2p_hip.so ABI version mismatch")
+    # the binding's view of the header against the library's (MP2P_HIP_ABI_CHECK of include/mp2p_hip.h): a stale .so, or
+    # ctypes structs that lag behind the header, fail HERE and not as a solver reading its weights from the wrong offsets
+    if L.mp2p_hip_abi_version() != ABI_VERSION:
+        raise ImportError(f"libmp2p_hip.so is ABI version {L.mp2p_hip_abi_version()}, this binding is version {ABI_VERSION}: rebuild the library")
+    if L.mp2p_hip_abi_check(ABI_VERSION, C.sizeof(Pt2PtParams), C.sizeof(Pt2PlParams), C.sizeof(GNParams), C.sizeof(GNResult),
+                            C.sizeof(Stats)) != 0:
+        msg = L.mp2p_hip_last_error(None)
+        raise ImportError("libmp2p_hip.so ABI mismatch: " + (msg.decode() if msg else "?"))
     _lib = L
     return L
 

@@ -36,11 +36,20 @@ int set_err(mp2p_hip_ctx* ctx, int code, const char* fmt, ...)
     return code;
 }
 
-// MP2P_HIP_TUNE="lane_cells=3,tile_cand_cap=4096,claim_dedup=0": measurement knobs (common.hpp)
-static void parse_tune(Tune& t, const char* e = nullptr)
+// MP2P_HIP_TUNE="lane_cells=3,tile_cand_cap=4096,claim_dedup=0": measurement knobs (common.hpp).
+// from_env: the string is the environment variable, read when the context is created -- every knob is taken but tile_sol
+// (timing-only launches are a run-time request of a profiling session, never a property of the process).
+// At run time (mp2p_hip_set_tune) the knobs a context has already consumed are refused.  Returns the number of entries that
+// were refused (unknown name, malformed value, not allowed here); `why` gets the first one.
+static int parse_tune(Tune& t, const char* e, bool from_env, std::string* why = nullptr)
 {
-    if (!e) e = getenv("MP2P_HIP_TUNE");
-    if (!e) return;
+    if (!e) return 0;
+    int         bad = 0;
+    auto        refuse = [&](const std::string& kv, const char* reason) {
+        if (!bad && why) *why = "'" + kv + "': " + reason;
+        bad++;
+        if (from_env) fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: '%s' ignored (%s)\n", kv.c_str(), reason);
+    };
     std::string s(e);
     size_t      i = 0;
     while (i < s.size())
@@ -48,50 +57,83 @@ static void parse_tune(Tune& t, const char* e = nullptr)
         size_t j = s.find(',', i);
         if (j == std::string::npos) j = s.size();
         const std::string kv = s.substr(i, j - i);
-        const size_t      q  = kv.find('=');
-        if (q != std::string::npos)
-        {
-            const std::string k = kv.substr(0, q);
-            const long        v = strtol(kv.c_str() + q + 1, nullptr, 10);
-            if (k == "lane_cells") t.lane_cells = (uint32_t)v;
-            else if (k == "tile_cand_cap") t.tile_cand_cap = (uint32_t)v;
-            else if (k == "hard_radius_pct") t.hard_radius_pct = (uint32_t)v;
-            else if (k == "sync_spin") t.sync_spin = (int)v;
-            else if (k == "pl_cert") t.pl_cert = (int)v;
-            else if (k == "pl_cert_pad") t.pl_cert_pad = (uint32_t)v;
-            else if (k == "pl_cert_margin_mm") t.pl_cert_margin_mm = (uint32_t)v;
-            else if (k == "pl_hard_cand") t.pl_hard_cand = (uint32_t)v;
-            else if (k == "spin_us") t.spin_us = (int)v;
-            else if (k == "single_waves") t.single_waves = (uint32_t)v;
-            else if (k == "xcd_map") t.xcd_map = (int)v;
-            else if (k == "single_blocks_per_cu") t.single_blocks_per_cu = (uint32_t)v;
-            else if (k == "pl_q") t.pl_q = (v == 8 || v == 32) ? (uint32_t)v : 0u;
-            else if (k == "claim_dedup") t.claim_dedup = (int)v;
-            else if (k == "tile_waves") t.tile_waves = (uint32_t)v;
-            else if (k == "pipelines") t.pipelines = (uint32_t)v;
-            else if (k == "mfma_scan") t.mfma_scan = (int)v;
-            else if (k == "dir_budget_mb") t.dir_budget_mb = (uint32_t)v;
-            else if (k == "claim_peek") t.claim_peek = (int)v;
-            else if (k == "compact_fused") t.compact_fused = (int)v;
-            else if (k == "pl_warm") t.pl_warm = (int)v;
-            else if (k == "tile_bricks") t.tile_bricks = (int)v;
-            else if (k == "tile_brick_budget") t.tile_brick_budget = (uint32_t)v;
-            else if (k == "hard_cand") t.hard_cand = (uint32_t)v;
-            else if (k == "empty_room") t.empty_room = (int)v;
-            else if (k == "nn_cert") t.nn_cert = (int)v;
-            else if (k == "coop_max") t.coop_max = (uint32_t)v;
-            else if (k == "nn_cert_step_mm") t.nn_cert_step_mm = (uint32_t)v;
-            else if (k == "tile_cand_cap_easy") t.tile_cand_cap_easy = (uint32_t)v;
-            else if (k == "copy_chunk_kb") t.copy_chunk_kb = (uint32_t)v;
-            else if (k == "copy_stage_mb") t.copy_stage_mb = (uint32_t)v;
-            else if (k == "tile_select") t.tile_select = (int)v;
-            else if (k == "nn_direct") t.nn_direct = (int)v;
-            else if (k == "tile_sol") t.tile_sol = (int)v;
-            else if (k == "grp_all_bricks") t.grp_all_bricks = (uint32_t)v;
-            else fprintf(stderr, "[libmp2p_hip] MP2P_HIP_TUNE: unknown knob '%s'\n", k.c_str());
-        }
         i = j + 1;
+        if (kv.empty()) continue;
+        const size_t q = kv.find('=');
+        if (q == std::string::npos || q == 0 || q + 1 >= kv.size())
+        {
+            refuse(kv, "not name=value");
+            continue;
+        }
+        const std::string k = kv.substr(0, q);
+        char*             endp = nullptr;
+        const long        v = strtol(kv.c_str() + q + 1, &endp, 10);
+        if (!endp || *endp != '\0')
+        {
+            refuse(kv, "value is not an integer");
+            continue;
+        }
+        // consumed when the context is created (buffers, events and streams are sized from them)
+        const bool creation_only = k == "copy_chunk_kb" || k == "copy_stage_mb" || k == "dir_budget_mb" || k == "spin_us" ||
+                                   k == "sync_spin" || k == "pipelines";
+        if (creation_only && !from_env)
+        {
+            refuse(kv, "read when the context is created: set it in MP2P_HIP_TUNE");
+            continue;
+        }
+        if (k == "lane_cells") t.lane_cells = (uint32_t)v;
+        else if (k == "tile_cand_cap") t.tile_cand_cap = (uint32_t)v;
+        else if (k == "hard_radius_pct") t.hard_radius_pct = (uint32_t)v;
+        else if (k == "sync_spin") t.sync_spin = (int)v;
+        else if (k == "pl_cert") t.pl_cert = (int)v;
+        else if (k == "pl_cert_pad") t.pl_cert_pad = (uint32_t)v;
+        else if (k == "pl_cert_margin_mm") t.pl_cert_margin_mm = (uint32_t)v;
+        else if (k == "pl_hard_cand") t.pl_hard_cand = (uint32_t)v;
+        else if (k == "spin_us") t.spin_us = (int)v;
+        else if (k == "single_waves") t.single_waves = (uint32_t)v;
+        else if (k == "xcd_map") t.xcd_map = (int)v;
+        else if (k == "single_blocks_per_cu") t.single_blocks_per_cu = (uint32_t)v;
+        else if (k == "pl_q") t.pl_q = (v == 8 || v == 32) ? (uint32_t)v : 0u;
+        else if (k == "claim_dedup") t.claim_dedup = (int)v;
+        else if (k == "tile_waves") t.tile_waves = (uint32_t)v;
+        else if (k == "pipelines") t.pipelines = (uint32_t)v;
+        else if (k == "mfma_scan") t.mfma_scan = (int)v;
+        else if (k == "dir_budget_mb") t.dir_budget_mb = (uint32_t)v;
+        else if (k == "claim_peek") t.claim_peek = (int)v;
+        else if (k == "compact_fused") t.compact_fused = (int)v;
+        else if (k == "pl_warm") t.pl_warm = (int)v;
+        else if (k == "tile_bricks") t.tile_bricks = (int)v;
+        else if (k == "tile_brick_budget") t.tile_brick_budget = (uint32_t)v;
+        else if (k == "hard_cand") t.hard_cand = (uint32_t)v;
+        else if (k == "empty_room") t.empty_room = (int)v;
+        else if (k == "nn_cert") t.nn_cert = (int)v;
+        else if (k == "coop_max") t.coop_max = (uint32_t)v;
+        else if (k == "nn_cert_step_mm") t.nn_cert_step_mm = (uint32_t)v;
+        else if (k == "tile_cand_cap_easy") t.tile_cand_cap_easy = (uint32_t)v;
+        else if (k == "copy_chunk_kb") t.copy_chunk_kb = (uint32_t)v;
+        else if (k == "copy_stage_mb") t.copy_stage_mb = (uint32_t)v;
+        else if (k == "tile_select") t.tile_select = (int)v;
+        else if (k == "nn_direct") t.nn_direct = (int)v;
+        else if (k == "tile_sol")
+        {
+            if (from_env) refuse(kv, "timing-only launches are requested through mp2p_hip_set_tune with profiling on");
+            else t.tile_sol = (int)v;
+        }
+        else if (k == "grp_all_bricks") t.grp_all_bricks = (uint32_t)v;
+        else if (k == "pl_select") t.pl_select = (int)v;
+        else if (k == "pl_waves") t.pl_waves = (uint32_t)v;
+        else if (k == "pl_sel_margin_mm") t.pl_sel_margin_mm = (uint32_t)v;
+        else if (k == "pl_sel_hard_cand") t.pl_sel_hard_cand = (uint32_t)v;
+        else if (k == "pl_no_touch") t.pl_no_touch = (int)v;
+        else if (k == "pl_sol")
+        {
+            if (from_env) refuse(kv, "timing-only launches are requested through mp2p_hip_set_tune with profiling on");
+            else t.pl_sol = (int)v;
+        }
+        else if (k == "gn_fuse") t.gn_fuse = (int)v;
+        else refuse(kv, "unknown knob");
     }
+    return bad;
 }
 
 static int upload3(mp2p_hip_ctx* ctx, const float* x, const float* y, const float* z, size_t n,
@@ -116,6 +158,23 @@ using namespace mp2p;
 extern "C" {
 
 int mp2p_hip_abi_version(void) { return MP2P_HIP_ABI_VERSION; }
+
+int mp2p_hip_abi_check(int header_version, size_t sizeof_pt2pt_params, size_t sizeof_pt2pl_params,
+                       size_t sizeof_gn_params, size_t sizeof_gn_result, size_t sizeof_stats)
+{
+    if (header_version != MP2P_HIP_ABI_VERSION)
+        return set_err(nullptr, MP2P_HIP_ERR_INVALID, "caller was built against mp2p_hip.h ABI version %d, this library is version %d",
+                       header_version, MP2P_HIP_ABI_VERSION);
+    if (sizeof_pt2pt_params != sizeof(mp2p_hip_pt2pt_params) || sizeof_pt2pl_params != sizeof(mp2p_hip_pt2pl_params) ||
+        sizeof_gn_params != sizeof(mp2p_hip_gn_params) || sizeof_gn_result != sizeof(mp2p_hip_gn_result) ||
+        sizeof_stats != sizeof(mp2p_hip_stats))
+        return set_err(nullptr, MP2P_HIP_ERR_INVALID,
+                       "struct sizes of the caller's mp2p_hip.h (%zu %zu %zu %zu %zu) differ from the library's (%zu %zu %zu %zu %zu)",
+                       sizeof_pt2pt_params, sizeof_pt2pl_params, sizeof_gn_params, sizeof_gn_result, sizeof_stats,
+                       sizeof(mp2p_hip_pt2pt_params), sizeof(mp2p_hip_pt2pl_params), sizeof(mp2p_hip_gn_params),
+                       sizeof(mp2p_hip_gn_result), sizeof(mp2p_hip_stats));
+    return MP2P_HIP_OK;
+}
 unsigned long long mp2p_hip_debug_alloc_count(void) { return mp2p::dev_alloc_counter(); }
 
 int mp2p_hip_device_count(void)
@@ -175,7 +234,7 @@ int mp2p_hip_ctx_create(int device_id, void* hip_stream, mp2p_hip_ctx** out)
             return set_err(nullptr, MP2P_HIP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
         }
     }
-    parse_tune(ctx->tune);
+    parse_tune(ctx->tune, getenv("MP2P_HIP_TUNE"), /*from_env=*/true);
     *out = ctx;
     return MP2P_HIP_OK;
 }
@@ -536,7 +595,15 @@ static int match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const 
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     if (map->n == 0 || cloud->n == 0)  // potential_pairings is added BEFORE the early-out (:64-67)
         return launch_add_potential(ctx, out, (unsigned long long)cloud->n * prm->pairingsPerPoint);
-    rc = launch_compact_pt2pt(ctx, map, cloud, prm, ms, out, bbox_from_tiles);
+    if (ctx->sol_no_records)
+    {  // a timing-only search (mp2p_hip_set_tune tile_sol, profiling sessions): the records are an earlier call's or nothing at
+       // all -- the list stays as the caller passed it, only potential_pairings grows (:64)
+        ctx->sol_no_records = false;
+        ctx->q_counters_clean = false;
+        rc = launch_add_potential(ctx, out, (unsigned long long)cloud->n * prm->pairingsPerPoint);
+    }
+    else
+        rc = launch_compact_pt2pt(ctx, map, cloud, prm, ms, out, bbox_from_tiles);
     if (!rc && ctx->profiling)
     {
         ctx->pending_match = ctx->profiling == 4 ? 3 : ctx->profiling;  // read back lazily in mp2p_hip_get_stats
@@ -759,13 +826,19 @@ int mp2p_hip_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
         ctx->stats.nn_queries = cloud->n;
         if (ctx->profiling == 2)
         {  // the k-NN kernel's own counters
-            unsigned long long c[50];
+            unsigned long long c[64];
             MP2P_TRY_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
             MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
             ctx->stats.nn_tiles = c[0], ctx->stats.nn_passes = c[1], ctx->stats.nn_candidates_tested = c[2];
             ctx->stats.nn_tile_ticks_sum = c[3], ctx->stats.nn_max_passes_one_tile = c[4];
             ctx->stats.nn_max_candidates_one_tile = c[5], ctx->stats.nn_tile_ticks_max = c[6];
             ctx->stats.nn_cells_visited = c[7];
+            // round 6 (pt2pl_seltile_kernel): chain iterations of the queue flushes, queued hits, flushes
+            ctx->stats.nn_coop_passes = c[9], ctx->stats.nn_single_queries = c[10], ctx->stats.nn_single_passes = c[11];
+            ctx->stats.nn_single_cells = c[12], ctx->stats.nn_single_candidates = c[13], ctx->stats.nn_single_ticks_sum = c[14];  // ticks: staging, prefilter, flushes
+            ctx->stats.nn_single_ticks_max = c[15], ctx->stats.nn_single_max_passes = c[48];  // ticks: whole passes up to the merge, merges
+            for (int i = 0; i < 6; i++) ctx->stats.nn_wave_phase_ticks[i] = c[50 + i];  // the slowest tile's {hits, chain iterations, enqueue iterations, prefilter positives, blocks}; [5] = enqueue iterations of all tiles
+            ctx->stats.nn_wave_inserts = c[56], ctx->stats.nn_wave_rounds = c[57];
             for (int i = 0; i < 24; i++) ctx->stats.nn_tile_ticks_hist[i] = c[16 + i];
             ctx->stats.nn_single_max_candidates = c[49];  // the slowest tile: ticks << 40 | passes << 32 | candidates
             std::vector<unsigned char> t(map->n);
@@ -1020,7 +1093,14 @@ int mp2p_hip_set_profiling(mp2p_hip_ctx* ctx, int enable)
 int mp2p_hip_set_tune(mp2p_hip_ctx* ctx, const char* settings)
 {
     if (!ctx || !settings) return MP2P_HIP_ERR_INVALID;
-    parse_tune(ctx->tune, settings);
+    // all or nothing: an A/B probe must be able to tell that a setting did not take effect
+    Tune        t = ctx->tune;
+    std::string why;
+    if (parse_tune(t, settings, /*from_env=*/false, &why) != 0)
+        return set_err(ctx, MP2P_HIP_ERR_INVALID, "mp2p_hip_set_tune: %s (nothing applied)", why.c_str());
+    if ((t.tile_sol != 0 || t.pl_sol != 0) && ctx->profiling == 0)
+        return set_err(ctx, MP2P_HIP_ERR_INVALID, "mp2p_hip_set_tune: tile_sol / pl_sol (timing-only launches) need profiling on");
+    ctx->tune = t;
     return MP2P_HIP_OK;
 }
 

@@ -173,6 +173,17 @@ struct Tune
                                     // 4-voxel bricks wide (0 = always the seed's neighbourhood, the rule of rounds 1-4)
     int      tile_sol      = 0;     // speed-of-light decomposition of that kernel (TIMING ONLY, no results): 1 = list + select + stage,
                                     // 2 = + matrix-pipe prefilter; set at run time through mp2p_hip_set_tune
+    int      pl_select     = -1;    // point-to-plane / k-NN search, round 6: the voxels of a pass SELECTED per query ball on the matrix pipe and the
+                                    // distance tests prefiltered there (nn_pl_seltile.hip); 0 = the box-rule tile kernel of rounds 2-5; -1 = by the
+                                    // layer's size: above 524 288 queries (measured: C5, 5 M queries, 6.46 -> 5.41 ms per step; C3, 120 k queries =
+                                    // 3 750 tiles of 32 for 3 072 wave slots, is as long as its longest tile and LOSES: 2 117 -> 1 771 it/s)
+    uint32_t pl_waves      = 0;     // ... 1 = every tile by ONE wave (no hard class); default: the tiles of the hard class by the four waves of a workgroup
+    uint32_t pl_sel_margin_mm = 5;  // ... the certificate's margin of that kernel: the selection's balls and the prefilter's limits are this much wider
+                                    // than the search needs, so that what is not evaluated exactly is provably this far beyond the list
+    uint32_t pl_sel_hard_cand = 3000;  // ... a query whose 32-query tile staged this many candidates at the previous call is listed in the class dispatched first (0 = one class)
+    int      pl_sol        = 0;     // timing-only cuts of pt2pl_seltile_kernel's instrumented build (1..4, nn_pl_seltile.hip): set_tune only, profiling on, results invalid
+    int      pl_no_touch   = 0;     // profiling level 2 of the point-to-plane search without the per-point 'touched' bytes (phase timers undisturbed)
+    int      gn_fuse       = 1;     // Gauss-Newton: the first inner iteration's sums are accumulated by the compaction's write pass (round 6)
     uint32_t pl_hard_cand  = 1500;  // pt2pl: a query whose tile staged this many candidates (per 4 queries) at the previous call is searched in the hard class, first and in smaller tiles (0 = one class)
 };
 
@@ -249,6 +260,7 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<float>              tile_bbox2;   // [64][6] second reduction level
     mp2p::DevBuf<float>              block_bbox;   // [compaction blocks][6] (fused box reduction, pairs.hip)
     uint32_t                         last_n_boxes = 0;       // per-wave boxes the last pt2pt search left in tile_bbox
+    bool                             sol_no_records = false;    // the last pt2pt search was a timing-only launch (Tune::tile_sol): nothing to compact
     bool                             q_counters_clean = false;  // the search's list counters are zero on the stream
     mp2p::DevBuf<float>              local_bbox;   // [6] min xyz, max xyz of transformed local
     mp2p::DevBuf<double>             exch;         // [8] what a sharded layer all-reduces (pairs.hip)

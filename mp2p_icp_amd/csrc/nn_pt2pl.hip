@@ -14,6 +14,7 @@
 // Same tile machinery as nn_query.hip (wave64 tile, LDS-staged voxel buckets); each lane keeps
 // a sorted k-list in registers.
 #include "device_utils.hpp"
+#include "nn_pl_seltile.hip"  // round 6: knn_sel_search (ball-rule selection + matrix-pipe prefilter, W waves per tile)
 
 namespace mp2p
 {
@@ -77,6 +78,8 @@ struct PlArgs
     float                rad_cert, cert_margin;
     int                  use_cert;
     unsigned char*       touched;   // profiling level 2: one byte per map point (sorted position), set when the point is fetched
+    int                  sol;             // timing-only cuts of pt2pl_seltile_kernel (profiling builds; MP2P_HIP_TUNE pl_sol through mp2p_hip_set_tune)
+    float                grp_all_bricks;  // round 6 (pt2pl_seltile_kernel): all pending queries of a tile form one pass while their box is this many bricks wide
     uint32_t             timeline_n; // tiles in the grid; after their {start, end}: one word {passes << 48 | voxels << 32 | candidates} each
     unsigned long long*  timeline;  // profiling level 4: {start, end} 100 MHz ticks per tile of pt2pl_tile_kernel (0 0: an empty tile)
 };
@@ -668,6 +671,76 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 4 :
     }
 }
 
+// ---- round 6: the same tile through knn_sel_search (nn_pl_seltile.hip): 32 queries per tile in both classes.  A workgroup is
+//      four waves.  The workgroups [0, n_hard_tiles) serve ONE tile of the hard class each (the queries whose tile staged many
+//      candidates at the previous call), the four waves dealing its selected voxels between them (W = 4); every other workgroup
+//      serves FOUR tiles of the easy class, a wave each (W = 1).  W is a run-time value of the workgroup, so both share one body
+//      (two instantiations would not fit the instruction cache together).  A KITTI scan is 3 750 tiles for 3 072 wave slots: the
+//      kernel lasts as long as its longest tile, which four waves cut to a third; four waves for EVERY tile (the first version)
+//      quadrupled the waves and the redundant listing with them.
+//      Register budget: 3 waves per SIMD up to K = 8 (168 registers; the LDS, 12.9 KB per wave, allows no more), 2 beyond.
+template <int K, bool INSTR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 3 : 2, K <= 8 ? 3 : 2))) void pt2pl_seltile_kernel(const PlArgs a, const uint32_t n_hard_tiles)
+{
+    // (sized at the launch: one PsLds per wave of the workgroup -- four with a hard class, one without: a large layer has no use for
+    //  the hard class, and four independent tiles per workgroup hold their LDS and wave slots until the slowest of the four is done:
+    //  C5 5.3 -> 6.0 ms)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    PsLds* const lds = reinterpret_cast<PsLds*>(lds_raw);
+    constexpr int    Q = 32;
+    const GridView&  g    = a.g;
+    const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool       hard = blockIdx.x < n_hard_tiles;
+    const int        W = hard ? 4 : 1, wv = hard ? wave : 0;
+    const uint32_t*  pend;
+    uint32_t         cnt, k;
+    if (hard)
+    {
+        cnt = min(a.list_cnt[1], a.hard_cap), k = blockIdx.x, pend = a.hard_list;
+    }
+    else
+    {
+        cnt = min(a.list_cnt[0], a.pend_cap), k = (blockIdx.x - n_hard_tiles) * (blockDim.x >> 6) + (uint32_t)wave, pend = a.pend;
+    }
+    if (k * Q >= cnt) return;  // hard: the whole workgroup; easy: this wave (its tile runs without workgroup barriers)
+    const uint32_t tile_id = hard ? blockIdx.x : n_hard_tiles + k;
+    const unsigned long long tl0 = (INSTR && a.timeline) ? wall_clock64() : 0ull;
+    const uint32_t slot  = k * Q + (uint32_t)(lane % Q);
+    const uint32_t ent   = slot < cnt ? pend[slot] : NONE_U32;  // (NONE: the padding of a block's part of a list)
+    const bool     valid = ent != NONE_U32;
+    const uint32_t qi    = valid ? ent : 0u;  // place in the sorted copy
+    const float4   lp    = a.lpts[qi];
+    const uint32_t orig  = __float_as_uint(lp.w);
+    float          qx, qy, qz;
+    compose_point_f(a.pose, lp.x, lp.y, lp.z, qx, qy, qz);
+    const bool active = valid;  // visited, finite and not taken: checked by pt2pl_cert_kernel
+
+    float r0 = a.r0;
+    if (a.use_hint && active)
+    {
+        float ox, oy, oz;
+        compose_point_f(a.prev_pose, lp.x, lp.y, lp.z, ox, oy, oz);
+        const float disp = sqrtf(dist2(qx, qy, qz, ox, oy, oz));
+        const float kp   = a.kth_io[qi];
+        if (kp < INFINITY) r0 = sqrtf(kp) * (1.0f + 1.0f / 512.0f) + disp * 1.00001f + 4.f * g.slack;  // NaN / inf: the full radius
+    }
+    float    kd2[K];
+    uint32_t kspos[K];
+    float    lb = 0.f;
+    uint32_t ncand = 0;
+    knn_sel_search<K, false, true, INSTR>(g, W, lane, wv, &lds[wave], hard ? &lds[0] : &lds[wave], qx, qy, qz, active, a.radSq, a.rad_cert, r0, a.knn,
+                                          a.grp_factor, a.grp_min, a.grp_all_bricks, a.cert_margin, kd2, kspos, &lb, &ncand, a.dbg,
+                                          a.timeline ? a.timeline + 2 * (size_t)a.timeline_n + tile_id : nullptr, a.touched, a.sol);
+    if (INSTR && a.timeline && lane == 0 && wv == 0) a.timeline[2 * (size_t)tile_id] = tl0, a.timeline[2 * (size_t)tile_id + 1] = wall_clock64();
+    if (!valid || lane >= Q || wv != 0) return;
+    a.kth_io[qi]  = ps_kth(kd2, a.knn);
+    a.lb_io[qi]   = lb;
+    a.cost_io[qi] = min(ncand, 0x7FFFFFFFu) | (hard ? 0x80000000u : 0u);  // what this query's tile staged: the next call's scheduling hint
+    uint32_t* o   = a.out_knn + (size_t)orig * K;
+#pragma unroll
+    for (int j = 0; j < K; j++) o[j] = kspos[j];
+}
+
 // ---- certificate + query list: one thread per local point (Morton order), see PlArgs::lb_io ------------------------
 // Also the per-point checks of the matcher's loop (Matcher_Point2Plane.cpp:76-85: visited, finite, not taken) and the
 // bounding boxes of the transformed points (one per wave).  A query that is not certified is appended to its
@@ -1048,11 +1121,23 @@ __global__ __launch_bounds__(PC_THREADS) void pl_write_kernel(const PlCompactArg
 }
 
 template <int K>
-static void launch_k(const PlArgs& a, uint32_t q, const mp2p_hip_cloud* cloud, hipStream_t st)
+static void launch_k(const PlArgs& a, uint32_t q, const mp2p_hip_cloud* cloud, hipStream_t st, uint32_t sel_waves)
 {
     const uint32_t n_blocks = (a.n_l + PL_CB - 1) / PL_CB;
     const bool classes = a.use_hint && a.hard_cand;
-    if (q == 8)
+    if (sel_waves)
+    {   // round 6: ball-rule selection + matrix-pipe prefilter, 32 queries per tile in both classes; a hard tile per workgroup of four
+        // waves, four easy tiles per workgroup (pt2pl_seltile_kernel)
+        const uint32_t nh  = classes ? a.hard_cap / 32u : 0u;
+        const uint32_t tpw = nh ? 4u : 1u;  // waves (= easy tiles) per workgroup
+        const dim3     grid(nh + (a.pend_cap / 32u + tpw - 1u) / tpw);
+        const size_t   lds_bytes = sizeof(PsLds) * tpw;
+        hipLaunchKernelGGL((pt2pl_cert_kernel<K, 32, 32>), dim3(n_blocks), dim3(PL_CB), 0, st, a);
+        const bool instr = a.dbg != nullptr || a.timeline != nullptr || a.touched != nullptr;  // profiling levels 2 and 4
+        if (instr) hipLaunchKernelGGL((pt2pl_seltile_kernel<K, true>), grid, dim3(64u * tpw), lds_bytes, st, a, nh);
+        else hipLaunchKernelGGL((pt2pl_seltile_kernel<K, false>), grid, dim3(64u * tpw), lds_bytes, st, a, nh);
+    }
+    else if (q == 8)
     {
         const uint32_t nh = classes ? a.hard_cap / 4u : 0u;
         hipLaunchKernelGGL((pt2pl_cert_kernel<K, 8, 4>), dim3(n_blocks), dim3(PL_CB), 0, st, a);
@@ -1080,7 +1165,13 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     // (round 2 took 32-query tiles above 400 k points; with the insertions bounded by the pass radius and the filtered
     //  staging the 8-query tile also wins at 1 M queries: 1.10..1.47 ms with 32, 0.75..0.88 ms with 8.  At 5 M queries
     //  with 30 % uniform outliers -- BASELINE C5 -- 32 is still 10 % ahead: 7.8 vs 8.7 ms per step)
-    const uint32_t Q       = ctx->tune.pl_q ? ctx->tune.pl_q : (n_l <= 2000000 ? 8u : (uint32_t)PL_Q);
+    // round 6: the ball-rule / matrix-pipe kernel (nn_pl_seltile.hip) whenever the map has its level-0 occupancy bricks and the
+    // search radius stays within what one query's voxel list addresses; else the box-rule kernel of rounds 2-5
+    const float    cell0_  = map->view.hf * (float)(1u << map->view.shift0);
+    const bool     sel     = (ctx->tune.pl_select < 0 ? n_l > 524288 : ctx->tune.pl_select != 0) && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE &&
+                             (float)prm->searchRadius * 1.01f + 0.05f <= PS_MAX_RADIUS_CELLS * cell0_;
+    const uint32_t Q       = sel ? 32u : (ctx->tune.pl_q ? ctx->tune.pl_q : (n_l <= 2000000 ? 8u : (uint32_t)PL_Q));
+    const uint32_t sel_waves = sel ? 1u : 0u;
     const uint32_t n_cblocks = (uint32_t)((n_l + PL_CB - 1) / PL_CB);
     const uint32_t n_boxes   = n_cblocks * (PL_CB / 64);  // one bounding box per wave of pt2pl_cert_kernel
     const uint32_t Kcap    = prm->knn <= 5 ? 5u : prm->knn <= 8 ? 8u : prm->knn <= 12 ? 12u : 16u;
@@ -1089,7 +1180,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     MP2P_TRY_HIP(ctx, ctx->pl_pend.ensure(std::max(pend_cap, 64u)));
     MP2P_TRY_HIP(ctx, ctx->pl_pend_cnt.ensure(2));
     // the hard class: at most an eighth of the layer (in whole tiles), and a grid prefix of at most 8192 workgroups
-    const uint32_t hard_cap = (uint32_t)std::min<size_t>(std::max<size_t>(n_l / 8, 64), 8192u * 4u) / 8u * 8u;
+    const uint32_t hard_cap = (uint32_t)std::min<size_t>(std::max<size_t>(n_l / (sel ? 4 : 8), 64), 8192u * 4u) / 32u * 32u;
     MP2P_TRY_HIP(ctx, ctx->pl_hard.ensure(hard_cap));
     MP2P_TRY_HIP(ctx, ctx->pl_lb.ensure(n_l ? n_l : 1));
     MP2P_TRY_HIP(ctx, ctx->pl_cost.ensure(n_l ? n_l : 1));
@@ -1137,7 +1228,10 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     a.grp_min = 2.0f * cell0;
     a.lb_io = ctx->pl_lb.p, a.pend = ctx->pl_pend.p, a.pend_cap = pend_cap, a.cert_stat = ctx->pl_cert_stat.p;
     a.use_cert = (a.use_hint && ctx->tune.pl_cert) ? ctx->tune.pl_cert : 0;
-    a.cost_io = ctx->pl_cost.p, a.hard_cand = ctx->tune.pl_hard_cand;
+    // (the hard class of the round-6 kernel: for layers whose tiles do not fill the chip several times over -- up to 16 384 tiles)
+    a.cost_io = ctx->pl_cost.p, a.hard_cand = sel ? ((ctx->tune.pl_waves == 1 || n_l > 524288) ? 0u : ctx->tune.pl_sel_hard_cand) : ctx->tune.pl_hard_cand;
+    a.grp_all_bricks = (float)ctx->tune.grp_all_bricks;
+    a.sol = (ctx->profiling != 0) ? ctx->tune.pl_sol : 0;
     a.hard_list = ctx->pl_hard.p, a.hard_cap = hard_cap, a.list_cnt = ctx->pl_pend_cnt.p;
     if (ctx->pl_hard_cnt_at != (const void*)a.list_cnt || ctx->pl_lists_dirty)
     {  // just allocated (or a call that did not get as far as its fit kernel): zero once; from then on the fit kernel leaves the counters zeroed
@@ -1147,7 +1241,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     // the radius a search that finds fewer than knn points has covered: searchRadius + pl_cert_pad per mille, the room
     // the certificate of such a query has before a point outside its list could come into reach (0.2 % without it)
     a.rad_cert = a.rad * (1.0f + 0.001f * (float)(ctx->tune.pl_cert ? std::max(2u, ctx->tune.pl_cert_pad) : 2u)) + map->view.slack;
-    a.cert_margin = ctx->tune.pl_cert ? 0.001f * (float)ctx->tune.pl_cert_margin_mm : 0.f;
+    a.cert_margin = ctx->tune.pl_cert ? 0.001f * (float)(sel ? ctx->tune.pl_sel_margin_mm : ctx->tune.pl_cert_margin_mm) : 0.f;
     a.dbg = nullptr, a.touched = nullptr;
     if (ctx->profiling == 2)
     {
@@ -1157,14 +1251,14 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
         // N_g,touched of SURVEY.md 8d, exactly: a byte per map point, set by the staging loop (scratch slot 15)
         MP2P_TRY_HIP(ctx, ctx->scratch[15].ensure(map->n ? map->n : 1));
         MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->scratch[15].p, 0, map->n, ctx->stream));
-        a.touched = ctx->scratch[15].p;
+        a.touched = ctx->tune.pl_no_touch ? nullptr : ctx->scratch[15].p;
     }
 
     a.timeline = nullptr;
     ctx->timeline_tiles = ctx->timeline_singles = 0;
     if (ctx->profiling == 4 && phase != 2)
     {
-        const size_t n_grid = (size_t)pend_cap / Q + (ctx->tune.pl_hard_cand ? (size_t)hard_cap / (Q == 8 ? 4 : 8) : 0);
+        const size_t n_grid = (size_t)pend_cap / Q + (a.hard_cand ? (size_t)hard_cap / (sel ? 32 : (Q == 8 ? 4 : 8)) : 0);
         // (read back as 2 x 1.5 n_grid words: the probe knows that the last third is the per-tile info)
         const size_t n_rec = n_grid + (n_grid + 1) / 2;
         MP2P_TRY_HIP(ctx, ctx->timeline.ensure(2 * std::max<size_t>(n_rec, 1)));
@@ -1177,10 +1271,10 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     {
     if (ctx->profiling) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->pl_lists_dirty = true;
-    if (Kcap == 5) launch_k<5>(a, Q, cloud, ctx->stream);
-    else if (Kcap == 8) launch_k<8>(a, Q, cloud, ctx->stream);
-    else if (Kcap == 12) launch_k<12>(a, Q, cloud, ctx->stream);
-    else launch_k<16>(a, Q, cloud, ctx->stream);
+    if (Kcap == 5) launch_k<5>(a, Q, cloud, ctx->stream, sel_waves);
+    else if (Kcap == 8) launch_k<8>(a, Q, cloud, ctx->stream, sel_waves);
+    else if (Kcap == 12) launch_k<12>(a, Q, cloud, ctx->stream, sel_waves);
+    else launch_k<16>(a, Q, cloud, ctx->stream, sel_waves);
     if (hipPeekAtLastError() == hipSuccess)
     {
         ctx->pl_lists_dirty = false;

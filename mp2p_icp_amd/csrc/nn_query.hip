@@ -588,11 +588,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             if (p >= pe) break;
             float4 c4[4];
 #pragma unroll
+            for (int k = 0; k < 4; k++) c4[k] = g.pts[(p + k < pe) ? p + k : p];  // (round 6: four loads in flight; see nn_seltile.hip)
+#pragma unroll
             for (int k = 0; k < 4; k++)
-            {
-                c4[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
-                if (p + k < pe) c4[k] = g.pts[p + k];
-            }
+                if (!(p + k < pe)) c4[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
 #pragma unroll
             for (int k = 0; k < 4; k++)
             {
@@ -900,9 +899,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                         // padding: FAR but finite.  An infinite coordinate makes the prefilter's S an inf - inf = NaN, and the
                         // integer minimum over the accumulators' bit patterns (below) would pick a NaN with the sign bit set
                         // ahead of every real candidate of the block (found by the parity suite: 897 of 904 pairs)
-                        c4[k] = make_float4(1e18f, 0.f, 0.f, __uint_as_float(NONE_U32));
-                        if (t0 + k < m) c4[k] = g.pts[src[k]];
+                        // (round 6: the load is unconditional -- an out-of-range slot reads point 0 -- so that all four are in flight
+                        //  together: behind `if (ok)` each one got an s_waitcnt vmcnt(0) of its own; nn_seltile.hip)
+                        c4[k] = g.pts[(t0 + k < m) ? src[k] : 0u];
                     }
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (!(t0 + k < m)) c4[k] = make_float4(1e18f, 0.f, 0.f, __uint_as_float(NONE_U32));
                     *reinterpret_cast<float4*>(&s_x[t0]) = make_float4(c4[0].x, c4[1].x, c4[2].x, c4[3].x);
                     *reinterpret_cast<float4*>(&s_y[t0]) = make_float4(c4[0].y, c4[1].y, c4[2].y, c4[3].y);
                     *reinterpret_cast<float4*>(&s_z[t0]) = make_float4(c4[0].z, c4[1].z, c4[2].z, c4[3].z);
@@ -1268,9 +1271,13 @@ __device__ __forceinline__ void scan_batch(const NNArgs& a, const GridView& g, i
 #pragma unroll
         for (int k = 0; k < 4; k++)
         {
+            ca[k] = g.pts[sa[k]];  // (round 6: unconditional -- sa is 0 beyond the list -- so that the four loads are in flight together)
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
             const uint32_t t = t0 + 64u * k + lane;
-            ca[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
-            if (t < total) ca[k] = g.pts[sa[k]];
+            if (!(t < total)) ca[k] = make_float4(INFINITY, 0.f, 0.f, __uint_as_float(NONE_U32));
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -1667,7 +1674,9 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     // (120 k x 2 M): 3 390 it/s against 3 030 with the large-layer policy, 3 280 with round 4's kernels.
     const bool small_layer = n_l <= 262144;
     const bool direct = sel && (ctx->tune.nn_direct < 0 ? small_layer : ctx->tune.nn_direct != 0);
-    const int  sol    = (direct && ctx->tune.tile_sol >= 1 && ctx->tune.tile_sol <= 5) ? ctx->tune.tile_sol : 0;  // speed-of-light decomposition (timing only: no results, no state)
+    // speed-of-light decomposition (timing only: no results, no state): a run-time request of a profiling session (mp2p_hip_set_tune
+    // refuses it without profiling, the environment variable cannot set it); the matcher call then appends NOTHING to the caller's list
+    const int  sol    = (direct && ctx->profiling != 0 && ctx->tune.tile_sol >= 1 && ctx->tune.tile_sol <= 5) ? ctx->tune.tile_sol : 0;
     const uint32_t n_boxes = direct ? (uint32_t)((n_l + 31) / 32) : n_waves;  // per-tile / per-wave bounding boxes
     MP2P_TRY_HIP(ctx, ctx->nn_rec.ensure(n_l));
     MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)std::max(n_boxes, 1u) * 6));
@@ -1687,6 +1696,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         ctx->q_counters_clean = false;
     }
     ctx->last_q       = Q;
+    ctx->sol_no_records = false;
 
     NNArgs a;
     memset(&a, 0, sizeof(a));
@@ -1869,6 +1879,14 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
                 else if (sol == 4) MP2P_LAUNCH_SEL(false, false, true, 4);
                 else if (sol == 5) MP2P_LAUNCH_SEL(false, false, true, 5);
                 else if (instr) { if (direct) MP2P_LAUNCH_SEL(true, false, true, 0); else MP2P_LAUNCH_SEL(true, false, false, 0); }
+                else if (ctx->tune.tile_waves == 3)
+                {   // round 6: the register budget of 3 waves per SIMD (168): with the four staging loads of a round in flight together
+                    // the 128-register build spills 7-12 dwords
+#define MP2P_LAUNCH_SEL3(CERT_, DIRECT_) hipLaunchKernelGGL((nn_seltile_kernel<false, CERT_, DIRECT_, 3, 0>), dim3(tn[p]), dim3(64), 0, st[p], ap[p])
+                    if (cert_track) { if (direct) MP2P_LAUNCH_SEL3(true, true); else MP2P_LAUNCH_SEL3(true, false); }
+                    else { if (direct) MP2P_LAUNCH_SEL3(false, true); else MP2P_LAUNCH_SEL3(false, false); }
+#undef MP2P_LAUNCH_SEL3
+                }
                 else if (cert_track) { if (direct) MP2P_LAUNCH_SEL(false, true, true, 0); else MP2P_LAUNCH_SEL(false, true, false, 0); }
                 else { if (direct) MP2P_LAUNCH_SEL(false, false, true, 0); else MP2P_LAUNCH_SEL(false, false, false, 0); }
             }
@@ -1918,6 +1936,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     {  // a timing-only launch wrote no record: the warm start of the previous call stands
         ctx->hint_map = keep_hint_map;
         ctx->nn_lb2nd_valid = a.cert_read != 0;
+        ctx->sol_no_records = true;  // phase 2 must not compact records this call did not write
         return MP2P_HIP_OK;
     }
     ctx->hint_map = map, ctx->hint_cloud = cloud, ctx->hint_n = n_l;

@@ -365,12 +365,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                             src[k]           = s_cstart[v] + (base + t0 + k - s_coff[v]);
                         }
                     }
+                    // round 6: all four loads issued before any is waited for.  Written as `if (ok) c4[k] = pts[src[k]]` (rounds 1-5)
+                    // the compiler gave every load an exec-masked block of its own with its own s_waitcnt vmcnt(0): four SERIAL round
+                    // trips per staging round -- the "4 us per round of 256 that no prefetch moved" of DESIGN.md section 4.  An
+                    // out-of-range slot reads point 0 and is overwritten by the padding.
+#pragma unroll
+                    for (int k = 0; k < 4; k++) c4[k] = g.pts[(t0 + k < m) ? src[k] : 0u];
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                    {
-                        c4[k] = make_float4(1e18f, 0.f, 0.f, __uint_as_float(NONE_U32));  // padding: far but FINITE (nn_tile_kernel)
-                        if (t0 + k < m) c4[k] = g.pts[src[k]];
-                    }
+                        if (!(t0 + k < m)) c4[k] = make_float4(1e18f, 0.f, 0.f, __uint_as_float(NONE_U32));  // padding: far but FINITE (nn_tile_kernel)
                     *reinterpret_cast<float4*>(&s_x[t0]) = make_float4(c4[0].x, c4[1].x, c4[2].x, c4[3].x);
                     *reinterpret_cast<float4*>(&s_y[t0]) = make_float4(c4[0].y, c4[1].y, c4[2].y, c4[3].y);
                     *reinterpret_cast<float4*>(&s_z[t0]) = make_float4(c4[0].z, c4[1].z, c4[2].z, c4[3].z);

@@ -18,6 +18,85 @@ def _declared_symbols():
     return sorted(set(re.findall(r"\b(mp2p_hip_[a-z0-9_]+)\s*\(", txt)))
 
 
+def _header_version():
+    return int(re.search(r"#define\s+MP2P_HIP_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+
+
+def _public_structs():
+    """{struct name: [field names]} of every `typedef struct { ... } mp2p_hip_xxx;` of the header (array fields by
+    their name; function-pointer typedefs and opaque handles have no body and are skipped)."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(mp2p_hip_[a-z0-9_]+)\s*;", txt, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            # "double w_pt2pt, w_pt2pl" / "uint64_t bins[MP2P_HIP_ADAPTIVE_BINS]" / "const size_t* weight_block_count"
+            first, *rest = decl.split(",")
+            names = [re.sub(r"\[.*", "", first.split()[-1]).lstrip("*")] + [re.sub(r"\[.*", "", r.strip()).lstrip("*") for r in rest]
+            fields += names
+        out[name] = fields
+    return out
+
+
+def _layout_table():
+    """sizeof + offsetof of every field of every public struct, as the C compiler sees the header."""
+    structs = _public_structs()
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mp2p_hip.h"', 'int main(){']
+    for name, fields in sorted(structs.items()):
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for f in fields:
+            lines.append(f'printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
+    lines.append("return 0;}")
+    d = os.path.join(ROOT, "tests", "_tmp_abi")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "layout.c"), "w") as f:
+        f.write("\n".join(lines))
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "layout.c"), "-o",
+                           os.path.join(d, "layout")])
+    return subprocess.check_output([os.path.join(d, "layout")]).decode()
+
+
+def test_struct_layout_table_is_pinned_to_the_abi_version():
+    """VERDICT r5 #4 / ADVICE r5: mp2p_hip_gn_params grew in round 5 while MP2P_HIP_ABI_VERSION stayed 3.  The layout of
+    every public struct (sizeof + every offsetof) is hashed and pinned, per ABI version, in tests/golden/abi_layout.json:
+    a layout change without a version bump fails here; after a bump the new hash is recorded with
+    `python tests/test_abi.py --record`."""
+    import hashlib
+    import json
+    table = _layout_table()
+    assert "mp2p_hip_gn_params.w_pt2ln" in table and "mp2p_hip_pt2pt_params.threshold 0" in table
+    h = hashlib.sha256(table.encode()).hexdigest()[:16]
+    pinned = json.load(open(os.path.join(ROOT, "tests", "golden", "abi_layout.json")))
+    v = str(_header_version())
+    assert v in pinned, f"ABI version {v} has no pinned layout: run `python tests/test_abi.py --record`"
+    assert pinned[v]["sha16"] == h, (
+        f"the layout of a public struct changed (hash {h}, pinned {pinned[v]['sha16']} for ABI version {v}): "
+        "bump MP2P_HIP_ABI_VERSION in include/mp2p_hip.h (+ _lib.ABI_VERSION) and record the new table")
+    # an older version's table must differ from this one's (a bump that changed nothing is allowed, the reverse is the bug)
+    from mp2p_icp_amd import _lib
+    assert _lib.ABI_VERSION == int(v)
+
+
+def test_abi_check_refuses_an_older_header():
+    """what a plugin built against the round-4 header (version 3, 8 weight blocks) gets from MP2P_HIP_ABI_CHECK()"""
+    from mp2p_icp_amd import _lib
+    L = _lib.load()
+    ok = L.mp2p_hip_abi_check(_lib.ABI_VERSION, C.sizeof(_lib.Pt2PtParams), C.sizeof(_lib.Pt2PlParams),
+                              C.sizeof(_lib.GNParams), C.sizeof(_lib.GNResult), C.sizeof(_lib.Stats))
+    assert ok == 0
+    assert L.mp2p_hip_abi_check(3, C.sizeof(_lib.Pt2PtParams), C.sizeof(_lib.Pt2PlParams), C.sizeof(_lib.GNParams),
+                                C.sizeof(_lib.GNResult), C.sizeof(_lib.Stats)) == _lib.ERR_INVALID
+    assert b"version 3" in L.mp2p_hip_last_error(None)
+    # same version number, the round-4 size of mp2p_hip_gn_params (24 blocks x 16 bytes smaller)
+    assert L.mp2p_hip_abi_check(_lib.ABI_VERSION, C.sizeof(_lib.Pt2PtParams), C.sizeof(_lib.Pt2PlParams),
+                                C.sizeof(_lib.GNParams) - 384, C.sizeof(_lib.GNResult), C.sizeof(_lib.Stats)) == _lib.ERR_INVALID
+    assert b"struct sizes" in L.mp2p_hip_last_error(None)
+
+
 def test_library_builds_and_exports_every_declared_symbol():
     from mp2p_icp_amd import _build, _lib
     so = _build.build()
@@ -29,7 +108,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in mp2p_hip.h but not exported"
     # the ctypes table covers exactly the header
     assert sorted(_lib.SIGNATURES) == declared
-    assert L.mp2p_hip_abi_version() == 3
+    assert L.mp2p_hip_abi_version() == _lib.ABI_VERSION == _header_version()
 
 
 def test_struct_layouts_match_header():
@@ -149,3 +228,17 @@ def test_hostpath_library_builds_loads_and_exports():
             s.match_pt2pt(np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0.0]), p)
         assert "no CPU fallback" in str(e.value)
     s.close()
+
+
+if __name__ == "__main__":
+    import hashlib
+    import json
+    import sys
+    if "--record" in sys.argv:
+        path = os.path.join(ROOT, "tests", "golden", "abi_layout.json")
+        pinned = json.load(open(path)) if os.path.exists(path) else {}
+        table = _layout_table()
+        pinned[str(_header_version())] = {"sha16": hashlib.sha256(table.encode()).hexdigest()[:16],
+                                          "sizeof": {l.split()[0]: int(l.split()[1]) for l in table.splitlines() if "." not in l}}
+        json.dump(pinned, open(path, "w"), indent=1, sort_keys=True)
+        print("recorded ABI version", _header_version(), pinned[str(_header_version())]["sha16"])

@@ -17,6 +17,19 @@ def amd():
     return mp2p_icp_amd
 
 
+@pytest.fixture(autouse=True, params=["box", "ball"])
+def pl_kernel(request, monkeypatch):
+    """every test of this module with BOTH search kernels of Matcher_Point2Plane: the box-rule tile kernel of rounds 2-5
+    (pt2pl_tile_kernel) and round 6's ball-rule / matrix-pipe kernel (pt2pl_seltile_kernel, nn_pl_seltile.hip).  The library
+    picks by the layer's size (the second one above 524 288 queries); the knob pl_select forces one.  Read when a context is
+    created (the tests on core.Context), and set on the shared context of the Matcher classes."""
+    from mp2p_icp_amd import core
+    monkeypatch.setenv("MP2P_HIP_TUNE", "pl_select=%d" % (request.param == "ball"))
+    core.default_context().set_tune("pl_select=%d" % (request.param == "ball"))  # (the Matcher classes' shared context)
+    yield request.param
+    core.default_context().set_tune("pl_select=-1")
+
+
 def _match(amd, g, l, pose, params, ms=None, layer_kw=None):
     pcG = amd.metric_map_t({"raw": amd.PointLayer(g, **(layer_kw or {}))})
     pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
@@ -359,7 +372,7 @@ def test_hard_class_overflow_and_visit_order_changes(amd, oracle, monkeypatch):
     rest stays in the easy class; then a visit list that changes between calls -- a point that was not visited has no
     certificate and goes through the search"""
     from mp2p_icp_amd import core, synthetic
-    monkeypatch.setenv("MP2P_HIP_TUNE", "pl_hard_cand=1")
+    monkeypatch.setenv("MP2P_HIP_TUNE", os.environ["MP2P_HIP_TUNE"] + ",pl_hard_cand=1,pl_sel_hard_cand=1")
     d = synthetic.make_pair(6000, 300000, 41)
     g, l = d["glob"], d["local"]
     tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])

@@ -46,3 +46,12 @@ print(dict(tiles=st["nn_tiles"], passes_avg=round(st["nn_passes"] / nt, 2), max_
            cand_avg=round(st["nn_candidates_tested"] / nt), max_cand=st["nn_max_candidates_one_tile"],
            cells_avg=round(st["nn_cells_visited"] / nt), us_avg=round(st["nn_tile_ticks_sum"] / nt / 100, 1),
            us_max=round(st["nn_tile_ticks_max"] / 100, 1)))
+# round 6 (pt2pl_seltile_kernel): chain iterations of the queue flushes, queued hits, flushes -- per tile
+print(dict(flush_iters_per_tile=round(st["nn_coop_passes"] / nt, 1), hits_per_tile=round(st["nn_single_queries"] / nt, 1),
+           flushes_per_tile=round(st["nn_single_passes"] / nt, 2)))
+print(dict(us_stage_per_tile=round(st["nn_single_cells"] / nt / 100, 1), us_prefilter_per_tile=round(st["nn_single_candidates"] / nt / 100, 1),
+           us_flush_per_tile=round(st["nn_single_ticks_sum"] / nt / 100, 1)))
+print(dict(us_passes_per_tile=round(st["nn_single_ticks_max"] / nt / 100, 1), us_merge_per_tile=round(st["nn_single_max_passes"] / nt / 100, 1)))
+ph = st["nn_wave_phase_ticks"]
+print(dict(slowest_tile=dict(hits=ph[0] & 0xFFFFFFFF, chain_iters=ph[1] & 0xFFFFFFFF, enqueue_iters=ph[2] & 0xFFFFFFFF, prefilter_pos=ph[3] & 0xFFFFFFFF, blocks=ph[4] & 0xFFFFFFFF),
+           per_tile=dict(enqueue_iters=round(ph[5] / nt, 1), prefilter_pos=round(st["nn_wave_inserts"] / nt, 1), blocks=round(st["nn_wave_rounds"] / nt, 1))))

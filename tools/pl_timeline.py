@@ -37,7 +37,7 @@ info = flat[2 * n_grid:2 * n_grid + n_grid]
 rec = flat[:2 * n_grid].reshape(-1, 2)
 n_cb = (n_l + 255) // 256
 Q = 8 if n_l <= 2000000 else 32
-n_hard_grid = len(rec) - ((n_l + Q - 1) // Q + n_cb)
+n_hard_grid = len(rec) - ((n_l + 31) // 32 + n_cb)
 is_hard = (np.arange(len(rec)) < n_hard_grid)[rec[:, 1] > 0]
 info = info[rec[:, 1] > 0]
 rec = rec[rec[:, 1] > 0].astype(np.int64)

@@ -81,6 +81,26 @@ def build_inputs(n_local, n_global, seed, rank, world, scene="a"):
     return d
 
 
+def physical_cores():
+    """distinct (socket, core) pairs of /proc/cpuinfo (SMT siblings counted once); os.cpu_count() when it cannot be read"""
+    try:
+        seen, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        return len(seen) or (os.cpu_count() or 1)
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(d, threshold, gn_iters, kernel_param, sample, cores):
     """The oracle (CPU port of the reference's algorithm class: exact KD-tree + GN), timed on this
     host's cores on a bounded sample of the same workload; plus the single-thread figure (the
@@ -123,8 +143,11 @@ def cpu_baseline(d, threshold, gn_iters, kernel_param, sample, cores):
         quota = None if q == "max" else float(q) / float(per)
     except Exception:
         pass
+    phys = physical_cores()
     return {"value": v, "unit": "iterations/s", "cores": cores, "kind": "port",
             "_gate": gate, "cpu_quota_cores": quota,
+            # what the host's cores could give at best: the measured 1-thread figure x the PHYSICAL cores (no quota, perfect scaling)
+            "physical_cores": phys, "ideal_scaling_of_single_thread": {"value": v1 * phys, "unit": "iterations/s"},
             "cpu_quota_note": "threads = os.cpu_count(); the cgroup of this container caps their total CPU time at cpu_quota_cores "
                               "cores' worth (cpu.max), which bounds multi_thread_over_single_thread whatever the port does",
 
@@ -556,32 +579,42 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
         if dist is not None and world == 1:
             sharded.b.init_native_comm(dist)  # MP2P_BENCH_FORCE_DIST: a one-rank RCCL communicator
         if world > 1 and not getattr(sharded.b, "native", False):
-            raise SystemExit("--config c3 --gpus N needs the native RCCL communicator (process group backend nccl)")
+            raise SystemExit("--config c3 --gpus N needs the communicator inside libmp2p_hip (RCCL, or the hooks over gloo of the test boxes)")
 
-    def step(pose):
+    def step(pose, tap=None):
+        """one ICP iteration; tap(matcher name) is called behind every matcher call (the replay reads its events there)"""
         if sharded is not None:
             return np.asarray(sharded.step(pose)[0])
         pairs.clear()
         if which == "c2":
             core.match_pt2pt(ctx, gmap, cloud, pose, pt, None, pairs)
+            tap and tap("pt2pt")
             T, ok = core.horn_solve(ctx, pairs)
             return np.asarray(T)
         if which == "c3":
             core.match_pt2pl(ctx, gmap, cloud, pose, pl, None, pairs)
+            tap and tap("pt2pl")
         else:
             ms_dev.reset()
             core.match_pt2pl(ctx, gmap, cloud, pose, pl, ms_dev, pairs)
+            tap and tap("pt2pl")
             core.match_pt2pt(ctx, gmap, cloud, pose, pt, ms_dev, pairs)
+            tap and tap("pt2pt")
         return np.array(core.gn_solve(ctx, pairs, pose, gnp).pose)
 
     import torch
     pose, k = d["T_init"].copy(), 0
 
-    def one():
+    per_matcher = {}  # matcher -> search ms of every replayed call (hipEvents around its search kernels, inside the library)
+
+    def tap(name):
+        per_matcher.setdefault(name, []).append(ctx.stats()["ms_nn"])
+
+    def one(tap_=None):
         nonlocal pose, k
         if k % CYCLE == 0:
             pose = d["T_init"].copy()
-        pose = step(pose)
+        pose = step(pose, tap_)
         k += 1
 
     elapsed, ts = timed_steps(one, args.steps, args.warmup, torch.cuda.synchronize, dist, world, torch.device("cuda"))
@@ -592,19 +625,28 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
     ctx.set_profiling(1)
     nn, cp, gn, npt, npl = [], [], [], [], []
     for _ in range(min(args.steps, CYCLE)):
-        one()
+        one(tap)
         st = ctx.stats()
         nn.append(st["ms_nn"]), cp.append(st["ms_compact"]), gn.append(st["ms_gn"])
         a, b, _ = pairs.counts()
         npt.append(a), npl.append(b)
     ctx.set_profiling(0)
     err = amd.se3.log(amd.se3.inverse_compose(pose, d["T_gt"]))
+    spread = None
+    if dist is not None and world > 1:
+        # every rank solved the same all-reduced 6x6 systems: one pose
+        t_ = torch.tensor(np.asarray(pose, dtype=np.float64).ravel(), dtype=torch.float64,
+                          device=torch.device("cuda") if dist.get_backend() == "nccl" else torch.device("cpu"))
+        lo, hi = t_.clone(), t_.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN), dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = float((hi - lo).abs().max().item())
     nn_ms = float(np.mean(nn))
     knn = 5
     # lower bound of the distinct global points touched (N_g,touched >= N_pairs): the
     # pairs' own neighbours; the fraction below is therefore a LOWER bound of the roofline fraction
     touched_lb = float(np.mean(npt)) + min(float(g.shape[0]), knn * float(np.mean(npl)))
     touched_exact = None
+    touched_by = {}  # matcher -> exact N_g,touched of its instrumented calls
     if sharded is None:
         # ... and exactly: the instrumented call of every matcher of the step marks each map point its staging loop fetches
         # (profiling level 2; the marks are cleared per call, a point both matchers of C5 fetch counts twice: it is read twice),
@@ -617,15 +659,20 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
             if which == "c2":
                 core.match_pt2pt(ctx, gmap, cloud, pose, pt, None, pairs)
                 t += ctx.stats()["nn_points_staged"]
+                touched_by.setdefault("pt2pt", []).append(t)
             elif which == "c3":
                 core.match_pt2pl(ctx, gmap, cloud, pose, pl, None, pairs)
                 t += ctx.stats()["nn_points_staged"]
+                touched_by.setdefault("pt2pl", []).append(t)
             else:
                 ms_dev.reset()
                 core.match_pt2pl(ctx, gmap, cloud, pose, pl, ms_dev, pairs)
                 t += ctx.stats()["nn_points_staged"]
+                touched_by.setdefault("pt2pl", []).append(t)
                 core.match_pt2pt(ctx, gmap, cloud, pose, pt, ms_dev, pairs)
-                t += ctx.stats()["nn_points_staged"]
+                t1_ = ctx.stats()["nn_points_staged"]
+                touched_by.setdefault("pt2pt", []).append(t1_)
+                t += t1_
             ctx.set_profiling(0)
             cnt.append(t)
             pose = np.asarray(core.horn_solve(ctx, pairs)[0]) if which == "c2" else np.array(core.gn_solve(ctx, pairs, pose, gnp).pose)
@@ -634,6 +681,27 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
     out_bytes = 8.0 * n_l if which == "c2" else 72.0 * float(np.mean(npl)) + (8.0 * n_l if which == "c5" else 0.0)
     alg = 12.0 * n_l * (2 if which == "c5" else 1) + 12.0 * touched_lb + out_bytes
     ach = alg / (nn_ms * 1e-3) / 1e9
+    # ---- one roofline per matcher of the step (C5's dominant kernel is the plane search, not the last matcher's):
+    #      algorithmic bytes = 12 N_l (the layer read) + 12 N_g,touched (exact, counted above) + the matcher's output
+    #      (72 B per plane pairing; 8 B per local point for the point matcher's records); duration = hipEvents around the
+    #      matcher's search kernels in the replay
+    pl_kernel = "pt2pl_seltile_kernel" if n_l > 524288 else "pt2pl_tile_kernel"  # (launch_match_pt2pl's choice, Tune::pl_select = -1)
+    names = {"pt2pl": f"pt2pl_cert_kernel + {pl_kernel} (K5: exact k-NN search; the plane fit is timed with the compaction)",
+             "pt2pt": "nn_lane_kernel + nn_seltile_kernel + nn_single_kernel (K1+K3: transform + exact NN search)"}
+    rooflines = []
+    for name, ms_list in per_matcher.items():
+        ms_m = float(np.mean(ms_list))
+        tch = float(np.mean(touched_by[name])) if name in touched_by else None
+        if tch is None or ms_m <= 0:
+            continue
+        out_b = 72.0 * float(np.mean(npl)) if name == "pt2pl" else 8.0 * n_l
+        alg_m = 12.0 * n_l + 12.0 * tch + out_b
+        ach_m = alg_m / (ms_m * 1e-3) / 1e9
+        rooflines.append({"matcher": "Matcher_Point2Plane" if name == "pt2pl" else "Matcher_Points_DistanceThreshold",
+                          "bound": "hbm", "kernel": names[name], "achieved": ach_m, "peak": 8000.0, "unit": "GB/s",
+                          "frac": ach_m / 8000.0, "algorithmic_bytes_per_launch": alg_m, "avg_launch_ms": ms_m, "traffic": None,
+                          "n_g_touched": tch, "n_g_touched_exact": True})
+    rooflines.sort(key=lambda r_: -r_["avg_launch_ms"])
     cpu = None
     if not args.no_cpu_baseline and world == 1 and sharded is None:
         cpu = cpu_baseline_config(d, which, min(256, os.cpu_count() or 1))
@@ -649,18 +717,23 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
         "config": {"workload": label, "n_local": int(n_l), "n_global": int(g.shape[0]), "baseline_config": which.upper(),
                    "pose_chain": f"real ICP chain, restart from perturbed guess every {CYCLE} steps"},
         "step_ms": stats_ms(ts),
-        "kernel_ms": {"search_last_matcher": nn_ms, "compact_last_matcher": float(np.mean(cp)), "solver": float(np.mean(gn)),
+        "kernel_ms": {**{"search_" + k_: float(np.mean(v_)) for k_, v_ in per_matcher.items()},
+                      "search_last_matcher": nn_ms, "compact_last_matcher": float(np.mean(cp)), "solver": float(np.mean(gn)),
                       "note": "hipEvents of the LAST matcher call of the step (c5 runs two matchers)"},
         "pairs_per_step": {"pt2pt": float(np.mean(npt)), "pt2pl": float(np.mean(npl))},
         "matched_pairs_per_sec": (float(np.mean(npt)) + float(np.mean(npl))) * args.steps / elapsed,
         "final_pose_error": {"trans_m": float(np.linalg.norm(err[:3])), "rot_rad": float(np.linalg.norm(err[3:]))},
-        "roofline": {"bound": "hbm", "kernel": "search kernel(s) of the last matcher of the step",
+        # the DOMINANT matcher's search (largest launch duration of the step); every matcher's: "rooflines"
+        **({"rooflines": rooflines} if rooflines else {}),
+        "roofline": rooflines[0] if rooflines else
+                    {"bound": "hbm", "kernel": "search kernel(s) of the last matcher of the step",
                      "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": nn_ms, "traffic": None,
                      "n_g_touched": touched_lb, "n_g_touched_exact": touched_exact is not None,
                      "note": ("N_g,touched counted by the instrumented search (a byte per map point fetched)" if touched_exact is not None else
                               "N_g,touched replaced by its lower bound (the pairs' own neighbours): frac is a lower bound")},
         **({"cpu_baseline": cpu} if cpu is not None else {}),
+        **({"final_pose_max_abs_diff_over_ranks": spread} if spread is not None else {}),
     }
 
 
@@ -1000,6 +1073,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(d, args.threshold, args.gn_iters, 0.15, args.cpu_sample or d["local"].shape[0], cores)
         out["cpu_baseline"]["wall_s"] = time.time() - t0
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        # (the measured multi-thread figure sits under this container's CPU quota -- cpu_quota_cores; the 50 x target of
+        #  BASELINE.json is to be read against BOTH: the quota-bound measurement and the quota-free ideal)
+        out["speedup_vs_ideal_scaling_of_single_thread"] = out["value"] / out["cpu_baseline"]["ideal_scaling_of_single_thread"]["value"]
         # ---- the parity gate: the oracle's lists of the WHOLE headline layer were just computed ------------
         gate = out["cpu_baseline"].pop("_gate")
         if gate:

@@ -180,6 +180,47 @@ class HipBackend:
             raise RuntimeError("the native communicator could not be created on every rank")
         self.native = True
 
+    def init_hooks_comm(self, dist, group=None):
+        """The library's sharded step (mp2p_hip_step_sharded[_pt2pl]) over a process group that is NOT RCCL -- gloo, i.e. the
+        one-GPU test boxes where N ranks share a device and RCCL refuses two ranks per GPU: the step's collectives go through
+        mp2p_hip_comm_init_hooks (include/mp2p_hip.h) to this process group, staged through the host.  Same code inside the
+        library as with RCCL from the collectives' call sites outwards; a transport for tests, not for speed."""
+        import ctypes as C
+        from . import _lib
+        torch = self.torch
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        dev = self.dev
+
+        def allreduce(user, buf, n, op, stream):
+            try:
+                t = torch.as_tensor(_DevArray(buf, n, "<f8"), device=dev)
+                torch.cuda.synchronize(dev)
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
+                torch.cuda.synchronize(dev)
+                return 0
+            except Exception:  # pragma: no cover
+                return 1
+
+        def allgather(user, send, recv, n, stream):
+            try:
+                s_ = torch.as_tensor(_DevArray(send, n, "<i8"), device=dev)
+                r_ = torch.as_tensor(_DevArray(recv, n * world, "<i8"), device=dev)
+                torch.cuda.synchronize(dev)
+                parts = [torch.empty(n, dtype=torch.int64) for _ in range(world)]
+                dist.all_gather(parts, s_.cpu(), group=group)
+                r_.copy_(torch.cat(parts))
+                torch.cuda.synchronize(dev)
+                return 0
+            except Exception:  # pragma: no cover
+                return 1
+
+        self._hooks = (_lib.ALLREDUCE_FN(allreduce), _lib.ALLGATHER_FN(allgather))  # kept alive with the backend
+        _lib.check(self.ctx._L.mp2p_hip_comm_init_hooks(self.ctx.handle, rank, world, self._hooks[0], self._hooks[1], None),
+                   self.ctx.handle)
+        self.native = True
+
     def step_native(self, pose):
         import ctypes as C
         from . import _lib
@@ -242,7 +283,10 @@ class ShardedRegistration:
         self.world = dist.get_world_size(group) if dist is not None else 1
         if native is None:
             native = os.environ.get("MP2P_HIP_NATIVE_COMM", "1") != "0"
-        if (native and self.world > 1 and hasattr(backend, "init_native_comm")
+        if (native and self.world > 1 and getattr(backend, "native_only", False) and hasattr(backend, "init_hooks_comm")
+                and dist.get_backend(group) != "nccl"):
+            backend.init_hooks_comm(dist, group)  # (test boxes: the library's sharded step over gloo)
+        elif (native and self.world > 1 and hasattr(backend, "init_native_comm")
                 and dist.get_backend(group) == "nccl"):
             try:
                 backend.init_native_comm(dist, group)

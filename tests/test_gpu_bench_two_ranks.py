@@ -13,13 +13,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.timeout(900)
-def test_bench_two_ranks_on_one_gpu():
+def _run(n, port, extra):
     env = dict(os.environ, MP2P_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--n-local", "60000", "--n-global", "600000", "--scene", "a", "--no-cpu-baseline", "--no-extras"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "6", "--warmup", "2",
+           "--no-cpu-baseline"] + extra
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_n_ranks_on_one_gpu(n):
+    """(n = 8: VERDICT r5 #7 -- the rank count of the node the driver's scaling run uses, before that run)"""
+    r = _run(n, 29611 + n, ["--n-local", "60000", "--n-global", "600000", "--scene", "a", "--no-extras"])
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line
@@ -27,10 +33,22 @@ def test_bench_two_ranks_on_one_gpu():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "strong_scaling", "value_strong_scaling", "parity_gate"):
         assert k in d, k
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == n and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
     s = d["strong_scaling"]
     assert "error" not in s, s
     assert s["scaling"] == "strong" and s["value"] > 0 and d["value_strong_scaling"] == s["value"]
     # every rank solves the same all-reduced normal equations: one pose
     assert s["final_pose_max_abs_diff_over_ranks"] == 0.0 and s["weak_chain_final_pose_max_abs_diff_over_ranks"] == 0.0
     assert "skipped" in d["parity_gate"]                           # the gate runs at N = 1
+
+
+@pytest.mark.timeout(900)
+def test_bench_c3_eight_ranks_on_one_gpu():
+    """--gpus 8 --config c3 (the point-to-plane chain, layer sharded over 8 ranks): rc 0, one complete line, one pose"""
+    r = _run(8, 29631, ["--config", "c3"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["value"] > 0 and "roofline" in d
+    assert d.get("final_pose_max_abs_diff_over_ranks", 0.0) == 0.0

@@ -129,7 +129,7 @@ class _Exchange:
         return _lib.ALLREDUCE_FN(allreduce), _lib.ALLGATHER_FN(allgather)
 
 
-@pytest.mark.parametrize("world,allow_global", [(2, 0), (3, 0), (2, 1)])
+@pytest.mark.parametrize("world,allow_global", [(2, 0), (3, 0), (2, 1), (4, 0), (8, 0)])
 def test_sharded_step_through_hooks(oracle, world, allow_global):
     import torch
     import mp2p_icp_amd as amd
@@ -213,7 +213,7 @@ def _step_sharded_pt2pl(ctx, gmap, cloud, pose, prm, offset, gnp, pairs):
     return np.array(res.pose)
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
 def test_sharded_pt2pl_step_through_hooks(oracle, world):
     """mp2p_hip_step_sharded_pt2pl (Matcher_Point2Plane + Gauss-Newton, BASELINE config C3 sharded): a chain of three
     iterations on `world` in-process ranks (world = 1: no communicator) against the UNSHARDED oracle chain -- the

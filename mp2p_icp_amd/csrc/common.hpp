@@ -138,6 +138,13 @@ struct Tune
     uint32_t tile_brick_budget = 512;  // ... when the group's box spans at most this many bricks
     uint32_t hard_cand     = 1700;  // a query whose tile staged this many candidates at the previous call joins the hard class
                                     // (dispatched first) whatever its radius; 0 = by radius only
+    uint32_t heavy_cand    = 4000;  // round 6: a wave of pending queries whose tile staged this many candidates at the previous call joins the
+                                    // HEAVY class: its tiles are searched by FOUR waves of one workgroup each (nn_seltile_kernel<.., W = 4>, own
+                                    // stream, beside the other tiles): the kernel's span was its ten longest tiles; 0 = no such class
+    uint32_t heavy_delay   = 1;     // ... empty launches in front of the tile kernel on its stream (see launch_nn_pt2pt)
+    int      heavy_prio    = 0;     // ... priority of the tile kernel's stream: 0 = default, 1 = lowest, 2 = highest
+    int      cost_ticks    = 0;     // the tile kernel records a tile's DURATION (in candidate equivalents of 16 ns) as its cost, not what it staged
+    uint32_t heavy_tiles   = 2048;  // ... capacity of that class's list in tiles (what does not fit joins the hard class)
     uint32_t hard_radius_pct = 100; // pending queries with a radius above this % of a level-0 voxel are "hard":
                                     // their tiles are dispatched first (nn_query.hip)
     int      xcd_map       = 1;     // tile kernel: one segment of the pending list per XCD (L2 locality)

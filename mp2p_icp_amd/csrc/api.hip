@@ -131,11 +131,6 @@ static int parse_tune(Tune& t, const char* e, bool from_env, std::string* why = 
             else t.pl_sol = (int)v;
         }
         else if (k == "gn_fuse") t.gn_fuse = (int)v;
-        else if (k == "heavy_cand") t.heavy_cand = (uint32_t)v;
-        else if (k == "heavy_tiles") t.heavy_tiles = (uint32_t)v;
-        else if (k == "heavy_delay") t.heavy_delay = (uint32_t)v;
-        else if (k == "heavy_prio") t.heavy_prio = (int)v;
-        else if (k == "cost_ticks") t.cost_ticks = (int)v;
         else refuse(kv, "unknown knob");
     }
     return bad;

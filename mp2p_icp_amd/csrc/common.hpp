@@ -138,13 +138,6 @@ struct Tune
     uint32_t tile_brick_budget = 512;  // ... when the group's box spans at most this many bricks
     uint32_t hard_cand     = 1700;  // a query whose tile staged this many candidates at the previous call joins the hard class
                                     // (dispatched first) whatever its radius; 0 = by radius only
-    uint32_t heavy_cand    = 4000;  // round 6: a wave of pending queries whose tile staged this many candidates at the previous call joins the
-                                    // HEAVY class: its tiles are searched by FOUR waves of one workgroup each (nn_seltile_kernel<.., W = 4>, own
-                                    // stream, beside the other tiles): the kernel's span was its ten longest tiles; 0 = no such class
-    uint32_t heavy_delay   = 1;     // ... empty launches in front of the tile kernel on its stream (see launch_nn_pt2pt)
-    int      heavy_prio    = 0;     // ... priority of the tile kernel's stream: 0 = default, 1 = lowest, 2 = highest
-    int      cost_ticks    = 0;     // the tile kernel records a tile's DURATION (in candidate equivalents of 16 ns) as its cost, not what it staged
-    uint32_t heavy_tiles   = 2048;  // ... capacity of that class's list in tiles (what does not fit joins the hard class)
     uint32_t hard_radius_pct = 100; // pending queries with a radius above this % of a level-0 voxel are "hard":
                                     // their tiles are dispatched first (nn_query.hip)
     int      xcd_map       = 1;     // tile kernel: one segment of the pending list per XCD (L2 locality)
@@ -157,9 +150,10 @@ struct Tune
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
     int      claim_peek    = 1;     // plain look at the claim word before the atomic
     int      compact_fused = 1;     // compaction: bounding-box reduction folded in
-    uint32_t tile_waves    = 4;     // tile kernel (matrix-pipe variant): register budget for this many waves per SIMD.
-                                    // 4 = 121 VGPRs, no spill: as fast as 5 (96 VGPRs, 13 spilled dwords) and without
-                                    // the scratch write-backs (38 MB of HBM writes per launch); 6 is slower
+    uint32_t tile_waves    = 0;     // tile kernel (matrix-pipe variant): register budget for this many waves per SIMD.  0 = by the path:
+                                    // nn_seltile_kernel behind the lane kernel 4 (128 VGPRs, 3 spilled dwords since the staging loads are
+                                    // issued four at a time: still the fastest, 2 254 vs 2 193 it/s with 3), with the fused prologue 3
+                                    // (no spill, as fast as 4 on C2); round 4's nn_tile_kernel: 4 (no spill; 5 and 6 spill / are slower)
     uint32_t pipelines     = 1;     // 2 = independent lane -> tile -> one-query chains over halves of the local layer
                                     // on two streams (one chain's drain filled by the other's kernels): -6 % search
                                     // time on scene B, +4 % on scene A

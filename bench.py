@@ -381,7 +381,7 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def roofline_block(n_l, touched_mean, nn_ms_avg, tag):
@@ -680,7 +680,7 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
         touched_lb = touched_exact
     out_bytes = 8.0 * n_l if which == "c2" else 72.0 * float(np.mean(npl)) + (8.0 * n_l if which == "c5" else 0.0)
     alg = 12.0 * n_l * (2 if which == "c5" else 1) + 12.0 * touched_lb + out_bytes
-    ach = alg / (nn_ms * 1e-3) / 1e9
+    ach = alg / (nn_ms * 1e-3) / 1e9 if nn_ms > 0 else 0.0  # (no per-stage events: the sharded step over the test boxes' hook communicator)
     # ---- one roofline per matcher of the step (C5's dominant kernel is the plane search, not the last matcher's):
     #      algorithmic bytes = 12 N_l (the layer read) + 12 N_g,touched (exact, counted above) + the matcher's output
     #      (72 B per plane pairing; 8 B per local point for the point matcher's records); duration = hipEvents around the

@@ -265,7 +265,7 @@ typedef struct
     uint64_t local_index_offset;
     /* tuning (0 = default): first search radius in units of the finest cell */
     float    initial_radius_cells;
-    uint32_t queries_per_wave;    /* 64, 32 or 16; 0 = default (32) */
+    uint32_t queries_per_wave;    /* 0 or 32; 16 and 64 (tile shapes of rounds 1-4) are accepted and served by the 32-query kernels: a tuning value, the lists never depended on it */
     float    group_radius_factor; /* queries of a tile farther than this many search radii
                                      from the first pending one wait for a later pass; 0 = 2.5 */
     uint32_t cell_budget;         /* max voxels of one search box before a coarser level is

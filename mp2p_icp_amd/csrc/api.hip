@@ -729,7 +729,7 @@ int mp2p_hip_adaptive_search(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const m
     if (const int rc = adaptive_check(ctx, map, cloud, prm, ms)) return rc;
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
     memset(hist, 0, sizeof(*hist));
-    ctx->ad_knn = 0, ctx->ad_cloud = nullptr, ctx->ad_map = nullptr;
+    ctx->ad_knn = 0, ctx->ad_cloud = nullptr, ctx->ad_map = nullptr, ctx->ad_apart = false;
     if (map->n == 0 || cloud->n == 0) return MP2P_HIP_OK;  // :72
     return launch_adaptive_search(ctx, map, cloud, pose, prm, ms, hist);
 }
@@ -778,6 +778,11 @@ int mp2p_hip_adaptive_select(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const m
     const uint32_t nn = prm->enableDetectPlanes ? prm->planeSearchPoints : prm->maxPt2PtCorrespondences;
     MP2P_REQUIRE(ctx, ctx->ad_knn == nn && ctx->ad_cloud == cloud && ctx->ad_map == map,
                  "mp2p_hip_adaptive_select without a matching mp2p_hip_adaptive_search");
+    if (ctx->ad_apart)
+    {  // the search returned before any launch (boxes apart, Matcher_Adaptive.cpp:78-81): no lists exist, nothing is paired
+        ctx->ad_apart = false, ctx->ad_knn = 0;
+        return MP2P_HIP_OK;
+    }
     MP2P_REQUIRE(ctx, ci_high == ci_high, "threshold is NaN");
     const int rc = launch_adaptive_select(ctx, map, cloud, prm, ci_high, ms, out);
     ctx->ad_knn = 0;  // the lists are consumed (select rewrites them)

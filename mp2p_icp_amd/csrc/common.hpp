@@ -141,8 +141,9 @@ struct Tune
     uint32_t hard_radius_pct = 100; // pending queries with a radius above this % of a level-0 voxel are "hard":
                                     // their tiles are dispatched first (nn_query.hip)
     int      xcd_map       = 1;     // tile kernel: one segment of the pending list per XCD (L2 locality)
-    uint32_t single_waves  = 0;     // one-query-per-wave kernel: register budget for 4, 6 or 8 waves per SIMD (0 = 5: 96 VGPRs,
-                                    // no spill; 4 = the compiler's own 98 VGPRs: -3..-11 % slower; 6 / 8 spill)
+    uint32_t single_waves  = 0;     // one-query-per-wave kernel: register budget for 4 waves per SIMD (0 = 5: 96 VGPRs; 4 = the compiler's
+                                    // own 108 VGPRs: -3..-11 % slower; the 6- and 8-wave builds spilled 68 / 140 bytes per lane, were
+                                    // slower and are gone since round 6: the values are accepted and mean the default)
     uint32_t single_blocks_per_cu = 0;  // ... and its grid, in workgroups per CU (0 = 40: two resident rounds at 5 waves)
     uint32_t pl_q          = 0;     // point-to-plane search: queries per wave (0 = by layer size: 8 up to 400 k points, else 32)
     int      sync_spin     = 1;     // wait for the stream by polling hipStreamQuery (lower wake-up latency)
@@ -157,7 +158,8 @@ struct Tune
     uint32_t pipelines     = 1;     // 2 = independent lane -> tile -> one-query chains over halves of the local layer
                                     // on two streams (one chain's drain filled by the other's kernels): -6 % search
                                     // time on scene B, +4 % on scene A
-    int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter
+    int      mfma_scan     = 1;     // tile kernel: distance tests of a tile on the matrix pipe as a prefilter (always, since round 6: the exact-scan
+                                    // builds of rounds 1-3 are gone; the knob is accepted without effect)
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
     int      pl_warm       = 1;     // point-to-plane search: start radius from the previous call's k-th distance (0 = full radius)
     int      pl_cert       = 2;     // pt2pl: skip the search of a query whose previous list is certainly still its k nearest (PlArgs::lb_io)
@@ -299,6 +301,7 @@ struct mp2p_hip_ctx
     uint32_t                         ad_knn   = 0;       //   lists held in nn_spos / nn_d2: neighbours per point,
     const void*                      ad_cloud = nullptr; //   and the handles they were searched for
     const void*                      ad_map   = nullptr;
+    bool                             ad_apart = false;   //   the search returned before any launch: the layers' boxes cannot meet (select emits nothing)
     mp2p::DevBuf<float>              nn_lb2nd;     // [n_local] pt2pt certificate: bound of the distance to every point but the nearest
     bool                             nn_lb2nd_valid = false;  // ... written by the previous pt2pt call (on hint_map / hint_cloud)
     mp2p::DevBuf<uint4>              nn_rec;       // [n_local] result + warm-start records of the pt2pt search

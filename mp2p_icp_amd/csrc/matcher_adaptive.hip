@@ -218,6 +218,33 @@ int launch_adaptive_search(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2
     const size_t   n_l     = cloud->n;
     const uint32_t K       = adaptive_nn(prm);
     const uint32_t n_tiles = (uint32_t)((n_l + PL_Q - 1) / PL_Q);
+    // Matcher_Adaptive.cpp:78-81 returns BEFORE any search when the two boxes (inflated by the epsilon) do not meet.  Every transformed
+    // local point lies within cloud->radius of the pose's translation: when that ball (a superset of the layer's box, also of a
+    // visited subset's) clears the map's box along some axis, the boxes are certainly apart and nothing is launched (ADVICE r5;
+    // disjoint layers used to pay a full search first).  The exact test on the reduced box, below, stays for everything else.
+    ctx->ad_apart = false;
+    if (cloud->radius == cloud->radius && cloud->radius < INFINITY)
+    {
+        // |R p| <= |p| for a rotation (checked: R^T R = I to 1e-6), else <= ||R||_F |p|
+        double dev = 0.0, fro = 0.0;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+            {
+                double dot = 0.0;
+                for (int k = 0; k < 3; k++) dot += pose[3 * k + i] * pose[3 * k + j];
+                dev = std::max(dev, std::fabs(dot - (i == j ? 1.0 : 0.0)));
+                fro += pose[3 * i + j] * pose[3 * i + j];
+            }
+        const double gain = dev <= 1e-6 ? 1.00001 : std::sqrt(fro) * 1.00001;
+        const double eps = prm->bounding_box_intersection_check_epsilon, R = (double)cloud->radius * gain + 1e-6 * (1.0 + (double)cloud->radius);
+        for (int d = 0; d < 3; d++)
+            if (pose[9 + d] - R - eps > (double)map->view.bbmax[d] || pose[9 + d] + R + eps < (double)map->view.bbmin[d])
+            {
+                memset(hist, 0, sizeof(*hist));
+                ctx->ad_knn = K, ctx->ad_cloud = cloud, ctx->ad_map = map, ctx->ad_apart = true;
+                return MP2P_HIP_OK;
+            }
+    }
     MP2P_TRY_HIP(ctx, ctx->tile_bbox.ensure((size_t)n_tiles * 6));
     MP2P_TRY_HIP(ctx, ctx->local_bbox.ensure(6));
     MP2P_TRY_HIP(ctx, ctx->nn_spos.ensure(n_l * K));

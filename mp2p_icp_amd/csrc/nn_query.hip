@@ -1663,11 +1663,16 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     const size_t n_l = cloud->n;
     uint32_t     Q   = prm->queries_per_wave ? prm->queries_per_wave : 32;
     MP2P_REQUIRE(ctx, Q == 64 || Q == 32 || Q == 16, "queries_per_wave must be 64, 32 or 16");
+    // round 6: every tile is 32 queries -- the shape of the matrix pipe's prefilter.  The 16- and 64-query tiles and the exact
+    // (non-matrix) scan of rounds 1-3 computed the same lists more slowly (2 202 / 2 390 / 1 945 it/s for 16 / 32 / 64)
+    // and cost eight instantiations of nn_tile_kernel, two of them with 92 bytes of scratch per lane; the parameter is still
+    // accepted (a tuning value: results never depended on it), as are the knobs mfma_scan and tile_waves = 5 / 6, without effect
+    Q = 32;
     const uint32_t n_waves = (uint32_t)((n_l + 63) / 64);     // lane kernel
 
     // round 5 (nn_seltile.hip): voxels selected on the matrix pipe; needs the level-0 occupancy bricks and the 32-query tile.
     // DIRECT: the per-query prologue runs in the tile itself (no lane kernel, no pending list)
-    const bool sel    = ctx->tune.tile_select && Q == 32 && ctx->tune.mfma_scan && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE;
+    const bool sel    = ctx->tune.tile_select && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE;
     // a SMALL layer (at most two rounds of resident tiles: 2 x 4 096 x 32 queries) is one wave of tiles -- the kernel is as
     // long as its longest tile, and what a long tile hands on is spread over the idle CUs by the one-query kernel: the budgets of
     // rounds 1-4, and the prologue in the tile (no hard-first order to lose, one launch less).  Measured on configuration C2
@@ -1730,7 +1735,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.empty_room        = ctx->tune.empty_room;
     a.claim_dedup   = ctx->tune.claim_dedup;
     a.claim_peek    = ctx->tune.claim_peek;
-    a.mfma_scan     = ctx->tune.mfma_scan;
+    a.mfma_scan     = 1;
     a.local_taken =
         (ms && !prm->allowMatchAlreadyMatchedPoints) ? ms->local_taken.p : nullptr;
     a.global_taken =
@@ -1775,8 +1780,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
             for (int i = 0; i < 9; i++) dr += (pose[i] - ctx->hint_pose[i]) * (pose[i] - ctx->hint_pose[i]);
             cert_track = std::sqrt(dt) + std::sqrt(dr) * (double)cloud->radius <= 1e-3 * (double)ctx->tune.nn_cert_step_mm;
         }
-        cert_track = cert_track && Q == 32 && ctx->tune.mfma_scan && ctx->profiling != 2 && sol == 0 &&
-                     (sel || ctx->tune.tile_waves == 4 || ctx->tune.tile_waves == 0);  // (the round-4 kernel has a tracking build for 4 waves per SIMD only)
+        cert_track = cert_track && ctx->profiling != 2 && sol == 0;
         a.lb2nd = nullptr, a.cert_read = 0;
         if (cert_track || cert_read)
         {
@@ -1861,12 +1865,6 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
             else hipLaunchKernelGGL(nn_lane_kernel<false>, dim3(wn[p]), dim3(64), 0, st[p], ap[p]);
         }
         if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
-#define MP2P_LAUNCH_TILE(QQ)                                                                                  \
-    do                                                                                                        \
-    {                                                                                                         \
-        if (instr) hipLaunchKernelGGL((nn_tile_kernel<QQ, true>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);   \
-        else hipLaunchKernelGGL((nn_tile_kernel<QQ, false>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);        \
-    } while (0)
 #define MP2P_LAUNCH_SEL(INSTR_, CERT_, DIRECT_, SOL_) \
     hipLaunchKernelGGL((nn_seltile_kernel<INSTR_, CERT_, DIRECT_, 4, SOL_>), dim3(tn[p]), dim3(64), 0, st[p], ap[p])
         for (uint32_t p = 0; p < P; p++)
@@ -1893,19 +1891,13 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
                 else if (cert_track) { if (direct) MP2P_LAUNCH_SEL(false, true, true, 0); else MP2P_LAUNCH_SEL(false, true, false, 0); }
                 else { if (direct) MP2P_LAUNCH_SEL(false, false, true, 0); else MP2P_LAUNCH_SEL(false, false, false, 0); }
             }
-            else if (Q == 64) MP2P_LAUNCH_TILE(64);
-            else if (Q == 32 && a.mfma_scan)
-            {
+            else
+            {   // a map without the level-0 occupancy bricks (or tile_select = 0): round 4's box-rule tile kernel, matrix-pipe prefilter
                 if (instr) hipLaunchKernelGGL((nn_tile_kernel<32, true, true>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
-                else if (ctx->tune.tile_waves == 6) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 6>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
-                else if (ctx->tune.tile_waves == 5) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 5>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
                 else if (cert_track) hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 4, true>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
                 else hipLaunchKernelGGL((nn_tile_kernel<32, false, true, 4>), dim3(tn[p]), dim3(64), 0, st[p], ap[p]);
             }
-            else if (Q == 32) MP2P_LAUNCH_TILE(32);
-            else MP2P_LAUNCH_TILE(16);
         }
-#undef MP2P_LAUNCH_TILE
 #undef MP2P_LAUNCH_SEL
         if (ctx->prof_all()) MP2P_TRY_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         // deferred queries: the count lives on the device; a fixed grid strides over it
@@ -1913,8 +1905,6 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         {
             if (instr) hipLaunchKernelGGL((nn_single_kernel<true, 1>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
             else if (ctx->tune.single_waves == 4) hipLaunchKernelGGL((nn_single_kernel<false, 1>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
-            else if (ctx->tune.single_waves == 6) hipLaunchKernelGGL((nn_single_kernel<false, 6>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
-            else if (ctx->tune.single_waves == 8) hipLaunchKernelGGL((nn_single_kernel<false, 8>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
             else hipLaunchKernelGGL((nn_single_kernel<false, 5>), dim3(sbn[p]), dim3(64), 0, st[p], ap[p]);
         }
         if (P > 1)

@@ -200,7 +200,9 @@ class HipBackend:
                 t.copy_(h)
                 torch.cuda.synchronize(dev)
                 return 0
-            except Exception:  # pragma: no cover
+            except Exception:  # pragma: no cover  (the library reports MP2P_HIP_ERR_COMM; say why)
+                import traceback
+                traceback.print_exc()
                 return 1
 
         def allgather(user, send, recv, n, stream):
@@ -213,7 +215,9 @@ class HipBackend:
                 r_.copy_(torch.cat(parts))
                 torch.cuda.synchronize(dev)
                 return 0
-            except Exception:  # pragma: no cover
+            except Exception:  # pragma: no cover  (the library reports MP2P_HIP_ERR_COMM; say why)
+                import traceback
+                traceback.print_exc()
                 return 1
 
         self._hooks = (_lib.ALLREDUCE_FN(allreduce), _lib.ALLGATHER_FN(allgather))  # kept alive with the backend

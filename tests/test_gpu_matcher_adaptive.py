@@ -212,3 +212,43 @@ def test_boxes_apart_but_neighbours_in_reach(amd, oracle):
         assert not m.last_histogram["valid"] and not called
         assert len(pairs.paired_pt2pt) == 0 and len(pairs.paired_pt2pl) == 0
         assert pairs.potential_pairings == r["potential"]
+
+
+def test_layers_far_apart_return_before_any_search(amd, oracle):
+    """round 6: when the ball that holds every transformed local point clears the map's box the library returns before
+    any launch, as Matcher_Adaptive.cpp:78-81 does; the split entry points stay consistent: a select after such a search emits nothing
+    (no stale lists of an earlier call are read), potential_pairings still grows (:69)"""
+    from mp2p_icp_amd import _lib, core
+    g, l = _scene(96, n_g=20_000, n_l=2_000)
+    l = l[50:].copy()
+    kw = dict(confidenceInterval=0.8, firstToSecondDistanceMax=1.2, absoluteMaxSearchDistance=1.5, minimumCorrDist=0.1,
+              enableDetectPlanes=True, maxPt2PtCorrespondences=2, planeSearchPoints=8, planeMinimumFoundPoints=4)
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    near, far = oracle.pose_identity(), amd.se3.from_xyzypr(500.0, -300.0, 40.0, 0.3, 0.0, 0.0)
+    pcG = amd.metric_map_t({"raw": amd.PointLayer(g)})
+    pcL = amd.metric_map_t({"raw": amd.PointLayer(l)})
+    m = amd.Matcher_Adaptive()
+    m.initialize(kw)
+    for pose in (near, far, near, far):       # a real search first: its lists must not leak into the far call
+        r = oracle.match_adaptive(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], pose, tree=tree, **kw)
+        pairs = amd.Pairings()
+        assert m.match(pcG, pcL, pose, amd.MatchContext(), amd.MatchState(pcG, pcL), pairs)
+        assert m.last_histogram["valid"] == r["hist"]["valid"]
+        assert len(pairs.paired_pt2pt) == len(r["pt2pt"]) and np.array_equal(pairs.paired_pt2pl_local_idx, r["pl_local_idx"])
+        assert pairs.potential_pairings == r["potential"]
+        if pose is far:
+            assert not m.last_histogram["valid"] and pairs.empty()
+    # the split entry points at the C ABI: a real search, then a search that returns early, then select -- which must not read the
+    # first search's lists
+    ctx = amd.Context(0)
+    gmap, cloud = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2]), core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+    dev = core.DevicePairs(ctx, 2 * l.shape[0], l.shape[0])
+    prm = m._params()
+    assert core.adaptive_search(ctx, gmap, cloud, near, prm, None).valid
+    h = core.adaptive_search(ctx, gmap, cloud, far, prm, None)
+    assert not h.valid
+    core.adaptive_select(ctx, gmap, cloud, prm, 1.0, None, dev)
+    n_pt, n_pl, pot = dev.counts()
+    assert n_pt == 0 and n_pl == 0 and pot == l.shape[0] * kw["maxPt2PtCorrespondences"]
+    with pytest.raises(_lib.Mp2pHipError):   # the (empty) lists are consumed: a second select has no search to refer to
+        core.adaptive_select(ctx, gmap, cloud, prm, 1.0, None, dev)

@@ -92,6 +92,7 @@ int mp2p_hostpath_match_pt2pt(void* h, const double pose[12], const mp2p_hip_pt2
             MatchCall    c;
             c.ms_key = &s->dummy_ms, c.iteration = icp_iteration;
             c.gbits = BitView{s->gbits.data(), s->ng}, c.lbits = BitView{s->lbits.data(), s->nl};
+            c.lx = s->lx, c.ly = s->ly, c.lz = s->lz, c.n_local = s->nl;
             s->potential += (uint64_t)s->nl * prm->pairingsPerPoint;  // :64
             size_t n = 0;
             if (s->ng && s->nl)
@@ -117,6 +118,7 @@ int mp2p_hostpath_match_pt2pl(void* h, const double pose[12], const mp2p_hip_pt2
             MatchCall    c;
             c.ms_key = &s->dummy_ms, c.iteration = icp_iteration;
             c.gbits = BitView{s->gbits.data(), s->ng}, c.lbits = BitView{s->lbits.data(), s->nl};
+            c.lx = s->lx, c.ly = s->ly, c.lz = s->lz, c.n_local = s->nl;
             s->potential += (uint64_t)s->nl;  // Matcher_Point2Plane.cpp:54
             size_t n = 0;
             if (s->ng && s->nl)
@@ -174,6 +176,7 @@ int mp2p_hostpath_match_inlier_ratio(void* h, const double pose[12], const mp2p_
             MatchCall    c;
             c.ms_key = &s->dummy_ms, c.iteration = icp_iteration;
             c.gbits = BitView{s->gbits.data(), s->ng}, c.lbits = BitView{s->lbits.data(), s->nl};
+            c.lx = s->lx, c.ly = s->ly, c.lz = s->lz, c.n_local = s->nl;
             s->potential += (uint64_t)s->nl;  // :53
             size_t n = 0;
             if (s->ng && s->nl)
@@ -201,6 +204,7 @@ int mp2p_hostpath_match_adaptive(void* h, const double pose[12], const mp2p_hip_
             MatchCall    c;
             c.ms_key = &s->dummy_ms, c.iteration = icp_iteration;
             c.gbits = BitView{s->gbits.data(), s->ng}, c.lbits = BitView{s->lbits.data(), s->nl};
+            c.lx = s->lx, c.ly = s->ly, c.lz = s->lz, c.n_local = s->nl;
             s->potential += (uint64_t)s->nl * prm->maxPt2PtCorrespondences;  // Matcher_Adaptive.cpp:75
             std::pair<size_t, size_t> n{0, 0};
             if (s->ng && s->nl)

@@ -543,7 +543,18 @@ struct MatchCall
     const void* ms_key    = nullptr;  // address of the MatchState (one run_matchers call = one state)
     uint32_t    iteration = 0;        // MatchContext::icpIteration
     BitView     gbits, lbits;         // packed host bit-fields of this (global layer, local layer)
+    // the local layer's own coordinate arrays (what its cloud handle was uploaded from): with them -- and MP2P_HIP_HOST_COPY_SOA=1 --
+    // the point pairings come back as 24 instead of 44 bytes per pair and their `local` member is filled from here
+    // (mp2p_hip_pairs_copy_pt2pt_begin_soa); else the record form
+    const float* lx = nullptr;
+    const float* ly = nullptr;
+    const float* lz = nullptr;
+    size_t       n_local = 0;
 };
+
+// the three-step copy of new point pairings: SoA form when the call carries the local layer's arrays
+inline int copy_pt2pt_begin(Runtime& rt, const MatchCall& c, mp2p_hip_pairs* dp, size_t first, size_t n, mp2p_hip_pair_pt2pt* dst,
+                            uint32_t* li, uint32_t* gi);
 
 // start of a matcher call: the device list is continued when it belongs to the same run_matchers call
 // (same MatchState object, same ICP iteration, and that state carries marks: a state without any is
@@ -559,6 +570,21 @@ inline mp2p_hip_pairs* begin_match(Runtime& rt, const MatchCall& c, bool fresh_s
     if (!same) rt.check(mp2p_hip_pairs_clear(rt.ctx, dp));
     tk.ms_key = c.ms_key, tk.iteration = c.iteration;
     return dp;
+}
+
+inline int copy_pt2pt_begin(Runtime& rt, const MatchCall& c, mp2p_hip_pairs* dp, size_t first, size_t n, mp2p_hip_pair_pt2pt* dst,
+                            uint32_t* li, uint32_t* gi)
+{
+    const bool soa = [] {
+        // opt-in: measured on two boxes (bench.py host_boundary, 1 M x 10 M, 238 k pairs per step, same call) the copy-out window was
+        // 1.36-1.43 ms in this form against 0.66-1.26 ms in the record form -- the host side of the copy (two threads writing the
+        // caller's vector) bounds it there, not the link, and assembling a record costs more than copying one
+        const char* e = std::getenv("MP2P_HIP_HOST_COPY_SOA");
+        return e && e[0] == '1';
+    }();
+    if (soa && c.lx && c.ly && c.lz && c.n_local)
+        return mp2p_hip_pairs_copy_pt2pt_begin_soa(rt.ctx, dp, first, n, dst, li, gi, c.lx, c.ly, c.lz, c.n_local, 0);
+    return mp2p_hip_pairs_copy_pt2pt_begin(rt.ctx, dp, first, n, dst, li, gi);
 }
 
 // ends an open split copy on every path out of a matcher call (an exception between begin and end would leave the
@@ -592,7 +618,7 @@ size_t fetch_new_pt2pt(Runtime& rt, const MatchCall& c, mp2p_hip_pairs* dp, Pair
         uint32_t* li = rt.idx_scratch(n);
         uint32_t* gi = li + rt.idx_stride();
         CopyGuard guard{rt};
-        rt.check(mp2p_hip_pairs_copy_pt2pt_begin(rt.ctx, dp, tk.n_pt, n, dst, li, gi));
+        rt.check(copy_pt2pt_begin(rt, c, dp, tk.n_pt, n, dst, li, gi));
         guard.open = true;
         rt.check(mp2p_hip_pairs_copy_wait_idx(rt.ctx));
         const double tm = Runtime::now_ms();
@@ -729,7 +755,7 @@ size_t match_pt2pt_layer(Runtime& rt, const MatchCall& c, mp2p_hip_map* map, mp2
         uint32_t* li = rt.idx_scratch(n);
         uint32_t* gi = li + rt.idx_stride();
         CopyGuard guard{rt};
-        rt.check(mp2p_hip_pairs_copy_pt2pt_begin(rt.ctx, dp, tk.n_pt, n, dst, li, gi));
+        rt.check(copy_pt2pt_begin(rt, c, dp, tk.n_pt, n, dst, li, gi));
         guard.open = true;
         rt.check(mp2p_hip_pairs_copy_wait_idx(rt.ctx));
         const double tm = Runtime::now_ms();

@@ -200,6 +200,13 @@ class MatcherCallContext
         c = rt.local_layer(&lc, lc.getPointsBufferRef_x().data(), lc.getPointsBufferRef_y().data(),
                            lc.getPointsBufferRef_z().data(), lc.size(), full);
     }
+    // the local layer's own arrays travel with the call: the point pairings then come back as 24 bytes per pair and their
+    // `local` member is read from here (mp2p_hip_host::copy_pt2pt_begin)
+    static void local_arrays(MatchCall& call, const mrpt::maps::CPointsMap& lc)
+    {
+        call.lx = lc.getPointsBufferRef_x().data(), call.ly = lc.getPointsBufferRef_y().data();
+        call.lz = lc.getPointsBufferRef_z().data(), call.n_local = lc.size();
+    }
 };
 
 // ================================================================================================
@@ -307,6 +314,7 @@ class Matcher_Points_DistanceThreshold : public mp2p_icp::Matcher_Points_Base, p
         MatchCall call;
         call.ms_key = cur_ms_ ? cur_ms_ : &ms, call.iteration = cur_iteration_;
         call.gbits = gbits.view(), call.lbits = lbits.view();
+        local_arrays(call, pcLocal);
         // mrpt::tfest::TMatchingPairList derives std::vector<TMatchingPair>: appended in place
         mp2p_hip_host::match_pt2pt_layer(rt, call, m, c, T, prm, visit.data(), visit.size(), out.paired_pt2pt);
         gbits.commit(), lbits.commit();
@@ -671,6 +679,7 @@ class Matcher_Points_InlierRatio : public mp2p_icp::Matcher_Points_Base, protect
         MatchCall call;
         call.ms_key = cur_ms_ ? cur_ms_ : &ms, call.iteration = cur_iteration_;
         call.gbits = gbits.view(), call.lbits = lbits.view();
+        local_arrays(call, pcLocal);
         mp2p_hip_host::match_inlier_ratio_layer(rt, call, m, c, T, prm, visit.data(), visit.size(), out.paired_pt2pt);
         gbits.commit(), lbits.commit();
     }
@@ -756,6 +765,7 @@ class Matcher_Adaptive : public mp2p_icp::Matcher_Points_Base, protected Matcher
         MatchCall call;
         call.ms_key = cur_ms_ ? cur_ms_ : &ms, call.iteration = cur_iteration_;
         call.gbits = gbits.view(), call.lbits = lbits.view();
+        local_arrays(call, pcLocal);
         const double ci = 1.0 - confidenceInterval;
         mp2p_hip_host::match_adaptive_layer(
             rt, call, m, c, T, prm,

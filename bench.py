@@ -539,11 +539,14 @@ def bench_config(args, which, local_rank, stream, rank=0, world=1, dist=None):
     from mp2p_icp_amd import _lib, core, synthetic
     ctx = amd.Context(local_rank, stream=stream)
     if which == "c3" and (world > 1 or dist is not None):
-        d = synthetic.make_scan_union_pair(120_000 * world, 10_000_000, 3001, map_scan_points=1_000_000)
+        # (--config-scale: a code-path run of the tests at a fraction of the size -- 8 ranks building a 10 M-point scene each on a
+        #  one-GPU box's few host cores take minutes; a scaled line says so in its workload and is no measurement of the configuration)
+        sc = float(getattr(args, "config_scale", 1.0) or 1.0)
+        d = synthetic.make_scan_union_pair(int(120_000 * sc) * world, int(10_000_000 * sc), 3001, map_scan_points=int(1_000_000 * sc))
         n_shard = d["local"].shape[0] // world
         d["local"] = np.ascontiguousarray(d["local"][rank * n_shard:(rank + 1) * n_shard])
-        label = (f"{world} x KITTI-shape scan shard (~{n_shard} pts each) vs 10 M-pt map (replicated), Matcher_Point2Plane "
-                 "(knn 5, r 0.4) + Solver_GaussNewton, sharded step")
+        label = (f"{world} x KITTI-shape scan shard (~{n_shard} pts each) vs {10 * sc:g} M-pt map (replicated), Matcher_Point2Plane "
+                 "(knn 5, r 0.4) + Solver_GaussNewton, sharded step" + ("" if sc == 1.0 else f" -- SCALED x{sc:g}: a test run, not the configuration"))
     elif which == "c2":
         d = synthetic.make_scan_union_pair(120_000, 2_000_000, 2001, map_scan_points=120_000)
         label = "KITTI-shape scan (~120 k pts) vs 2 M-pt map, Matcher_Points_DistanceThreshold + Solver_Horn"
@@ -861,6 +864,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--config", choices=["c2", "c3", "c5"], default=None,
                     help="another BASELINE config as a bench line of its own (1 GPU)")
+    ap.add_argument("--config-scale", type=float, default=1.0, help="tests only: --gpus N --config c3 at this fraction of its sizes")
     ap.add_argument("--scene", choices=["a", "b"], default="b", help="scene of `value` (see the module docstring)")
     ap.add_argument("--q", type=int, default=0, help="queries per wave (tuning)")
     ap.add_argument("--r0", type=float, default=0.0, help="initial radius in cells (tuning)")

@@ -229,6 +229,20 @@ int  mp2p_hip_pairs_copy_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_
  * mp2p_hip_ctx_destroy, so `out` must stay valid until then. */
 int  mp2p_hip_pairs_copy_pt2pt_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
                                      mp2p_hip_pair_pt2pt* out, uint32_t* idx_local, uint32_t* idx_global);
+/* round 6: the same three-step copy with 24 instead of 44 bytes per pair on the link (BASELINE.md section 3 counts the D->H of the pairs):
+ * the index arrays first, as above; then only the global point and the squared error (16 bytes per pair); the 36-byte records are ASSEMBLED on the host by the copy threads -- globalIdx / localIdx from the two index
+ * arrays (which must be the page-locked ones of mp2p_hip_host_alloc and stay valid until _end), local_xyz read from the CALLER'S own
+ * layer arrays at localIdx - local_index_base (localIdx is ascending in a matcher's output: a stream, not a gather).  The caller
+ * vouches that local_x/y/z[0 .. n_local) are the coordinates the cloud handle was uploaded from (the host layer's layer cache verifies
+ * exactly that per call); an index outside them is reported by _end as MP2P_HIP_ERR_INVALID.  Lists of less than 256 KB, or of more
+ * than one round of the staging buffer, take the record form above.  Byte-identical result (tests/test_gpu_boundary_hostpath.py).
+ * Measured (bench.py host_boundary, 238 k pairs per step): NOT faster on the boxes of this pool -- the copy-out window is bound by the
+ * host threads that write the caller's vector, and assembling a record costs more than copying one; the host layer uses it only on
+ * request (MP2P_HIP_HOST_COPY_SOA=1): for hosts with a slow link and fast cores. */
+int  mp2p_hip_pairs_copy_pt2pt_begin_soa(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
+                                         mp2p_hip_pair_pt2pt* out, uint32_t* idx_local, uint32_t* idx_global,
+                                         const float* local_x, const float* local_y, const float* local_z, size_t n_local,
+                                         uint64_t local_index_base);
 int  mp2p_hip_pairs_copy_wait_idx(mp2p_hip_ctx* ctx);
 int  mp2p_hip_pairs_copy_end(mp2p_hip_ctx* ctx);
 int  mp2p_hip_pairs_copy_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,

@@ -206,6 +206,8 @@ SIGNATURES = {
     "mp2p_hip_pairs_copy_pt2pt": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P]),
     "mp2p_hip_pairs_copy_pt2pt_begin": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.POINTER(C.c_uint32),
                                                   C.POINTER(C.c_uint32)]),
+    "mp2p_hip_pairs_copy_pt2pt_begin_soa": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.POINTER(C.c_uint32),
+                                                      C.POINTER(C.c_uint32), _fp, _fp, _fp, C.c_size_t, C.c_uint64]),
     "mp2p_hip_pairs_copy_wait_idx": (C.c_int, [_P]),
     "mp2p_hip_pairs_copy_end": (C.c_int, [_P]),
     "mp2p_hip_pairs_copy_pt2pl": (C.c_int, [_P, _P, C.c_size_t, C.c_size_t, _P, C.POINTER(C.c_uint32)]),

@@ -130,7 +130,6 @@ static int parse_tune(Tune& t, const char* e, bool from_env, std::string* why = 
             if (from_env) refuse(kv, "timing-only launches are requested through mp2p_hip_set_tune with profiling on");
             else t.pl_sol = (int)v;
         }
-        else if (k == "gn_fuse") t.gn_fuse = (int)v;
         else refuse(kv, "unknown knob");
     }
     return bad;

@@ -186,7 +186,6 @@ struct Tune
     uint32_t pl_sel_hard_cand = 3000;  // ... a query whose 32-query tile staged this many candidates at the previous call is listed in the class dispatched first (0 = one class)
     int      pl_sol        = 0;     // timing-only cuts of pt2pl_seltile_kernel's instrumented build (1..4, nn_pl_seltile.hip): set_tune only, profiling on, results invalid
     int      pl_no_touch   = 0;     // profiling level 2 of the point-to-plane search without the per-point 'touched' bytes (phase timers undisturbed)
-    int      gn_fuse       = 1;     // Gauss-Newton: the first inner iteration's sums are accumulated by the compaction's write pass (round 6)
     uint32_t pl_hard_cand  = 1500;  // pt2pl: a query whose tile staged this many candidates (per 4 queries) at the previous call is searched in the hard class, first and in smaller tiles (0 = one class)
 };
 
@@ -227,6 +226,16 @@ struct CopyStage
     std::thread             th;                  // helper (started with the first copy of more than one chunk)
     bool                    stop     = false;
     bool                    no_helper = false;   // the helper could not be started: the caller copies alone
+    // ---- round 6, the point pairings as 24 instead of 44 bytes per pair on the link (mp2p_hip_pairs_copy_pt2pt_begin_soa): the
+    //      staging buffer holds {gx, gy, gz, err} per pair (packed on the device), DMA'd chunk by chunk (soa_cp pairs each); whoever claims a chunk ASSEMBLES its 36-byte records: indices from the caller's two index arrays
+    //      (copied first, same stream: there when the chunk's event is), `local` from the caller's own layer arrays
+    size_t                  soa_n = 0, soa_cp = 0;  // soa_n != 0: the round in flight is such a copy
+    const uint32_t*         soa_li = nullptr;
+    const uint32_t*         soa_gi = nullptr;
+    const float*            soa_l[3] = {nullptr, nullptr, nullptr};
+    size_t                  soa_nl = 0;
+    unsigned long long      soa_base = 0;        // localIdx - soa_base indexes soa_l
+    int                     soa_bad = 0;         // a localIdx outside the caller's arrays was met (reported by _end)
 };
 
 struct GnState

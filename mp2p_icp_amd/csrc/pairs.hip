@@ -528,6 +528,16 @@ __global__ __launch_bounds__(256) void pack_pt2pt_kernel(
     out[k]                           = p;
 }
 
+// the part of a point pairing the host cannot know: global point + squared error, 16 bytes (mp2p_hip_pairs_copy_pt2pt_begin_soa)
+__global__ __launch_bounds__(256) void pack_pt2pt_g16_kernel(const float* gx, const float* gy, const float* gz, const float* err, uint32_t n,
+                                                             float4* out, uint32_t first)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = first + k;
+    out[k]           = make_float4(gx[i], gy[i], gz[i], err[i]);
+}
+
 __global__ __launch_bounds__(256) void unpack_pt2pt_kernel(const mp2p_hip_pair_pt2pt* in,
                                                            uint32_t n, uint32_t* lidx,
                                                            uint32_t* gidx, float* lx, float* ly,
@@ -614,6 +624,32 @@ static void stage_chunk(mp2p_hip_ctx* ctx, size_t k)
     hipError_t  e;
     for (unsigned it = 1; (e = hipEventQuery(s.ev[k])) == hipErrorNotReady; ++it)
         if ((it & 1023u) == 0) std::this_thread::yield();
+    if (s.soa_n)
+    {   // assemble the records of the pairs [i0, i1)
+        const size_t i0 = k * s.soa_cp, i1 = std::min(s.soa_n, i0 + s.soa_cp);
+        int          bad = 0;
+        if (e == hipSuccess)
+        {
+            const float* G = reinterpret_cast<const float*>(s.host);  // {gx, gy, gz, err} per pair
+            auto*        o = reinterpret_cast<mp2p_hip_pair_pt2pt*>(s.out);
+            for (size_t i = i0; i < i1; i++)
+            {
+                mp2p_hip_pair_pt2pt r;
+                r.globalIdx = s.soa_gi[i], r.localIdx = s.soa_li[i];
+                r.global_xyz[0] = G[4 * i], r.global_xyz[1] = G[4 * i + 1], r.global_xyz[2] = G[4 * i + 2];
+                const unsigned long long l = (unsigned long long)r.localIdx - s.soa_base;
+                if (l < s.soa_nl) r.local_xyz[0] = s.soa_l[0][l], r.local_xyz[1] = s.soa_l[1][l], r.local_xyz[2] = s.soa_l[2][l];
+                else r.local_xyz[0] = r.local_xyz[1] = r.local_xyz[2] = NAN, bad = 1;
+                r.errorSquareAfterTransformation = G[4 * i + 3];
+                o[i] = r;
+            }
+        }
+        std::lock_guard<std::mutex> lk(s.mu);
+        if (e != hipSuccess && !s.err) s.err = (int)e;
+        if (bad) s.soa_bad = 1;
+        if (++s.done == s.n_chunks) s.cv_done.notify_all();
+        return;
+    }
     const size_t off = k * s.chunk, len = std::min(s.chunk, s.bytes - off);
     if (e == hipSuccess) memcpy(s.out + off, s.host + off, len);
     std::lock_guard<std::mutex> lk(s.mu);
@@ -683,10 +719,76 @@ static int stage_round(mp2p_hip_ctx* ctx, const unsigned char* dev, unsigned cha
     }
     {
         std::lock_guard<std::mutex> lk(s.mu);
-        s.out = out, s.bytes = round, s.n_chunks = nc, s.next = 0, s.done = 0;
+        s.out = out, s.bytes = round, s.n_chunks = nc, s.next = 0, s.done = 0, s.soa_n = 0;
         s.dev_rest = dev + round, s.out_rest = out + round, s.rest = bytes - round;
     }
     if (nc > 1) s.cv_work.notify_one();
+    return MP2P_HIP_OK;
+}
+// the SoA form of a round (CopyStage::soa_*): n pairs from `first` on, all in ONE round (the caller checked that 16 n bytes fit)
+static int stage_post_soa(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n, mp2p_hip_pair_pt2pt* out,
+                          const uint32_t* li, const uint32_t* gi, const float* lx, const float* ly, const float* lz, size_t n_local,
+                          unsigned long long base)
+{
+    CopyStage& s = ctx->cstage;
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.err = 0, s.soa_bad = 0;
+    }
+    s.chunk     = std::max<size_t>(4096, (size_t)ctx->tune.copy_chunk_kb << 10);
+    s.stage_max = std::max<size_t>(s.chunk, (size_t)ctx->tune.copy_stage_mb << 20);
+    const size_t bytes = 16 * n;
+    if (s.cap < bytes)
+    {
+        if (s.host) (void)hipHostFree(s.host);
+        s.host = nullptr, s.cap = 0;
+        const size_t want = std::min(s.stage_max, std::max(bytes + bytes / 4, (size_t)(8u << 20)));
+        MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&s.host, want, hipHostMallocDefault));
+        s.cap = want;
+    }
+    const size_t cp = std::max<size_t>(1024, s.chunk / 16), nc = (n + cp - 1) / cp;
+    while (s.ev.size() < nc)
+    {
+        hipEvent_t e = nullptr;
+        MP2P_TRY_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s.ev.push_back(e);
+    }
+    // (one DMA command per chunk: four -- one per device array -- cost more in command overhead than the bytes they saved)
+    MP2P_TRY_HIP(ctx, ctx->aos_stage.ensure(bytes));
+    float4* const D = reinterpret_cast<float4*>(ctx->aos_stage.p);
+    hipLaunchKernelGGL(pack_pt2pt_g16_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, p->gx.p, p->gy.p, p->gz.p, p->err.p,
+                       (uint32_t)n, D, (uint32_t)first);
+    for (size_t k = 0; k < nc; k++)
+    {
+        const size_t i0 = k * cp, len = std::min(cp, n - i0);
+        hipError_t   e  = hipMemcpyAsync(s.host + 16 * i0, D + i0, 16 * len, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(s.ev[k], ctx->stream);
+        if (e != hipSuccess)
+        {
+            (void)hipStreamSynchronize(ctx->stream);  // (chunks already on the link land in s.host: nobody may free it meanwhile)
+            MP2P_TRY_HIP(ctx, e);
+        }
+    }
+    if (nc > 1 && !s.th.joinable() && !s.no_helper)
+    {
+        try
+        {
+            s.th = std::thread(stage_worker, ctx);
+        }
+        catch (...)
+        {
+            s.no_helper = true;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.out = reinterpret_cast<unsigned char*>(out), s.bytes = bytes, s.n_chunks = nc, s.next = 0, s.done = 0;
+        s.dev_rest = nullptr, s.out_rest = nullptr, s.rest = 0;
+        s.soa_n = n, s.soa_cp = cp, s.soa_li = li, s.soa_gi = gi, s.soa_l[0] = lx, s.soa_l[1] = ly, s.soa_l[2] = lz;
+        s.soa_nl = n_local, s.soa_base = base;
+    }
+    if (nc > 1) s.cv_work.notify_one();
+    s.open = true;
     return MP2P_HIP_OK;
 }
 // start a copy; the caller may do other work before stage_finish()
@@ -722,9 +824,13 @@ static int stage_finish(mp2p_hip_ctx* ctx)
         const unsigned char* const dev = s.dev_rest;
         unsigned char* const       out = s.out_rest;
         const size_t               rest = s.rest;
-        s.n_chunks = s.next = s.done = 0, s.rest = 0;
+        const int                  bad  = s.soa_n ? s.soa_bad : 0;
+        s.n_chunks = s.next = s.done = 0, s.rest = 0, s.soa_n = 0, s.soa_bad = 0;
         lk.unlock();
         if (err) MP2P_TRY_HIP(ctx, (hipError_t)err);
+        if (bad)
+            return set_err(ctx, MP2P_HIP_ERR_INVALID, "copy_pt2pt_begin_soa: a pairing's localIdx lies outside the local arrays the caller passed "
+                                                     "(local_index_base / n_local do not describe the layer the pairs were matched on)");
         if (!rest) return MP2P_HIP_OK;
         const int rc = stage_round(ctx, dev, out, rest);  // a list beyond the staging buffer's bound: the next round
         if (rc) return rc;
@@ -965,6 +1071,35 @@ int mp2p_hip_pairs_copy_pt2pt_begin(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, 
     }
     else
         rc = stage_post(ctx, d, out, bytes);
+    if (rc)
+    {
+        (void)mp2p_hip_pairs_copy_end(ctx);
+        return rc;
+    }
+    return MP2P_HIP_OK;
+}
+
+int mp2p_hip_pairs_copy_pt2pt_begin_soa(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* p, size_t first, size_t n,
+                                        mp2p_hip_pair_pt2pt* out, uint32_t* idx_local, uint32_t* idx_global,
+                                        const float* local_x, const float* local_y, const float* local_z, size_t n_local,
+                                        uint64_t local_index_base)
+{
+    if (!ctx || !p) return MP2P_HIP_ERR_INVALID;
+    MP2P_REQUIRE(ctx, local_x && local_y && local_z, "copy_pt2pt_begin_soa: null local arrays");
+    // small lists and lists beyond one round of the staging buffer: the record form (same result, 44 bytes per pair on the link)
+    const size_t stage_max = std::max<size_t>((size_t)ctx->tune.copy_chunk_kb << 10, (size_t)ctx->tune.copy_stage_mb << 20);
+    if (n * sizeof(mp2p_hip_pair_pt2pt) < (256u << 10) || 16 * n > stage_max)
+        return mp2p_hip_pairs_copy_pt2pt_begin(ctx, p, first, n, out, idx_local, idx_global);
+    if (ctx->copy_open) (void)mp2p_hip_pairs_copy_end(ctx);
+    MP2P_REQUIRE(ctx, n > 0 && out && idx_local && idx_global && first + n <= p->cap_pt2pt,
+                 "copy_pt2pt_begin_soa: empty range, null destination or range outside the list");
+    MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_ev) MP2P_TRY_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(idx_local, p->lidx.p + first, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(idx_global, p->gidx.p + first, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipEventRecord(ctx->copy_ev, ctx->stream));
+    ctx->copy_open = true;
+    const int rc = stage_post_soa(ctx, p, first, n, out, idx_local, idx_global, local_x, local_y, local_z, n_local, local_index_base);
     if (rc)
     {
         (void)mp2p_hip_pairs_copy_end(ctx);

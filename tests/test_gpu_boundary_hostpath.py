@@ -465,3 +465,73 @@ def test_quality_paired_ratio_counts_only_and_leaves_the_resident_list(oracle):
     q, hard, npairs = s.quality_paired_ratio(pose, _pt2pt_prm(1e-4, allowMatchAlreadyMatchedGlobalPoints=1))
     assert npairs == 0 and q == 0.0 and hard
     s.close()
+
+
+def test_copy_out_24_bytes_per_pair_equals_the_record_form(oracle, monkeypatch):
+    """round 6: the point pairings come back as index arrays + {global point, squared error} (24 bytes per pair on the link), the
+    36-byte records assembled on the host with `local` read from the caller's own layer arrays
+    (mp2p_hip_pairs_copy_pt2pt_begin_soa).  Byte-identical to the record form (MP2P_HIP_HOST_COPY_SOA=0) and to the oracle, over a
+    pose chain whose lists are long enough for the staged path (> 256 KB)."""
+    from mp2p_icp_amd import hostpath, synthetic
+    d = synthetic.make_pair(60_000, 400_000, 23)
+    g, l = d["glob"], d["local"]
+    tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+    prm = _pt2pt_prm(1.5, allowMatchAlreadyMatchedGlobalPoints=1)   # (every local point keeps its pair: a list beyond 256 KB)
+    lists = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("MP2P_HIP_HOST_COPY_SOA", form)
+        s = hostpath.Session(g, l)
+        pose, got = d["T_init"].copy(), []
+        for it in range(3):
+            s.begin_iteration()
+            n = s.match_pt2pt(pose, prm, icp_iteration=it)
+            got.append(s.pairs_pt2pt().copy())
+            assert n == len(got[-1]) and n * 36 > 256 * 1024
+            pose = s.solve_gn(pose, _gn_prm())[0]
+        lists[form] = got
+        s.close()
+    want, _ = oracle.match_pt2pt(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], d["T_init"], 1.5, 0.0, tree=tree,
+                                 allowMatchAlreadyMatchedGlobalPoints=True)
+    _same_pt2pt(lists["1"][0], want)
+    for a, b in zip(lists["1"], lists["0"]):
+        assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("tune", ["", "copy_chunk_kb=64", "copy_chunk_kb=4"])
+def test_copy_pt2pt_begin_soa_entry_point(oracle, monkeypatch, tune):
+    """the C entry point itself (one chunk, many chunks shared by the helper thread and the caller; a range that starts inside the
+    list): records byte-equal to the plain download; local arrays that do not cover a pairing's localIdx are reported by _end"""
+    import ctypes as C
+    import mp2p_icp_amd as amd
+    from mp2p_icp_amd import _lib, core, synthetic
+    if tune:
+        monkeypatch.setenv("MP2P_HIP_TUNE", tune)
+    d = synthetic.make_pair(60_000, 400_000, 24)
+    g, l = d["glob"], d["local"]
+    ctx = amd.Context(0)
+    gmap, cloud = core.GlobalMap(ctx, *_xyz(g)), core.LocalCloud(ctx, *_xyz(l))
+    pairs = core.DevicePairs(ctx, l.shape[0], 0)
+    core.match_pt2pt(ctx, gmap, cloud, d["T_init"], _pt2pt_prm(1.5, allowMatchAlreadyMatchedGlobalPoints=1), None, pairs)
+    want = pairs.download_pt2pt()
+    n = len(want)
+    assert n * 36 > 256 * 1024
+    L = ctx._L
+    raw = L.mp2p_hip_host_alloc(ctx.handle, 8 * n)
+    li, gi = C.cast(raw, C.POINTER(C.c_uint32)), C.cast(raw + 4 * n, C.POINTER(C.c_uint32))
+    lx, ly, lz = (np.ascontiguousarray(l[:, k]) for k in range(3))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    for first in (0, 777):
+        m = n - first
+        out = np.zeros(m, _lib.PAIR_PT2PT)
+        _lib.check(L.mp2p_hip_pairs_copy_pt2pt_begin_soa(ctx.handle, pairs.handle, first, m, out.ctypes.data, li, gi, fp(lx), fp(ly), fp(lz),
+                                                         l.shape[0], 0), ctx.handle)
+        _lib.check(L.mp2p_hip_pairs_copy_wait_idx(ctx.handle), ctx.handle)
+        assert np.array_equal(np.ctypeslib.as_array(li, (m,)), want["localIdx"][first:])
+        _lib.check(L.mp2p_hip_pairs_copy_end(ctx.handle), ctx.handle)
+        assert out.tobytes() == want[first:].tobytes()
+    out = np.zeros(n, _lib.PAIR_PT2PT)
+    _lib.check(L.mp2p_hip_pairs_copy_pt2pt_begin_soa(ctx.handle, pairs.handle, 0, n, out.ctypes.data, li, gi, fp(lx), fp(ly), fp(lz), 100, 0),
+               ctx.handle)
+    assert L.mp2p_hip_pairs_copy_end(ctx.handle) == _lib.ERR_INVALID
+    assert b"localIdx" in L.mp2p_hip_last_error(ctx.handle)
+    L.mp2p_hip_host_free(ctx.handle, raw)

@@ -369,6 +369,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     // the compiler gave every load an exec-masked block of its own with its own s_waitcnt vmcnt(0): four SERIAL round
                     // trips per staging round -- the "4 us per round of 256 that no prefetch moved" of DESIGN.md section 4.  An
                     // out-of-range slot reads point 0 and is overwritten by the padding.
+                    // (the sorted positions go to LDS BEFORE the loads are issued: four registers less across the wait -- 28 -> 12 bytes of
+                    //  scratch per lane in the 128-register build)
+                    *reinterpret_cast<uint4*>(&s_spos[t0]) = make_uint4(src[0], src[1], src[2], src[3]);
 #pragma unroll
                     for (int k = 0; k < 4; k++) c4[k] = g.pts[(t0 + k < m) ? src[k] : 0u];
 #pragma unroll
@@ -379,7 +382,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     *reinterpret_cast<float4*>(&s_z[t0]) = make_float4(c4[0].z, c4[1].z, c4[2].z, c4[3].z);
                     *reinterpret_cast<uint4*>(&s_idx[t0]) =
                         make_uint4(__float_as_uint(c4[0].w), __float_as_uint(c4[1].w), __float_as_uint(c4[2].w), __float_as_uint(c4[3].w));
-                    *reinterpret_cast<uint4*>(&s_spos[t0]) = make_uint4(src[0], src[1], src[2], src[3]);
                     {  // |c - centre|^2 over the lane's own four owner slots (read already)
                         float n4[4];
 #pragma unroll

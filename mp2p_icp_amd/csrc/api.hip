@@ -105,10 +105,6 @@ static int parse_tune(Tune& t, const char* e, bool from_env, std::string* why = 
         else if (k == "tile_bricks") t.tile_bricks = (int)v;
         else if (k == "tile_brick_budget") t.tile_brick_budget = (uint32_t)v;
         else if (k == "hard_cand") t.hard_cand = (uint32_t)v;
-        else if (k == "persist") t.persist = (uint32_t)v;
-        else if (k == "heavy_cand") t.heavy_cand = (uint32_t)v;
-        else if (k == "heavy_tiles") t.heavy_tiles = (uint32_t)v;
-        else if (k == "cost_ticks") t.cost_ticks = (int)v;
         else if (k == "empty_room") t.empty_room = (int)v;
         else if (k == "nn_cert") t.nn_cert = (int)v;
         else if (k == "coop_max") t.coop_max = (uint32_t)v;
@@ -216,10 +212,6 @@ int mp2p_hip_ctx_create(int device_id, void* hip_stream, mp2p_hip_ctx** out)
         return set_err(nullptr, MP2P_HIP_ERR_HIP, "hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
     auto* ctx   = new mp2p_hip_ctx();
     ctx->device = device_id;
-    {
-        int cu = 0;
-        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cu > 0) ctx->n_cu = cu;
-    }
     if (hip_stream)
         ctx->stream = (hipStream_t)hip_stream, ctx->own_stream = false;
     else

@@ -138,13 +138,6 @@ struct Tune
     uint32_t tile_brick_budget = 512;  // ... when the group's box spans at most this many bricks
     uint32_t hard_cand     = 1700;  // a query whose tile staged this many candidates at the previous call joins the hard class
                                     // (dispatched first) whatever its radius; 0 = by radius only
-    uint32_t persist       = 1;     // round 6: the tile stage as ONE persistent launch of 1 024 four-wave workgroups (nn_seltile_persist_kernel):
-                                    // the HEAVY tiles first, each by the four waves of a workgroup, then every wave by itself through the
-                                    // per-XCD tile queues; 0 = one workgroup per tile (rounds 1-5: the hardware's dispatcher is the queue)
-    uint32_t heavy_cand    = 4000;  // ... a wave of pending queries whose tile staged this many candidates at the previous call joins the
-                                    // HEAVY class (the kernel's span was its ten longest tiles); 0 = no such class
-    uint32_t heavy_tiles   = 2048;  // ... capacity of that class's list in tiles (what does not fit joins the hard class)
-    int      cost_ticks    = 0;     // the tile kernel records a tile's DURATION (in candidate equivalents of 16 ns) as its cost, not what it staged
     uint32_t hard_radius_pct = 100; // pending queries with a radius above this % of a level-0 voxel are "hard":
                                     // their tiles are dispatched first (nn_query.hip)
     int      xcd_map       = 1;     // tile kernel: one segment of the pending list per XCD (L2 locality)
@@ -259,7 +252,6 @@ struct GnState
 struct mp2p_hip_ctx
 {
     int         device     = 0;
-    int         n_cu       = 256;  // compute units of the device (the persistent tile kernel's grid)
     hipStream_t stream     = nullptr;
     bool        own_stream = false;
     std::string err;

@@ -100,15 +100,6 @@ __device__ __forceinline__ uint32_t dpp_u0(uint32_t v)  // out-of-row source lan
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-// a wave's own LDS writes made visible to its own later reads (other lanes): LDS executes a wave's instructions in order,
-// so only the compiler has to be told (a workgroup barrier here would have to be reached by the workgroup's other waves as
-// well, whose trip counts differ: the multi-wave tiles of nn_pl_seltile.hip and nn_seltile.hip)
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 __device__ __forceinline__ float readlane_f(float v, int l)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));

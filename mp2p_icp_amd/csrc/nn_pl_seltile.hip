@@ -62,7 +62,15 @@ struct __attribute__((aligned(16))) PsLds
     unsigned short hl[PS_HL];           // the hits of a block: (lane << 4 | row) of every prefilter value within its lane's limit
 };
 
-// (wave_lds_sync: device_utils.hpp)
+// a wave's own LDS writes made visible to its own later reads (other lanes): LDS executes a wave's instructions in order,
+// so only the compiler has to be told (a workgroup barrier here would have to be reached by the tile's other waves as well,
+// whose trip counts differ)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <int K>
 __device__ __forceinline__ float ps_kth(const float (&kd2)[K], uint32_t knn)

@@ -59,9 +59,8 @@ constexpr int NN_CAP      = 256;  // staged candidates per round (LDS: 5 x 1 KB)
 constexpr int NN_COOP_MAX = 4;    // groups of up to this many queries are deferred
 constexpr int NN_CLAIM_SLOTS = 128;  // in-wave claim table (LDS)
 constexpr int NN_MAX_SEG     = 256;  // segments of a query list
-constexpr int NN_LISTS       = 3;    // 0 = pending/hard, 1 = deferred, 2 = pending/easy (segmented)
-constexpr int NN_ALL_LISTS   = 4;    // ... 3 = pending/heavy: ONE list (the counter of its "segment 0"), entries in whole tiles of 32
-constexpr int NN_HEAVY_WORDS = 10;   // ... words of list 3's counter block in use: [0] entries of the heavy list, [1] the heavy tile queue, [2..9] the per-XCD tile queues
+constexpr int NN_LISTS       = 3;    // 0 = pending/hard, 1 = deferred, 2 = pending/easy
+constexpr int NN_ALL_LISTS   = 3;
 constexpr int NN_CNT_STRIDE  = 32;   // uint32 words between two segment counters (128 bytes)
 constexpr int NN_TVLIST      = 512;  // tile kernel, wide groups: occupied voxels listed per round (LDS)
 constexpr uint32_t NN_PASS_COST  = 320; // tile kernel: what a pass costs, in staged candidates (10 us against 30 us per 960)
@@ -94,9 +93,6 @@ struct NNArgs
     uint32_t      tile_brick_budget; // ... when the box spans at most this many bricks (else the coarser dense box)
     uint32_t      coop_max;          // a group of at most this many queries leaves its tile for the one-query kernel
     uint32_t      hard_cand;         // a query whose tile staged at least this many candidates at the previous call is hard (0: by radius only)
-    uint32_t      heavy_cand;        // ... and at least this many: heavy -- its tile is searched by four waves (0: no heavy class)
-    int           cost_ticks;        // the cost a tile records for the next call's classes: 0 = staged candidates, 1 = its duration in candidate equivalents
-    uint32_t      heavy_cap;         // entries of the heavy list (a multiple of 32), stored behind the two classes at pend + 2 list_cap
     int           claim_dedup, claim_peek;
     int           mfma_scan;         // tile kernel, Q = 32: distance tests on the matrix pipe as a prefilter
     const unsigned char* local_taken;   // by original local index, or null
@@ -143,7 +139,7 @@ struct NNArgs
     // profiling level 4: {start, end} 100 MHz ticks of every workgroup of the tile and one-query
     // kernels ([n_tiles] then [single blocks]); the plain kernels only pay a uniform null test
     unsigned long long*  timeline;
-    uint32_t             timeline_single_base, timeline_heavy_base;
+    uint32_t             timeline_single_base;
 };
 
 // ---- geometry of one search pass (all values wave-uniform) -----------------------------------
@@ -294,7 +290,6 @@ __device__ __forceinline__ void claim_global(const NNArgs& a, uint32_t spos, uin
 
 // Result records + claims of one wave (ONE wave per workgroup: the barriers are wave-local).
 // do_emit: this lane writes the record of query qi.  s_claim: NN_CLAIM_SLOTS words of LDS.
-template <bool WAVE_SYNC = false>  // true: the caller is one wave of a larger workgroup (its LDS table ordered at wave scope)
 __device__ __forceinline__ void emit_wave(const NNArgs& a, unsigned long long* s_claim, int lane, bool do_emit,
                                           uint32_t qi, uint32_t orig, bool active, float thr, float best_d2,
                                           uint32_t best_idx, uint32_t best_spos, float lb2_all, uint32_t cost = 0u)
@@ -323,17 +318,17 @@ __device__ __forceinline__ void emit_wave(const NNArgs& a, unsigned long long* s
     // lowest (spos, rank) key hashed to it; a lane whose global point owns its slot claims only if it
     // is that minimum, a lane whose slot went to another global point claims by itself
     s_claim[lane] = ~0ull, s_claim[lane + 64] = ~0ull;
-    if (WAVE_SYNC) wave_lds_sync(); else __syncthreads();
+    __syncthreads();
     const unsigned long long key  = ((unsigned long long)best_spos << 32) | rank32;
     const uint32_t           slot = (best_spos * 0x9E3779B1u) >> 25;  // 7 bits
     if (acc) atomicMin(&s_claim[slot], key);
-    if (WAVE_SYNC) wave_lds_sync(); else __syncthreads();
+    __syncthreads();
     if (acc)
     {
         const unsigned long long v = s_claim[slot];
         if ((uint32_t)(v >> 32) != best_spos || v == key) claim_global(a, best_spos, rank32);
     }
-    if (WAVE_SYNC) wave_lds_sync(); else __syncthreads();
+    __syncthreads();
 }
 
 // push the lanes of `push` (at most one per query) onto segment `seg` of a query list
@@ -633,35 +628,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         // spatially loose, stage more and run more passes (measured: 1 382 -> 1 182 it/s with per-query classes).
         const bool               by_cost = a.use_hint && a.hard_cand != 0u;
         const bool               costly  = __ballot(pending && (h.w >> NN_COST_SHIFT) >= a.hard_cand) != 0ull;
-        // ---- the HEAVY class (round 6): the whole wave's pending queries as one or two tiles of a list of its own, padded to
-        //      whole tiles (a tile never mixes the queries of two waves: they would be metres apart).  One counter for the whole
-        //      layer: ~1 % of the waves bump it.  A reservation that does not fit falls back to the hard class (and blanks the
-        //      part of it that lies within the capacity: the tile kernel reads whole tiles).
-        bool in_heavy = false;
-        if (by_cost && a.heavy_cand != 0u && pmask != 0ull && __ballot(pending && (h.w >> NN_COST_SHIFT) >= a.heavy_cand) != 0ull)
-        {
-            const uint32_t npush = (uint32_t)__popcll(pmask), nres = (npush + 31u) & ~31u;
-            uint32_t       base  = 0;
-            if (lane == 0) base = atomicAdd(a.q_counters + (size_t)3 * NN_MAX_SEG * NN_CNT_STRIDE, nres);
-            base     = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            in_heavy = base + nres <= a.heavy_cap;
-            uint4* const l_rec = a.pend + 2u * (size_t)a.list_cap;
-            uint4* const l_q   = a.pend_q + 2u * (size_t)a.list_cap;
-            if (in_heavy)
-            {
-                if (pending)
-                {
-                    const size_t slot = base + (uint32_t)__popcll(pmask & ((1ull << lane) - 1ull));
-                    l_rec[slot] = make_uint4(qi, __float_as_uint(r), __float_as_uint(best_d2), best_idx);
-                    l_q[slot]   = make_uint4(__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz), best_spos);
-                }
-                if ((uint32_t)lane >= npush && (uint32_t)lane < nres) l_rec[base + (uint32_t)lane] = make_uint4(NONE_U32, 0u, 0u, NONE_U32);
-            }
-            else if (base + (uint32_t)lane < a.heavy_cap && (uint32_t)lane < nres)
-                l_rec[base + (uint32_t)lane] = make_uint4(NONE_U32, 0u, 0u, NONE_U32);
-        }
-        const bool               hard  = pending && !in_heavy && (by_cost ? costly : r > a.r_hard);
-        const unsigned long long hmask = __ballot(hard), emask = in_heavy ? 0ull : (pmask & ~hmask);
+        const bool               hard  = pending && (by_cost ? costly : r > a.r_hard);
+        const unsigned long long hmask = __ballot(hard), emask = pmask & ~hmask;
         if (hmask)
             push_lanes(a, 0, wv / a.seg_waves, hard, hmask, lane, qi, r, best_d2, best_idx, best_spos, qx, qy,
                        qz);
@@ -1621,11 +1589,6 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
 #include "nn_seltile.hip"
 namespace mp2p
 {
-__global__ void nn_nop_kernel(uint32_t* p)
-{
-    if (p) *p = 0u;
-}
-
 // resets the segment counters of the two query lists
 __global__ __launch_bounds__(NN_MAX_SEG) void nn_reset_kernel(uint32_t* q_counters)
 {
@@ -1730,14 +1693,8 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     const size_t   list_cap  = (size_t)n_seg * seg_cap;
     MP2P_TRY_HIP(ctx, ctx->work.ensure(list_cap));
     MP2P_TRY_HIP(ctx, ctx->work_q.ensure(list_cap));
-    // round 6: the tile stage as one persistent launch (nn_seltile_persist_kernel) behind the lane kernel; its HEAVY class needs the
-    // previous call's costs (a warm start: the lane kernel fills the heavy list only then).  The instrumented build (profiling 2),
-    // the two-pipeline split and small layers (fused prologue) keep one workgroup per tile.
-    const bool     persist     = sel && !direct && ctx->tune.persist != 0u && ctx->tune.pipelines < 2 && ctx->profiling != 2;
-    const uint32_t heavy_tiles = (persist && ctx->tune.heavy_cand != 0u && ctx->tune.hard_cand != 0u)
-                                     ? (uint32_t)std::min<size_t>(std::max<uint32_t>(ctx->tune.heavy_tiles, 1u), std::max<size_t>(n_l / 256, 1)) : 0u;
-    MP2P_TRY_HIP(ctx, ctx->pend.ensure(2 * list_cap + 32u * (size_t)heavy_tiles));  // hard class, then easy class, then the heavy list
-    MP2P_TRY_HIP(ctx, ctx->pend_q.ensure(2 * list_cap + 32u * (size_t)heavy_tiles));
+    MP2P_TRY_HIP(ctx, ctx->pend.ensure(2 * list_cap));  // hard class, then easy class
+    MP2P_TRY_HIP(ctx, ctx->pend_q.ensure(2 * list_cap));
     if (ctx->q_counters.n < (size_t)NN_ALL_LISTS * NN_MAX_SEG * NN_CNT_STRIDE)
     {
         MP2P_TRY_HIP(ctx, ctx->q_counters.ensure((size_t)NN_ALL_LISTS * NN_MAX_SEG * NN_CNT_STRIDE));
@@ -1774,9 +1731,6 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.tile_bricks       = (ctx->tune.tile_bricks && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE) ? 1 : 0;
     a.tile_brick_budget = ctx->tune.tile_brick_budget;
     a.hard_cand         = ctx->tune.hard_cand;
-    a.heavy_cand        = heavy_tiles ? ctx->tune.heavy_cand : 0u;
-    a.heavy_cap         = 32u * heavy_tiles;
-    a.cost_ticks        = ctx->tune.cost_ticks;
     a.coop_max          = ctx->tune.coop_max != 0xFFFFFFFFu ? ctx->tune.coop_max : ((sel && !small_layer) ? 0u : 4u);
     a.empty_room        = ctx->tune.empty_room;
     a.claim_dedup   = ctx->tune.claim_dedup;
@@ -1848,18 +1802,17 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
         MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->pl_slots.p, 0, map->n, ctx->stream));
         a.touched = ctx->pl_slots.p;
     }
-    a.timeline = nullptr, a.timeline_heavy_base = n_tiles, a.timeline_single_base = n_tiles + heavy_tiles;
+    a.timeline = nullptr, a.timeline_single_base = n_tiles;
     ctx->timeline_tiles = ctx->timeline_singles = 0;
     if (ctx->profiling == 4)
     {
         // (upper bound of the one-query kernel's grid, see below)
         const size_t single_blocks = 256u * (size_t)(ctx->tune.single_blocks_per_cu ? ctx->tune.single_blocks_per_cu : 40u);
-        // (the heavy class's workgroups: the last heavy_tiles records of the tile part)
-        MP2P_TRY_HIP(ctx, ctx->timeline.ensure(2 * (std::max<size_t>(n_tiles + heavy_tiles, n_waves) + single_blocks)));
-        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->timeline.p, 0, 2 * (std::max<size_t>(n_tiles + heavy_tiles, n_waves) + single_blocks) * sizeof(unsigned long long),
+        MP2P_TRY_HIP(ctx, ctx->timeline.ensure(2 * (std::max<size_t>(n_tiles, n_waves) + single_blocks)));
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->timeline.p, 0, 2 * (std::max<size_t>(n_tiles, n_waves) + single_blocks) * sizeof(unsigned long long),
                                          ctx->stream));
         a.timeline = ctx->timeline.p;
-        ctx->timeline_tiles = n_tiles + heavy_tiles, ctx->timeline_singles = single_blocks;
+        ctx->timeline_tiles = n_tiles, ctx->timeline_singles = single_blocks;
     }
     ctx->pending_lane = direct ? 0 : 1;
     ctx->last_n_boxes = n_boxes;
@@ -1924,17 +1877,6 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
                 else if (sol == 4) MP2P_LAUNCH_SEL(false, false, true, 4);
                 else if (sol == 5) MP2P_LAUNCH_SEL(false, false, true, 5);
                 else if (instr) { if (direct) MP2P_LAUNCH_SEL(true, false, true, 0); else MP2P_LAUNCH_SEL(true, false, false, 0); }
-                else if (persist)
-                {   // (P == 1: the whole layer; four workgroups of 256 threads per CU = the resident set at 128 registers and 37 KB of LDS)
-                    const uint32_t ncu = (uint32_t)ctx->n_cu;
-                    if (cert_track) hipLaunchKernelGGL((nn_seltile_persist_kernel<true>), dim3(4u * ncu), dim3(256), 0, st[p], ap[p]);
-                    else if (ctx->tune.persist == 2) hipLaunchKernelGGL((nn_seltile_persist_kernel<false, 0, 4>), dim3(4u * ncu), dim3(256), 0, st[p], ap[p]);
-                    else if (ctx->tune.persist == 4) hipLaunchKernelGGL((nn_seltile_persist_kernel<false, 4, 4>), dim3(4u * ncu), dim3(256), 0, st[p], ap[p]);
-                    else if (ctx->tune.persist == 6) hipLaunchKernelGGL((nn_seltile_persist_kernel<false, 1, 3>), dim3(3u * ncu), dim3(256), 0, st[p], ap[p]);
-                    else if (ctx->tune.persist == 7) hipLaunchKernelGGL((nn_seltile_persist_kernel<false, 0, 3>), dim3(3u * ncu), dim3(256), 0, st[p], ap[p]);
-                    else if (ctx->tune.persist == 8) hipLaunchKernelGGL((nn_seltile_persist_kernel<false, 4, 3>), dim3(3u * ncu), dim3(256), 0, st[p], ap[p]);
-                    else hipLaunchKernelGGL((nn_seltile_persist_kernel<false>), dim3(4u * ncu), dim3(256), 0, st[p], ap[p]);
-                }
                 else if (ctx->tune.tile_waves == 3 || (ctx->tune.tile_waves == 0 && direct))
                 {   // round 6: the register budget of 3 waves per SIMD (168): with the four staging loads of a round in flight together
                     // the 128-register build spills 3 dwords per lane behind the lane kernel and 11 with the prologue fused in

@@ -105,61 +105,32 @@ __device__ __forceinline__ void query_prologue(const NNArgs& a, const GridView& 
 // SOL (speed-of-light decomposition, profiles/r05_tile_sol.txt; results are NOT valid, nothing is written): the kernel cut after
 // 3 = the prologue, 4 = + pass set-up and the voxel list, 5 = + selection and directory look-up, 1 = + staging,
 // 2 = + the matrix-pipe prefilter and its min-tree (no recomputation); 0 = the product
-// LDS of one wave of a tile
-struct __attribute__((aligned(16))) SelLds
-{
-    float    x[NN_CAP], y[NN_CAP], z[NN_CAP];
-    uint32_t idx[NN_CAP], spos[NN_CAP], owner[NN_CAP];
-    uint32_t cstart[64], coff[64];
-    uint32_t vox[NN_TVLIST];  // occupied voxels of the box (listed), then those some query needs (compacted in place)
-};
-constexpr int NN_DEAL_SHIFT = 3;  // W > 1: the selected voxels of a pass are dealt to the tile's waves in runs of 8
-
-// W (round 6): the waves of one tile.  1: a workgroup is one wave, the kernel of round 5.  4: the HEAVY class (NNArgs::heavy_cand: the
-// tiles that staged the most at the previous call -- the kernel's span was its ten longest tiles, 180-250 us of 10-15 000
-// candidates each at ~16 ns per candidate, whatever the chip's load: a wave's own dependent chain).  The four waves of the
-// workgroup serve the SAME 32 queries: every wave lists and selects (redundant: a quarter of a tile's instructions, but in
-// parallel), the selected voxels are dealt round-robin in runs of 8, each wave stages and scans its share in its own LDS, and at
-// the end of a pass the waves exchange their queries' best (d2, index) through LDS -- the only workgroup barriers; inside a pass
-// a wave orders its own LDS traffic with wave-scope fences.  Every wave then takes the same decisions (final / next radius /
-// next group), so the passes stay in step.  Round 5 split tiles ACROSS workgroups and lost to the agent-scope fences of the
-// hand-off; inside a workgroup there are none.
-// WSYNC: the calling wave is one of a larger workgroup whose other waves are elsewhere (the persistent kernel): its LDS traffic is
-// ordered at wave scope, never by a workgroup barrier.
-template <bool INSTR, bool CERT, bool DIRECT, int SOL, int W, bool WSYNC>
-__device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t tile, SelLds& L, uint32_t* const s_mrg, const int wv)
+template <bool INSTR, bool CERT, bool DIRECT, int WAVES, int SOL = 0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void nn_seltile_kernel(const NNArgs a)
 {
     constexpr int Q = 32;
-    static_assert(W == 1 || (W == 4 && !DIRECT && SOL == 0), "multi-wave tiles: the heavy class behind the lane kernel");
-    // (s_mrg, W > 1: the waves' per-query {d2, index, position, t1, t2} at the end of a pass, W * 32 * 5 words)
-    float* const    s_x = L.x;
-    float* const    s_y = L.y;
-    float* const    s_z = L.z;
-    uint32_t* const s_idx = L.idx;
-    uint32_t* const s_spos = L.spos;
-    uint32_t* const s_owner = L.owner;
-    uint32_t* const s_cstart = L.cstart;
-    uint32_t* const s_coff = L.coff;
-    uint32_t* const s_vox = L.vox;
+    __shared__ __attribute__((aligned(16))) float s_x[NN_CAP];
+    __shared__ __attribute__((aligned(16))) float s_y[NN_CAP];
+    __shared__ __attribute__((aligned(16))) float s_z[NN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_idx[NN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_spos[NN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_owner[NN_CAP];
+    __shared__ uint32_t s_cstart[64];
+    __shared__ uint32_t s_coff[64];
+    __shared__ uint32_t s_vox[NN_TVLIST];  // occupied voxels of the box (listed), then those some query needs (compacted in place)
     static_assert(NN_CLAIM_SLOTS * sizeof(unsigned long long) <= NN_CAP * sizeof(float), "claim table fits s_x");
     unsigned long long* s_claim = reinterpret_cast<unsigned long long*>(s_x);
-    // a wave's own LDS traffic in order: one wave per workgroup -- the (elided) workgroup barrier of rounds 1-5; else wave scope
-    auto tsync = [&]() __attribute__((always_inline)) {
-        if (W == 1 && !WSYNC) __syncthreads();
-        else wave_lds_sync();
-    };
 
     const GridView& g    = a.g;
-    const int       lane = threadIdx.x & 63;
+    const int       lane = threadIdx.x;
+    const uint32_t  tile = blockIdx.x;
     // one class in DIRECT mode (every tile is a fixed slice of the layer), two (hard first) behind the lane kernel
     const uint32_t segs8          = (a.n_seg + 7u) / 8u;
     const uint32_t tiles_per_list = segs8 * 8u * a.tiles_per_seg;
     const uint32_t cls            = (!DIRECT && tile >= tiles_per_list) ? 1u : 0u;  // 0 = hard (first), 1 = easy
     const uint32_t tl             = tile - cls * tiles_per_list;
-    uint32_t       seg = 0, tk = 0;
-    if (W > 1)
-        tk = tile;  // the heavy list: tile t = its entries 32 t .. 32 t + 31 (seg: below, from the tile's own queries)
-    else if (a.xcd_map)
+    uint32_t       seg, tk;
+    if (a.xcd_map)
     {
         const uint32_t x = tl & 7u, j = tl >> 3;
         const uint32_t sl = j / a.tiles_per_seg;
@@ -167,12 +138,10 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
     }
     else
         seg = tl / a.tiles_per_seg, tk = tl - seg * a.tiles_per_seg;
-    if (W == 1 && seg >= a.n_seg) return;
+    if (seg >= a.n_seg) return;
     seg += a.seg_base;
     uint32_t n_pend;
-    if (W > 1)
-        n_pend = min(a.q_counters[(size_t)3 * NN_MAX_SEG * NN_CNT_STRIDE], a.heavy_cap);  // (whole tiles; a slot may be blank)
-    else if (DIRECT)
+    if (DIRECT)
     {
         const unsigned long long first = (unsigned long long)seg * a.seg_cap;
         n_pend = first >= a.n_l ? 0u : (uint32_t)min((unsigned long long)a.seg_cap, (unsigned long long)a.n_l - first);
@@ -181,11 +150,11 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
         n_pend = a.q_counters[((size_t)(cls ? 2 : 0) * NN_MAX_SEG + seg) * NN_CNT_STRIDE];
     if (tk * (uint32_t)Q >= n_pend) return;
     const unsigned long long tl0 = wall_clock64();
-    const uint32_t cand_cap = W > 1 ? 0xFFFFFFFFu : (cls ? a.tile_cand_cap_easy : a.tile_cand_cap);  // (four waves: no tile gives up)
+    const uint32_t cand_cap = cls ? a.tile_cand_cap_easy : a.tile_cand_cap;
     const int      qslot = lane & (Q - 1);
     const int      slice = lane / Q;
     const bool     hi    = lane >= 32;
-    bool           valid = tk * Q + qslot < n_pend;
+    const bool     valid = tk * Q + qslot < n_pend;
 
     uint32_t qi = 0, orig = 0, best_idx = NONE_U32, best_spos = NONE_U32;
     float    qx = 0.f, qy = 0.f, qz = 0.f, thr = 0.f, rmax = 0.f, r = 0.f, best_d2 = INFINITY;
@@ -215,20 +184,9 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
     }
     else
     {
-        const size_t pslot = W > 1 ? 2u * (size_t)a.list_cap + tk * Q + qslot
-                                   : (size_t)cls * a.list_cap + (size_t)seg * a.seg_cap + tk * Q + qslot;
+        const size_t pslot = (size_t)cls * a.list_cap + (size_t)seg * a.seg_cap + tk * Q + qslot;
         uint4        w = make_uint4(0u, 0u, __float_as_uint(INFINITY), NONE_U32), wq = make_uint4(0u, 0u, 0u, NONE_U32);
-        if (valid) w = a.pend[pslot];
-        if (W > 1)
-        {
-            valid = valid && w.x != NONE_U32;  // (the padding of a wave's part of the list)
-            const unsigned long long vm = __ballot(valid);
-            if (vm == 0ull) return;
-            // the segment its queries' lane-kernel wave belongs to (all of a tile's queries come from one wave): where it defers to
-            seg = ((uint32_t)__builtin_amdgcn_readlane((int)w.x, __ffsll((long long)vm) - 1) >> 6) / a.seg_waves;
-            if (!valid) w = make_uint4(0u, 0u, __float_as_uint(INFINITY), NONE_U32);
-        }
-        if (valid) wq = a.pend_q[pslot];
+        if (valid) w = a.pend[pslot], wq = a.pend_q[pslot];
         qi = w.x;
         if (valid) orig = __float_as_uint(a.lpts[qi].w);
         qx = __uint_as_float(wq.x), qy = __uint_as_float(wq.y), qz = __uint_as_float(wq.z);
@@ -253,7 +211,7 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
         const unsigned long long wmask = __ballot(wide);
         if (wmask)
         {
-            if (SOL == 0 && wv == 0) defer_lanes<Q>(a, seg, wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
+            if (SOL == 0) defer_lanes<Q>(a, seg, wide, wmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
             if (wide) done = true, deferred = true;
         }
     }
@@ -302,7 +260,7 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
         const unsigned long long gmask = __ballot(grp);
         if (__popcll(gmask) <= (int)a.coop_max * 2)
         {  // a few isolated queries: the one-query kernel
-            if (SOL == 0 && wv == 0) st_defer += defer_lanes<Q>(a, seg, grp, gmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
+            if (SOL == 0) st_defer += defer_lanes<Q>(a, seg, grp, gmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
             if (grp) done = true, deferred = true;
             continue;
         }
@@ -358,7 +316,7 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
         // (thresholds of tens of metres): the one-query kernel picks its own level for such a radius
         if (cx1 - cx0 >= 1024u || cy1 - cy0 >= 1024u || cz1 - cz0 >= 1024u || nb > 32768u)
         {
-            if (SOL == 0 && wv == 0) st_defer += defer_lanes<Q>(a, seg, grp, gmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
+            if (SOL == 0) st_defer += defer_lanes<Q>(a, seg, grp, gmask, lane, slice, qi, r, best_d2, best_idx, best_spos, qx, qy, qz);
             if (grp) done = true, deferred = true;
             continue;
         }
@@ -380,13 +338,13 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
                 const uint32_t m_pad = (m + 31u) & ~31u;
                 // ---- stage: lane l fills slots 4l..4l+3; a segmented broadcast tells which voxel a slot belongs to ----------
                 *reinterpret_cast<uint4*>(&s_owner[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
-                tsync();
+                __syncthreads();
                 if (cnt > 0)
                 {
                     if (off >= base && off < base + NN_CAP) s_owner[off - base] = (uint32_t)lane + 1u;
                     else if (off < base && off + cnt > base) s_owner[0] = (uint32_t)lane + 1u;
                 }
-                tsync();
+                __syncthreads();
                 {
                     const uint4    o4 = *reinterpret_cast<const uint4*>(&s_owner[4 * lane]);
                     const uint32_t p0 = o4.x, p1 = max(p0, o4.y), p2 = max(p1, o4.z), p3 = max(p2, o4.w);
@@ -441,7 +399,7 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
                             if (t0 + k < m) a.touched[src[k]] = 1;
                     }
                 }
-                tsync();
+                __syncthreads();
                 if (SOL != 1)
                 {
                     const float* s_n  = reinterpret_cast<const float*>(s_owner);
@@ -502,7 +460,7 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
                         }
                     }
                 }
-                tsync();
+                __syncthreads();
             }
         };
 
@@ -559,7 +517,6 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
                 }
             }
         };
-        uint32_t nsel_all = 0;  // W > 1: voxels selected so far in this pass (every wave counts alike: the deal)
         // one round of <= 64 bricks (lane = brick: bm, pb): list, select, resolve, stage + scan
         auto serve = [&](unsigned long long bm, int pb, uint32_t vcap) __attribute__((always_inline)) {
             const uint32_t bcnt   = (uint32_t)__popcll(bm);
@@ -569,13 +526,13 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
             for (uint32_t r0 = 0; r0 < vtotal && !over; r0 += vcap)
             {
                 list_bits(bm, pb, bcnt, bincl, r0, vcap, s_vox);
-                tsync();
+                __syncthreads();
                 const uint32_t nv = min(vcap, vtotal - r0);
                 if (INSTR || SOL != 0) st_listed += nv;
                 if (SOL == 4)
                 {
                     st_cand += s_vox[lane] & 1u;
-                    tsync();
+                    __syncthreads();
                     continue;
                 }
                 // ---- selection: 32 listed voxels (columns) x the tile's 32 queries (rows) per three MFMAs ----------------------
@@ -607,23 +564,10 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
                     //  ones the integer order is the float order)
                     const unsigned long long nb64 = __ballot(vi < nv && __int_as_float(mni) <= vlim);
                     const uint32_t           m32  = (uint32_t)nb64 | (uint32_t)(nb64 >> 32);  // both halves hold the same voxel
-                    const uint32_t           below = (1u << (lane & 31)) - 1u;
-                    if (W == 1)
-                    {
-                        if (!hi && ((m32 >> lane) & 1u)) s_vox[nsel + (uint32_t)__popc(m32 & below)] = pk;  // (writes at or below vb + lane)
-                        nsel += (uint32_t)__popc(m32);
-                    }
-                    else
-                    {   // this wave's share: runs of 8 selected voxels dealt round-robin (every wave computes the same m32)
-                        const uint32_t gi   = nsel_all + (uint32_t)__popc(m32 & below);
-                        const bool     keep = !hi && ((m32 >> lane) & 1u) && (((gi >> NN_DEAL_SHIFT) & (uint32_t)(W - 1)) == (uint32_t)wv);
-                        const uint32_t k32  = (uint32_t)__ballot(keep);
-                        if (keep) s_vox[nsel + (uint32_t)__popc(k32 & below)] = pk;
-                        nsel += (uint32_t)__popc(k32);
-                        nsel_all += (uint32_t)__popc(m32);
-                    }
+                    if (!hi && ((m32 >> lane) & 1u)) s_vox[nsel + (uint32_t)__popc(m32 & ((1u << lane) - 1u))] = pk;  // (writes at or below vb + lane)
+                    nsel += (uint32_t)__popc(m32);
                 }
-                tsync();
+                __syncthreads();
                 if (INSTR || SOL != 0) st_needed += nsel;
                 for (uint32_t cb = 0; cb < nsel && !over; cb += 64u)
                 {
@@ -642,7 +586,7 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
                     }
                     batch(start, cnt);
                 }
-                tsync();  // the list is rewritten by the next round
+                __syncthreads();  // the list is rewritten by the next round
             }
         };
         // A box of more than one round of bricks (wide balls, or a spatially loose tile of far-field points: the box of 32 points
@@ -687,7 +631,7 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
                     list_bits(w2, pl, c2, i2 + T, chunk_lo, CH, s_bl);
                     T += (uint32_t)__builtin_amdgcn_readlane((int)i2, 63);
                 }
-                tsync();
+                __syncthreads();
                 n_all = T;
             }
             if (n_all <= chunk_lo) break;
@@ -714,7 +658,7 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
                 brick_word(ok, Bx, By, Bz, bm, pb);
                 serve(bm, pb, vcap);
             }
-            if (two_stage) tsync();  // the brick list is rewritten by the next chunk
+            if (two_stage) __syncthreads();  // the brick list is rewritten by the next chunk
             if (n_all <= chunk_lo + CH) break;
         }
 
@@ -729,31 +673,6 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
         {
             const int o1_ = __shfl_xor(t1, 32, 64), o2_ = __shfl_xor(t2, 32, 64);
             t2 = min(max(t1, o1_), min(t2, o2_)), t1 = min(t1, o1_);
-        }
-        if (W > 1)
-        {   // ---- ... and the tile's waves (each scanned its share of the pass's voxels): the only workgroup barriers.  Every wave
-            //      reaches them: their queries' state is identical at the top of every pass, hence their control flow between passes
-            uint32_t* const mine = s_mrg + (size_t)(wv * 32 + (lane & 31)) * 5;
-            if (!hi)
-            {
-                mine[0] = __float_as_uint(best_d2), mine[1] = best_idx, mine[2] = best_spos;
-                if (track) mine[3] = (uint32_t)t1, mine[4] = (uint32_t)t2;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int w2 = 0; w2 < W; w2++)
-            {
-                const uint32_t* o  = s_mrg + (size_t)(w2 * 32 + (lane & 31)) * 5;
-                const float     od = __uint_as_float(o[0]);
-                const uint32_t  oi = o[1], os = o[2];
-                if (w2 != wv && (od < best_d2 || (od == best_d2 && oi < best_idx))) best_d2 = od, best_idx = oi, best_spos = os;
-                if (track && w2 != wv)
-                {
-                    const int o1_ = (int)o[3], o2_ = (int)o[4];
-                    t2 = min(max(t1, o1_), min(t2, o2_)), t1 = min(t1, o1_);
-                }
-            }
-            __syncthreads();  // (the table is rewritten at the end of the next pass)
         }
         bool too_wide = false;
         if (grp && !over)  // (a pass cut short has not covered its balls: nobody concludes)
@@ -779,7 +698,7 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
         const unsigned long long wmask = __ballot(too_wide);
         if (wmask)
         {
-            if (SOL == 0 && wv == 0)
+            if (SOL == 0)
                 st_defer += defer_lanes<Q>(a, seg, too_wide, wmask, lane, slice, qi, st_cand > cand_cap ? -r : r, best_d2, best_idx, best_spos, qx, qy, qz);
             if (too_wide) done = true, deferred = true;
         }
@@ -789,17 +708,6 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
     //      around it empty?  Then that is its bound and the warm start skips it until it has moved by the difference
     //      (nn_single_kernel has the reasoning; isolated queries used to be handed to that kernel, with the selection they stay).
     //      The whole wave serves one such query at a time: a handful of coarse occupancy bits each.
-    if (W > 1)
-    {   // what the TILE staged (the next call's classes read it from the records): the waves' shares, the per-pass charge once
-        __syncthreads();
-        if (lane == 0) s_mrg[wv] = st_cand;
-        __syncthreads();
-        uint32_t sum = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < W; w2++) sum += s_mrg[w2];
-        st_cand = sum - (uint32_t)(W - 1) * NN_PASS_COST * st_pass;
-        if (wv != 0) return;  // records, claims, empty-room bounds, counters: the first wave (no workgroup barrier below)
-    }
     float lb2_room = -1.f;
     if (SOL == 0 && a.empty_room)
     {
@@ -815,22 +723,16 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
     // ---- output (Morton order of the local layer) + claim of the global point -----------------
     if (SOL == 0)
     {
-        // the tile's cost for the next call's classes: what it staged -- or (cost_ticks) how long it took, in candidate equivalents
-        // (16 ns each; a four-wave tile: what one wave would have needed, about): the long tiles are not all
-        // dense ones -- a loose far-field tile lists thousands of voxels for 3 000 candidates and runs as long as a dense one with 9 000
-        uint32_t cost = st_cand;
-        if (a.cost_ticks) cost = (uint32_t)min((wall_clock64() - tl0) * (W > 1 ? 15ull : 5ull) / 8ull, 0xFFFFFFull);
-        emit_wave<(W > 1 || WSYNC)>(a, s_claim, lane, valid && slice == 0 && !deferred, qi, orig, active, thr, best_d2, best_idx, best_spos,
-                           (pro_done && lb2_out >= 0.f) ? lb2_out : (lb2_room >= 0.f ? lb2_room : fminf(best_d2, thr)), cost);
+        emit_wave(a, s_claim, lane, valid && slice == 0 && !deferred, qi, orig, active, thr, best_d2, best_idx, best_spos,
+                  (pro_done && lb2_out >= 0.f) ? lb2_out : (lb2_room >= 0.f ? lb2_room : fminf(best_d2, thr)), st_cand);
         if (a.lb2nd && valid && slice == 0 && !deferred) a.lb2nd[qi] = pro_done ? lb2nd_out : (track ? lbq : 0.f);
     }
     else if ((best_d2 == -1.f || st_cand == 0xFFFFFFFFu) && lane == 0) a.rec[0].x = best_idx + st_listed + st_needed;  // (never true: keeps the timing-only build's work alive)
 
     // (profiling level 4: the spare high bits carry what the tile did -- staged candidates / 32, passes, rounds of 64 bricks)
-    const size_t tl_at = W > 1 ? (size_t)a.timeline_heavy_base + tile : (size_t)tile;
     if (a.timeline && lane == 0)
-        a.timeline[2 * tl_at]     = (tl0 & 0xFFFFFFFFFFull) | ((unsigned long long)min(st_cand >> 5, 0xFFFFFFu) << 40),
-        a.timeline[2 * tl_at + 1] = (wall_clock64() & 0xFFFFFFFFFFull) | ((unsigned long long)min(st_pass, 255u) << 40) |
+        a.timeline[2 * (size_t)tile]     = (tl0 & 0xFFFFFFFFFFull) | ((unsigned long long)min(st_cand >> 5, 0xFFFFFFu) << 40),
+        a.timeline[2 * (size_t)tile + 1] = (wall_clock64() & 0xFFFFFFFFFFull) | ((unsigned long long)min(st_pass, 255u) << 40) |
                                            ((unsigned long long)min(st_cells >> 6, 0xFFFFu) << 48);
     if (INSTR && lane == 0)
     {
@@ -850,82 +752,6 @@ __device__ __forceinline__ void seltile_body(const NNArgs& a, const uint32_t til
         atomicAdd(&a.counters[16 + b], 1ull);
         atomicAdd(&a.counters[49], (unsigned long long)st_listed);
         atomicAdd(&a.counters[50], (unsigned long long)st_needed);
-    }
-}
-
-// one workgroup = one wave = one tile; the hardware's dispatcher hands the tiles out in grid order (rounds 1-5; small layers, the
-// instrumented and timing-only builds, persist = 0)
-template <bool INSTR, bool CERT, bool DIRECT, int WAVES, int SOL = 0>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void nn_seltile_kernel(const NNArgs a)
-{
-    __shared__ SelLds s_lds;
-    seltile_body<INSTR, CERT, DIRECT, SOL, 1, false>(a, blockIdx.x, s_lds, nullptr, 0);
-}
-
-// Round 6: the tile stage as ONE persistent launch (grid = the chip's resident set: four workgroups of four waves per CU).
-//   phase 1: the HEAVY tiles (lane kernel: the waves whose tile staged >= heavy_cand candidates at the previous call), one per
-//            workgroup turn, searched by its four waves together (W = 4 above).  They are on the chip at t = 0 and run 1.8-2.1 x
-//            faster than on one wave: the kernel's span used to be its ten longest tiles.  Launched as a kernel of their own
-//            beside the other tiles (second stream) the same workgroups starved or paid the fork / join;
-//            inside one launch there is nothing to fork;
-//   phase 2: every wave by itself: tiles from the queue of its XCD (tile = 8 j + x: the segments x, x + 8, ... whose records that
-//            XCD's L2 holds; hard class first, the grid order of the one-tile-per-workgroup launch), then from the other XCDs'
-//            queues.  A segment's tiles beyond its pending count are skipped in one step (atomicMax on the queue).
-// No workgroup barrier outside phase 1: the waves of a workgroup part ways for good when the heavy queue is empty.
-// VAR (experiment): bit 0 = the heavy phase compiled in, bit 2 = static striding instead of the queues; WAVES = register budget
-template <bool CERT, int VAR = 1, int WAVES = 4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void nn_seltile_persist_kernel(const NNArgs a)
-{
-    __shared__ SelLds   s_lds[4];
-    __shared__ uint32_t s_mrg[(VAR & 1) ? 4 * 32 * 5 : 1];
-    __shared__ uint32_t s_t;
-    const int       wv   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: the LDS bases stay scalar)
-    const int       lane = threadIdx.x & 63;
-    uint32_t* const qw   = a.q_counters + (size_t)3 * NN_MAX_SEG * NN_CNT_STRIDE;  // list 3's counter block (NN_HEAVY_WORDS)
-    if ((VAR & 1) && a.heavy_cand != 0u)
-    {
-        const uint32_t n_heavy = (min(qw[0], a.heavy_cap) + 31u) / 32u;
-        while (true)
-        {
-            if (threadIdx.x == 0) s_t = atomicAdd(qw + NN_CNT_STRIDE, 1u);
-            __syncthreads();
-            const uint32_t t = s_t;
-            __syncthreads();
-            if (t >= n_heavy) break;
-            if constexpr ((VAR & 1) != 0) seltile_body<false, CERT, false, 0, 4, true>(a, t, s_lds[wv], s_mrg, wv);
-        }
-    }
-    const uint32_t tps = a.tiles_per_seg, per_cls = ((a.n_seg + 7u) / 8u) * tps, per_q = 2u * per_cls;  // tiles of one queue
-    if (VAR & 4)
-    {
-        for (uint32_t t = blockIdx.x * 4u + (uint32_t)wv; t < per_q * 8u; t += gridDim.x * 4u)
-            seltile_body<false, CERT, false, 0, 1, true>(a, t, s_lds[wv], nullptr, 0);
-        return;
-    }
-    uint32_t       x = blockIdx.x & 7u;
-    for (uint32_t tried = 0; tried < 8u;)
-    {
-        uint32_t* const qc = qw + (size_t)(2u + x) * NN_CNT_STRIDE;
-        uint32_t        j  = 0;
-        if (lane == 0) j = atomicAdd(qc, 1u);
-        j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
-        if (j >= per_q)
-        {
-            x = (x + 1u) & 7u, tried++;
-            continue;
-        }
-        const uint32_t cls = j >= per_cls ? 1u : 0u, jj = j - cls * per_cls;
-        if (a.xcd_map)
-        {
-            const uint32_t sl = jj / tps, tk = jj - sl * tps, seg = sl * 8u + x;
-            const uint32_t n_pend = seg < a.n_seg ? a.q_counters[((size_t)(cls ? 2 : 0) * NN_MAX_SEG + seg + a.seg_base) * NN_CNT_STRIDE] : 0u;
-            if (tk * 32u >= n_pend)
-            {   // the rest of this segment's tiles are empty: the queue jumps to the next segment
-                if (lane == 0) atomicMax(qc, cls * per_cls + (sl + 1u) * tps);
-                continue;
-            }
-        }
-        seltile_body<false, CERT, false, 0, 1, true>(a, cls * per_cls * 8u + jj * 8u + x, s_lds[wv], nullptr, 0);
     }
 }
 

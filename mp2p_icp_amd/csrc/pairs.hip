@@ -253,7 +253,7 @@ __global__ __launch_bounds__(1024) void compact_scan_bbox_kernel(const CompactAr
         a.counts[2] += a.potential_add;
         a.counts[7] = overlap ? 1ull : 0ull;
     }
-    if (a.q_counters && threadIdx.x < NN_LISTS * NN_MAX_SEG + NN_HEAVY_WORDS) a.q_counters[(size_t)threadIdx.x * NN_CNT_STRIDE] = 0u;  // (the last ones: the heavy list's counter, the nine tile queues)
+    if (a.q_counters && threadIdx.x < NN_LISTS * NN_MAX_SEG) a.q_counters[(size_t)threadIdx.x * NN_CNT_STRIDE] = 0u;
 }
 
 __global__ __launch_bounds__(CP_THREADS) void compact_write_kernel(const CompactArgs a)

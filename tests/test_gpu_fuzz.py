@@ -174,8 +174,7 @@ def test_fuzz_round4_search_paths(oracle, seed, monkeypatch):
     """the point-to-point search's round-4 paths under random knobs, a fresh context per case: brick lists in the tile
     kernel (also with a budget of 1 or 8 bricks: the coarse dense fallback), tiny candidate budgets (passes cut short in
     flight, queries handed on with partial bounds), cost classes with a threshold everything / nothing exceeds, the
-    search-skip certificate in all three modes, the empty-room bound, round 6's persistent tile kernel with its heavy class (every
-    costed wave in it, its list overflowing); pose sequences from 10^-5 to 0.3 of the scene with
+    search-skip certificate in all three modes, the empty-room bound; pose sequences from 10^-5 to 0.3 of the scene with
     jumps, local points taken in some calls, large and tiny thresholds.  Lists bit-exact against the oracle at every call."""
     import mp2p_icp_amd as amd
     from mp2p_icp_amd import _lib, core
@@ -198,11 +197,7 @@ def test_fuzz_round4_search_paths(oracle, seed, monkeypatch):
                      f"empty_room={int(rng.choice([1, 1, 0]))}", f"coop_max={int(rng.choice([4, 0]))}",
                      # round 5 (drawn after the clouds and the threshold: those are the ones of round 4's campaign)
                      f"tile_select={int(rng.choice([1, 1, 1, 0]))}", f"nn_direct={int(rng.choice([1, 0, 0]))}",
-                     f"grp_all_bricks={int(rng.choice([6, 0, 100]))}",
-                     # round 6: the persistent tile kernel and its heavy class (tiles searched by the four waves of a workgroup;
-                     # every costed wave in it; a list that overflows)
-                     f"persist={int(rng.choice([1, 1, 1, 0]))}", f"heavy_cand={int(rng.choice([4000, 1, 1, 30, 0]))}",
-                     f"heavy_tiles={int(rng.choice([2048, 1, 3]))}", f"xcd_map={int(rng.choice([1, 1, 0]))}"])
+                     f"grp_all_bricks={int(rng.choice([6, 0, 100]))}"])
     monkeypatch.setenv("MP2P_HIP_TUNE", tune)
     layer_kw = {}
     if rng.random() < 0.3:

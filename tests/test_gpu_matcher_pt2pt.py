@@ -414,10 +414,7 @@ def test_max_local_points_visit_order(amd, oracle, K):
                                   "tile_select=0", "nn_direct=0", "nn_direct=0,nn_cert=2,hard_cand=50", "pipelines=2,nn_cert=2",
                                   "tile_cand_cap=300,coop_max=0", "nn_direct=0,pipelines=2,tile_cand_cap=500",
                                   # all pending queries in one pass, always or never
-                                  "grp_all_bricks=0", "pipelines=2,grp_all_bricks=64", "nn_direct=1,grp_all_bricks=0", "nn_direct=1,grp_all_bricks=200",
-                                  # round 6: the persistent tile kernel (behind the lane kernel), every costed wave heavy / none / a list of one tile
-                                  "nn_direct=0,persist=1,heavy_cand=1", "nn_direct=0,persist=1,heavy_cand=0,nn_cert=2", "nn_direct=0,persist=0",
-                                  "nn_direct=0,persist=1,heavy_cand=1,heavy_tiles=1,xcd_map=0,nn_cert=2"])
+                                  "grp_all_bricks=0", "pipelines=2,grp_all_bricks=64", "nn_direct=1,grp_all_bricks=0", "nn_direct=1,grp_all_bricks=200"])
 def test_tune_knobs_do_not_change_the_lists(amd, oracle, tune, monkeypatch):
     """MP2P_HIP_TUNE is read once per context: every setting is a measurement aid that must compute the
     same lists (two search pipelines on two streams, exact scan instead of the matrix-pipe prefilter, another

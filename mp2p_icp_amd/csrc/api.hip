@@ -87,6 +87,7 @@ static int parse_tune(Tune& t, const char* e, bool from_env, std::string* why = 
         else if (k == "sync_spin") t.sync_spin = (int)v;
         else if (k == "pl_cert") t.pl_cert = (int)v;
         else if (k == "pl_cert_pad") t.pl_cert_pad = (uint32_t)v;
+        else if (k == "pl_cert_step_mm") t.pl_cert_step_mm = (uint32_t)v;
         else if (k == "pl_cert_margin_mm") t.pl_cert_margin_mm = (uint32_t)v;
         else if (k == "pl_hard_cand") t.pl_hard_cand = (uint32_t)v;
         else if (k == "spin_us") t.spin_us = (int)v;

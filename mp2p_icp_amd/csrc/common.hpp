@@ -163,6 +163,9 @@ struct Tune
     uint32_t dir_budget_mb = 8192;  // dense voxel directories of a map: at most this many MB (0 = none)
     int      pl_warm       = 1;     // point-to-plane search: start radius from the previous call's k-th distance (0 = full radius)
     int      pl_cert       = 2;     // pt2pl: skip the search of a query whose previous list is certainly still its k nearest (PlArgs::lb_io)
+    uint32_t pl_cert_step_mm = 10;  // ... only when the farthest local point moved less than this since the previous call (0 = always): the gap
+                                    // between a query's k-th and (k+1)-th neighbour is millimetres, so after a larger step no list is
+                                    // certified, while reading the lists (five gathers per query) and staging the margin cost 7 % of a C3 step
     uint32_t pl_cert_pad   = 2;     // ... searchRadius + this many per mille is what a search that comes up short asks for
     uint32_t pl_cert_margin_mm = 20; // ... voxels up to this far beyond the search radius of a pass are staged as well (the covered region's margin)
     uint32_t copy_chunk_kb = 2048;  // staged copy-out of the pair lists (CopyStage): bytes per DMA + event ...

@@ -1227,7 +1227,18 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     if (phase != 2) ctx->pl_hint_map = nullptr;
     a.grp_min = 2.0f * cell0;
     a.lb_io = ctx->pl_lb.p, a.pend = ctx->pl_pend.p, a.pend_cap = pend_cap, a.cert_stat = ctx->pl_cert_stat.p;
-    a.use_cert = (a.use_hint && ctx->tune.pl_cert) ? ctx->tune.pl_cert : 0;
+    // the certificate is worth reading (and its margin worth staging) only after a small step (Tune::pl_cert_step_mm; the same
+    // bound as the point matcher's: |T p - T' p| <= |t - t'| + |R - R'|_F |p| for every local point p).  A call that skips it still
+    // leaves valid bounds (without the margin: weaker), and results never depend on it.
+    bool cert_on = ctx->tune.pl_cert != 0;
+    if (cert_on && ctx->tune.pl_cert_step_mm != 0u && a.use_hint)
+    {
+        double dt = 0, dr = 0;
+        for (int i = 0; i < 3; i++) dt += (pose[9 + i] - ctx->pl_hint_pose[9 + i]) * (pose[9 + i] - ctx->pl_hint_pose[9 + i]);
+        for (int i = 0; i < 9; i++) dr += (pose[i] - ctx->pl_hint_pose[i]) * (pose[i] - ctx->pl_hint_pose[i]);
+        cert_on = std::sqrt(dt) + std::sqrt(dr) * (double)cloud->radius <= 1e-3 * (double)ctx->tune.pl_cert_step_mm;
+    }
+    a.use_cert = (a.use_hint && cert_on) ? ctx->tune.pl_cert : 0;
     // (the hard class of the round-6 kernel: for layers whose tiles do not fill the chip several times over -- up to 16 384 tiles)
     a.cost_io = ctx->pl_cost.p, a.hard_cand = sel ? ((ctx->tune.pl_waves == 1 || n_l > 524288) ? 0u : ctx->tune.pl_sel_hard_cand) : ctx->tune.pl_hard_cand;
     a.grp_all_bricks = (float)ctx->tune.grp_all_bricks;
@@ -1241,7 +1252,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     // the radius a search that finds fewer than knn points has covered: searchRadius + pl_cert_pad per mille, the room
     // the certificate of such a query has before a point outside its list could come into reach (0.2 % without it)
     a.rad_cert = a.rad * (1.0f + 0.001f * (float)(ctx->tune.pl_cert ? std::max(2u, ctx->tune.pl_cert_pad) : 2u)) + map->view.slack;
-    a.cert_margin = ctx->tune.pl_cert ? 0.001f * (float)(sel ? ctx->tune.pl_sel_margin_mm : ctx->tune.pl_cert_margin_mm) : 0.f;
+    a.cert_margin = cert_on ? 0.001f * (float)(sel ? ctx->tune.pl_sel_margin_mm : ctx->tune.pl_cert_margin_mm) : 0.f;
     a.dbg = nullptr, a.touched = nullptr;
     if (ctx->profiling == 2)
     {

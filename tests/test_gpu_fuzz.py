@@ -359,9 +359,13 @@ def test_fuzz_pt2pl_pose_sequences(oracle, seed):
     forced = "pl_select" in os.environ.get("MP2P_HIP_TUNE", "")
     if not forced:
         core.default_context().set_tune("pl_select=%d" % (seed % 2))
+    # ... and the certificate read / its margin staged after steps below 10 mm only (the default), always, after any step below 1 mm or
+    # 100 m: calls that skip it leave bounds without the margin, which the next small step's call certifies from
+    core.default_context().set_tune("pl_cert_step_mm=%d" % [10, 0, 1, 100000][(seed // 2) % 4])
     try:
         _pl_pose_sequence(amd, oracle, rng, g, l, tree, pcG, pcL, P, m, scale, seed, kind, n_g, n_l)
     finally:
+        core.default_context().set_tune("pl_cert_step_mm=10")
         if not forced:
             core.default_context().set_tune("pl_select=-1")
 

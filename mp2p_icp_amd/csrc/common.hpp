@@ -189,7 +189,7 @@ struct Tune
     uint32_t pl_sel_hard_cand = 3000;  // ... a query whose 32-query tile staged this many candidates at the previous call is listed in the class dispatched first (0 = one class)
     int      pl_sol        = 0;     // timing-only cuts of pt2pl_seltile_kernel's instrumented build (1..4, nn_pl_seltile.hip): set_tune only, profiling on, results invalid
     int      pl_no_touch   = 0;     // profiling level 2 of the point-to-plane search without the per-point 'touched' bytes (phase timers undisturbed)
-    uint32_t pl_hard_cand  = 1500;  // pt2pl: a query whose tile staged this many candidates (per 4 queries) at the previous call is searched in the hard class, first and in smaller tiles (0 = one class)
+    uint32_t pl_hard_cand  = 3000;  // pt2pl: a query whose tile staged this many candidates (per 4 queries) at the previous call is searched in the hard class, first and in smaller tiles (0 = one class)
 };
 
 // multi-GPU communicator of a context (comm.hip): RCCL, or caller-provided collectives

@@ -20,10 +20,10 @@ poses = []
 for _ in range(10):
     poses.append(rig.state["pose"].copy()); rig.one_step()
 rig.ctx.set_profiling(1)
-out = {0: [], 1: [], 2: []}
+out = {0: [], 1: [], 2: [], 3: [], 4: [], 5: []}
 for k in range(1, 10):
     rig.ctx.set_tune("tile_sol=0"); rig.reg.match(poses[k - 1])
-    for m in (1, 2, 0):
+    for m in (3, 4, 5, 1, 2, 0):
         rig.ctx.set_tune(f"tile_sol={m}"); rig.reg.match(poses[k]); out[m].append(rig.ctx.stats()["ms_nn_tile"])
 rig.ctx.set_tune("tile_sol=0")
 print(json.dumps({f"sol{m}_ms": float(np.mean(v)) for m, v in out.items()}))

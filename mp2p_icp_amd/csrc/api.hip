@@ -125,6 +125,7 @@ static int parse_tune(Tune& t, const char* e, bool from_env, std::string* why = 
         else if (k == "pl_waves") t.pl_waves = (uint32_t)v;
         else if (k == "pl_sel_margin_mm") t.pl_sel_margin_mm = (uint32_t)v;
         else if (k == "pl_sel_hard_cand") t.pl_sel_hard_cand = (uint32_t)v;
+        else if (k == "pl_sel_hard_large") t.pl_sel_hard_large = (uint32_t)v;
         else if (k == "pl_no_touch") t.pl_no_touch = (int)v;
         else if (k == "pl_sol")
         {

@@ -187,6 +187,7 @@ struct Tune
     uint32_t pl_sel_margin_mm = 5;  // ... the certificate's margin of that kernel: the selection's balls and the prefilter's limits are this much wider
                                     // than the search needs, so that what is not evaluated exactly is provably this far beyond the list
     uint32_t pl_sel_hard_cand = 3000;  // ... a query whose 32-query tile staged this many candidates at the previous call is listed in the class dispatched first (0 = one class)
+    uint32_t pl_sel_hard_large = 1500; // ... the same for layers above 524 288 queries, where the class is served by single waves and only sets the dispatch order (0 = Morton order)
     int      pl_sol        = 0;     // timing-only cuts of pt2pl_seltile_kernel's instrumented build (1..4, nn_pl_seltile.hip): set_tune only, profiling on, results invalid
     int      pl_no_touch   = 0;     // profiling level 2 of the point-to-plane search without the per-point 'touched' bytes (phase timers undisturbed)
     uint32_t pl_hard_cand  = 3000;  // pt2pl: a query whose tile staged this many candidates (per 4 queries) at the previous call is searched in the hard class, first and in smaller tiles (0 = one class)

@@ -43,7 +43,7 @@ namespace mp2p
 constexpr int PS_CAP   = 256;  // staged candidates per round
 constexpr int PS_VLIST = 256;  // occupied voxels listed per round (LDS is what bounds the kernel's occupancy: 12.5 KB per wave = 3 waves per SIMD)
 constexpr int PS_HITQ  = 8;    // queued hits per lane (flushed before a block's hits would not fit)
-constexpr int PS_HL    = 512;  // hits of one staging round (else of a quarter of a block: <= 256) listed for the wave-wide exact test
+constexpr int PS_HL    = 384;  // hits of one staging round (else of a quarter of a block: <= 256) listed for the wave-wide exact test
 constexpr int PS_MARKS = 512;  // level-2 cells (4x4x4 bricks each) of a wide pass's box: one u64 of brick marks each (the staging area's first 4 KB)
 
 // LDS of ONE wave of a tile (12.9 KB: 3 waves per SIMD).  At the end of a pass of a W > 1 tile the first 4 KB carry the wave's k-lists to

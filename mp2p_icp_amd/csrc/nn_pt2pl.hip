@@ -691,7 +691,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 3 
     const GridView&  g    = a.g;
     const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool       hard = blockIdx.x < n_hard_tiles;
-    const int        W = hard ? 4 : 1, wv = hard ? wave : 0;
+    // (a hard tile by the four waves of its workgroup -- or, launched with one wave per workgroup (large layers: the hard class is only
+    //  the ORDER there, long tiles first), by that wave alone)
+    const int        W = (hard && blockDim.x == 256u) ? 4 : 1, wv = W == 4 ? wave : 0;
     const uint32_t*  pend;
     uint32_t         cnt, k;
     if (hard)
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 3 
     }
     if (k * Q >= cnt) return;  // hard: the whole workgroup; easy: this wave (its tile runs without workgroup barriers)
     const uint32_t tile_id = hard ? blockIdx.x : n_hard_tiles + k;
-    const unsigned long long tl0 = (INSTR && a.timeline) ? wall_clock64() : 0ull;
+    const unsigned long long tl0 = a.timeline ? wall_clock64() : 0ull;  // (profiling level 4; the plain build pays a uniform null test)
     const uint32_t slot  = k * Q + (uint32_t)(lane % Q);
     const uint32_t ent   = slot < cnt ? pend[slot] : NONE_U32;  // (NONE: the padding of a block's part of a list)
     const bool     valid = ent != NONE_U32;
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(K <= 8 ? 3 
     knn_sel_search<K, false, true, INSTR>(g, W, lane, wv, &lds[wave], hard ? &lds[0] : &lds[wave], qx, qy, qz, active, a.radSq, a.rad_cert, r0, a.knn,
                                           a.grp_factor, a.grp_min, a.grp_all_bricks, a.cert_margin, kd2, kspos, &lb, &ncand, a.dbg,
                                           a.timeline ? a.timeline + 2 * (size_t)a.timeline_n + tile_id : nullptr, a.touched, a.sol);
-    if (INSTR && a.timeline && lane == 0 && wv == 0) a.timeline[2 * (size_t)tile_id] = tl0, a.timeline[2 * (size_t)tile_id + 1] = wall_clock64();
+    if (a.timeline && lane == 0 && wv == 0) a.timeline[2 * (size_t)tile_id] = tl0, a.timeline[2 * (size_t)tile_id + 1] = wall_clock64();
     if (!valid || lane >= Q || wv != 0) return;
     a.kth_io[qi]  = ps_kth(kd2, a.knn);
     a.lb_io[qi]   = lb;
@@ -1129,11 +1131,11 @@ static void launch_k(const PlArgs& a, uint32_t q, const mp2p_hip_cloud* cloud, h
     {   // round 6: ball-rule selection + matrix-pipe prefilter, 32 queries per tile in both classes; a hard tile per workgroup of four
         // waves, four easy tiles per workgroup (pt2pl_seltile_kernel)
         const uint32_t nh  = classes ? a.hard_cap / 32u : 0u;
-        const uint32_t tpw = nh ? 4u : 1u;  // waves (= easy tiles) per workgroup
+        const uint32_t tpw = (nh && sel_waves == 4u) ? 4u : 1u;  // waves (= easy tiles) per workgroup
         const dim3     grid(nh + (a.pend_cap / 32u + tpw - 1u) / tpw);
         const size_t   lds_bytes = sizeof(PsLds) * tpw;
         hipLaunchKernelGGL((pt2pl_cert_kernel<K, 32, 32>), dim3(n_blocks), dim3(PL_CB), 0, st, a);
-        const bool instr = a.dbg != nullptr || a.timeline != nullptr || a.touched != nullptr;  // profiling levels 2 and 4
+        const bool instr = a.dbg != nullptr || a.touched != nullptr;  // profiling level 2 (level 4, the timeline: the plain build stamps {start, end} itself)
         if (instr) hipLaunchKernelGGL((pt2pl_seltile_kernel<K, true>), grid, dim3(64u * tpw), lds_bytes, st, a, nh);
         else hipLaunchKernelGGL((pt2pl_seltile_kernel<K, false>), grid, dim3(64u * tpw), lds_bytes, st, a, nh);
     }
@@ -1171,7 +1173,12 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     const bool     sel     = (ctx->tune.pl_select < 0 ? n_l > 524288 : ctx->tune.pl_select != 0) && map->view.occ != nullptr && map->view.occ_off[0] != OCC_NONE &&
                              (float)prm->searchRadius * 1.01f + 0.05f <= PS_MAX_RADIUS_CELLS * cell0_;
     const uint32_t Q       = sel ? 32u : (ctx->tune.pl_q ? ctx->tune.pl_q : (n_l <= 2000000 ? 8u : (uint32_t)PL_Q));
-    const uint32_t sel_waves = sel ? 1u : 0u;
+    // the ball-rule kernel's hard class: small layers (their tiles do not fill the chip several times over) -- a hard tile by the FOUR
+    // waves of a workgroup; large layers -- one wave per tile, the class is only the dispatch ORDER (the tiles that staged the most at
+    // the previous call first: in Morton order the 150-190 us tiles of a 1 M-query layer started anywhere up to 230 us into a 470 us
+    // kernel, the last quarter of which ran below half residency)
+    const bool     sel_large = sel && n_l > 524288;
+    const uint32_t sel_waves = sel ? ((sel_large || ctx->tune.pl_waves == 1) ? 1u : 4u) : 0u;
     const uint32_t n_cblocks = (uint32_t)((n_l + PL_CB - 1) / PL_CB);
     const uint32_t n_boxes   = n_cblocks * (PL_CB / 64);  // one bounding box per wave of pt2pl_cert_kernel
     const uint32_t Kcap    = prm->knn <= 5 ? 5u : prm->knn <= 8 ? 8u : prm->knn <= 12 ? 12u : 16u;
@@ -1180,7 +1187,8 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     MP2P_TRY_HIP(ctx, ctx->pl_pend.ensure(std::max(pend_cap, 64u)));
     MP2P_TRY_HIP(ctx, ctx->pl_pend_cnt.ensure(2));
     // the hard class: at most an eighth of the layer (in whole tiles), and a grid prefix of at most 8192 workgroups
-    const uint32_t hard_cap = (uint32_t)std::min<size_t>(std::max<size_t>(n_l / (sel ? 4 : 8), 64), 8192u * 4u) / 32u * 32u;
+    const uint32_t hard_cap = sel_large ? (uint32_t)(std::max<size_t>(n_l / 16, 64) / 32u * 32u)
+                                        : (uint32_t)std::min<size_t>(std::max<size_t>(n_l / (sel ? 4 : 8), 64), 8192u * 4u) / 32u * 32u;
     MP2P_TRY_HIP(ctx, ctx->pl_hard.ensure(hard_cap));
     MP2P_TRY_HIP(ctx, ctx->pl_lb.ensure(n_l ? n_l : 1));
     MP2P_TRY_HIP(ctx, ctx->pl_cost.ensure(n_l ? n_l : 1));
@@ -1240,7 +1248,7 @@ int launch_match_pt2pl(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hi
     }
     a.use_cert = (a.use_hint && cert_on) ? ctx->tune.pl_cert : 0;
     // (the hard class of the round-6 kernel: for layers whose tiles do not fill the chip several times over -- up to 16 384 tiles)
-    a.cost_io = ctx->pl_cost.p, a.hard_cand = sel ? ((ctx->tune.pl_waves == 1 || n_l > 524288) ? 0u : ctx->tune.pl_sel_hard_cand) : ctx->tune.pl_hard_cand;
+    a.cost_io = ctx->pl_cost.p, a.hard_cand = sel ? (sel_large ? ctx->tune.pl_sel_hard_large : (ctx->tune.pl_waves == 1 ? 0u : ctx->tune.pl_sel_hard_cand)) : ctx->tune.pl_hard_cand;
     a.grp_all_bricks = (float)ctx->tune.grp_all_bricks;
     a.sol = (ctx->profiling != 0) ? ctx->tune.pl_sol : 0;
     a.hard_list = ctx->pl_hard.p, a.hard_cap = hard_cap, a.list_cnt = ctx->pl_pend_cnt.p;

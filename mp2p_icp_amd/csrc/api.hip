@@ -1175,9 +1175,10 @@ int mp2p_hip_get_stats(mp2p_hip_ctx* ctx, mp2p_hip_stats* out)
         }
         if (ctx->pending_pl && ctx->pl_cert_stat.p)
         {
-            unsigned long long c2[2];
+            unsigned long long c2[64 * 16];
             MP2P_TRY_HIP(ctx, hipMemcpy(c2, ctx->pl_cert_stat.p, sizeof(c2), hipMemcpyDeviceToHost));
-            ctx->stats.pl_certified = c2[0], ctx->stats.pl_searched = c2[1];
+            ctx->stats.pl_certified = 0, ctx->stats.pl_searched = 0;
+            for (int i = 0; i < 64; i++) ctx->stats.pl_certified += c2[i * 16], ctx->stats.pl_searched += c2[i * 16 + 1];
         }
         ctx->pending_pl    = 0;
         ctx->pending_match = 0;

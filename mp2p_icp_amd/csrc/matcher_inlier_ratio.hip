@@ -34,8 +34,16 @@ __global__ __launch_bounds__(256) void ir_keys_kernel(const uint32_t* __restrict
         keys[r] = found ? (((unsigned long long)__float_as_uint(nn_d2[q]) << 32) | (unsigned long long)(~r)) : ~0ull;
         vals[r] = i;
     }
+    // (one atomic per block, not per wave: 15 000 same-address atomics per 1 M-point layer are serialised at ~12 ns each)
     const unsigned long long m = __ballot(found);
-    if (lane == 0 && m) atomicAdd(n_found, (uint32_t)__popcll(m));
+    __shared__ uint32_t s_n[4];
+    if (lane == 0) s_n[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const uint32_t tot = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+        if (tot) atomicAdd(n_found, tot);
+    }
 }
 
 // nKeep = mrpt::round(double(nTotal) * inliersRatio)   (:119; ties to even, as lrint does)

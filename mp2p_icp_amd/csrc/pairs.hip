@@ -390,7 +390,8 @@ int launch_compact_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
 // index) of a local point that survived this rank's own unique-global filter: only these can
 // win across ranks, and there are at most as many as distinct global points hit (a few per cent
 // of the map), so the ranks all-gather records instead of reducing one word per global point.
-__global__ __launch_bounds__(256) void claims_export_kernel(const uint32_t* __restrict__ nn_spos,
+constexpr int CE_THREADS = 1024;
+__global__ __launch_bounds__(CE_THREADS) void claims_export_kernel(const uint32_t* __restrict__ nn_spos,
                                                             const uint4* __restrict__ rec,
                                                             uint32_t n_slots, uint32_t K,
                                                             const uint32_t* order, const uint32_t* pos,
@@ -419,12 +420,25 @@ __global__ __launch_bounds__(256) void claims_export_kernel(const uint32_t* __re
     }
     const bool mine = spos != NONE_U32 && claims[spos] == (claim_hi | id);
     const unsigned long long m = __ballot(mine);
-    if (m == 0ull) return;
-    unsigned long long base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
+    // one reservation per BLOCK of 1 024 slots (round 6: one per wave was 15 000 atomics on one address per rank and step of a
+    // 1 M-point shard -- serialised at ~12 ns each, a third of a 0.45 ms step; the records' order in the list means nothing:
+    // they are imported with atomicMin)
+    __shared__ uint32_t           s_cnt[CE_THREADS / 64];
+    __shared__ unsigned long long s_base;
+    const int w = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < CE_THREADS / 64; i++)
+    {
+        if (i < w) off += s_cnt[i];
+        tot += s_cnt[i];
+    }
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
+    __syncthreads();
     if (mine)
-        list[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)spos << 32) | (id & 0xFFFFFFFFull);
+        list[s_base + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)spos << 32) | (id & 0xFFFFFFFFull);
 }
 
 __global__ void exchange_pack_kernel(const float* bbox, int have_bbox, const unsigned long long* counter,
@@ -472,7 +486,7 @@ int launch_exchange_pack(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
         MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->claim_list.p, 0xFF, n_l * sizeof(unsigned long long), ctx->stream));
         MP2P_TRY_HIP(ctx, hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
         if (searched)
-            hipLaunchKernelGGL(claims_export_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0,
+            hipLaunchKernelGGL(claims_export_kernel, dim3((unsigned)((n_l + CE_THREADS - 1) / CE_THREADS)), dim3(CE_THREADS), 0,
                                ctx->stream, ctx->nn_spos.p, K == 1 ? ctx->nn_rec.p : nullptr, (uint32_t)n_l, K,
                                cloud->n_visit ? cloud->order.p : nullptr, cloud->pos.p, map->claims.p,
                                (~(unsigned long long)ctx->epoch) << 32,

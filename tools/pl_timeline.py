@@ -35,7 +35,7 @@ n_grid = (len(flat) // 3) if len(flat) % 3 == 0 else int(round(len(flat) / 3))
 n_grid = len(rec) * 2 // 3
 info = flat[2 * n_grid:2 * n_grid + n_grid]
 rec = flat[:2 * n_grid].reshape(-1, 2)
-n_cb = (n_l + 255) // 256
+n_cb = (n_l + 1023) // 1024
 Q = 8 if n_l <= 2000000 else 32
 n_hard_grid = len(rec) - ((n_l + 31) // 32 + n_cb)
 is_hard = (np.arange(len(rec)) < n_hard_grid)[rec[:, 1] > 0]

@@ -1,11 +1,9 @@
 #!/bin/bash
-O=gpurun_out/${1:-r6_p1}; mkdir -p $O; export TMPDIR=/tmp
-MP2P_FUZZ_PLSEQ_SEEDS=0:200 timeout 900 python -m pytest tests/test_gpu_matcher_pt2pl.py tests/test_gpu_matcher_inlier_ratio.py tests/test_gpu_matcher_adaptive.py tests/test_gpu_fuzz.py -x -q -m gpu -p no:cacheprovider -k "pt2pl or inlier or adaptive or pose_seq" > $O/pytest.log 2>&1; echo "tests rc=$? $(grep -E 'passed|failed' $O/pytest.log | tail -1)" | tee -a $O/rc.txt
-for c in c5 c3 c5 c3; do
-  timeout 600 python bench.py --config $c --steps 30 --warmup 5 2>$O/$c.err | grep '^{"metric"' > $O/$c.json
-  python - <<PY
-import json
-d=json.load(open("$O/$c.json"))
-print("$c", round(d["value"],1), round(d["ms_per_step"],4), d["step_ms"], {k:round(v,4) for k,v in d["kernel_ms"].items() if isinstance(v,float)})
-PY
-done | tee $O/c.txt
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r6_p20; mkdir -p $O
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c5 -o bench -- python $GRAFT_REPO_ROOT/bench.py --config c5 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/c5.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c3 -o bench -- python $GRAFT_REPO_ROOT/bench.py --config c3 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/c3.log 2>&1
+cd $GRAFT_REPO_ROOT
+find $O -name "*_kernel_trace.csv" -delete
+for c in c5 c3; do echo "== $c"; f=$(find $O/kt_$c -name "*kernel_stats.csv" | head -1); head -14 $f | cut -c1-140; done

@@ -594,6 +594,11 @@ static int match_pt2pt_phase2(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const 
     if (rc) return rc;
     MP2P_REQUIRE(ctx, out && out->ctx == ctx, "bad Pairings handle");
     MP2P_TRY_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->clear_deferred == out && (map->n == 0 || cloud->n == 0 || ctx->sol_no_records || prm->pairingsPerPoint > 1))
+    {   // (a clear left to the compaction by mp2p_hip_step_sharded, on a path that does not run the fused compaction)
+        ctx->clear_deferred = nullptr;
+        MP2P_TRY_HIP(ctx, hipMemsetAsync(out->counts.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    }
     if (map->n == 0 || cloud->n == 0)  // potential_pairings is added BEFORE the early-out (:64-67)
         return launch_add_potential(ctx, out, (unsigned long long)cloud->n * prm->pairingsPerPoint);
     if (ctx->sol_no_records)

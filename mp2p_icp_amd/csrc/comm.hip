@@ -268,12 +268,21 @@ int mp2p_hip_step_sharded(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p
     const bool claims = c.nranks > 1 && !prm->allowMatchAlreadyMatchedGlobalPoints;
     for (int attempt = 0; attempt < 2; attempt++)
     {
-        int rc = mp2p_hip_pairs_clear(ctx, pairs);
+        // one rank: the clear is folded into the compaction's scan kernel (its 64-byte memset was a launch of its own at the head of
+        // every step); whatever path does not reach that kernel clears here, before it returns
+        int rc = MP2P_HIP_OK;
+        if (c.nranks <= 1) ctx->clear_deferred = pairs;
+        else rc = mp2p_hip_pairs_clear(ctx, pairs);
         if (rc) return rc;
         size_t cap = 0;
         // first attempt: the list length predicted from the previous iteration (no host round trip
         // between the matcher's phases); second attempt: the exact length
         rc = sharded_match(ctx, map, cloud, pose, prm, pairs, attempt == 0 ? c.cap_guess : 0, &cap);
+        if (ctx->clear_deferred)
+        {   // (not consumed: an error return, or a path without a compaction -- the flag must not outlive this call)
+            ctx->clear_deferred = nullptr;
+            if (!rc) rc = mp2p_hip_pairs_clear(ctx, pairs);
+        }
         if (rc) return rc;
         // ends with the pose read-back; the true longest list of this iteration (all-reduced MAX in exch[6]) rides along
         rc = sharded_solve(ctx, pairs, pose, gn, out, claims);

@@ -277,6 +277,7 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<float>              block_bbox;   // [compaction blocks][6] (fused box reduction, pairs.hip)
     uint32_t                         last_n_boxes = 0;       // per-wave boxes the last pt2pt search left in tile_bbox
     bool                             sol_no_records = false;    // the last pt2pt search was a timing-only launch (Tune::tile_sol): nothing to compact
+    mp2p_hip_pairs*                  clear_deferred = nullptr;  // a list whose clear the next compaction into it performs (mp2p_hip_step_sharded on one rank)
     bool                             q_counters_clean = false;  // the search's list counters are zero on the stream
     mp2p::DevBuf<float>              local_bbox;   // [6] min xyz, max xyz of transformed local
     mp2p::DevBuf<double>             exch;         // [8] what a sharded layer all-reduces (pairs.hip)

@@ -26,6 +26,7 @@ struct CompactArgs
     // fused form (point-to-point matcher on one GPU): the bounding box of the transformed local layer
     // is reduced here -- per-wave boxes -> per-block boxes in the count kernel -> the layer's box and
     // the overlap decision (counts[7]) in the scan kernel -- instead of by two launches of its own
+    int                       fresh;         // (fused form) the list is cleared first: mp2p_hip_pairs_clear folded in (its memset was a launch of its own at the head of every step)
     const float*              tile_bbox;     // [n_tile_boxes][6] or null (local_bbox is final already)
     uint32_t                  n_tile_boxes;
     float*                    block_bbox;    // [n_blocks][6]
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(1024) void compact_scan_bbox_kernel(const CompactAr
     if (threadIdx.x == 0)
     {
         const unsigned long long total = s_run;
+        if (a.fresh) a.counts[0] = 0ull, a.counts[1] = 0ull, a.counts[2] = 0ull, a.counts[4] = 0ull, a.counts[5] = 0ull, a.counts[6] = 0ull;  // (the list's deferred clear)
         const unsigned long long old   = a.counts[0];
         a.counts[3]                    = old;  // write base for the scatter kernel
         unsigned long long nw          = old + total;
@@ -341,6 +343,12 @@ int launch_compact_slots(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_
     a.ms_global = (ms && mark_global) ? ms->global_taken.p : nullptr;
 
     const bool fused = bbox_from_tiles && n_blocks > 0 && ctx->last_n_boxes > 0;
+    if (ctx->clear_deferred == out)
+    {   // mp2p_hip_step_sharded left the list's clear to this call: the fused scan kernel does it, any other form by the memset
+        ctx->clear_deferred = nullptr;
+        if (fused) a.fresh = 1;
+        else MP2P_TRY_HIP(ctx, hipMemsetAsync(out->counts.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    }
     if (fused)
     {
         MP2P_TRY_HIP(ctx, ctx->block_bbox.ensure((size_t)n_blocks * 6));

@@ -392,3 +392,41 @@ def test_hard_class_overflow_and_visit_order_changes(amd, oracle, monkeypatch):
         pose = amd.se3.compose(pose, amd.se3.exp(np.array([1e-4, 1e-4, 0, 0, 0, 1e-5])))
     cloud.set_visit_order(None)
     _pl_equal(oracle, core, ctx, gmap, cloud, pairs, g, l, pose, tree)
+
+
+@pytest.mark.timeout(900)
+def test_large_layer_hard_first_order_does_not_change_the_lists(amd, oracle):
+    """round 6: above 524 288 queries the ball-rule kernel serves its hard class with single waves -- the class is only the dispatch
+    ORDER (the tiles that staged the most at the previous call first).  A 600 000-point layer along a warm chain: Morton order
+    (pl_sel_hard_large=0), the default threshold, a threshold every tile exceeds (the hard list, n / 16 entries, overflows and the
+    rest stays in the easy class) -- the same lists from every one, and the oracle's at the last pose."""
+    from mp2p_icp_amd import core, synthetic
+    d = synthetic.make_scan_union_pair(600_000, 2_000_000, 77, map_scan_points=400_000)
+    g, l = d["glob"], d["local"]
+    assert l.shape[0] > 524_288
+    rng = np.random.default_rng(3)
+    poses = [d["T_init"]]
+    for step in (0.05, 0.004, 0.0004):
+        poses.append(amd.se3.compose(poses[-1], amd.se3.exp(np.concatenate([rng.normal(0, step, 3), rng.normal(0, 0.1 * step, 3)]))))
+    ref = None
+    for knob in ("pl_sel_hard_large=0", "pl_sel_hard_large=1500", "pl_sel_hard_large=1", "pl_sel_hard_large=1,pl_cert_step_mm=0"):
+        ctx = amd.Context(0)
+        ctx.set_tune(knob)
+        gmap, cloud = core.GlobalMap(ctx, g[:, 0], g[:, 1], g[:, 2]), core.LocalCloud(ctx, l[:, 0], l[:, 1], l[:, 2])
+        pairs = core.DevicePairs(ctx, 0, l.shape[0])
+        got = []
+        for pose in poses:
+            pairs.clear()
+            core.match_pt2pl(ctx, gmap, cloud, pose, _pl_prm(0.4, 5), None, pairs)
+            rec, idx = pairs.download_pt2pl()
+            got.append((idx.copy(), rec["plane"].copy(), rec["centroid"].copy()))
+        if ref is None:
+            ref = got
+            tree = oracle.KDTree(g[:, 0], g[:, 1], g[:, 2])
+            want, widx, _ = oracle.match_pt2pl(g[:, 0], g[:, 1], g[:, 2], l[:, 0], l[:, 1], l[:, 2], poses[-1], 0.25, 0.4, 5, 5, 0.05, tree=tree)
+            assert np.array_equal(got[-1][0], widx) and len(widx) > 50_000
+            assert np.allclose(got[-1][1], want["plane"], rtol=0, atol=1e-9)
+        else:
+            for k, (a, b) in enumerate(zip(ref, got)):
+                assert np.array_equal(a[0], b[0]), (knob, k)
+                assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (knob, k)

@@ -288,6 +288,28 @@ __global__ __launch_bounds__(GN_THREADS) void gn_accum_pt2pl_kernel(
     accum_pt2pl_body(coef, lx, ly, lz, lines, planes, counts, done, R, t, prm, partials);
 }
 
+// both kinds of pairings in ONE launch (round 6): a list that CAN hold point pairings next to the plane ones (its capacity says so; the
+// counts live on the device) used to cost the point kernel's launch at every inner iteration even when it holds none -- C3: three
+// empty launches per step, 6 % of it.  The same two bodies one after the other, the same partial rows: sums bit-identical.
+__global__ __launch_bounds__(GN_THREADS) void gn_accum_both_kernel(
+    const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+    const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz,
+    const double* __restrict__ coef, const float* __restrict__ lx, const float* __restrict__ ly,
+    const float* __restrict__ lz, const mp2p_hip_pair_pt2ln* __restrict__ lines,
+    const mp2p_hip_pair_pl2pl* __restrict__ planes, const unsigned long long* __restrict__ counts,
+    const double* __restrict__ state, const GnKernelPrm prm, double* __restrict__ partials,
+    const GnInit init, const int first)
+{
+    const bool done = first ? false : state[ST_DONE] != 0.0;
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = first ? init.pose[k] : state[ST_POSE + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = first ? init.pose[9 + k] : state[ST_POSE + 9 + k];
+    accum_pt2pt_body(px, py, pz, gx, gy, gz, done ? 0ull : counts[0], R, t, prm, partials);
+    accum_pt2pl_body(coef, lx, ly, lz, lines, planes, counts, done, R, t, prm, partials);
+}
+
 // fixed-order sum of the block partials -> sums[48] (16 interleaved partial sums per quantity,
 // combined as a fixed tree: deterministic run to run).  The 16 loads of a thread are independent (one
 // round trip, not 16); the result goes to global memory (the all-reduce buffer) and to s_sums (LDS).
@@ -795,6 +817,14 @@ static void launch_partials(mp2p_hip_ctx* ctx, int& use_pt, int& use_pl, int fir
     const mp2p_hip_pairs* P = ctx->gn.pairs;
     const GnKernelPrm     k = make_kernel_prm(ctx->gn.prm);
     use_pt = P->cap_pt2pt > 0, use_pl = P->cap_pt2pl > 0 || P->ln.p || P->pp.p;
+    if (use_pt && use_pl)
+    {
+        hipLaunchKernelGGL(gn_accum_both_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
+                           P->lx.p, P->ly.p, P->lz.p, P->gx.p, P->gy.p, P->gz.p,
+                           P->cap_pt2pl > 0 ? P->pl_coef.p : nullptr, P->pl_lx.p, P->pl_ly.p, P->pl_lz.p,
+                           P->ln.p, P->pp.p, P->counts.p, ctx->gn_state.p, k, ctx->gn_partials.p, init, first);
+        return;
+    }
     if (use_pt)
         hipLaunchKernelGGL(gn_accum_pt2pt_kernel, dim3(GN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
                            P->lx.p, P->ly.p, P->lz.p, P->gx.p, P->gy.p, P->gz.p, P->counts.p,

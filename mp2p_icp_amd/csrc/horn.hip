@@ -173,16 +173,34 @@ __global__ __launch_bounds__(GN_THREADS) void horn_cov_kernel(
 }
 
 // fixed-order sum of [HORN_BLOCKS][16] partials; centroid mode: the first 6 scaled by 1/count
-__global__ __launch_bounds__(64) void horn_sum_kernel(const double* __restrict__ partials, int nq,
-                                                      int centroid_mode, double* __restrict__ out)
+__global__ __launch_bounds__(256) void horn_sum_kernel(const double* __restrict__ partials, int nq,
+                                                       int centroid_mode, double* __restrict__ out)
 {
+    // (round 6: 16 parts x 16 quantities, every thread's HORN_BLOCKS / 16 loads independent, the parts combined as a fixed tree --
+    //  deterministic run to run like the Gauss-Newton sums; one thread per quantity walking all 512 rows was 12.6 us per launch, two
+    //  launches per solve = 9 % of a C2 step)
+    static_assert(HORN_BLOCKS % 16 == 0, "16 parts");
+    __shared__ double s[16][16];
     __shared__ double s_t[16];
-    const int         q = threadIdx.x;
-    double            t = 0;
-    if (q < nq)
-        for (int b = 0; b < HORN_BLOCKS; b++) t += partials[(size_t)b * 16 + q];
-    if (q < 16) s_t[q] = t;
+    const int         q = threadIdx.x & 15, part = threadIdx.x >> 4;
+    double            v[HORN_BLOCKS / 16];
+#pragma unroll
+    for (int k = 0; k < HORN_BLOCKS / 16; k++) v[k] = q < nq ? partials[(size_t)(part + 16 * k) * 16 + q] : 0.0;
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < HORN_BLOCKS / 16; k++) t += v[k];
+    s[part][q] = t;
     __syncthreads();
+    if (threadIdx.x < 16)
+    {
+        const int i = threadIdx.x;
+        double    r[8];
+        for (int k = 0; k < 8; k++) r[k] = s[2 * k][i] + s[2 * k + 1][i];
+        s_t[i] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    }
+    __syncthreads();
+    if (threadIdx.x >= 16) return;
+    t = s_t[q];
     if (q >= nq) return;
     if (centroid_mode && q < 6)
     {
@@ -244,20 +262,27 @@ static int horn_pass(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const HornKerne
     unsigned char* fl = ctx->horn_flags.p;
     hipLaunchKernelGGL(horn_centroid_kernel, dim3(HORN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream,
                        P->lx.p, P->ly.p, P->lz.p, P->gx.p, P->gy.p, P->gz.p, P->counts.p, fl, part);
-    hipLaunchKernelGGL(horn_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, part, 7, 1, sums);
+    hipLaunchKernelGGL(horn_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, part, 7, 1, sums);
     if (k.n_blocks)
         hipLaunchKernelGGL(horn_block_bounds_kernel, dim3(1), dim3(64), 0, ctx->stream, fl, P->counts.p, k,
                            ctx->horn_bounds.p);
     hipLaunchKernelGGL(horn_cov_kernel, dim3(HORN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream, P->lx.p,
                        P->ly.p, P->lz.p, P->gx.p, P->gy.p, P->gz.p, P->pp.p, P->counts.p, sums,
                        ctx->horn_bounds.p, k, fl, part);
-    hipLaunchKernelGGL(horn_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, part, 12, 0, sums + 8);
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync(h, sums, 20 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    unsigned long long bad_blocks = 0;
+    hipLaunchKernelGGL(horn_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, part, 12, 0, sums + 8);
+    // (round 6: into the context's page-locked page and waited for by polling, like the Gauss-Newton read-back -- a copy to the
+    //  caller's stack is staged by the runtime, and the blocking wait adds its wake-up latency: two of each per C2 step)
+    if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
+    double* const             ph = reinterpret_cast<double*>((char*)ctx->pinned + 1024);
+    unsigned long long* const pb = reinterpret_cast<unsigned long long*>((char*)ctx->pinned + 1024 + 20 * sizeof(double));
+    *pb = 0ull;
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ph, sums, 20 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (k.n_blocks)
-        MP2P_TRY_HIP(ctx, hipMemcpyAsync(&bad_blocks, ctx->horn_bounds.p + MP2P_HIP_MAX_WEIGHT_BLOCKS, sizeof(bad_blocks),
+        MP2P_TRY_HIP(ctx, hipMemcpyAsync(pb, ctx->horn_bounds.p + MP2P_HIP_MAX_WEIGHT_BLOCKS, sizeof(unsigned long long),
                                          hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
+    memcpy(h, ph, 20 * sizeof(double));
+    const unsigned long long bad_blocks = *pb;
     MP2P_REQUIRE(ctx, bad_blocks == 0, "Pairings::point_weights blocks cover fewer pairs than paired_pt2pt");
     MP2P_REQUIRE(ctx, h[8 + 10] == 0.0, "Horn: a visited pairing has weight <= 0 (ASSERT_(wi > .0))");
     return MP2P_HIP_OK;
@@ -276,8 +301,10 @@ int horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const mp2p_hip_horn_p
     MP2P_TRY_HIP(ctx, ctx->gn_sums.ensure(NS));
     MP2P_TRY_HIP(ctx, ctx->horn_bounds.ensure(MP2P_HIP_MAX_WEIGHT_BLOCKS + 8));
     unsigned long long h_counts[8];
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync(h_counts, P->counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync((char*)ctx->pinned + 1536, P->counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
+    memcpy(h_counts, (char*)ctx->pinned + 1536, sizeof(h_counts));
     const unsigned long long n = h_counts[0], nPl = h_counts[6];
     MP2P_REQUIRE(ctx, h_counts[1] == 0 && h_counts[5] == 0,
                  "This solver cannot handle point-to-plane / point-to-line pairings (convert them first)");

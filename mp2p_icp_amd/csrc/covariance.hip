@@ -191,7 +191,7 @@ int covariance_run(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const double pose
 {
     unsigned long long c[8];
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(c, P->counts.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
     const unsigned long long n_terms = c[0] + c[1] + (P->ln.p ? c[5] : 0) + (P->pp.p ? c[6] : 0);
     *positive_definite = 0;
     if (n_terms == 0)
@@ -224,7 +224,7 @@ int covariance_run(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const double pose
     hipLaunchKernelGGL(cov_final_kernel, dim3(1), dim3(64), 0, ctx->stream, partials.p, h21.p);
     double s[CV_N];
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(s, h21.p, sizeof(s), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
     MP2P_TRY_HIP(ctx, hipGetLastError());
     double H[36];
     int    k = 0;

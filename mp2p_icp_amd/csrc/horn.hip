@@ -21,7 +21,8 @@ struct HornKernelPrm
 {
     int                use_scale;
     double             scale_thr;
-    double             waPoints, waPlanes;
+    double             waPoints, waPlanes;  // (computed by horn_cov_kernel from the list's own counts: no host round trip before the pass)
+    double             w_pt2pt, w_ln2ln, w_pl2pl;
     GnKernelPrm        rk;  // robust kernel (kernel, c, c2)
     double             est[12];
     uint32_t           n_blocks;  // point_weights blocks (0: one block of weight 1)
@@ -109,6 +110,9 @@ __global__ __launch_bounds__(GN_THREADS) void horn_cov_kernel(
 #pragma unroll
     for (int k = 0; k < 12; k++) acc[k] = 0;
     const unsigned long long nPt = counts[0], nPl = counts[6];
+    // visit_correspondences.h:76-86 (no line pairs on this path); the host's expression of rounds 1-5, evaluated here
+    const double kk = 1.0 / (prm.w_pt2pt * (double)nPt + prm.w_ln2ln * 0.0 + prm.w_pl2pl * (double)nPl);
+    const double waPoints = prm.w_pt2pt * kk, waPlanes = prm.w_pl2pl * kk;
     const double cg0 = cent[0], cg1 = cent[1], cg2 = cent[2], cl0 = cent[3], cl1 = cent[4], cl2 = cent[5];
     for (unsigned long long i = (unsigned long long)blockIdx.x * GN_THREADS + threadIdx.x; i < nPt + nPl;
          i += (unsigned long long)HORN_BLOCKS * GN_THREADS)
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(GN_THREADS) void horn_cov_kernel(
                 acc[11] += 1.0;
                 continue;
             }
-            wi = prm.waPoints;
+            wi = waPoints;
             if (prm.n_blocks)
             {
                 uint32_t b = 0;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(GN_THREADS) void horn_cov_kernel(
         else
         {  // :181-192 plane normals as stored (getNormalVector)
             const mp2p_hip_pair_pl2pl& q = pp[i - nPt];
-            wi = prm.waPlanes;
+            wi = waPlanes;
             b0 = q.pl_global[0], b1 = q.pl_global[1], b2 = q.pl_global[2];
             r0 = q.pl_local[0], r1 = q.pl_local[1], r2 = q.pl_local[2];
         }
@@ -255,7 +259,8 @@ static void host_jacobi4(const double* Ain, double* eval, double* V)
 
 // one pass of se3_l2_internal (optimal_tf_horn.cpp:77-196) for the current flags; h = {cg, cl,
 // count, -, S(9), w_sum, bad, n_outliers}
-static int horn_pass(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const HornKernelPrm& k, double h[20])
+static int horn_pass(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const HornKernelPrm& k, double h[20], unsigned long long* bad_blocks,
+                     unsigned long long* h_counts /* [8] or null */)
 {
     double* part = ctx->gn_partials.p;
     double* sums = ctx->gn_sums.p;
@@ -271,20 +276,22 @@ static int horn_pass(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const HornKerne
                        ctx->horn_bounds.p, k, fl, part);
     hipLaunchKernelGGL(horn_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, part, 12, 0, sums + 8);
     // (round 6: into the context's page-locked page and waited for by polling, like the Gauss-Newton read-back -- a copy to the
-    //  caller's stack is staged by the runtime, and the blocking wait adds its wake-up latency: two of each per C2 step)
+    //  caller's stack is staged by the runtime, and the blocking wait adds its wake-up latency; the list's counts ride along with
+    //  the first pass: they used to be a round trip of their own in front of it)
     if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
     double* const             ph = reinterpret_cast<double*>((char*)ctx->pinned + 1024);
     unsigned long long* const pb = reinterpret_cast<unsigned long long*>((char*)ctx->pinned + 1024 + 20 * sizeof(double));
+    unsigned long long* const pc = reinterpret_cast<unsigned long long*>((char*)ctx->pinned + 1536);
     *pb = 0ull;
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(ph, sums, 20 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (k.n_blocks)
         MP2P_TRY_HIP(ctx, hipMemcpyAsync(pb, ctx->horn_bounds.p + MP2P_HIP_MAX_WEIGHT_BLOCKS, sizeof(unsigned long long),
                                          hipMemcpyDeviceToHost, ctx->stream));
+    if (h_counts) MP2P_TRY_HIP(ctx, hipMemcpyAsync(pc, P->counts.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     MP2P_TRY_HIP(ctx, stream_wait(ctx));
     memcpy(h, ph, 20 * sizeof(double));
-    const unsigned long long bad_blocks = *pb;
-    MP2P_REQUIRE(ctx, bad_blocks == 0, "Pairings::point_weights blocks cover fewer pairs than paired_pt2pt");
-    MP2P_REQUIRE(ctx, h[8 + 10] == 0.0, "Horn: a visited pairing has weight <= 0 (ASSERT_(wi > .0))");
+    *bad_blocks = *pb;
+    if (h_counts) memcpy(h_counts, pc, 8 * sizeof(unsigned long long));
     return MP2P_HIP_OK;
 }
 
@@ -300,28 +307,12 @@ int horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const mp2p_hip_horn_p
     MP2P_TRY_HIP(ctx, ctx->gn_partials.ensure((size_t)GN_BLOCKS * NS));  // >= HORN_BLOCKS*16
     MP2P_TRY_HIP(ctx, ctx->gn_sums.ensure(NS));
     MP2P_TRY_HIP(ctx, ctx->horn_bounds.ensure(MP2P_HIP_MAX_WEIGHT_BLOCKS + 8));
-    unsigned long long h_counts[8];
-    if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync((char*)ctx->pinned + 1536, P->counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, stream_wait(ctx));
-    memcpy(h_counts, (char*)ctx->pinned + 1536, sizeof(h_counts));
-    const unsigned long long n = h_counts[0], nPl = h_counts[6];
-    MP2P_REQUIRE(ctx, h_counts[1] == 0 && h_counts[5] == 0,
-                 "This solver cannot handle point-to-plane / point-to-line pairings (convert them first)");
-    MP2P_TRY_HIP(ctx, ctx->horn_flags.ensure(n ? n : 1));
-    MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->horn_flags.p, 0, n ? n : 1, ctx->stream));
-    ctx->horn_n = n;
-    // eval_centroids_robust: ASSERT_GT_(nPt2Pt, outliers.size())  (Pairings.cpp:76)
-    MP2P_REQUIRE(ctx, n > 0, "Horn: needs more point pairings than outliers (none given)");
-    if (n + nPl < 3) return MP2P_HIP_OK;  // :98 needs >= 3 references
-
+    // visit_correspondences.h:76-86 (no line pairs on this path)
+    MP2P_REQUIRE(ctx, w->w_pt2pt + w->w_ln2ln + w->w_pl2pl > 0.0, "all attitude weights are <= 0");
     HornKernelPrm k;
     memset(&k, 0, sizeof(k));
     k.use_scale = w->use_scale_outlier_detector ? 1 : 0, k.scale_thr = w->scale_outlier_threshold;
-    // visit_correspondences.h:76-86 (no line pairs on this path)
-    MP2P_REQUIRE(ctx, w->w_pt2pt + w->w_ln2ln + w->w_pl2pl > 0.0, "all attitude weights are <= 0");
-    const double kk = 1.0 / (w->w_pt2pt * (double)n + w->w_ln2ln * 0.0 + w->w_pl2pl * (double)nPl);
-    k.waPoints = w->w_pt2pt * kk, k.waPlanes = w->w_pl2pl * kk;
+    k.w_pt2pt = w->w_pt2pt, k.w_ln2ln = w->w_ln2ln, k.w_pl2pl = w->w_pl2pl;  // (the attitude weights: horn_cov_kernel, from the list's counts)
     k.rk.kernel = w->robust_kernel, k.rk.c = w->robust_kernel_param;
     k.rk.c2 = w->robust_kernel_param * w->robust_kernel_param;
     for (int i = 0; i < 12; i++) k.est[i] = w->current_estimate[i];
@@ -329,14 +320,31 @@ int horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const mp2p_hip_horn_p
     for (uint32_t b = 0; b < w->n_weight_blocks; b++)
         k.blk_count[b] = w->weight_block_count[b], k.blk_w[b] = w->weight_block_w[b];
 
-    double h[20];
-    int    rc = horn_pass(ctx, P, k, h);
+    // the outlier flags: one byte per point pairing the list CAN hold (its length is on the device; it comes back with the first pass)
+    const size_t n_cap = P->cap_pt2pt ? P->cap_pt2pt : 1;
+    MP2P_TRY_HIP(ctx, ctx->horn_flags.ensure(n_cap));
+    MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->horn_flags.p, 0, n_cap, ctx->stream));
+    double             h[20];
+    unsigned long long h_counts[8], bad_blocks = 0;
+    int                rc = horn_pass(ctx, P, k, h, &bad_blocks, h_counts);
     if (rc) return rc;
+    const unsigned long long n = h_counts[0], nPl = h_counts[6];
+    ctx->horn_n = n;
+    // (the checks in the order of rounds 1-5, when the counts were read before the pass)
+    MP2P_REQUIRE(ctx, h_counts[1] == 0 && h_counts[5] == 0,
+                 "This solver cannot handle point-to-plane / point-to-line pairings (convert them first)");
+    // eval_centroids_robust: ASSERT_GT_(nPt2Pt, outliers.size())  (Pairings.cpp:76)
+    MP2P_REQUIRE(ctx, n > 0, "Horn: needs more point pairings than outliers (none given)");
+    if (n + nPl < 3) return MP2P_HIP_OK;  // :98 needs >= 3 references
+    MP2P_REQUIRE(ctx, bad_blocks == 0, "Pairings::point_weights blocks cover fewer pairs than paired_pt2pt");
+    MP2P_REQUIRE(ctx, h[8 + 10] == 0.0, "Horn: a visited pairing has weight <= 0 (ASSERT_(wi > .0))");
     if (w->use_scale_outlier_detector && h[8 + 11] > 0.0)  // :224-236
     {
         MP2P_REQUIRE(ctx, (double)n > h[8 + 11], "Horn: every point pairing is a scale outlier");
-        rc = horn_pass(ctx, P, k, h);
+        rc = horn_pass(ctx, P, k, h, &bad_blocks, nullptr);
         if (rc) return rc;
+        MP2P_REQUIRE(ctx, bad_blocks == 0, "Pairings::point_weights blocks cover fewer pairs than paired_pt2pt");
+        MP2P_REQUIRE(ctx, h[8 + 10] == 0.0, "Horn: a visited pairing has weight <= 0 (ASSERT_(wi > .0))");
     }
     res->n_outliers = (uint64_t)h[8 + 11];
     const double* cg = h;
@@ -481,7 +489,7 @@ static int cv_append(mp2p_hip_ctx* ctx, size_t n, Scratch<unsigned long long>& k
     hipLaunchKernelGGL(cv_write_kernel, dim3(nb), dim3(256), 0, ctx->stream, v1.p, pairs.p, (unsigned long long)n,
                        take.p, out->lidx.p, out->gidx.p, out->lx.p, out->ly.p, out->lz.p, out->gx.p, out->gy.p,
                        out->gz.p, out->err.p);
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));  // tmp is a temporary
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));  // tmp is a temporary
     return MP2P_HIP_OK;
 }
 
@@ -490,7 +498,7 @@ int pt2ln_pl_to_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* in, const double 
 {
     unsigned long long h_counts[8];
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(h_counts, in->counts.p, sizeof(h_counts), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
     const size_t n_pl = h_counts[1], n_ln = h_counts[5];
     MP2P_REQUIRE(ctx, out->cap_pt2pt >= n_pl + n_ln, "output Pairings too small for the converted pairs");
     const size_t m = std::max<size_t>(std::max(n_pl, n_ln), 1);

@@ -279,7 +279,7 @@ int launch_adaptive_search(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2
     float    h_bb[6];
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(h_mm, minmax, sizeof(h_mm), hipMemcpyDeviceToHost, ctx->stream));
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(h_bb, ctx->local_bbox.p, sizeof(h_bb), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
     memset(hist, 0, sizeof(*hist));
     ctx->ad_knn = K, ctx->ad_cloud = cloud, ctx->ad_map = map;
     if (h_mm[0] == 0xFFFFFFFFu) return MP2P_HIP_OK;  // nobody found a neighbour: hist->valid = 0
@@ -298,7 +298,7 @@ int launch_adaptive_search(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2
                        (uint32_t)n_l, K, minmax, ctx->ad_hist.p);
     unsigned long long h_b[AD_BINS + 1];
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(h_b, ctx->ad_hist.p, sizeof(h_b), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));
     for (int i = 0; i < AD_BINS; i++) hist->bins[i] = h_b[i];
     hist->count = h_b[AD_BINS];
     return MP2P_HIP_OK;

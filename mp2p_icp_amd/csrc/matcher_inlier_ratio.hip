@@ -129,7 +129,7 @@ int launch_match_inlier_ratio(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const 
     if (rc) return rc;
     uint32_t h_cnt[2] = {0, 0};
     MP2P_TRY_HIP(ctx, hipMemcpyAsync(h_cnt, cnt.p, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx->stream));
-    MP2P_TRY_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also: the sorted list is a temporary
+    MP2P_TRY_HIP(ctx, stream_wait(ctx));  // also: the sorted list is a temporary
     // ASSERT_(nTotal > 0)  (:117) -- only reached when the bounding boxes overlap (:63-66), which the
     // device decided; a layer whose every point is already paired is the caller's error there too
     MP2P_REQUIRE(ctx, h_cnt[0] > 0, "Matcher_Points_InlierRatio: no local point has a candidate (nTotal == 0)");

@@ -1,6 +1,7 @@
 #!/bin/bash
 O=gpurun_out/${1:-r6_p1}; mkdir -p $O; export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_horn.py tests/test_gpu_icp.py tests/test_gpu_configs.py -x -q -m gpu -p no:cacheprovider -k "not c5 and not c4 and not c3" > $O/pytest.log 2>&1; echo "tests rc=$? $(grep -E 'passed|failed' $O/pytest.log | tail -1)" | tee -a $O/rc.txt
+MP2P_FUZZ_HORN_SEEDS=0:600 timeout 1500 python -m pytest tests/test_gpu_horn.py tests/test_gpu_icp.py tests/test_gpu_configs.py tests/test_gpu_fuzz.py tests/test_gpu_matcher_adaptive.py tests/test_gpu_matcher_inlier_ratio.py tests/test_gpu_gn.py -x -q -m gpu -p no:cacheprovider -k "(horn or icp or c2 or adaptive or inlier or covariance or quality) and not c5" > $O/pytest.log 2>&1; echo "tests rc=$? $(grep -E 'passed|failed' $O/pytest.log | tail -1)" | tee -a $O/rc.txt
+tail -3 $O/pytest.log
 for c in c2 c2; do
   timeout 600 python bench.py --config $c --steps 40 --warmup 5 2>$O/$c.err | grep '^{"metric"' > $O/$c.json
   python - <<PY

@@ -37,7 +37,12 @@ info = flat[2 * n_grid:2 * n_grid + n_grid]
 rec = flat[:2 * n_grid].reshape(-1, 2)
 n_cb = (n_l + 1023) // 1024
 Q = 8 if n_l <= 2000000 else 32
-n_hard_grid = len(rec) - ((n_l + 31) // 32 + n_cb)
+# the grid: [hard tiles][easy tiles]; ball-rule kernel (layers above 524 288 queries): 32-query tiles in both classes, hard list n / 16;
+# box-rule kernel: 8-query tiles, hard tiles of 4, hard list min(n / 8, 32 768) entries (launch_match_pt2pl)
+if n_l > 524288:
+    n_hard_grid = (max(n_l // 16, 64) // 32 * 32) // 32
+else:
+    n_hard_grid = (min(max(n_l // 8, 64), 32768) // 32 * 32) // 4
 is_hard = (np.arange(len(rec)) < n_hard_grid)[rec[:, 1] > 0]
 info = info[rec[:, 1] > 0]
 rec = rec[rec[:, 1] > 0].astype(np.int64)
@@ -52,6 +57,10 @@ for k in range(slices):
     resident.append(round(float(ov) / float(b - a), 1))
 dur = (rec[:, 1] - rec[:, 0]) / 100.0
 order = np.argsort(-dur)[:8]
+hard_info = dict(hard_grid=int(n_hard_grid), hard_tiles_run=int(is_hard.sum()),
+                 easy_first_start_us=(round(float((rec[~is_hard, 0] - t0).min()) / 100.0, 1) if (~is_hard).any() else None),
+                 top100_by_duration_in_hard_class=int(is_hard[np.argsort(-dur)[:100]].sum()))
+print(json.dumps(hard_info))
 print(json.dumps(dict(ms_search_fit=round(ms, 3), span_us=round(span / 100.0, 1), tiles=int(len(rec)), resident_per_slice=resident,
                       dur_us=dict(mean=round(float(dur.mean()), 1), p50=round(float(np.percentile(dur, 50)), 1),
                                   p90=round(float(np.percentile(dur, 90)), 1), p99=round(float(np.percentile(dur, 99)), 1),

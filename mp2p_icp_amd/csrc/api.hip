@@ -107,6 +107,7 @@ static int parse_tune(Tune& t, const char* e, bool from_env, std::string* why = 
         else if (k == "tile_brick_budget") t.tile_brick_budget = (uint32_t)v;
         else if (k == "hard_cand") t.hard_cand = (uint32_t)v;
         else if (k == "empty_room") t.empty_room = (int)v;
+        else if (k == "far_pass") t.far_pass = (int)v;
         else if (k == "nn_cert") t.nn_cert = (int)v;
         else if (k == "coop_max") t.coop_max = (uint32_t)v;
         else if (k == "nn_cert_step_mm") t.nn_cert_step_mm = (uint32_t)v;

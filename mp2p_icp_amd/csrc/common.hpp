@@ -148,6 +148,8 @@ struct Tune
     uint32_t pl_q          = 0;     // point-to-plane search: queries per wave (0 = by layer size: 8 up to 400 k points, else 32)
     int      sync_spin     = 1;     // wait for the stream by polling hipStreamQuery (lower wake-up latency)
     int      spin_us       = 2000;  // ... tight for this long, then yielding, then (8x) the blocking wait
+    int      far_pass      = 1;     // one-query kernel: one pass at 1.5 r_max for a query with nothing within the threshold and no empty room around it:
+                                    // its bound then outlives displacements (C5: 300 000 outliers were searched again at every call; 4.49 -> 4.26 ms/step)
     int      claim_dedup   = 1;     // in-wave minimum per global point before the global atomic
     int      claim_peek    = 1;     // plain look at the claim word before the atomic
     int      compact_fused = 1;     // compaction: bounding-box reduction folded in

@@ -93,6 +93,7 @@ struct NNArgs
     uint32_t      tile_brick_budget; // ... when the box spans at most this many bricks (else the coarser dense box)
     uint32_t      coop_max;          // a group of at most this many queries leaves its tile for the one-query kernel
     uint32_t      hard_cand;         // a query whose tile staged at least this many candidates at the previous call is hard (0: by radius only)
+    int           far_pass;          // one-query kernel: a query with nothing within the threshold gets one pass at 1.5 r_max for its bound
     int           claim_dedup, claim_peek;
     int           mfma_scan;         // tile kernel, Q = 32: distance tests on the matrix pipe as a prefilter
     const unsigned char* local_taken;   // by original local index, or null
@@ -1401,6 +1402,7 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
         }
         uint32_t st_pass = 0, st_cand = 0, st_cells = 0;
         const long long t_start = INSTR ? (long long)wall_clock64() : 0;
+        bool            far_done = false;
 
         for (; search;)
         {
@@ -1536,8 +1538,30 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
             }
             wave_argmin(pd, pi, ps);
             if (pd < best_d2 || (pd == best_d2 && pi < best_idx)) best_d2 = pd, best_idx = pi, best_spos = ps;
-            if (is_final(r, rmax, best_d2, g.slack)) break;
+            if (is_final(r, rmax, best_d2, g.slack))
+            {
+                // round 6 (NNArgs::far_pass): nothing within the threshold, and no empty room around the query either -- ONE wider
+                // pass (1.5 r_max) finds its true nearest distance, or that nothing lies within that ball: the bound the record
+                // then carries lets the warm start skip the query until it has moved by the difference, instead of searching the
+                // r_max ball again at every call (C5: 300 000 outliers per call)
+                if (a.far_pass && !far_done && !(best_d2 < thr) && r < 1.5f * rmax)
+                {
+                    far_done = true;
+                    if (best_idx == NONE_U32 && a.empty_room) lb2_skip = empty_room_bound(g, lane, qx, qy, qz, rmax);
+                    if (lb2_skip < 0.f)
+                    {
+                        r = 1.5f * rmax;
+                        continue;
+                    }
+                }
+                break;
+            }
             r = next_radius(r, rmax, best_d2, best_idx != NONE_U32, g.slack);
+        }
+        if (far_done && lb2_skip < 0.f)
+        {   // the ball of radius cover was searched completely: every map point is at least min(nearest found, cover) away
+            const float cover = 1.5f * rmax * (1.0f - 1.0f / 1024.0f) - g.slack;
+            lb2_skip = fminf(best_d2, cover * cover);
         }
         // ---- NOTHING within reach (an outlier of the local layer, metres from every surface).  The record's bound would be
         //      the radius just covered, so the next call -- any displacement at all -- would search the whole ball again,
@@ -1550,7 +1574,7 @@ __global__ __launch_bounds__(64, W) void nn_single_kernel(const NNArgs a)
         //      and the next (round 3: 3 of the 8 ms of configuration C5 were such searches).  Room is cheap for such a
         //      query: if the cube of half-edge 2 r_max (else 1.5 r_max) around it is empty, every map point is farther
         //      than that and the warm start lets the query skip its search until it has moved by the difference.
-        if (search && best_idx == NONE_U32 && a.empty_room) lb2_skip = empty_room_bound(g, lane, qx, qy, qz, rmax);
+        if (search && !far_done && best_idx == NONE_U32 && a.empty_room) lb2_skip = empty_room_bound(g, lane, qx, qy, qz, rmax);
         if (lane == 0)
         {
             bool acc = active && best_idx != NONE_U32 && best_d2 < thr;         // :259
@@ -1733,6 +1757,7 @@ int launch_nn_pt2pt(mp2p_hip_ctx* ctx, const mp2p_hip_map* map, const mp2p_hip_c
     a.hard_cand         = ctx->tune.hard_cand;
     a.coop_max          = ctx->tune.coop_max != 0xFFFFFFFFu ? ctx->tune.coop_max : ((sel && !small_layer) ? 0u : 4u);
     a.empty_room        = ctx->tune.empty_room;
+    a.far_pass          = ctx->tune.far_pass;
     a.claim_dedup   = ctx->tune.claim_dedup;
     a.claim_peek    = ctx->tune.claim_peek;
     a.mfma_scan     = 1;

@@ -197,7 +197,9 @@ def test_fuzz_round4_search_paths(oracle, seed, monkeypatch):
                      f"empty_room={int(rng.choice([1, 1, 0]))}", f"coop_max={int(rng.choice([4, 0]))}",
                      # round 5 (drawn after the clouds and the threshold: those are the ones of round 4's campaign)
                      f"tile_select={int(rng.choice([1, 1, 1, 0]))}", f"nn_direct={int(rng.choice([1, 0, 0]))}",
-                     f"grp_all_bricks={int(rng.choice([6, 0, 100]))}"])
+                     f"grp_all_bricks={int(rng.choice([6, 0, 100]))}",
+                     # round 6: the one-query kernel's wider pass for a query with nothing within the threshold (its bound only)
+                     f"far_pass={int(rng.choice([1, 0]))}"])
     monkeypatch.setenv("MP2P_HIP_TUNE", tune)
     layer_kw = {}
     if rng.random() < 0.3:

@@ -311,6 +311,7 @@ struct mp2p_hip_ctx
     mp2p::DevBuf<unsigned long long> timeline;     // profiling level 4: {start, end} ticks per workgroup
     size_t                           timeline_tiles = 0, timeline_singles = 0;
     mp2p::DevBuf<unsigned char>      horn_flags;   // Horn: scale-outlier flag per point pairing
+    size_t                           horn_flags_zero = 0;  // bytes of horn_flags known to be zero on the stream (no pass with the scale detector wrote them since)
     mp2p::DevBuf<unsigned long long> horn_bounds;  //   first pair of each point_weights block, [MP2P_HIP_MAX_WEIGHT_BLOCKS] = error
     size_t                           horn_n = 0;   //   pairings the flags belong to
     mp2p::DevBuf<unsigned long long> ad_hist;      // Matcher_Adaptive: 50 bins, count, {min,max} words

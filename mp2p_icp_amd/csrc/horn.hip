@@ -322,8 +322,18 @@ int horn_solve(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const mp2p_hip_horn_p
 
     // the outlier flags: one byte per point pairing the list CAN hold (its length is on the device; it comes back with the first pass)
     const size_t n_cap = P->cap_pt2pt ? P->cap_pt2pt : 1;
-    MP2P_TRY_HIP(ctx, ctx->horn_flags.ensure(n_cap));
-    MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->horn_flags.p, 0, n_cap, ctx->stream));
+    {   // (the flags are only ever SET by a pass with the scale-outlier detector on: without it the previous call's zeros stand -- one
+        //  launch less per solve, C2 is a dozen launches long)
+        const size_t before = ctx->horn_flags.n;
+        MP2P_TRY_HIP(ctx, ctx->horn_flags.ensure(n_cap));
+        if (ctx->horn_flags.n != before) ctx->horn_flags_zero = 0;  // (a new allocation: contents unknown)
+        if (ctx->horn_flags_zero < n_cap)
+        {
+            MP2P_TRY_HIP(ctx, hipMemsetAsync(ctx->horn_flags.p, 0, n_cap, ctx->stream));
+            ctx->horn_flags_zero = n_cap;
+        }
+        if (w->use_scale_outlier_detector) ctx->horn_flags_zero = 0;  // this call may set some
+    }
     double             h[20];
     unsigned long long h_counts[8], bad_blocks = 0;
     int                rc = horn_pass(ctx, P, k, h, &bad_blocks, h_counts);

@@ -178,8 +178,11 @@ __global__ __launch_bounds__(GN_THREADS) void horn_cov_kernel(
 
 // fixed-order sum of [HORN_BLOCKS][16] partials; centroid mode: the first 6 scaled by 1/count
 __global__ __launch_bounds__(256) void horn_sum_kernel(const double* __restrict__ partials, int nq,
-                                                       int centroid_mode, double* __restrict__ out)
+                                                       int centroid_mode, double* __restrict__ out,
+                                                       const unsigned long long* __restrict__ counts = nullptr)
 {
+    // (counts: the list's eight counters ride behind the sums -- out[12 .. 19] as raw bits -- so that ONE copy brings both back)
+    if (counts && threadIdx.x >= 248) reinterpret_cast<unsigned long long*>(out + 12)[threadIdx.x - 248] = counts[threadIdx.x - 248];
     // (round 6: 16 parts x 16 quantities, every thread's HORN_BLOCKS / 16 loads independent, the parts combined as a fixed tree --
     //  deterministic run to run like the Gauss-Newton sums; one thread per quantity walking all 512 rows was 12.6 us per launch, two
     //  launches per solve = 9 % of a C2 step)
@@ -274,24 +277,22 @@ static int horn_pass(mp2p_hip_ctx* ctx, const mp2p_hip_pairs* P, const HornKerne
     hipLaunchKernelGGL(horn_cov_kernel, dim3(HORN_BLOCKS), dim3(GN_THREADS), 0, ctx->stream, P->lx.p,
                        P->ly.p, P->lz.p, P->gx.p, P->gy.p, P->gz.p, P->pp.p, P->counts.p, sums,
                        ctx->horn_bounds.p, k, fl, part);
-    hipLaunchKernelGGL(horn_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, part, 12, 0, sums + 8);
+    hipLaunchKernelGGL(horn_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, part, 12, 0, sums + 8, (const unsigned long long*)(h_counts ? P->counts.p : nullptr));
     // (round 6: into the context's page-locked page and waited for by polling, like the Gauss-Newton read-back -- a copy to the
     //  caller's stack is staged by the runtime, and the blocking wait adds its wake-up latency; the list's counts ride along with
     //  the first pass: they used to be a round trip of their own in front of it)
     if (!ctx->pinned) MP2P_TRY_HIP(ctx, hipHostMalloc((void**)&ctx->pinned, 4096, hipHostMallocDefault));
     double* const             ph = reinterpret_cast<double*>((char*)ctx->pinned + 1024);
-    unsigned long long* const pb = reinterpret_cast<unsigned long long*>((char*)ctx->pinned + 1024 + 20 * sizeof(double));
-    unsigned long long* const pc = reinterpret_cast<unsigned long long*>((char*)ctx->pinned + 1536);
+    unsigned long long* const pb = reinterpret_cast<unsigned long long*>((char*)ctx->pinned + 1024 + 28 * sizeof(double));
     *pb = 0ull;
-    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ph, sums, 20 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MP2P_TRY_HIP(ctx, hipMemcpyAsync(ph, sums, (h_counts ? 28 : 20) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (k.n_blocks)
         MP2P_TRY_HIP(ctx, hipMemcpyAsync(pb, ctx->horn_bounds.p + MP2P_HIP_MAX_WEIGHT_BLOCKS, sizeof(unsigned long long),
                                          hipMemcpyDeviceToHost, ctx->stream));
-    if (h_counts) MP2P_TRY_HIP(ctx, hipMemcpyAsync(pc, P->counts.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     MP2P_TRY_HIP(ctx, stream_wait(ctx));
     memcpy(h, ph, 20 * sizeof(double));
     *bad_blocks = *pb;
-    if (h_counts) memcpy(h_counts, pc, 8 * sizeof(unsigned long long));
+    if (h_counts) memcpy(h_counts, ph + 20, 8 * sizeof(unsigned long long));
     return MP2P_HIP_OK;
 }
 
